@@ -1,0 +1,137 @@
+/* gpsa_hip.h — C ABI of libgpsa_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * GPSA variational deep-GP forward / ELBO / backward hot path.
+ *
+ * Boundary contract
+ *   - plain C: device pointers + sizes + a hipStream_t passed as void*; no torch types.
+ *   - every entry point returns 0 on success or a (positive) hipError_t / negative GPSA_E* code;
+ *     nothing allocates, frees or synchronises (safe for stream capture into a hipGraph);
+ *     scratch memory is passed in by the caller (size from the matching *_workspace() query).
+ *   - all matrices are dense row-major.  dtype: GPSA_F32 (float) or GPSA_F64 (double).
+ *   - scalar kernel hyper-parameters are passed as DEVICE pointers (unconstrained = log values,
+ *     as the reference stores them) so that no host<->device sync is ever needed.
+ *
+ * Each entry point cites the reference code (python, /root/reference) it replaces.  The reference
+ * has no FFI of its own (pure PyTorch); the binding a maintainer would add is the ctypes stub shown
+ * in INTEGRATION.md and implemented in spatial_alignment_amd/_lib.py.
+ */
+#ifndef GPSA_HIP_H
+#define GPSA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GPSA_F32 = 0, GPSA_F64 = 1 };
+enum { GPSA_K_RBF = 0, GPSA_K_MATERN12 = 1, GPSA_K_MATERN32 = 2 };
+enum { GPSA_EINVAL = -1, GPSA_EWORKSPACE = -2, GPSA_EUNSUPPORTED = -3 };
+
+/* library / build info */
+int gpsa_version(void);               /* 100*major + minor */
+const char* gpsa_build_arch(void);    /* "gfx950" */
+
+/* ---- covariance ("kernel") matrices ---------------------------------------------------------
+ * K[m,c] = k(Z[m,:], X[c,:]) (+ jitter on the diagonal m==c, used for K_uu).
+ * replaces gpsa/util/util.py:8-23 (rbf_kernel), :33-47 (matern12_kernel), :50-66 (matern32_kernel)
+ * as called from gpsa/models/vgpsa.py:314-318, 390-392, 409.
+ * Z [M,D], X [C,D], K [M,C]; ls_u / var_u: device scalars (log lengthscale, log variance). D <= 4. */
+int gpsa_kmat(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
+              const void* ls_u, const void* var_u, double jitter, void* K, void* stream);
+
+/* Backward of gpsa_kmat: given Kbar = dLoss/dK [M,C] produce
+ *   dZ [M,D], dX [C,D] (may be NULL), dparams[2] = {dLoss/d ls_u, dLoss/d var_u}.
+ * (autograd of util.py:8-66 in the reference).  Deterministic (two-pass reduction in workspace). */
+long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D);
+int gpsa_kmat_bwd(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
+                  const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
+                  void* dparams, void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- dense products ---------------------------------------------------------------------------
+ * C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b];  op(A): m x k, op(B): k x n, row-major, strided batch.
+ * splitk > 1 splits the k loop over workgroups (deterministic: partials in workspace, then summed).
+ * replaces the torch.matmul / torch.mm calls of vgpsa.py:179-196, 207-210, 227, 302, 430. */
+long long gpsa_gemm_workspace(int dtype, int m, int n, int batch, int splitk);
+int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, double alpha,
+              const void* A, long long lda, long long strideA, const void* B, long long ldb,
+              long long strideB, double beta, void* C, long long ldc, long long strideC, int batch,
+              int splitk, void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- inducing-point factorisations (fp64, batched, one workgroup per matrix) -----------------
+ * gpsa_chol_f64: in-place lower Cholesky of A[b] (upper triangle zeroed); logdet[b] = 2*sum(log diag);
+ *   info[b] = 0 or (1 + index of the first non-positive pivot) — the reference raises
+ *   torch.linalg.LinAlgError there (vgpsa.py:257, 320, 394, 412 torch.cholesky).
+ * gpsa_tri_inv_f64: Linv[b] = inverse of the lower-triangular L[b] (replaces the triangular solves
+ *   inside torch.cholesky_solve, vgpsa.py:177). */
+int gpsa_chol_f64(void* A, int M, int batch, void* logdet, int* info, void* stream);
+int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream);
+
+/* ---- the dominant contraction: variational variance term --------------------------------------
+ * v[l,c] = alpha[:,c]^T Omega[l] alpha[:,c]            (vgpsa.py:192-196 a_t_Omega_tril, square, sum;
+ *                                                        Omega_tril Omega_tril^T == Omega exactly)
+ * alpha [M,C], Omega [L,M,M] symmetric, v [L,C].  Never materialises the [S,L,N,M] tensor.
+ * fp32 + M <= 256 runs on the MFMA (v_mfma_f32_16x16x4_f32) path; otherwise a tiled generic path. */
+long long gpsa_quadform_workspace(int dtype, int M, long long C, int L);
+int gpsa_quadform_fwd(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
+                      void* v, void* workspace, long long workspace_bytes, void* stream);
+/* dalpha[:,c] = 2 * sum_l g[l,c] * Omega[l] alpha[:,c]      (autograd of the above wrt alpha) */
+int gpsa_quadform_bwd_alpha(int dtype, const void* alpha, const void* Omega, const void* g, int M,
+                            long long C, int L, void* dalpha, void* workspace,
+                            long long workspace_bytes, void* stream);
+/* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]) */
+int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, long long C, int L,
+                            void* dOmega, void* workspace, long long workspace_bytes, void* stream);
+
+/* Y = P X with P [M,M], X [M,C]  (+ optional colsq[c] = sum_m Y[m,c]^2, may be NULL).
+ * The whitening products beta = L^-1 K_uf, alpha = L^-T beta of vgpsa.py:177-180. */
+int gpsa_panel_mm(int dtype, const void* P, const void* X, int M, long long C, void* Y, void* colsq,
+                  void* workspace, long long workspace_bytes, void* stream);
+
+/* out[m,c] = Y[m,c] + s * d[c] * X[m,c]   (X, Y, out [M,C]; d [C]; out may alias Y).
+ * Column-scaled update used by the whitening backward (autograd of vgpsa.py:177-180). */
+int gpsa_col_axpy(int dtype, const void* Y, const void* X, const void* d, double s, int M,
+                  long long C, void* out, void* stream);
+
+/* ---- reparameterised sampling -----------------------------------------------------------------
+ * data GP (vgpsa.py:197-204, 423-426):  var = exp(var_u) - q[c] + v[l,c] + 2e-5 ;
+ *   F[c,l] = meanT[l,c] + sqrt(var) * eps[c,l] ;  Sigma[l,c] = var (kept for backward). */
+int gpsa_data_sample_fwd(const float* meanT, const float* v, const float* q, const float* var_u,
+                         const float* eps, long long C, int L, float* F, float* Sigma, void* stream);
+/* given dF [C,L]:  g[l,c] = dF*eps/(2 sqrt(Sigma)),  dmeanT[l,c] = dF[c,l],  qbar[c] = -sum_l g,
+ *   dvar_u (device scalar, overwritten) = exp(var_u) * sum g.   workspace >= 8*(C/32+2) bytes */
+int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, const float* var_u,
+                         long long C, int L, float* g, float* dmeanT, float* qbar, float* dvar_u,
+                         void* workspace, long long workspace_bytes, void* stream);
+/* warp GP (vgpsa.py:186-191, 334-351; variance used as the std), fp64 inside:
+ *   var = exp(var_u) - q[c] + v[j,c] + 2e-5 ; Gmean[c,j] = mux[c,j] + meanT[j,c] ;
+ *   Gs[s,c,j] = Gmean[c,j] + var * eps[s,c,j].   bad[0] is set to 1 if any var <= 0 or NaN
+ *   (the reference's Normal(...) argument validation raises ValueError there). */
+int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const double* var_u,
+                         const double* mux, const float* eps, long long n, int D, int S,
+                         float* Gmean, float* Gs, double* Sigma, int* bad, void* stream);
+/* given dGmean [n,D] (may be NULL), dGs [S,n,D]:  dmeanT[j,c], g[j,c] = sum_s dGs*eps, qbar[c],
+ *   dvar_u (overwritten).  workspace >= 8*(n/256+2) bytes */
+int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps,
+                         const double* var_u, long long n, int D, int S, double* dmeanT, double* g,
+                         double* qbar, double* dvar_u, void* workspace, long long workspace_bytes,
+                         void* stream);
+
+/* ---- Gaussian likelihood (vgpsa.py:532-538; "variance" used as std) -----------
+ * scale = exp(noise_u[0]) + 1e-5 ;  out[0] = sum_{s,n,p} log N(Y[n,p]; F[s,n,p], scale) / S.
+ * workspace >= 8*(blocks+2) bytes with blocks = min(4096, ceil(S*N*P/1024)). */
+int gpsa_loglik_fwd(const float* F, const float* Y, const float* noise_u, int S, long long N, int P,
+                    double* out, void* workspace, long long workspace_bytes, void* stream);
+/* dF = gout[0] * dLL/dF ; dnoise_u[0] = gout[0] * dLL/d noise_u  (gout: device scalar, double) */
+int gpsa_loglik_bwd(const float* F, const float* Y, const float* noise_u, const double* gout, int S,
+                    long long N, int P, float* dF, float* dnoise_u, void* workspace,
+                    long long workspace_bytes, void* stream);
+
+/* ---- small helpers used by the KL terms (vgpsa.py:498-530) -------------------------------------
+ * out[b] = sum_i A[b,i]*B[b,i] (strideA/strideB in elements; 0 broadcasts) */
+int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long long strideB,
+              long long n, int batch, void* out, void* stream);
+/* A[b] += s * I  (A [batch,M,M]) */
+int gpsa_add_diag(int dtype, void* A, int M, int batch, double s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSA_HIP_H */

@@ -1,0 +1,337 @@
+// Reparameterised Gaussian sampling, its backward, and the Gaussian likelihood sum.
+// HBM-bound elementwise / reduction kernels: coalesced on both the sample-major ([C,L]) API tensors
+// and the output-major ([L,C]) internal ones via 32x32 LDS tile transposes; wave-shuffle + two-pass
+// (deterministic) reductions.  Reference: gpsa/models/vgpsa.py:186-204, 334-351, 423-426, 532-538.
+#include "common.hpp"
+
+namespace gpsa {
+
+constexpr double TWO_JITTER = 2e-5;  // diagonal_offset added twice (vgpsa.py:191/201 and :204)
+
+// out[0] = (TO)( sum(part[0..n)) * cscale * (expo ? exp(*expo) : 1) * (mul ? *mul : 1) )
+template <typename TE, typename TO>
+__global__ void sum_scale_kernel(const double* __restrict__ part, long long n,
+                                 const TE* __restrict__ expo, const double* __restrict__ mul,
+                                 double cscale, TO* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    double r = s * cscale;
+    if (expo) r *= exp((double)expo[0]);
+    if (mul) r *= mul[0];
+    out[0] = (TO)r;
+  }
+}
+
+// ---- data GP ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+data_sample_fwd_kernel(const float* __restrict__ meanT, const float* __restrict__ v,
+                       const float* __restrict__ q, const float* __restrict__ var_u,
+                       const float* __restrict__ eps, long long C, int L, float* __restrict__ F,
+                       float* __restrict__ Sigma) {
+  __shared__ float tm[32][33], tv[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long c0 = (long long)blockIdx.x * 32;
+  const int l0 = blockIdx.y * 32;
+  const float var0 = expf(var_u[0]);
+  {
+    const long long c = c0 + tx;
+    const float qc = (c < C) ? q[c] : 0.f;
+#pragma unroll
+    for (int ly = 0; ly < 32; ly += 8) {
+      const int l = l0 + ty + ly;
+      if (c < C && l < L) {
+        const long long o = (long long)l * C + c;
+        const float var = var0 - qc + v[o] + (float)TWO_JITTER;
+        Sigma[o] = var;
+        tv[ty + ly][tx] = var;
+        tm[ty + ly][tx] = meanT[o];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int l = l0 + tx;
+#pragma unroll
+    for (int cy = 0; cy < 32; cy += 8) {
+      const long long c = c0 + ty + cy;
+      if (c < C && l < L) {
+        const long long o = c * L + l;
+        F[o] = tm[tx][ty + cy] + sqrtf(tv[tx][ty + cy]) * eps[o];
+      }
+    }
+  }
+}
+
+// one block per 32-column tile, loops over all L
+__global__ void __launch_bounds__(256)
+data_sample_bwd_kernel(const float* __restrict__ dF, const float* __restrict__ eps,
+                       const float* __restrict__ Sigma, long long C, int L, float* __restrict__ g,
+                       float* __restrict__ dmeanT, float* __restrict__ qbar,
+                       double* __restrict__ part) {
+  __shared__ float td[32][33], te[32][33];
+  __shared__ float colacc[8][32];
+  __shared__ double red[4];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long c0 = (long long)blockIdx.x * 32;
+  float gsum = 0.f;
+  for (int l0 = 0; l0 < L; l0 += 32) {
+    __syncthreads();
+    {
+      const int l = l0 + tx;
+#pragma unroll
+      for (int cy = 0; cy < 32; cy += 8) {
+        const long long c = c0 + ty + cy;
+        float a = 0.f, b = 0.f;
+        if (c < C && l < L) {
+          a = dF[c * L + l];
+          b = eps[c * L + l];
+        }
+        td[ty + cy][tx] = a;
+        te[ty + cy][tx] = b;
+      }
+    }
+    __syncthreads();
+    {
+      const long long c = c0 + tx;
+#pragma unroll
+      for (int ly = 0; ly < 32; ly += 8) {
+        const int l = l0 + ty + ly;
+        if (c < C && l < L) {
+          const long long o = (long long)l * C + c;
+          const float d = td[tx][ty + ly];
+          const float gv = d * te[tx][ty + ly] * 0.5f / sqrtf(Sigma[o]);
+          g[o] = gv;
+          dmeanT[o] = d;
+          gsum += gv;
+        }
+      }
+    }
+  }
+  colacc[ty][tx] = gsum;
+  __syncthreads();
+  if (ty == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += colacc[i][tx];
+    if (c0 + tx < C) qbar[c0 + tx] = -s;
+  }
+  double tot = block_sum((double)gsum, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---- warp GP (fp64 inside) ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+warp_sample_fwd_kernel(const double* __restrict__ meanT, const double* __restrict__ v,
+                       const double* __restrict__ q, const double* __restrict__ var_u,
+                       const double* __restrict__ mux, const float* __restrict__ eps, long long n,
+                       int D, int S, float* __restrict__ Gmean, float* __restrict__ Gs,
+                       double* __restrict__ Sigma, int* __restrict__ bad) {
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= n) return;
+  const double var0 = exp(var_u[0]), qc = q[c];
+  for (int j = 0; j < D; ++j) {
+    const long long o = (long long)j * n + c;
+    const double var = var0 - qc + v[o] + TWO_JITTER;
+    const double mu = mux[c * D + j] + meanT[o];
+    Sigma[o] = var;
+    if (!(var > 0.0)) bad[0] = 1;
+    Gmean[c * D + j] = (float)mu;
+    for (int s = 0; s < S; ++s) {
+      const long long e = ((long long)s * n + c) * D + j;
+      Gs[e] = (float)(mu + var * (double)eps[e]);  // variance used as the std
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+warp_sample_bwd_kernel(const float* __restrict__ dGmean, const float* __restrict__ dGs,
+                       const float* __restrict__ eps, long long n, int D, int S,
+                       double* __restrict__ dmeanT, double* __restrict__ g,
+                       double* __restrict__ qbar, double* __restrict__ part) {
+  __shared__ double red[4];
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  double gtot = 0.0;
+  if (c < n) {
+    for (int j = 0; j < D; ++j) {
+      double dm = dGmean ? (double)dGmean[c * D + j] : 0.0, gj = 0.0;
+      for (int s = 0; s < S; ++s) {
+        const long long e = ((long long)s * n + c) * D + j;
+        const double d = (double)dGs[e];
+        dm += d;
+        gj += d * (double)eps[e];
+      }
+      dmeanT[(long long)j * n + c] = dm;
+      g[(long long)j * n + c] = gj;
+      gtot += gj;
+    }
+    qbar[c] = -gtot;
+  }
+  double tot = block_sum(gtot, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---- Gaussian likelihood --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+loglik_fwd_kernel(const float* __restrict__ F, const float* __restrict__ Y,
+                  const float* __restrict__ noise_u, long long tot, long long NP,
+                  double* __restrict__ part) {
+  __shared__ double red[4];
+  const double s = exp((double)noise_u[0]) + 1e-5;  // "variance" used as std
+  const float inv = (float)(1.0 / s);
+  const double cst = -log(s) - 0.9189385332046727;  // -log(s) - 0.5*log(2*pi)
+  double acc = 0.0;
+  for (long long i0 = blockIdx.x * 256LL * 4; i0 < tot; i0 += (long long)gridDim.x * 256 * 4) {
+    float a = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * 256 + threadIdx.x;
+      if (i < tot) {
+        const float z = (Y[i % NP] - F[i]) * inv;
+        a += z * z;
+        ++cnt;
+      }
+    }
+    acc += -0.5 * (double)a + cst * cnt;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+loglik_bwd_kernel(const float* __restrict__ F, const float* __restrict__ Y,
+                  const float* __restrict__ noise_u, const double* __restrict__ gout, int S,
+                  long long tot, long long NP, float* __restrict__ dF, double* __restrict__ part) {
+  __shared__ double red[4];
+  const double s = exp((double)noise_u[0]) + 1e-5;
+  const float inv = (float)(1.0 / s);
+  const float coef = (float)(gout[0] / (s * s * (double)S));
+  double acc = 0.0;  // sum z^2 - 1 ; dLL/ds = acc / s / S
+  for (long long i0 = blockIdx.x * 256LL * 4; i0 < tot; i0 += (long long)gridDim.x * 256 * 4) {
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * 256 + threadIdx.x;
+      if (i < tot) {
+        const float r = Y[i % NP] - F[i];
+        dF[i] = coef * r;
+        const float z = r * inv;
+        a += z * z - 1.f;
+      }
+    }
+    acc += (double)a;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// dnoise_u = gout * (sum(z^2-1)/s/S) * exp(noise_u)
+__global__ void loglik_bwd_finish_kernel(const double* __restrict__ part, int n,
+                                         const float* __restrict__ noise_u,
+                                         const double* __restrict__ gout, int S,
+                                         float* __restrict__ dnoise_u) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const double e = exp((double)noise_u[0]), sc = e + 1e-5;
+    dnoise_u[0] = (float)(gout[0] * s / sc / (double)S * e);
+  }
+}
+
+static inline int loglik_blocks(long long tot) {
+  long long b = cdiv(tot, 1024);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace gpsa
+
+extern "C" {
+
+int gpsa_data_sample_fwd(const float* meanT, const float* v, const float* q, const float* var_u,
+                         const float* eps, long long C, int L, float* F, float* Sigma, void* stream) {
+  if (C < 1 || L < 1) return GPSA_EINVAL;
+  dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(L, 32));
+  gpsa::data_sample_fwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(meanT, v, q, var_u, eps, C, L, F, Sigma);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, const float* var_u,
+                         long long C, int L, float* g, float* dmeanT, float* qbar, float* dvar_u,
+                         void* workspace, long long workspace_bytes, void* stream) {
+  if (C < 1 || L < 1) return GPSA_EINVAL;
+  const long long nb = cdiv(C, 32);
+  if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* part = (double*)workspace;
+  gpsa::data_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dF, eps, Sigma, C, L, g, dmeanT, qbar, part);
+  gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const double* var_u,
+                         const double* mux, const float* eps, long long n, int D, int S,
+                         float* Gmean, float* Gs, double* Sigma, int* bad, void* stream) {
+  if (n < 1 || D < 1 || S < 0) return GPSA_EINVAL;
+  gpsa::warp_sample_fwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, as_stream(stream)>>>(
+      meanT, v, q, var_u, mux, eps, n, D, S, Gmean, Gs, Sigma, bad);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps,
+                         const double* var_u, long long n, int D, int S, double* dmeanT, double* g,
+                         double* qbar, double* dvar_u, void* workspace, long long workspace_bytes,
+                         void* stream) {
+  if (n < 1 || D < 1 || S < 0) return GPSA_EINVAL;
+  const long long nb = cdiv(n, 256);
+  if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* part = (double*)workspace;
+  gpsa::warp_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dGmean, dGs, eps, n, D, S, dmeanT, g, qbar, part);
+  gpsa::sum_scale_kernel<double, double><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_loglik_fwd(const float* F, const float* Y, const float* noise_u, int S, long long N, int P,
+                    double* out, void* workspace, long long workspace_bytes, void* stream) {
+  if (S < 1 || N < 1 || P < 1) return GPSA_EINVAL;
+  const long long NP = N * P, tot = NP * S;
+  const int nb = gpsa::loglik_blocks(tot);
+  if (workspace_bytes < (long long)nb * 8) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* part = (double*)workspace;
+  gpsa::loglik_fwd_kernel<<<nb, 256, 0, st>>>(F, Y, noise_u, tot, NP, part);
+  gpsa::sum_scale_kernel<float, double><<<1, 256, 0, st>>>(part, nb, nullptr, nullptr, 1.0 / S, out);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_loglik_bwd(const float* F, const float* Y, const float* noise_u, const double* gout, int S,
+                    long long N, int P, float* dF, float* dnoise_u, void* workspace,
+                    long long workspace_bytes, void* stream) {
+  if (S < 1 || N < 1 || P < 1) return GPSA_EINVAL;
+  const long long NP = N * P, tot = NP * S;
+  const int nb = gpsa::loglik_blocks(tot);
+  if (workspace_bytes < (long long)nb * 8) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* part = (double*)workspace;
+  gpsa::loglik_bwd_kernel<<<nb, 256, 0, st>>>(F, Y, noise_u, gout, S, tot, NP, dF, part);
+  gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(part, nb, noise_u, gout, S, dnoise_u);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_version(void) { return 100; }
+const char* gpsa_build_arch(void) { return "gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// Generic strided-batched dense product (fp32 / fp64), LDS-tiled, optional deterministic split-K.
+// Used for the small M x M inducing-point algebra (fp64) and as the shape-generic path next to the
+// MFMA panel kernels in quadform.hip.  Replaces torch.matmul / torch.mm calls of
+// gpsa/models/vgpsa.py:179-196, 207-210, 227, 302, 430.
+#include "common.hpp"
+
+namespace gpsa {
+
+constexpr int GB_M = 64, GB_N = 64, GB_K = 16;
+
+template <typename T, bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long long lda,
+            long long sA, const T* __restrict__ B, long long ldb, long long sB, T beta,
+            T* __restrict__ C, long long ldc, long long sC, int splitk, T* __restrict__ part) {
+  __shared__ T As[GB_K][GB_M + 4];
+  __shared__ T Bs[GB_K][GB_N + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int b = blockIdx.z / splitk, sp = blockIdx.z % splitk;
+  const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+  long long kchunk = (k + splitk - 1) / splitk;
+  kchunk = (kchunk + GB_K - 1) / GB_K * GB_K;
+  const long long kbeg = (long long)sp * kchunk;
+  const long long kend = (kbeg + kchunk < k) ? kbeg + kchunk : k;
+  const T* Ab = A + (long long)b * sA;
+  const T* Bb = B + (long long)b * sB;
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
+
+  for (long long k0 = kbeg; k0 < kend; k0 += GB_K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int r, kk;
+      if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }
+      const long long gr = m0 + r, gk = k0 + kk;
+      T v = T(0);
+      if (gr < m && gk < kend) v = TA ? Ab[gk * lda + gr] : Ab[gr * lda + gk];
+      As[kk][r] = v;
+      int c, kb;
+      if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }
+      const long long gc = n0 + c, gk2 = k0 + kb;
+      T u = T(0);
+      if (gc < n && gk2 < kend) u = TB ? Bb[gc * ldb + gk2] : Bb[gk2 * ldb + gc];
+      Bs[kb][c] = u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GB_K; ++kk) {
+      T a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+    }
+    __syncthreads();
+  }
+  if (splitk == 1) {
+    T* Cb = C + (long long)b * sC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = m0 + ty * 4 + i;
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = n0 + tx * 4 + j;
+        if (c >= n) continue;
+        T* p = Cb + (long long)r * ldc + c;
+        *p = (beta == T(0)) ? alpha * acc[i][j] : alpha * acc[i][j] + beta * (*p);
+      }
+    }
+  } else {
+    T* P = part + ((long long)blockIdx.z) * m * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = m0 + ty * 4 + i;
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = n0 + tx * 4 + j;
+        if (c < n) P[(long long)r * n + c] = acc[i][j];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void splitk_reduce_kernel(const T* __restrict__ part, int batch, int splitk, int m, int n,
+                                     T alpha, T beta, T* __restrict__ C, long long ldc,
+                                     long long sC) {
+  const long long mn = (long long)m * n;
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= mn * batch) return;
+  const int b = (int)(idx / mn);
+  const long long e = idx % mn;
+  const int r = (int)(e / n), c = (int)(e % n);
+  T s = T(0);
+  for (int sp = 0; sp < splitk; ++sp) s += part[((long long)b * splitk + sp) * mn + e];
+  T* p = C + (long long)b * sC + (long long)r * ldc + c;
+  *p = (beta == T(0)) ? alpha * s : alpha * s + beta * (*p);
+}
+
+template <typename T>
+int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
+                T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
+                long long ws_bytes, hipStream_t st) {
+  if (m < 1 || n < 1 || k < 1 || batch < 1 || splitk < 1) return GPSA_EINVAL;
+  if ((long long)batch * splitk > 65535) return GPSA_EINVAL;
+  T* part = nullptr;
+  if (splitk > 1) {
+    if (ws_bytes < (long long)batch * splitk * m * n * (long long)sizeof(T)) return GPSA_EWORKSPACE;
+    part = reinterpret_cast<T*>(ws);
+  }
+  dim3 grid((unsigned)cdiv(n, GB_N), (unsigned)cdiv(m, GB_M), (unsigned)(batch * splitk));
+#define GPSA_GEMM_CASE(TA, TB)                                                               \
+  gemm_kernel<T, TA, TB><<<grid, 256, 0, st>>>(m, n, k, (T)alpha, A, lda, sA, B, ldb, sB,     \
+                                               (T)beta, C, ldc, sC, splitk, part)
+  if (!transA && !transB) GPSA_GEMM_CASE(false, false);
+  else if (transA && !transB) GPSA_GEMM_CASE(true, false);
+  else if (!transA && transB) GPSA_GEMM_CASE(false, true);
+  else GPSA_GEMM_CASE(true, true);
+#undef GPSA_GEMM_CASE
+  GPSA_LAUNCH_CHECK();
+  if (splitk > 1) {
+    const long long tot = (long long)m * n * batch;
+    splitk_reduce_kernel<T><<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(part, batch, splitk, m, n,
+                                                                     (T)alpha, (T)beta, C, ldc, sC);
+    GPSA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// explicit instantiations used from other translation units
+template int gemm_launch<float>(int, int, int, int, long long, double, const float*, long long,
+                                long long, const float*, long long, long long, double, float*,
+                                long long, long long, int, int, void*, long long, hipStream_t);
+template int gemm_launch<double>(int, int, int, int, long long, double, const double*, long long,
+                                 long long, const double*, long long, long long, double, double*,
+                                 long long, long long, int, int, void*, long long, hipStream_t);
+
+}  // namespace gpsa
+
+extern "C" {
+
+long long gpsa_gemm_workspace(int dtype, int m, int n, int batch, int splitk) {
+  if (splitk <= 1) return 0;
+  return (long long)batch * splitk * m * n * (dtype == GPSA_F64 ? 8 : 4);
+}
+
+int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, double alpha,
+              const void* A, long long lda, long long strideA, const void* B, long long ldb,
+              long long strideB, double beta, void* C, long long ldc, long long strideC, int batch,
+              int splitk, void* workspace, long long workspace_bytes, void* stream) {
+  if (dtype == GPSA_F32)
+    return gpsa::gemm_launch<float>(transA, transB, m, n, k, alpha, (const float*)A, lda, strideA,
+                                    (const float*)B, ldb, strideB, beta, (float*)C, ldc, strideC,
+                                    batch, splitk, workspace, workspace_bytes, as_stream(stream));
+  if (dtype == GPSA_F64)
+    return gpsa::gemm_launch<double>(transA, transB, m, n, k, alpha, (const double*)A, lda,
+                                     strideA, (const double*)B, ldb, strideB, beta, (double*)C,
+                                     ldc, strideC, batch, splitk, workspace, workspace_bytes,
+                                     as_stream(stream));
+  return GPSA_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// Covariance-matrix generation and its backward (RBF / Matern-1/2 / Matern-3/2).
+// Replaces gpsa/util/util.py:8-66 of the reference as called from gpsa/models/vgpsa.py:314-318,
+// 390-392, 409.  HBM/VALU-bound: coalesced reads of the [C,D] coordinate block, Z staged in LDS,
+// wavefront shuffle reductions for the per-inducing-point gradient sums.
+#include "common.hpp"
+
+namespace gpsa {
+
+// k and the two derivative coefficients:  dk/dz_d = cd * (z_d - x_d),  pl = dk/d ls_u
+template <typename T, int KIND>
+__device__ __forceinline__ void cov_eval(const T* z, const T* x, int D, T ell, T inv_ell, T var,
+                                         T& k, T& cd, T& pl) {
+  if (KIND == GPSA_K_RBF) {
+    T s = T(0);
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < D) {
+        T u = (z[d] - x[d]) * inv_ell;  // reference divides by the lengthscale before squaring
+        s += u * u;
+      }
+    k = var * t_exp<T>(T(-0.5) * s);
+    cd = -k * inv_ell * inv_ell;
+    pl = k * s;
+  } else {
+    T s = T(0);
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < D) {
+        T u = z[d] - x[d];
+        s += u * u;
+      }
+    T dist = t_sqrt<T>(s + T(1e-10));  // eps inside the sqrt (util.py:44-45, 61-62)
+    if (KIND == GPSA_K_MATERN12) {
+      k = var * t_exp<T>(T(-0.5) * dist * inv_ell);  // reference's non-standard 0.5 factor
+      cd = T(-0.5) * k * inv_ell / dist;
+      pl = T(0.5) * k * dist * inv_ell;
+    } else {
+      T zz = T(1.7320508075688772) * dist * inv_ell;
+      T e = var * t_exp<T>(-zz);
+      k = (T(1) + zz) * e;
+      cd = T(-3) * e * inv_ell * inv_ell;
+      pl = e * zz * zz;
+    }
+  }
+}
+
+constexpr int KM_ROWS = 16;
+
+template <typename T, int KIND>
+__global__ void __launch_bounds__(256)
+kmat_fwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long long C, int D,
+                const T* __restrict__ ls_u, const T* __restrict__ var_u, T jitter,
+                T* __restrict__ K) {
+  __shared__ T Zs[KM_ROWS][MAXD];
+  const int m0 = blockIdx.y * KM_ROWS;
+  if (threadIdx.x < KM_ROWS * MAXD) {
+    int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
+    Zs[r][d] = (m0 + r < M && d < D) ? Z[(long long)(m0 + r) * D + d] : T(0);
+  }
+  __syncthreads();
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= C) return;
+  const T ell = t_exp<T>(ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>(var_u[0]);
+  T x[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) x[d] = (d < D) ? X[c * D + d] : T(0);
+  const int mend = min(KM_ROWS, M - m0);
+  for (int r = 0; r < mend; ++r) {
+    T k, cd, pl;
+    cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
+    if ((long long)(m0 + r) == c) k += jitter;
+    K[(long long)(m0 + r) * C + c] = k;
+  }
+}
+
+constexpr int KB_MCHUNK = 128;  // inducing rows per LDS pass of the backward kernel
+
+// One thread per column c; loops over all M inducing rows.  Per block writes a partial row
+// part[blk][0 .. M*D) = dZ partial, part[blk][M*D] = d ls_u, part[blk][M*D+1] = d var_u.
+template <typename T, int KIND>
+__global__ void __launch_bounds__(256)
+kmat_bwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long long C, int D,
+                const T* __restrict__ ls_u, const T* __restrict__ var_u,
+                const T* __restrict__ Kbar, T* __restrict__ dX, T* __restrict__ part) {
+  __shared__ T Zs[KB_MCHUNK][MAXD];
+  __shared__ T acc[4][KB_MCHUNK][MAXD];
+  __shared__ T red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  const bool live = c < C;
+  const T ell = t_exp<T>(ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>(var_u[0]);
+  T x[MAXD], dx[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) {
+    x[d] = (live && d < D) ? X[c * D + d] : T(0);
+    dx[d] = T(0);
+  }
+  T s_ls = T(0), s_var = T(0);
+  const long long stride = (long long)M * D + 2;
+  T* prow = part + (long long)blockIdx.x * stride;
+  for (int m0 = 0; m0 < M; m0 += KB_MCHUNK) {
+    const int mc = min(KB_MCHUNK, M - m0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < KB_MCHUNK * MAXD; i += 256) {
+      int r = i / MAXD, d = i % MAXD;
+      Zs[r][d] = (r < mc && d < D) ? Z[(long long)(m0 + r) * D + d] : T(0);
+    }
+    __syncthreads();
+    for (int r = 0; r < mc; ++r) {
+      T k, cd, pl;
+      cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
+      T kb = live ? Kbar[(long long)(m0 + r) * C + c] : T(0);
+      s_ls += kb * pl;
+      s_var += kb * k;
+      T wgt = kb * cd;
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d)
+        if (d < D) {
+          T t = wgt * (Zs[r][d] - x[d]);  // dLoss/dz_d contribution ; dLoss/dx_d = -t
+          dx[d] -= t;
+          T tz = wave_sum(t);
+          if (lane == 0) acc[w][r][d] = tz;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < mc * D; i += 256) {
+      int r = i / D, d = i % D;
+      prow[(long long)(m0 + r) * D + d] = acc[0][r][d] + acc[1][r][d] + acc[2][r][d] + acc[3][r][d];
+    }
+  }
+  if (dX != nullptr && live)
+    for (int d = 0; d < D; ++d) dX[c * D + d] = dx[d];
+  T a = block_sum(s_ls, red);
+  if (threadIdx.x == 0) prow[(long long)M * D] = a;
+  T b = block_sum(s_var, red);
+  if (threadIdx.x == 0) prow[(long long)M * D + 1] = b;
+}
+
+template <typename T>
+int kmat_launch(int kind, const T* Z, int M, const T* X, long long C, int D, const T* ls_u,
+                const T* var_u, double jitter, T* K, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(C, 256), (unsigned)cdiv(M, KM_ROWS));
+  switch (kind) {
+    case GPSA_K_RBF:
+      kmat_fwd_kernel<T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      break;
+    case GPSA_K_MATERN12:
+      kmat_fwd_kernel<T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      break;
+    case GPSA_K_MATERN32:
+      kmat_fwd_kernel<T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      break;
+    default:
+      return GPSA_EINVAL;
+  }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int kmat_bwd_launch(int kind, const T* Z, int M, const T* X, long long C, int D, const T* ls_u,
+                    const T* var_u, const T* Kbar, T* dZ, T* dX, T* dparams, void* ws,
+                    long long ws_bytes, hipStream_t st) {
+  const long long nblk = cdiv(C, 256), stride = (long long)M * D + 2;
+  if (ws_bytes < nblk * stride * (long long)sizeof(T)) return GPSA_EWORKSPACE;
+  T* part = reinterpret_cast<T*>(ws);
+  switch (kind) {
+    case GPSA_K_RBF:
+      kmat_bwd_kernel<T, GPSA_K_RBF><<<(unsigned)nblk, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, dX, part);
+      break;
+    case GPSA_K_MATERN12:
+      kmat_bwd_kernel<T, GPSA_K_MATERN12><<<(unsigned)nblk, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, dX, part);
+      break;
+    case GPSA_K_MATERN32:
+      kmat_bwd_kernel<T, GPSA_K_MATERN32><<<(unsigned)nblk, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, dX, part);
+      break;
+    default:
+      return GPSA_EINVAL;
+  }
+  GPSA_LAUNCH_CHECK();
+  const long long nz = (long long)M * D;
+  reduce_rows_kernel<T, T><<<(unsigned)cdiv(nz, 256), 256, 0, st>>>(part, nblk, stride, nz, dZ, 1.0);
+  reduce_rows_kernel<T, T><<<1, 64, 0, st>>>(part + nz, nblk, stride, 2, dparams, 1.0);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gpsa
+
+extern "C" {
+
+int gpsa_kmat(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
+              const void* ls_u, const void* var_u, double jitter, void* K, void* stream) {
+  if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
+  if (dtype == GPSA_F32)
+    return gpsa::kmat_launch<float>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                    (const float*)ls_u, (const float*)var_u, jitter, (float*)K,
+                                    as_stream(stream));
+  if (dtype == GPSA_F64)
+    return gpsa::kmat_launch<double>(kind, (const double*)Z, M, (const double*)X, C, D,
+                                     (const double*)ls_u, (const double*)var_u, jitter, (double*)K,
+                                     as_stream(stream));
+  return GPSA_EINVAL;
+}
+
+long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D) {
+  return cdiv(C, 256) * ((long long)M * D + 2) * (dtype == GPSA_F64 ? 8 : 4);
+}
+
+int gpsa_kmat_bwd(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
+                  const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
+                  void* dparams, void* workspace, long long workspace_bytes, void* stream) {
+  if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
+  if (dtype == GPSA_F32)
+    return gpsa::kmat_bwd_launch<float>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                        (const float*)ls_u, (const float*)var_u,
+                                        (const float*)Kbar, (float*)dZ, (float*)dX,
+                                        (float*)dparams, workspace, workspace_bytes,
+                                        as_stream(stream));
+  if (dtype == GPSA_F64)
+    return gpsa::kmat_bwd_launch<double>(kind, (const double*)Z, M, (const double*)X, C, D,
+                                         (const double*)ls_u, (const double*)var_u,
+                                         (const double*)Kbar, (double*)dZ, (double*)dX,
+                                         (double*)dparams, workspace, workspace_bytes,
+                                         as_stream(stream));
+  return GPSA_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// fp64 inducing-point factorisations: batched Cholesky and lower-triangular inverse, one workgroup
+// per M x M matrix.  For M <= 200 the lower triangle lives packed in LDS (M(M+1)/2 * 8 B = 160.8 KB
+// of the CU's 160 KiB at M = 200); larger M runs the same algorithm on the L2-resident matrix.
+// Replaces torch.cholesky (gpsa/models/vgpsa.py:257, 320, 394, 412) and the triangular solves of
+// torch.cholesky_solve (vgpsa.py:177).  Also: batched dot product and diagonal shift for the KL terms.
+#include "common.hpp"
+
+namespace gpsa {
+
+constexpr int LA_THREADS = 1024;
+constexpr int LA_PACKED_MAX = 200;  // packed lower triangle + one row of scratch fits in 160 KiB
+
+struct PackedLower {  // LDS, lower triangle only
+  double* p;
+  __device__ __forceinline__ double& at(int i, int j) const { return p[(i * (i + 1) >> 1) + j]; }
+};
+struct DenseGlobal {  // global row-major [M][M]
+  double* p;
+  int M;
+  __device__ __forceinline__ double& at(int i, int j) const { return p[(long long)i * M + j]; }
+};
+
+// Right-looking Cholesky on accessor `a`; sdiag[M] scratch receives the diagonal of L.
+template <typename Acc>
+__device__ void chol_body(Acc a, int M, double* sdiag, double* logdet_out, int* info_out) {
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;  // 32 x 32
+  double ld = 0.0;
+  int info = 0;
+  for (int j = 0; j < M; ++j) {
+    const double d = a.at(j, j);
+    if (!(d > 0.0)) {  // uniform across the workgroup (everyone read the same value)
+      info = j + 1;
+      break;
+    }
+    const double s = sqrt(d), inv = 1.0 / s;
+    ld += log(s);
+    if (tid == 0) sdiag[j] = s;
+    for (int i = j + 1 + tid; i < M; i += LA_THREADS) a.at(i, j) *= inv;
+    __syncthreads();
+    for (int i = j + 1 + ty; i < M; i += 32) {
+      const double lij = a.at(i, j);
+      for (int k = j + 1 + tx; k <= i; k += 32) a.at(i, k) -= lij * a.at(k, j);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *logdet_out = (info == 0) ? 2.0 * ld : __builtin_nan("");
+    *info_out = info;
+  }
+  __syncthreads();
+  if (info == 0)
+    for (int j = tid; j < M; j += LA_THREADS) a.at(j, j) = sdiag[j];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(LA_THREADS)
+chol_packed_kernel(double* __restrict__ A, int M, double* __restrict__ logdet,
+                   int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* G = A + (long long)blockIdx.x * M * M;
+  PackedLower a{lds};
+  double* sdiag = lds + (M * (M + 1) >> 1);
+  for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
+    const int i = e / M, j = e - i * M;
+    if (j <= i) a.at(i, j) = G[e];
+  }
+  __syncthreads();
+  chol_body(a, M, sdiag, logdet + blockIdx.x, info + blockIdx.x);
+  for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
+    const int i = e / M, j = e - i * M;
+    G[e] = (j <= i) ? a.at(i, j) : 0.0;
+  }
+}
+
+constexpr int LA_GLOBAL_MAX = 4096;
+__global__ void __launch_bounds__(LA_THREADS)
+chol_global_kernel(double* __restrict__ A, int M, double* __restrict__ logdet,
+                   int* __restrict__ info) {
+  __shared__ double sdiag[LA_GLOBAL_MAX];
+  DenseGlobal a{A + (long long)blockIdx.x * M * M, M};
+  chol_body(a, M, sdiag, logdet + blockIdx.x, info + blockIdx.x);
+  for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
+    const int i = e / M, j = e - i * M;
+    if (j > i) a.p[e] = 0.0;
+  }
+}
+
+// Row-oriented in-place inverse of a lower-triangular matrix held in accessor `a`.
+// Row i of the inverse needs rows < i of the inverse and row i of L only, so L is overwritten row by
+// row.  256 columns x 4-way split of the inner sum per pass; the 4 partial sums meet by shuffles.
+template <typename Acc>
+__device__ void tri_inv_body(Acc a, int M, double* rowL) {
+  const int tid = threadIdx.x, ks = tid & 3, cl = tid >> 2;
+  for (int i = 0; i < M; ++i) {
+    for (int k = tid; k <= i; k += LA_THREADS) rowL[k] = a.at(i, k);
+    __syncthreads();
+    const double inv = 1.0 / rowL[i];
+    for (int c0 = 0; c0 < i; c0 += LA_THREADS / 4) {
+      const int c = c0 + cl;
+      double s = 0.0;
+      if (c < i)
+        for (int k = c + ks; k < i; k += 4) s += rowL[k] * a.at(k, c);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (c < i && ks == 0) a.at(i, c) = -s * inv;
+    }
+    if (tid == 0) a.at(i, i) = inv;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(LA_THREADS)
+tri_inv_packed_kernel(const double* __restrict__ L, double* __restrict__ Linv, int M) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const double* G = L + (long long)blockIdx.x * M * M;
+  double* O = Linv + (long long)blockIdx.x * M * M;
+  PackedLower a{lds};
+  double* rowL = lds + (M * (M + 1) >> 1);
+  for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
+    const int i = e / M, j = e - i * M;
+    if (j <= i) a.at(i, j) = G[e];
+  }
+  __syncthreads();
+  tri_inv_body(a, M, rowL);
+  for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
+    const int i = e / M, j = e - i * M;
+    O[e] = (j <= i) ? a.at(i, j) : 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(LA_THREADS)
+tri_inv_global_kernel(const double* __restrict__ L, double* __restrict__ Linv, int M) {
+  __shared__ double rowL[LA_GLOBAL_MAX];
+  const double* G = L + (long long)blockIdx.x * M * M;
+  DenseGlobal a{Linv + (long long)blockIdx.x * M * M, M};
+  for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
+    const int i = e / M, j = e - i * M;
+    a.p[e] = (j <= i) ? G[e] : 0.0;
+  }
+  __syncthreads();
+  tri_inv_body(a, M, rowL);
+}
+
+template <typename T>
+__global__ void bdot_kernel(const T* __restrict__ A, long long sA, const T* __restrict__ B,
+                            long long sB, long long n, T* __restrict__ out) {
+  __shared__ double red[4];
+  const T* a = A + (long long)blockIdx.x * sA;
+  const T* b = B + (long long)blockIdx.x * sB;
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) s += (double)a[i] * (double)b[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = (T)s;
+}
+
+template <typename T>
+__global__ void add_diag_kernel(T* __restrict__ A, int M, int batch, T s) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * batch) return;
+  const long long b = idx / M, i = idx % M;
+  A[b * M * M + i * M + i] += s;
+}
+
+}  // namespace gpsa
+
+extern "C" {
+
+int gpsa_chol_f64(void* A, int M, int batch, void* logdet, int* info, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (M <= LA_PACKED_MAX) {
+    const size_t lds = ((size_t)M * (M + 1) / 2 + M) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)chol_packed_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    chol_packed_kernel<<<batch, LA_THREADS, lds, st>>>((double*)A, M, (double*)logdet, info);
+  } else {
+    if (M > LA_GLOBAL_MAX) return GPSA_EUNSUPPORTED;
+    chol_global_kernel<<<batch, LA_THREADS, 0, st>>>((double*)A, M, (double*)logdet, info);
+  }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (M <= LA_PACKED_MAX) {
+    const size_t lds = ((size_t)M * (M + 1) / 2 + M) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)tri_inv_packed_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    tri_inv_packed_kernel<<<batch, LA_THREADS, lds, st>>>((const double*)L, (double*)Linv, M);
+  } else {
+    if (M > LA_GLOBAL_MAX) return GPSA_EUNSUPPORTED;
+    tri_inv_global_kernel<<<batch, LA_THREADS, 0, st>>>((const double*)L, (double*)Linv, M);
+  }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long long strideB,
+              long long n, int batch, void* out, void* stream) {
+  if (n < 1 || batch < 1) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (dtype == GPSA_F32)
+    gpsa::bdot_kernel<float><<<batch, 256, 0, st>>>((const float*)A, strideA, (const float*)B,
+                                                    strideB, n, (float*)out);
+  else if (dtype == GPSA_F64)
+    gpsa::bdot_kernel<double><<<batch, 256, 0, st>>>((const double*)A, strideA, (const double*)B,
+                                                     strideB, n, (double*)out);
+  else
+    return GPSA_EINVAL;
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_add_diag(int dtype, void* A, int M, int batch, double s, void* stream) {
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const unsigned nb = (unsigned)cdiv((long long)M * batch, 256);
+  if (dtype == GPSA_F32)
+    gpsa::add_diag_kernel<float><<<nb, 256, 0, st>>>((float*)A, M, batch, (float)s);
+  else if (dtype == GPSA_F64)
+    gpsa::add_diag_kernel<double><<<nb, 256, 0, st>>>((double*)A, M, batch, s);
+  else
+    return GPSA_EINVAL;
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+"""Autograd nodes of the GPSA hot path.  Every forward AND backward below is a sequence of
+hand-written HIP kernels (through ``ops``); autograd is used only to chain the nodes.
+
+Math (one sparse-GP layer; reference gpsa/models/vgpsa.py:174-204, columns c = spots or (sample, spot)):
+
+    K = k(Z,Z) + 1e-5 I = L L^T          k_c = k(Z, x_c)
+    beta_c = L^-1 k_c ,  alpha_c = L^-T beta_c = K^-1 k_c ,  q_c = |beta_c|^2 = k_c^T K^-1 k_c
+    mean[l,c] = alpha_c^T dc[:,l]                       (dc = delta - mu_z)
+    v[l,c]    = alpha_c^T Omega_l alpha_c               (Omega_l = A_l A_l^T + 1e-5 I;  the reference
+                                                          computes |Omega_tril_l^T alpha_c|^2 — identical)
+    var[l,c]  = sigma^2 - q_c + v[l,c] + 2e-5
+
+Backward, with abar = d/d alpha, qbar = d/dq  (derivation in DESIGN.md §4):
+    abar_c  = dc dmean[:,c] + 2 sum_l g[l,c] Omega_l alpha_c
+    gamma_c = K^-1 abar_c ,   W_c = gamma_c + qbar_c alpha_c
+    dK_uf[:,c] = W_c + qbar_c alpha_c ,   dK_uu = - W alpha^T
+    d dc = alpha dmean^T ,    dOmega_l = sum_c g[l,c] alpha_c alpha_c^T
+The M x M factorisations run in fp64 (cond(K_uu) ~ 2e7 for the warp GP); the warp
+layer runs entirely in fp64, the data layer's N-scaled work in fp32 on the MFMA units.
+"""
+import torch
+
+from . import ops as _ops_mod
+
+JITTER = 1e-5  # gpsa/models/gpsa.py:153
+
+
+def ops():
+    return _ops_mod.get_ops()
+
+
+class Factor:
+    """fp64 factorisation of one prior covariance K_uu (shared by the layer and its KL term)."""
+
+    __slots__ = ("Linv", "Kinv", "logdet", "info", "_cast")
+
+    def __init__(self, Kuu64):
+        o = ops()
+        L, logdet, info = o.chol(Kuu64.detach().unsqueeze(0))
+        Linv = o.tri_inv(L)
+        self.Linv = Linv[0]
+        self.Kinv = o.gemm(self.Linv, self.Linv, transA=True)
+        self.logdet = logdet
+        self.info = info
+        self._cast = {}
+
+    def linv(self, dtype):
+        """(L^-1, L^-T) in the layer's working precision"""
+        if dtype not in self._cast:
+            a = self.Linv.to(dtype)
+            self._cast[dtype] = (a, self.Linv.t().contiguous().to(dtype))
+        return self._cast[dtype]
+
+
+class KmatFn(torch.autograd.Function):
+    """K = k(Z, X) (+ jitter on the diagonal), computed in ``dtype``; fused HIP forward and backward.
+    Replaces the built-in plugins gpsa/util/util.py:8-66."""
+
+    @staticmethod
+    def forward(ctx, kind, Z, X, ls_u, var_u, jitter, dtype, same):
+        o = ops()
+        Zc, Xc = Z.detach().to(dtype), X.detach().to(dtype)
+        ls = ls_u.detach().to(dtype).reshape(1)
+        var = var_u.detach().to(dtype).reshape(1)
+        K = o.kmat(kind, Zc, Xc, ls, var, jitter)
+        ctx.kind, ctx.same = kind, bool(same)
+        ctx.save_for_backward(Zc, Xc, ls, var)
+        ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, var_u.dtype, ls_u.shape, var_u.shape)
+        return K
+
+    @staticmethod
+    def backward(ctx, Kbar):
+        o = ops()
+        Zc, Xc, ls, var = ctx.saved_tensors
+        zdt, xdt, ldt, vdt, lshape, vshape = ctx.meta
+        need_x = ctx.needs_input_grad[2] or ctx.same
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.contiguous(), need_dX=need_x)
+        if ctx.same:
+            dZ = dZ + dX
+            dX = None
+        gZ = dZ.to(zdt) if ctx.needs_input_grad[1] else None
+        gX = dX.to(xdt) if (dX is not None and ctx.needs_input_grad[2]) else None
+        gl = dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None
+        gv = dpar[1].to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None
+        return None, gZ, gX, gl, gv, None, None, None
+
+
+class OmegaFn(torch.autograd.Function):
+    """Omega = A A^T + 1e-5 I in fp64 (vgpsa.py:206-210).  A [B,M,M] fp32 parameter rows."""
+
+    @staticmethod
+    def forward(ctx, A):
+        o = ops()
+        A64 = A.detach().double().contiguous()
+        Om = o.gemm(A64, A64, transB=True)
+        o.add_diag(Om, JITTER)
+        ctx.save_for_backward(A64)
+        ctx.adt = A.dtype
+        return Om
+
+    @staticmethod
+    def backward(ctx, dOm):
+        (A64,) = ctx.saved_tensors
+        sym = dOm + dOm.transpose(-1, -2)
+        return ops().gemm(sym.contiguous(), A64).to(ctx.adt)
+
+
+class SGPCoreFn(torch.autograd.Function):
+    """(K_uf, dc, Omega; factor of K_uu) -> meanT [L,C], v [L,C], q [C]   (vgpsa.py:174-204)."""
+
+    @staticmethod
+    def forward(ctx, Kuu, Kuf, dc, Omega, fac):
+        o = ops()
+        T = Kuf.dtype
+        Li, LiT = fac.linv(T)
+        Kuf = Kuf.detach()
+        dcT = dc.detach().to(T).contiguous()
+        Om = Omega.detach().to(T).contiguous()
+        beta, q = o.panel_mm(Li, Kuf, want_colsq=True)
+        alpha, _ = o.panel_mm(LiT, beta)
+        meanT = o.gemm(dcT, alpha, transA=True)
+        v = o.quadform_fwd(alpha, Om)
+        ctx.save_for_backward(alpha, dcT, Om, Li, LiT)
+        ctx.meta = (Kuu.dtype, dc.dtype, Omega.dtype)
+        return meanT, v, q
+
+    @staticmethod
+    def backward(ctx, dmeanT, g, qbar):
+        o = ops()
+        alpha, dcT, Om, Li, LiT = ctx.saved_tensors
+        kdt, ddt, odt = ctx.meta
+        M, Cn = alpha.shape
+        L = Om.shape[0]
+        T = alpha.dtype
+        zeros = lambda *s: torch.zeros(*s, dtype=T, device=alpha.device)
+        dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.contiguous()
+        g = zeros(L, Cn) if g is None else g.contiguous()
+        qbar = zeros(Cn) if qbar is None else qbar.contiguous()
+        abar = o.quadform_bwd_alpha(alpha, Om, g)
+        o.gemm(dcT, dmeanT, beta=1.0, out=abar)
+        ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
+        dOm = o.quadform_bwd_omega(alpha, g) if ctx.needs_input_grad[3] else None
+        t, _ = o.panel_mm(Li, abar)
+        gamma, _ = o.panel_mm(LiT, t)
+        W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
+        dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
+        dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
+        return (
+            dKuu.to(kdt),
+            dKuf,
+            ddc.to(ddt),
+            dOm.to(odt) if dOm is not None else None,
+            None,
+        )
+
+
+class WarpSampleFn(torch.autograd.Function):
+    """G_mean, G_samples of the warp GP (vgpsa.py:186-191, 334-351).  var is used as the std
+    (SURVEY quirk 1).  Outputs fp32; internals fp64."""
+
+    @staticmethod
+    def forward(ctx, meanT, v, q, var_u, mux, eps):
+        o = ops()
+        var64 = var_u.detach().double().reshape(1)
+        Gmean, Gs, Sigma, bad = o.warp_sample_fwd(meanT.detach(), v.detach(), q.detach(), var64,
+                                                  mux.detach().double(), eps)
+        ctx.save_for_backward(eps, var64)
+        ctx.vmeta = (var_u.dtype, var_u.shape)
+        ctx.mark_non_differentiable(bad)
+        return Gmean, Gs, bad
+
+    @staticmethod
+    def backward(ctx, dGmean, dGs, _dbad):
+        o = ops()
+        eps, var64 = ctx.saved_tensors
+        if dGs is None:
+            dGs = torch.zeros(eps.shape, dtype=torch.float32, device=eps.device)
+        dmeanT, g, qbar, dvar = o.warp_sample_bwd(dGmean, dGs.float(), eps, var64)
+        vdt, vshape = ctx.vmeta
+        return dmeanT, g, qbar, dvar.to(vdt).reshape(vshape), None, None
+
+
+class DataSampleFn(torch.autograd.Function):
+    """F = mean + sqrt(var) eps of the data GP (vgpsa.py:197-204, 423-426)."""
+
+    @staticmethod
+    def forward(ctx, meanT, v, q, var_u, eps):
+        o = ops()
+        var32 = var_u.detach().float().reshape(1)
+        F, Sigma = o.data_sample_fwd(meanT.detach(), v.detach(), q.detach(), var32, eps)
+        ctx.save_for_backward(eps, Sigma, var32)
+        ctx.vmeta = (var_u.dtype, var_u.shape)
+        return F
+
+    @staticmethod
+    def backward(ctx, dF):
+        o = ops()
+        eps, Sigma, var32 = ctx.saved_tensors
+        g, dmeanT, qbar, dvar = o.data_sample_bwd(dF.contiguous(), eps, Sigma, var32)
+        vdt, vshape = ctx.vmeta
+        return dmeanT, g, qbar, dvar.to(vdt).reshape(vshape), None
+
+
+class MatmulFn(torch.autograd.Function):
+    """F_obs = F_latent @ W (LMC, vgpsa.py:428-432) on the HIP gemm."""
+
+    @staticmethod
+    def forward(ctx, F, W):
+        o = ops()
+        F2 = F.detach().reshape(-1, F.shape[-1])
+        Wc = W.detach().contiguous()
+        ctx.save_for_backward(F2, Wc)
+        ctx.fshape = F.shape
+        return o.gemm(F2, Wc).reshape(*F.shape[:-1], W.shape[1])
+
+    @staticmethod
+    def backward(ctx, dO):
+        o = ops()
+        F2, Wc = ctx.saved_tensors
+        dO2 = dO.contiguous().reshape(-1, dO.shape[-1])
+        dF = o.gemm(dO2, Wc, transB=True).reshape(ctx.fshape)
+        dW = o.gemm(F2, dO2, transA=True, splitk=o.pick_splitk(F2.shape[0], Wc.shape[0], Wc.shape[1]))
+        return dF, dW
+
+
+class LogLikFn(torch.autograd.Function):
+    """sum log N(Y; F, scale) / S with scale = exp(noise_u) + 1e-5 used as a std (vgpsa.py:532-538)."""
+
+    @staticmethod
+    def forward(ctx, F, Y, noise_u):
+        o = ops()
+        nu = noise_u.detach().float().reshape(1)
+        Fc, Yc = F.detach().contiguous(), Y.detach().contiguous()
+        ctx.save_for_backward(Fc, Yc, nu)
+        ctx.nmeta = (noise_u.dtype, noise_u.shape)
+        return o.loglik_fwd(Fc, Yc, nu).reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        o = ops()
+        Fc, Yc, nu = ctx.saved_tensors
+        dF, dn = o.loglik_bwd(Fc, Yc, nu, gout.detach().double().reshape(1))
+        ndt, nshape = ctx.nmeta
+        return dF, None, dn.to(ndt).reshape(nshape)
+
+
+class MvnKLFn(torch.autograd.Function):
+    """KL( N(delta_l, Omega_l) || N(mu_l, K) ) for l = 1..L, fp64 (vgpsa.py:498-530; torch's MVN-MVN
+    formula): 0.5 [ logdet K - logdet Omega_l + tr(K^-1 Omega_l) + d_l^T K^-1 d_l - M ], d = delta - mu.
+    Inputs: Kuu [M,M] (for the gradient path), Dm [M,L], Omega [L,M,M]; ``fac`` = Factor(Kuu)."""
+
+    @staticmethod
+    def forward(ctx, Kuu, Dm, Omega, fac):
+        o = ops()
+        Om = Omega.detach().contiguous()
+        D64 = Dm.detach().double().contiguous()
+        Lo, logdetO, info = o.chol(Om)
+        Loinv = o.tri_inv(Lo)
+        Oinv = o.gemm(Loinv, Loinv, transA=True)
+        tr = o.bdot(fac.Kinv, Om)
+        KD = o.gemm(fac.Kinv, D64)
+        maha = (D64 * KD).sum(0)
+        M = Om.shape[-1]
+        kl = 0.5 * (fac.logdet - logdetO + tr + maha - M)
+        ctx.save_for_backward(Om, Oinv, KD, fac.Kinv)
+        ctx.meta = (Dm.dtype,)
+        ctx.info = info
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        o = ops()
+        Om, Oinv, KD, Kinv = ctx.saved_tensors
+        gkl = gkl.double()
+        dOm = (0.5 * gkl)[:, None, None] * (Kinv.unsqueeze(0) - Oinv)
+        dDm = KD * gkl.unsqueeze(0)
+        Ssum = (gkl[:, None, None] * Om).sum(0)
+        inner = o.gemm(o.gemm(Kinv, Ssum.contiguous()), Kinv)
+        outer = o.gemm((KD * gkl.unsqueeze(0)).contiguous(), KD, transB=True)
+        dK = 0.5 * (gkl.sum() * Kinv - inner - outer)
+        return dK, dDm.to(ctx.meta[0]), dOm, None

@@ -1,0 +1,344 @@
+"""``VariationalGPSA``: the variational two-layer (deep) GP of GPSA on MI355X.
+
+Drop-in for the reference class gpsa/models/vgpsa.py:14-540 — same constructor keywords (including
+the ones the reference accepts and ignores), parameter names, ``forward`` / ``loss_fn`` signatures and
+return structure — with the numerical work done by hand-written HIP kernels (see ../engine.py and
+../csrc).  The index and scale quirks of the reference are reproduced on purpose; they are listed in
+SURVEY.md §8a and flagged ``# quirk N`` below.
+"""
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from ..kernels import builtin_kind, rbf_kernel
+from .gpsa import GPSA
+
+
+def _as_index(idx, device):
+    """view row indices -> (slice | LongTensor, count); contiguous ranges become slices"""
+    a = np.asarray(idx.cpu() if torch.is_tensor(idx) else idx)
+    n = int(a.shape[0])
+    if n == 0:
+        return slice(0, 0), 0
+    if int(a[-1]) - int(a[0]) == n - 1 and (n == 1 or bool(np.all(np.diff(a) == 1))):
+        return slice(int(a[0]), int(a[0]) + n), n
+    return torch.as_tensor(a, dtype=torch.long, device=device), n
+
+
+class _StepCache:
+    """forward -> loss_fn hand-off (the reference keeps the same state on ``self``, vgpsa.py:217-412)."""
+
+    def __init__(self):
+        self.warp = {}  # view -> (Kuu, Factor)
+        self.data = None  # (Kuu_F, Factor)
+        self.Omega_G = None  # [V*D, M, M] fp64
+        self.Omega_F = {}  # mod -> [L, M, M] fp64
+        self.flags = []  # device int tensors: Cholesky info / non-positive variance flags
+
+
+class VariationalGPSA(GPSA):
+    def __init__(
+        self,
+        data_dict,
+        m_X_per_view,
+        m_G,
+        data_init=True,
+        minmax_init=False,
+        grid_init=False,
+        n_spatial_dims=2,
+        n_noise_variance_params=2,
+        kernel_func_warp=rbf_kernel,
+        kernel_func_data=rbf_kernel,
+        n_latent_gps=None,
+        mean_function="identity_fixed",
+        mean_penalty_param=0.0,
+        fixed_warp_kernel_variances=None,
+        fixed_warp_kernel_lengthscales=None,
+        fixed_data_kernel_lengthscales=None,
+        fixed_view_idx=None,
+    ):
+        # quirk 6: n_spatial_dims / n_noise_variance_params / mean_function / minmax_init are accepted
+        # and ignored by the reference (vgpsa.py:35-46): the mean function is always identity, fixed.
+        super().__init__(
+            data_dict,
+            data_init=True,
+            n_spatial_dims=2,
+            n_noise_variance_params=2,
+            kernel_func_warp=kernel_func_warp,
+            kernel_func_data=kernel_func_data,
+            mean_penalty_param=mean_penalty_param,
+            fixed_warp_kernel_variances=fixed_warp_kernel_variances,
+            fixed_warp_kernel_lengthscales=fixed_warp_kernel_lengthscales,
+            fixed_data_kernel_lengthscales=fixed_data_kernel_lengthscales,
+        )
+        self.m_X_per_view = m_X_per_view
+        self.m_G = m_G
+        if n_latent_gps is None:  # the reference requires a dict; None means "no LMC anywhere"
+            n_latent_gps = {m: None for m in self.modality_names}
+        self.n_latent_gps = n_latent_gps
+        self.n_latent_outputs = {
+            m: (n_latent_gps[m] if n_latent_gps[m] is not None else self.Ps[m])
+            for m in self.modality_names
+        }
+        self.fixed_view_idx = fixed_view_idx
+        self.check_numerics = True  # one host sync per forward; raises like the reference would
+        self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
+        self._cache = None
+
+        V, D = self.n_views, self.n_spatial_dims
+        mods = self.modality_names
+        if data_init:
+            # inducing locations = k-means centres of the data (vgpsa.py:61-92)
+            from sklearn.cluster import KMeans
+
+            Xt = torch.zeros([V, self.m_X_per_view, D])
+            for v in range(V):
+                Xv = torch.cat([data_dict[m]["spatial_coords"][self.view_idx[m][v], :] for m in mods], 0)
+                km = KMeans(n_clusters=self.m_X_per_view).fit(Xv.detach().cpu().numpy())
+                Xt[v] = torch.tensor(km.cluster_centers_)
+            self.Xtilde = nn.Parameter(Xt.clone())
+            # the reference draws (and discards) a subset here: raises if m_G > spots of the last view
+            np.random.choice(np.arange(Xv.shape[0]), size=self.m_G, replace=False)
+            allX = torch.cat([data_dict[m]["spatial_coords"] for m in mods])
+            km = KMeans(n_clusters=self.m_G).fit(allX.detach().cpu().numpy())
+            self.Gtilde = nn.Parameter(torch.tensor(km.cluster_centers_))
+            if self.Gtilde.dtype != self.Xtilde.dtype:
+                self.Gtilde = nn.Parameter(self.Gtilde.data.to(self.Xtilde.dtype))
+        elif grid_init:
+            if D == 2:  # lattice over the bounding box of the first modality (vgpsa.py:94-121)
+                xy = data_dict[mods[0]]["spatial_coords"].detach().cpu().numpy()
+                lo, hi = xy.min(0), xy.max(0)
+                ticks = int(np.ceil(np.sqrt(self.m_G)))
+                self.m_G = self.m_X_per_view = ticks**2
+                g1, g2 = np.meshgrid(np.linspace(lo[0], hi[0], ticks), np.linspace(lo[1], hi[1], ticks))
+                lattice = torch.tensor(np.vstack([g1.ravel(), g2.ravel()]).T).float()
+                self.Xtilde = nn.Parameter(lattice.unsqueeze(0).repeat(V, 1, 1).clone())
+                self.Gtilde = nn.Parameter(lattice.clone())
+        else:
+            self.Xtilde = nn.Parameter(torch.randn([V, self.m_X_per_view, D]))
+            self.Gtilde = nn.Parameter(torch.randn([self.m_G, D]))
+
+        M_X, M_G = self.m_X_per_view, self.m_G
+        # variational covariance square roots; row of (view v, dim j) is j*V + v (vgpsa.py:131-143)
+        A = torch.zeros([V * D, M_X, M_X])
+        for v in range(V):
+            for j in range(D):
+                A[j * V + v] = 0.1 * torch.randn(size=[M_X, M_X])
+        self.Omega_sqt_G_list = nn.Parameter(A)
+        self.Omega_sqt_F_dict = nn.ParameterDict()
+        for m in mods:
+            L = self.n_latent_outputs[m]
+            A = torch.zeros([L, M_G, M_G])
+            for l in range(L):
+                A[l] = 0.1 * torch.randn(size=[M_G, M_G])
+            self.Omega_sqt_F_dict[m] = nn.Parameter(A)
+        # variational means; delta_G starts at Xtilde => G_means == X at initialisation (quirk 9)
+        self.delta_G_list = nn.Parameter(self.Xtilde.detach().clone())
+        self.delta_F_dict = nn.ParameterDict()
+        for m in mods:
+            self.delta_F_dict[m] = nn.Parameter(torch.randn(size=[M_G, self.n_latent_outputs[m]]))
+        self.W_dict = nn.ParameterDict()
+        for m in mods:
+            if self.n_latent_gps[m] is not None:
+                self.W_dict[m] = nn.Parameter(torch.randn([self.n_latent_gps[m], self.Ps[m]]))
+
+    # ------------------------------------------------------------------------------------------
+    def _is_fixed(self, v):
+        f = self.fixed_view_idx
+        if f is None:
+            return False
+        return (v in f) if isinstance(f, Iterable) else (f == v)
+
+    def inject_noise(self, eps_G=None, eps_F=None, eps_F_test=None):
+        """Use the given standard-normal draws in the NEXT forward instead of drawing them.
+
+        eps_G: list over the non-fixed, non-empty views in order, each [S, n_v, D];
+        eps_F / eps_F_test: {mod: [S, N, L]} — the draw order of vgpsa.py:346-348, 423, 465.
+        """
+        self._noise = dict(G=eps_G, F=eps_F, F_test=eps_F_test)
+
+    def compute_mean_and_var(self, Kff_diag, Kuf, Kuu_chol, mu_x, mu_z, delta, Omega_tril):
+        raise NotImplementedError(
+            "the sparse-GP conditional is fused into the HIP layer kernels (engine.SGPCoreFn); "
+            "there is no eager path"
+        )
+
+    def get_Omega_from_Omega_sqt(self, Omega_sqt):
+        """Omega = A A^T + 1e-5 I (vgpsa.py:206-210); fp64 result."""
+        return E.OmegaFn.apply(Omega_sqt)
+
+    def _kmat(self, which, Z, X, ls_u, var_u, jitter, dtype, same):
+        fn = self.kernel_func_warp if which == "warp" else self.kernel_func_data
+        kind = builtin_kind(fn)
+        if kind is not None:
+            return E.KmatFn.apply(kind, Z, X, ls_u, var_u, jitter, dtype, same)
+        # arbitrary plugin callable: evaluate it as the reference does (vgpsa.py:275-281, 382-388)
+        K = fn(
+            Z.to(dtype),
+            X.to(dtype),
+            lengthscale_unconstrained=ls_u.to(dtype),
+            output_variance_unconstrained=var_u.to(dtype),
+            diag=False,
+        )
+        if jitter:
+            K = K + jitter * torch.eye(K.shape[-1], dtype=dtype, device=K.device)
+        return K
+
+    def _draw(self, shape, device):
+        return torch.empty(shape, dtype=torch.float32, device=device).normal_()
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, X_spatial, view_idx, Ns, S=1, prediction_mode=False, G_test=None):
+        if prediction_mode:
+            self.eval()
+        dev = self.Xtilde.device
+        mods = self.modality_names
+        V, D = self.n_views, self.n_spatial_dims
+        f64 = torch.float64
+        noise, self._noise = self._noise, None
+        cache = _StepCache()
+
+        self.noise_variance_pos = torch.exp(self.noise_variance) + self.diagonal_offset  # vgpsa.py:217
+        mu_z = []
+        for v in range(V):
+            mz = self.Xtilde[v] @ self.mean_slopes[v] + self.mean_intercepts[v]
+            if self._is_fixed(v):
+                mz = mz * 100.0  # inert (quirk 7)
+            mu_z.append(mz)
+        self.mu_z_G = torch.stack(mu_z)
+
+        cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list)
+
+        nan = float("nan")
+        G_means = {m: torch.full([int(Ns[m]), D], nan, device=dev) for m in mods}
+        G_samples = {m: torch.full([S, int(Ns[m]), D], nan, device=dev) for m in mods}
+
+        draw = 0
+        for v in range(V):
+            rows = {m: _as_index(view_idx[m][v], dev) for m in mods}
+            if self._is_fixed(v):  # vgpsa.py:262-273
+                for m in mods:
+                    r, _ = rows[m]
+                    G_means[m][r] = X_spatial[m][r]
+                    G_samples[m][:, r, :] = X_spatial[m][r]
+                continue
+            Xv = torch.cat([X_spatial[m][rows[m][0]] for m in mods], 0)
+            n = Xv.shape[0]
+            if n == 0:
+                continue  # outputs stay NaN (vgpsa.py:296-297)
+            Z = self.Xtilde[v]
+            ls_u, var_u = self.warp_kernel_lengthscales[v], self.warp_kernel_variances[v]
+            Kuu = self._kmat("warp", Z, Z, ls_u, var_u, self.diagonal_offset, f64, True)
+            Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
+            fac = E.Factor(Kuu)
+            cache.warp[v] = (Kuu, fac)
+            cache.flags.append(fac.info)
+            dc = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
+            Om = cache.Omega_G[v * D : (v + 1) * D]  # quirk 2: forward uses rows v*D+j
+            meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac)
+            mux = Xv @ self.mean_slopes[v] + self.mean_intercepts[v]
+            if noise is not None and noise["G"] is not None:
+                eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
+            else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
+                eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
+                    torch.empty(0, n, D, device=dev)
+            draw += 1
+            Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, mux, eps)  # quirk 1 inside
+            cache.flags.append(bad)
+            a = 0
+            for m in mods:
+                r, cnt = rows[m]
+                G_means[m][r] = Gm[a : a + cnt]
+                G_samples[m][:, r, :] = Gs[:, a : a + cnt]
+                a += cnt
+
+        # ---- data GP (vgpsa.py:353-477) ----------------------------------------------------------
+        ls_u, var_u = self.data_kernel_lengthscale, self.data_kernel_variance
+        KuuF = self._kmat("data", self.Gtilde, self.Gtilde, ls_u, var_u, self.diagonal_offset, f64, True)
+        facF = E.Factor(KuuF)
+        cache.data = (KuuF, facF)
+        cache.flags.append(facF.info)
+
+        def data_layer(G, eps_key, m):
+            S_, N_ = G.shape[0], G.shape[1]
+            L = self.n_latent_outputs[m]
+            Gf = G.reshape(S_ * N_, D)
+            Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, torch.float32, False)
+            meanT, vq, q = E.SGPCoreFn.apply(KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF)
+            if noise is not None and noise[eps_key] is not None:
+                eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
+            else:
+                eps = torch.randn([S_, N_, L], device=dev).reshape(S_ * N_, L)
+            Fl = E.DataSampleFn.apply(meanT, vq, q, var_u, eps).reshape(S_, N_, L)
+            if self.n_latent_gps[m] is not None:
+                return Fl, E.MatmulFn.apply(Fl, self.W_dict[m])
+            return Fl, Fl  # same tensor object when there is no LMC (quirk 10)
+
+        self.F_latent_samples, self.F_observed_samples = {}, {}
+        if G_test is not None:
+            self.F_latent_samples_test, self.F_observed_samples_test = {}, {}
+        for m in mods:
+            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m])
+            self.F_latent_samples[m], self.F_observed_samples[m] = data_layer(G_samples[m], "F", m)
+            if G_test is not None:
+                Gt = G_test[m].to(device=dev, dtype=torch.float32)
+                lt, ot = data_layer(Gt, "F_test", m)
+                self.F_latent_samples_test[m], self.F_observed_samples_test[m] = lt, ot
+
+        self._cache = cache
+        if self.check_numerics:
+            self._raise_on_flags(cache)
+        if G_test is not None:
+            return (
+                G_means,
+                G_samples,
+                self.F_latent_samples,
+                self.F_observed_samples,
+                self.F_latent_samples_test,
+                self.F_observed_samples_test,
+            )
+        return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
+
+    @staticmethod
+    def _raise_on_flags(cache):
+        if not cache.flags:
+            return
+        flags = torch.cat([f.reshape(-1).to(torch.int32) for f in cache.flags])
+        if int(flags.abs().max().item()) != 0:  # the one host sync of forward
+            raise torch.linalg.LinAlgError(
+                "GPSA forward: an inducing-point covariance is not positive-definite or a warp "
+                "variance is not positive (the reference raises from torch.cholesky / "
+                "Normal(...) argument validation here)"
+            )
+
+    # ------------------------------------------------------------------------------------------
+    def loss_fn(self, data_dict, F_samples):
+        """Negative (approximate) ELBO (vgpsa.py:491-540).  Valid only after ``forward`` on the same
+        parameters: like the reference it reads the factorisations forward left behind."""
+        cache = self._cache
+        if cache is None:
+            raise AttributeError("loss_fn called before forward (no factorisations cached)")
+        V, D = self.n_views, self.n_spatial_dims
+        f64 = torch.float64
+        kl = None
+        for v in range(V):
+            if self._is_fixed(v) or v not in cache.warp:
+                continue
+            Kuu, fac = cache.warp[v]
+            Dm = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
+            Om = cache.Omega_G[v::V]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
+            term = E.MvnKLFn.apply(Kuu, Dm, Om, fac).sum()
+            kl = term if kl is None else kl + term
+        KuuF, facF = cache.data
+        ll = None
+        for i, m in enumerate(self.modality_names):
+            term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF).sum()
+            kl = term if kl is None else kl + term
+            noise_u = self.noise_variance[-self.n_modalities + i]  # quirk 5 (used as a std)
+            Y = data_dict[m]["outputs"]
+            t = E.LogLikFn.apply(F_samples[m], Y, noise_u)
+            ll = t if ll is None else ll + t
+        return (-ll + kl).to(self.Xtilde.dtype)

@@ -1,0 +1,301 @@
+"""Tensor-level wrappers over the C ABI (include/gpsa_hip.h).
+
+PyTorch is used here only as plumbing: it owns device memory (torch.empty), the HIP stream
+(torch.cuda.current_stream) and autograd bookkeeping.  Every numerical kernel below is a
+hand-written HIP kernel in csrc/, reached through ctypes with raw device pointers.
+"""
+import torch
+
+from . import _lib
+
+F32, F64 = 0, 1
+KINDS = {"rbf": 0, "matern12": 1, "matern32": 2}
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class HipOps:
+    """All ops run on the current HIP stream of the tensors' device; outputs are freshly allocated."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GpsaHipError("no HIP device visible: the GPSA hot path has no CPU fallback")
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    @staticmethod
+    def _ws(nbytes, like):
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+
+    @staticmethod
+    def _c(t):
+        return t if t.is_contiguous() else t.contiguous()
+
+    # ------------------------------------------------------------------ covariance matrices
+    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0):
+        Z, X = self._c(Z), self._c(X)
+        M, D = Z.shape
+        Cn = X.shape[0]
+        K = torch.empty(M, Cn, dtype=Z.dtype, device=Z.device)
+        rc = self.lib.gpsa_kmat(_dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
+                                float(jitter), _p(K), self._stream(Z))
+        _lib.check(rc, "gpsa_kmat")
+        return K
+
+    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True):
+        Z, X, Kbar = self._c(Z), self._c(X), self._c(Kbar)
+        M, D = Z.shape
+        Cn = X.shape[0]
+        dZ = torch.empty_like(Z)
+        dX = torch.empty_like(X) if need_dX else None
+        dpar = torch.empty(2, dtype=Z.dtype, device=Z.device)
+        wsb = self.lib.gpsa_kmat_bwd_workspace(_dt(Z), M, Cn, D)
+        ws = self._ws(wsb, Z)
+        rc = self.lib.gpsa_kmat_bwd(_dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
+                                    _p(Kbar), _p(dZ), _p(dX), _p(dpar), _p(ws), ws.numel(),
+                                    self._stream(Z))
+        _lib.check(rc, "gpsa_kmat_bwd")
+        return dZ, dX, dpar
+
+    # ------------------------------------------------------------------ dense products
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, splitk=1):
+        """out = alpha * op(A) @ op(B) + beta * out.  A, B: 2-D, or 3-D batched (a 2-D operand is
+        broadcast over the batch).  Last-dim stride must be 1."""
+        batched = A.dim() == 3 or B.dim() == 3
+        nb = (A.shape[0] if A.dim() == 3 else B.shape[0]) if batched else 1
+        A = A if A.stride(-1) == 1 else A.contiguous()
+        B = B if B.stride(-1) == 1 else B.contiguous()
+        ar, ac = A.shape[-2], A.shape[-1]
+        br, bc = B.shape[-2], B.shape[-1]
+        m, k = (ac, ar) if transA else (ar, ac)
+        k2, n = (bc, br) if transB else (br, bc)
+        assert k == k2, (A.shape, B.shape, transA, transB)
+        if out is None:
+            assert beta == 0.0
+            out = torch.empty((nb, m, n) if batched else (m, n), dtype=A.dtype, device=A.device)
+        sA = A.stride(0) if A.dim() == 3 else 0
+        sB = B.stride(0) if B.dim() == 3 else 0
+        sC = out.stride(0) if out.dim() == 3 else 0
+        wsb = self.lib.gpsa_gemm_workspace(_dt(A), m, n, nb, splitk)
+        ws = self._ws(wsb, A) if splitk > 1 else None
+        rc = self.lib.gpsa_gemm(_dt(A), int(transA), int(transB), m, n, k, float(alpha), _p(A),
+                                A.stride(-2), sA, _p(B), B.stride(-2), sB, float(beta), _p(out),
+                                out.stride(-2), sC, nb, splitk, _p(ws), wsb if ws is not None else 0,
+                                self._stream(A))
+        _lib.check(rc, "gpsa_gemm")
+        return out
+
+    @staticmethod
+    def pick_splitk(k, m, n):
+        """split the reduction dim so that a skinny product still fills the chip"""
+        tiles = ((m + 63) // 64) * ((n + 63) // 64)
+        s = max(1, min(64, 512 // max(tiles, 1), k // 1024))
+        return int(s)
+
+    # ------------------------------------------------------------------ factorisations (fp64)
+    def chol(self, A):
+        """A [B,M,M] fp64 (not modified) -> L, logdet [B], info [B] (int32)"""
+        L = A.contiguous().clone()
+        Bn, M = L.shape[0], L.shape[-1]
+        logdet = torch.empty(Bn, dtype=torch.float64, device=A.device)
+        info = torch.empty(Bn, dtype=torch.int32, device=A.device)
+        rc = self.lib.gpsa_chol_f64(_p(L), M, Bn, _p(logdet), _p(info), self._stream(A))
+        _lib.check(rc, "gpsa_chol_f64")
+        return L, logdet, info
+
+    def tri_inv(self, L):
+        L = self._c(L)
+        out = torch.empty_like(L)
+        rc = self.lib.gpsa_tri_inv_f64(_p(L), _p(out), L.shape[-1], L.shape[0], self._stream(L))
+        _lib.check(rc, "gpsa_tri_inv_f64")
+        return out
+
+    # ------------------------------------------------------------------ quadratic forms
+    def _qf_ws(self, alpha, L):
+        M, Cn = alpha.shape
+        return self._ws(self.lib.gpsa_quadform_workspace(_dt(alpha), M, Cn, L), alpha)
+
+    def quadform_fwd(self, alpha, Omega):
+        alpha, Omega = self._c(alpha), self._c(Omega)
+        M, Cn = alpha.shape
+        L = Omega.shape[0]
+        v = torch.empty(L, Cn, dtype=alpha.dtype, device=alpha.device)
+        ws = self._qf_ws(alpha, L)
+        rc = self.lib.gpsa_quadform_fwd(_dt(alpha), _p(alpha), _p(Omega), M, Cn, L, _p(v), _p(ws),
+                                        ws.numel(), self._stream(alpha))
+        _lib.check(rc, "gpsa_quadform_fwd")
+        return v
+
+    def quadform_bwd_alpha(self, alpha, Omega, g):
+        alpha, Omega, g = self._c(alpha), self._c(Omega), self._c(g)
+        M, Cn = alpha.shape
+        L = Omega.shape[0]
+        out = torch.empty_like(alpha)
+        ws = self._qf_ws(alpha, L)
+        rc = self.lib.gpsa_quadform_bwd_alpha(_dt(alpha), _p(alpha), _p(Omega), _p(g), M, Cn, L,
+                                              _p(out), _p(ws), ws.numel(), self._stream(alpha))
+        _lib.check(rc, "gpsa_quadform_bwd_alpha")
+        return out
+
+    def quadform_bwd_omega(self, alpha, g):
+        alpha, g = self._c(alpha), self._c(g)
+        M, Cn = alpha.shape
+        L = g.shape[0]
+        out = torch.empty(L, M, M, dtype=alpha.dtype, device=alpha.device)
+        ws = self._qf_ws(alpha, L)
+        rc = self.lib.gpsa_quadform_bwd_omega(_dt(alpha), _p(alpha), _p(g), M, Cn, L, _p(out), _p(ws),
+                                              ws.numel(), self._stream(alpha))
+        _lib.check(rc, "gpsa_quadform_bwd_omega")
+        return out
+
+    def panel_mm(self, P, X, want_colsq=False):
+        P, X = self._c(P), self._c(X)
+        M, Cn = X.shape
+        Y = torch.empty_like(X)
+        q = torch.empty(Cn, dtype=X.dtype, device=X.device) if want_colsq else None
+        ws = self._ws(4 * 256 * 256 + 256, X)
+        rc = self.lib.gpsa_panel_mm(_dt(X), _p(P), _p(X), M, Cn, _p(Y), _p(q), _p(ws), ws.numel(),
+                                    self._stream(X))
+        _lib.check(rc, "gpsa_panel_mm")
+        return Y, q
+
+    def col_axpy(self, Y, X, d, s=1.0, out=None):
+        Y, X, d = self._c(Y), self._c(X), self._c(d)
+        M, Cn = X.shape
+        out = torch.empty_like(Y) if out is None else out
+        rc = self.lib.gpsa_col_axpy(_dt(X), _p(Y), _p(X), _p(d), float(s), M, Cn, _p(out),
+                                    self._stream(X))
+        _lib.check(rc, "gpsa_col_axpy")
+        return out
+
+    # ------------------------------------------------------------------ sampling
+    def data_sample_fwd(self, meanT, v, q, var_u, eps):
+        meanT, v, q, eps = self._c(meanT), self._c(v), self._c(q), self._c(eps)
+        L, Cn = meanT.shape
+        F = torch.empty(Cn, L, dtype=torch.float32, device=meanT.device)
+        Sigma = torch.empty_like(meanT)
+        rc = self.lib.gpsa_data_sample_fwd(_p(meanT), _p(v), _p(q), _p(var_u), _p(eps), Cn, L, _p(F),
+                                           _p(Sigma), self._stream(meanT))
+        _lib.check(rc, "gpsa_data_sample_fwd")
+        return F, Sigma
+
+    def data_sample_bwd(self, dF, eps, Sigma, var_u):
+        dF, eps = self._c(dF), self._c(eps)
+        L, Cn = Sigma.shape
+        g = torch.empty_like(Sigma)
+        dmeanT = torch.empty_like(Sigma)
+        qbar = torch.empty(Cn, dtype=torch.float32, device=Sigma.device)
+        dvar = torch.empty(1, dtype=torch.float32, device=Sigma.device)
+        ws = self._ws(8 * (Cn // 32 + 2), Sigma)
+        rc = self.lib.gpsa_data_sample_bwd(_p(dF), _p(eps), _p(Sigma), _p(var_u), Cn, L, _p(g),
+                                           _p(dmeanT), _p(qbar), _p(dvar), _p(ws), ws.numel(),
+                                           self._stream(Sigma))
+        _lib.check(rc, "gpsa_data_sample_bwd")
+        return g, dmeanT, qbar, dvar
+
+    def warp_sample_fwd(self, meanT, v, q, var_u, mux, eps):
+        meanT, v, q, mux, eps = self._c(meanT), self._c(v), self._c(q), self._c(mux), self._c(eps)
+        D, n = meanT.shape
+        S = eps.shape[0]
+        Gmean = torch.empty(n, D, dtype=torch.float32, device=meanT.device)
+        Gs = torch.empty(S, n, D, dtype=torch.float32, device=meanT.device)
+        Sigma = torch.empty_like(meanT)
+        bad = torch.zeros(1, dtype=torch.int32, device=meanT.device)
+        rc = self.lib.gpsa_warp_sample_fwd(_p(meanT), _p(v), _p(q), _p(var_u), _p(mux), _p(eps), n, D,
+                                           S, _p(Gmean), _p(Gs), _p(Sigma), _p(bad),
+                                           self._stream(meanT))
+        _lib.check(rc, "gpsa_warp_sample_fwd")
+        return Gmean, Gs, Sigma, bad
+
+    def warp_sample_bwd(self, dGmean, dGs, eps, var_u):
+        dGs, eps = self._c(dGs), self._c(eps)
+        dGmean = None if dGmean is None else self._c(dGmean)
+        S, n, D = dGs.shape
+        dev = dGs.device
+        dmeanT = torch.empty(D, n, dtype=torch.float64, device=dev)
+        g = torch.empty(D, n, dtype=torch.float64, device=dev)
+        qbar = torch.empty(n, dtype=torch.float64, device=dev)
+        dvar = torch.empty(1, dtype=torch.float64, device=dev)
+        ws = self._ws(8 * (n // 256 + 2), dGs)
+        rc = self.lib.gpsa_warp_sample_bwd(_p(dGmean), _p(dGs), _p(eps), _p(var_u), n, D, S,
+                                           _p(dmeanT), _p(g), _p(qbar), _p(dvar), _p(ws), ws.numel(),
+                                           self._stream(dGs))
+        _lib.check(rc, "gpsa_warp_sample_bwd")
+        return dmeanT, g, qbar, dvar
+
+    # ------------------------------------------------------------------ likelihood
+    def loglik_fwd(self, F, Y, noise_u):
+        F, Y = self._c(F), self._c(Y)
+        S, N, P = F.shape
+        out = torch.empty(1, dtype=torch.float64, device=F.device)
+        ws = self._ws(8 * 4100, F)
+        rc = self.lib.gpsa_loglik_fwd(_p(F), _p(Y), _p(noise_u), S, N, P, _p(out), _p(ws), ws.numel(),
+                                      self._stream(F))
+        _lib.check(rc, "gpsa_loglik_fwd")
+        return out
+
+    def loglik_bwd(self, F, Y, noise_u, gout):
+        F, Y = self._c(F), self._c(Y)
+        S, N, P = F.shape
+        dF = torch.empty_like(F)
+        dn = torch.empty(1, dtype=torch.float32, device=F.device)
+        ws = self._ws(8 * 4100, F)
+        rc = self.lib.gpsa_loglik_bwd(_p(F), _p(Y), _p(noise_u), _p(gout), S, N, P, _p(dF), _p(dn),
+                                      _p(ws), ws.numel(), self._stream(F))
+        _lib.check(rc, "gpsa_loglik_bwd")
+        return dF, dn
+
+    # ------------------------------------------------------------------ small helpers
+    def bdot(self, A, B):
+        """A, B: [batch, ...] or un-batched (broadcast): out[b] = <A[b], B[b]>"""
+        nb = A.shape[0] if A.dim() == 3 else B.shape[0]
+        A2 = self._c(A)
+        B2 = self._c(B)
+        n = A2.shape[-1] * A2.shape[-2]
+        sA = n if A2.dim() == 3 else 0
+        sB = n if B2.dim() == 3 else 0
+        out = torch.empty(nb, dtype=A2.dtype, device=A2.device)
+        rc = self.lib.gpsa_bdot(_dt(A2), _p(A2), sA, _p(B2), sB, n, nb, _p(out), self._stream(A2))
+        _lib.check(rc, "gpsa_bdot")
+        return out
+
+    def add_diag(self, A, s):
+        assert A.is_contiguous()
+        M = A.shape[-1]
+        nb = A.numel() // (M * M)
+        rc = self.lib.gpsa_add_diag(_dt(A), _p(A), M, nb, float(s), self._stream(A))
+        _lib.check(rc, "gpsa_add_diag")
+        return A
+
+
+_ops = None
+
+
+def get_ops():
+    """The process-wide ops backend (HIP).  Fails loudly without the extension or a device."""
+    global _ops
+    if _ops is None:
+        _ops = HipOps()
+    return _ops
+
+
+def set_ops(obj):
+    """Test hook: tests/ may install a fake backend to exercise the host logic without a GPU."""
+    global _ops
+    _ops = obj

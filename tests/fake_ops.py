@@ -1,0 +1,133 @@
+"""TEST-ONLY fake backend: the ``ops`` interface of spatial_alignment_amd/ops.py restated with plain
+torch tensor ops, so that the host logic (model classes, autograd node wiring, the hand-derived
+backward formulas of engine.py) can be exercised on a machine without a GPU.
+
+Never imported by the package.  Each method documents the contract the matching HIP kernel meets;
+the ``-m gpu`` tests check the real kernels against the same contracts.
+"""
+import math
+
+import torch
+
+JIT2 = 2e-5
+
+
+def _cov(kind, Z, X, ls_u, var_u):
+    ell, var = torch.exp(ls_u[0]), torch.exp(var_u[0])
+    d = Z.unsqueeze(1) - X.unsqueeze(0)
+    if kind == "rbf":
+        u = d / ell
+        return var * torch.exp(-0.5 * (u * u).sum(-1))
+    dist = torch.sqrt((d * d).sum(-1) + 1e-10)
+    if kind == "matern12":
+        return var * torch.exp(-0.5 * dist / ell)
+    z = math.sqrt(3.0) * dist / ell
+    return var * (1 + z) * torch.exp(-z)
+
+
+class FakeOps:
+    name = "fake-cpu"
+
+    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0):
+        K = _cov(kind, Z, X, ls_u, var_u)
+        if jitter:
+            n = min(K.shape)
+            K = K.clone()
+            K[range(n), range(n)] += jitter
+        return K
+
+    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True):
+        with torch.enable_grad():
+            Zr, Xr = Z.clone().requires_grad_(True), X.clone().requires_grad_(True)
+            lr, vr = ls_u.clone().requires_grad_(True), var_u.clone().requires_grad_(True)
+            K = _cov(kind, Zr, Xr, lr, vr)
+            gz, gx, gl, gv = torch.autograd.grad(K, [Zr, Xr, lr, vr], Kbar)
+        return gz, (gx if need_dX else None), torch.cat([gl.reshape(1), gv.reshape(1)])
+
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, splitk=1):
+        a = A.transpose(-1, -2) if transA else A
+        b = B.transpose(-1, -2) if transB else B
+        r = alpha * (a @ b)
+        if out is None:
+            return r
+        out.copy_(r + beta * out if beta != 0.0 else r)
+        return out
+
+    @staticmethod
+    def pick_splitk(k, m, n):
+        return 1
+
+    def chol(self, A):
+        L, info = torch.linalg.cholesky_ex(A)
+        logdet = 2.0 * torch.log(torch.diagonal(L, dim1=-2, dim2=-1)).sum(-1)
+        return L, logdet, info.to(torch.int32)
+
+    def tri_inv(self, L):
+        eye = torch.eye(L.shape[-1], dtype=L.dtype).expand_as(L)
+        return torch.linalg.solve_triangular(L, eye, upper=False)
+
+    def quadform_fwd(self, alpha, Omega):
+        return torch.einsum("mc,lmk,kc->lc", alpha, Omega, alpha)
+
+    def quadform_bwd_alpha(self, alpha, Omega, g):
+        return 2.0 * torch.einsum("lc,lmk,kc->mc", g, Omega, alpha)
+
+    def quadform_bwd_omega(self, alpha, g):
+        return torch.einsum("lc,mc,kc->lmk", g, alpha, alpha)
+
+    def panel_mm(self, P, X, want_colsq=False):
+        Y = P @ X
+        return Y, ((Y * Y).sum(0) if want_colsq else None)
+
+    def col_axpy(self, Y, X, d, s=1.0, out=None):
+        r = Y + s * d.unsqueeze(0) * X
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    def data_sample_fwd(self, meanT, v, q, var_u, eps):
+        Sigma = torch.exp(var_u[0]) - q.unsqueeze(0) + v + JIT2
+        F = meanT.t() + torch.sqrt(Sigma).t() * eps
+        return F.contiguous(), Sigma
+
+    def data_sample_bwd(self, dF, eps, Sigma, var_u):
+        g = (dF * eps).t() * 0.5 / torch.sqrt(Sigma)
+        return g, dF.t().contiguous(), -g.sum(0), (torch.exp(var_u[0]) * g.sum()).reshape(1)
+
+    def warp_sample_fwd(self, meanT, v, q, var_u, mux, eps):
+        Sigma = torch.exp(var_u[0]) - q.unsqueeze(0) + v + JIT2  # [D,n]
+        mu = mux + meanT.t()
+        Gs = mu.unsqueeze(0) + Sigma.t().unsqueeze(0) * eps.double()
+        bad = (~(Sigma > 0)).any().to(torch.int32).reshape(1)
+        return mu.float(), Gs.float(), Sigma, bad
+
+    def warp_sample_bwd(self, dGmean, dGs, eps, var_u):
+        d = dGs.double()
+        dm = d.sum(0)
+        if dGmean is not None:
+            dm = dm + dGmean.double()
+        g = (d * eps.double()).sum(0)  # [n,D]
+        return dm.t().contiguous(), g.t().contiguous(), -g.sum(1), (torch.exp(var_u[0]) * g.sum()).reshape(1)
+
+    def loglik_fwd(self, F, Y, noise_u):
+        s = torch.exp(noise_u[0].double()) + 1e-5
+        z = (Y.double().unsqueeze(0) - F.double()) / s
+        ll = (-0.5 * z * z - torch.log(s) - 0.5 * math.log(2 * math.pi)).sum() / F.shape[0]
+        return ll.reshape(1)
+
+    def loglik_bwd(self, F, Y, noise_u, gout):
+        S = F.shape[0]
+        e = torch.exp(noise_u[0].double())
+        s = e + 1e-5
+        r = Y.double().unsqueeze(0) - F.double()
+        dF = gout[0] * r / (s * s) / S
+        ds = ((r * r) / s**3 - 1.0 / s).sum() / S
+        return dF.float(), (gout[0] * ds * e).float().reshape(1)
+
+    def bdot(self, A, B):
+        return (A * B).sum((-1, -2)).reshape(-1)
+
+    def add_diag(self, A, s):
+        A.diagonal(dim1=-2, dim2=-1).add_(s)
+        return A
