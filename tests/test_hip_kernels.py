@@ -1,0 +1,194 @@
+"""GPU: every C-ABI kernel against its contract (tests/fake_ops.py evaluated on the CPU in fp64)."""
+import os
+
+import pytest
+import torch
+
+from fake_ops import FakeOps
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+FK = FakeOps()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from spatial_alignment_amd.ops import HipOps
+
+    return HipOps()
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def close(got, want, tol):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = (got - want).norm() / max(want.norm().item(), 1e-30)
+    assert err <= tol, f"rel err {err:.3e} > {tol}"
+
+
+TOL = {torch.float32: 2e-5, torch.float64: 1e-11}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32"])
+@pytest.mark.parametrize("M,C,D", [(7, 300, 2), (25, 1000, 1), (200, 777, 3), (33, 33, 2)])
+def test_kmat_fwd_bwd(hip, dtype, kind, M, C, D):
+    Z, X = rnd(M, D, dtype=dtype, scale=3), rnd(C, D, dtype=dtype, seed=1, scale=3)
+    ls, var = torch.tensor([0.4], dtype=dtype), torch.tensor([-0.3], dtype=dtype)
+    Kb = rnd(M, C, dtype=dtype, seed=2)
+    K = hip.kmat(kind, Z.to(DEV), X.to(DEV), ls.to(DEV), var.to(DEV), 1e-5)
+    close(K, FK.kmat(kind, Z.double(), X.double(), ls.double(), var.double(), 1e-5), TOL[dtype])
+    dZ, dX, dp = hip.kmat_bwd(kind, Z.to(DEV), X.to(DEV), ls.to(DEV), var.to(DEV), Kb.to(DEV))
+    rZ, rX, rp = FK.kmat_bwd(kind, Z.double(), X.double(), ls.double(), var.double(), Kb.double())
+    t = TOL[dtype] * 20
+    close(dZ, rZ, t)
+    close(dX, rX, t)
+    close(dp, rp, t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm(hip, dtype, ta, tb):
+    m, n, k = 70, 45, 133
+    A = rnd(*((k, m) if ta else (m, k)), dtype=dtype)
+    B = rnd(*((n, k) if tb else (k, n)), dtype=dtype, seed=3)
+    want = FK.gemm(A.double(), B.double(), bool(ta), bool(tb), alpha=0.7)
+    close(hip.gemm(A.to(DEV), B.to(DEV), bool(ta), bool(tb), alpha=0.7), want, TOL[dtype])
+    C0 = rnd(m, n, dtype=dtype, seed=4)
+    out = C0.clone().to(DEV)
+    hip.gemm(A.to(DEV), B.to(DEV), bool(ta), bool(tb), alpha=0.7, beta=0.5, out=out)
+    close(out, want + 0.5 * C0.double(), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_gemm_batched_broadcast_splitk(hip, dtype):
+    A, B = rnd(5, 40, 40, dtype=dtype), rnd(40, 3000, dtype=dtype, seed=1)
+    close(hip.gemm(A.to(DEV), B.to(DEV)), A.double() @ B.double(), TOL[dtype])
+    X, Yt = rnd(30, 5000, dtype=dtype), rnd(17, 5000, dtype=dtype, seed=2)
+    got = hip.gemm(X.to(DEV), Yt.to(DEV), transB=True, splitk=7)
+    close(got, X.double() @ Yt.double().t(), TOL[dtype] * 3)
+    A3 = rnd(4, 33, 33, dtype=dtype)
+    close(hip.gemm(A3.to(DEV), A3.to(DEV), transB=True), A3.double() @ A3.double().transpose(1, 2), TOL[dtype])
+
+
+@pytest.mark.parametrize("M,B", [(1, 2), (5, 3), (50, 4), (200, 6), (233, 2)])
+def test_chol_and_tri_inv(hip, M, B):
+    A = rnd(B, M, M, dtype=torch.float64)
+    K = A @ A.transpose(1, 2) + 0.1 * torch.eye(M, dtype=torch.float64)
+    L, logdet, info = hip.chol(K.to(DEV))
+    rL, rld, _ = FK.chol(K)
+    assert int(info.abs().max()) == 0
+    close(L, rL, 1e-10)
+    close(logdet, rld, 1e-12)
+    close(hip.tri_inv(L), FK.tri_inv(rL), 1e-9)
+
+
+def test_chol_flags_indefinite(hip):
+    K = torch.eye(20, dtype=torch.float64).repeat(2, 1, 1)
+    K[1, 7, 7] = -1.0
+    _, _, info = hip.chol(K.to(DEV))
+    assert info.cpu().tolist() == [0, 8]
+
+
+QF = [(10, 100, 3), (25, 1000, 5), (50, 333, 2), (100, 500, 4), (200, 2100, 7), (256, 300, 2), (16, 64, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("M,C,L", QF)
+def test_quadform(hip, dtype, M, C, L):
+    al = rnd(M, C, dtype=dtype)
+    A = rnd(L, M, M, dtype=torch.float64, seed=1, scale=0.3)
+    Om = (A @ A.transpose(1, 2)).to(dtype)
+    g = rnd(L, C, dtype=dtype, seed=2)
+    t = 3e-5 if dtype == torch.float32 else 1e-11
+    close(hip.quadform_fwd(al.to(DEV), Om.to(DEV)), FK.quadform_fwd(al.double(), Om.double()), t)
+    close(hip.quadform_bwd_alpha(al.to(DEV), Om.to(DEV), g.to(DEV)),
+          FK.quadform_bwd_alpha(al.double(), Om.double(), g.double()), t)
+    close(hip.quadform_bwd_omega(al.to(DEV), g.to(DEV)), FK.quadform_bwd_omega(al.double(), g.double()), t)
+
+
+def test_quadform_mfma_matches_generic_large(hip):
+    """MFMA path vs the generic tiled path (same inputs, both on the GPU) at a headline-like shape."""
+    M, C, L = 200, 20000, 6
+    al, g = rnd(M, C).to(DEV), rnd(L, C, seed=2).to(DEV)
+    A = rnd(L, M, M, seed=1, scale=0.1).to(DEV)
+    Om = A @ A.transpose(1, 2)
+    Om64, al64 = Om.double(), al.double()
+    want = torch.einsum("mc,lmk,kc->lc", al64, Om64, al64)
+    close(hip.quadform_fwd(al, Om), want, 3e-5)
+    want_a = 2 * torch.einsum("lc,lmk,kc->mc", g.double(), Om64, al64)
+    close(hip.quadform_bwd_alpha(al, Om, g), want_a, 3e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("M,C", [(12, 50), (200, 1500), (64, 257)])
+def test_panel_mm_col_axpy(hip, dtype, M, C):
+    P, X = rnd(M, M, dtype=dtype), rnd(M, C, dtype=dtype, seed=1)
+    Y, q = hip.panel_mm(P.to(DEV), X.to(DEV), want_colsq=True)
+    rY, rq = FK.panel_mm(P.double(), X.double(), True)
+    close(Y, rY, TOL[dtype] * 2)
+    close(q, rq, TOL[dtype] * 2)
+    d = rnd(C, dtype=dtype, seed=5)
+    close(hip.col_axpy(Y, X.to(DEV), d.to(DEV), 0.5), FK.col_axpy(rY, X.double(), d.double(), 0.5), TOL[dtype] * 2)
+
+
+@pytest.mark.parametrize("C,L", [(100, 5), (4097, 50), (33, 33)])
+def test_data_sample(hip, C, L):
+    meanT, v = rnd(L, C), rnd(L, C, seed=1).abs()
+    q, eps = rnd(C, seed=2).abs() * 0.1, rnd(C, L, seed=3)
+    var_u = torch.tensor([0.5])
+    F, Sig = hip.data_sample_fwd(meanT.to(DEV), v.to(DEV), q.to(DEV), var_u.to(DEV), eps.to(DEV))
+    rF, rS = FK.data_sample_fwd(meanT.double(), v.double(), q.double(), var_u.double(), eps.double())
+    close(F, rF, 1e-6)
+    close(Sig, rS, 1e-6)
+    dF = rnd(C, L, seed=4)
+    got = hip.data_sample_bwd(dF.to(DEV), eps.to(DEV), Sig, var_u.to(DEV))
+    want = FK.data_sample_bwd(dF.double(), eps.double(), rS, var_u.double())
+    for a, b in zip(got, want):
+        close(a, b, 2e-6)
+
+
+@pytest.mark.parametrize("n,D,S", [(100, 2, 3), (5000, 1, 1), (777, 3, 5)])
+def test_warp_sample(hip, n, D, S):
+    f64 = torch.float64
+    meanT, v = rnd(D, n, dtype=f64), rnd(D, n, dtype=f64, seed=1).abs()
+    q, mux = rnd(n, dtype=f64, seed=2).abs() * 0.1, rnd(n, D, dtype=f64, seed=3)
+    eps, var_u = rnd(S, n, D, seed=4), torch.tensor([0.2], dtype=f64)
+    Gm, Gs, Sig, bad = hip.warp_sample_fwd(meanT.to(DEV), v.to(DEV), q.to(DEV), var_u.to(DEV), mux.to(DEV), eps.to(DEV))
+    rGm, rGs, rSig, rbad = FK.warp_sample_fwd(meanT, v, q, var_u, mux, eps)
+    close(Gm, rGm, 1e-6)
+    close(Gs, rGs, 1e-6)
+    close(Sig, rSig, 1e-12)
+    assert int(bad) == 0
+    dGm, dGs = rnd(n, D, seed=5), rnd(S, n, D, seed=6)
+    got = hip.warp_sample_bwd(dGm.to(DEV), dGs.to(DEV), eps.to(DEV), var_u.to(DEV))
+    want = FK.warp_sample_bwd(dGm, dGs, eps, var_u)
+    for a, b in zip(got, want):
+        close(a, b, 1e-11)
+    _, _, _, bad = hip.warp_sample_fwd(meanT.to(DEV), (v - 100).to(DEV), q.to(DEV), var_u.to(DEV), mux.to(DEV), eps.to(DEV))
+    assert int(bad) == 1
+
+
+@pytest.mark.parametrize("S,N,P", [(1, 100, 3), (5, 2000, 50), (2, 33, 7)])
+def test_loglik(hip, S, N, P):
+    F, Y, nu = rnd(S, N, P), rnd(N, P, seed=1), torch.tensor([-0.8])
+    close(hip.loglik_fwd(F.to(DEV), Y.to(DEV), nu.to(DEV)), FK.loglik_fwd(F, Y, nu), 1e-6)
+    go = torch.tensor([-1.3], dtype=torch.float64)
+    dF, dn = hip.loglik_bwd(F.to(DEV), Y.to(DEV), nu.to(DEV), go.to(DEV))
+    rdF, rdn = FK.loglik_bwd(F, Y, nu, go)
+    close(dF, rdF, 1e-6)
+    close(dn, rdn, 1e-5)
+
+
+def test_bdot_add_diag(hip):
+    A, B = rnd(40, 40, dtype=torch.float64), rnd(6, 40, 40, dtype=torch.float64, seed=1)
+    close(hip.bdot(A.to(DEV), B.to(DEV)), FK.bdot(A, B), 1e-12)
+    X = B.clone().to(DEV)
+    hip.add_diag(X, 0.25)
+    close(X, FK.add_diag(B.clone(), 0.25), 1e-15)
