@@ -1,0 +1,223 @@
+"""Headline benchmark: GPSA training steps/sec on the 2-view x 10k-spot, M=200, 50-output grid.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward(S) + loss_fn + backward + Adam update (the reference loop,
+examples/grid_example.py:62-78) on synthetic inputs already resident in HBM.  N > 1: the rows of
+every view are sharded over the ranks (strong scaling: total problem fixed), one RCCL all-reduce of the
+flattened gradient per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md:42 (fp32-input MFMA = fp32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--S", type=int, default=5, help="MC samples per step (reference training value)")
+    ap.add_argument("--side", type=int, default=100, help="grid side per view (100 -> 10k spots)")
+    ap.add_argument("--views", type=int, default=2)
+    ap.add_argument("--outputs", type=int, default=50)
+    ap.add_argument("--M", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="disable the per-forward numerics sync")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of the contraction kernels on the stream they are launched on."""
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.on = ops, {}, False
+        for name in ("quadform_fwd", "quadform_bwd_alpha", "quadform_bwd_omega"):
+            self._wrap(name)
+
+    def _wrap(self, name):
+        inner = getattr(self.ops, name)
+
+        def timed(*a, **k):
+            if not self.on or a[0].dtype != torch.float32:
+                return inner(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = inner(*a, **k)
+            e1.record()
+            M, C = a[0].shape
+            L = a[1].shape[0] if name != "quadform_bwd_omega" else a[1].shape[0]
+            self.rec.setdefault(name, []).append((e0, e1, 2.0 * M * M * C * L))
+            return r
+
+        setattr(self.ops, name, timed)
+
+    def summary(self):
+        out = {}
+        for name, evs in self.rec.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            fl = [f for _, _, f in evs]
+            out[name] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), flops=fl[0],
+                             tflops=sum(fl) / (sum(ms) * 1e-3) / 1e12)
+        return out
+
+
+def cpu_baseline(args, state, dd_cpu):
+    """The oracle (op-for-op PyTorch-CPU restatement of the reference) timed on this host."""
+    import psutil
+
+    from oracle import gpsa_oracle as orc
+
+    torch.autograd.set_detect_anomaly(False)  # the shipped reference turns it ON (1.3-1.4x slower)
+    m = "expression"
+    N, L = dd_cpu[m]["spatial_coords"].shape[0], args.outputs
+    avail = psutil.virtual_memory().available / 2**30
+    need = 6.0 * args.S * L * N * args.M * 4 / 2**30  # ~22 GB at the headline config
+    S_run = args.S if avail > need * 1.3 else 1
+    cfg = dict(modality_names=[m], n_views=args.views, n_spatial_dims=2, kernel_warp="rbf",
+               kernel_data="rbf", n_latent_gps={m: None}, fixed_view_idx=None)
+    gen = torch.Generator().manual_seed(1)
+    n_v = N // args.views
+    eps_G = [torch.randn(S_run, n_v, 2, generator=gen) for _ in range(args.views)]
+    eps_F = {m: torch.randn(S_run, N, L, generator=gen)}
+    ns = {m: dd_cpu[m]["n_samples_list"]}
+    X, Y = {m: dd_cpu[m]["spatial_coords"]}, {m: dd_cpu[m]["outputs"]}
+    t0 = time.time()
+    r = orc.evaluate(state, cfg, X, Y, ns, S_run, eps_G, eps_F, dtype=torch.float32)
+    dt = time.time() - t0
+    assert torch.isfinite(r["loss"])
+    scale = args.S / S_run
+    return dict(
+        value=1.0 / (dt * scale), unit="steps/s", cores=torch.get_num_threads(), kind="port",
+        sample=f"1 oracle step (forward+ELBO+backward, no optimizer) at the full config with S={S_run}"
+               + (f", time scaled x{scale:.0f} to S={args.S}" if scale != 1 else "")
+               + f"; {dt:.1f} s wall, anomaly mode off, host RAM avail {avail:.0f} GB",
+    )
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from spatial_alignment_amd import ops as ops_mod
+    from spatial_alignment_amd.parallel import GradAllReducer, shard_data_dict
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+    dd_full = make_grid_problem(side=args.side, n_views=args.views, n_outputs=args.outputs, device="cpu")
+    model = make_model(dd_full, m=args.M, device=dev)  # identical parameters on every rank (seeded)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    dd = shard_data_dict(dd_full, rank, world)
+    dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
+              "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
+    model.kl_scale = 1.0 / world
+    if args.no_check:
+        model.check_numerics = False
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {m: d["spatial_coords"] for m, d in dd.items()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    reducer = GradAllReducer(model.parameters())
+    torch.manual_seed(1000 + rank)
+    timer = KernelTimer(ops_mod.get_ops())
+
+    def step():
+        out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=args.S)
+        loss = model.loss_fn(dd, out[3])
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        reducer()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ks = timer.summary()
+        dom = ks.get("quadform_fwd")
+        N = int(sum(dd_full["expression"]["n_samples_list"]))
+        roof = None
+        if dom:
+            roof = dict(bound="mfma", kernel="panel_mfma_kernel<MODE_QUAD> (gpsa_quadform_fwd)",
+                        achieved=dom["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=dom["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                        avg_launch_ms=dom["avg_ms"], flops_per_launch=dom["flops"],
+                        other_kernels={k: dict(avg_ms=v["avg_ms"], tflops=v["tflops"]) for k, v in ks.items()
+                                       if k != "quadform_fwd"})
+        line = {
+            "metric": "training steps/sec (ELBO fwd+bwd), 2-view N=10k M=200, 1/2/4/8 GPU",
+            "value": args.steps / dt,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 (fp64 warp layer, covariance whitening and M x M factorisations)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic 2D grid, {args.views} views x {args.side * args.side} spots, "
+                            f"{args.outputs} outputs, M_G=M_X={args.M}, RBF warp+data, S={args.S}, "
+                            "forward+ELBO+backward+Adam",
+                "n_spots_total": N,
+                "parallelism": f"rows-of-views sharded x{world}, 1 all-reduce/step" if world > 1 else "single GPU",
+                "check_numerics_sync": not args.no_check,
+                "final_loss": final_loss,
+            },
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, state, dd_full)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,9 +91,9 @@ int gpsa_col_axpy(int dtype, const void* Y, const void* X, const void* d, double
                   long long C, void* out, void* stream);
 
 /* ---- reparameterised sampling -----------------------------------------------------------------
- * data GP (vgpsa.py:197-204, 423-426):  var = exp(var_u) - q[c] + v[l,c] + 2e-5 ;
+ * data GP (vgpsa.py:197-204, 423-426):  var = (exp(var_u) - q[c])_fp64 + v[l,c] + 2e-5 ;
  *   F[c,l] = meanT[l,c] + sqrt(var) * eps[c,l] ;  Sigma[l,c] = var (kept for backward). */
-int gpsa_data_sample_fwd(const float* meanT, const float* v, const float* q, const float* var_u,
+int gpsa_data_sample_fwd(const float* meanT, const float* v, const double* q, const float* var_u,
                          const float* eps, long long C, int L, float* F, float* Sigma, void* stream);
 /* given dF [C,L]:  g[l,c] = dF*eps/(2 sqrt(Sigma)),  dmeanT[l,c] = dF[c,l],  qbar[c] = -sum_l g,
  *   dvar_u (device scalar, overwritten) = exp(var_u) * sum g.   workspace >= 8*(C/32+2) bytes */

@@ -28,23 +28,24 @@ __global__ void sum_scale_kernel(const double* __restrict__ part, long long n,
 // ---- data GP ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 data_sample_fwd_kernel(const float* __restrict__ meanT, const float* __restrict__ v,
-                       const float* __restrict__ q, const float* __restrict__ var_u,
+                       const double* __restrict__ q, const float* __restrict__ var_u,
                        const float* __restrict__ eps, long long C, int L, float* __restrict__ F,
                        float* __restrict__ Sigma) {
   __shared__ float tm[32][33], tv[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long long c0 = (long long)blockIdx.x * 32;
   const int l0 = blockIdx.y * 32;
-  const float var0 = expf(var_u[0]);
+  const double var0 = exp((double)var_u[0]);
   {
     const long long c = c0 + tx;
-    const float qc = (c < C) ? q[c] : 0.f;
+    // sigma^2 - q formed in fp64 before rounding: it cancels to ~1e-3 sigma^2 for dense inducing sets
+    const float resid = (c < C) ? (float)(var0 - q[c]) : 0.f;
 #pragma unroll
     for (int ly = 0; ly < 32; ly += 8) {
       const int l = l0 + ty + ly;
       if (c < C && l < L) {
         const long long o = (long long)l * C + c;
-        const float var = var0 - qc + v[o] + (float)TWO_JITTER;
+        const float var = resid + v[o] + (float)TWO_JITTER;
         Sigma[o] = var;
         tv[ty + ly][tx] = var;
         tm[ty + ly][tx] = meanT[o];
@@ -254,7 +255,7 @@ static inline int loglik_blocks(long long tot) {
 
 extern "C" {
 
-int gpsa_data_sample_fwd(const float* meanT, const float* v, const float* q, const float* var_u,
+int gpsa_data_sample_fwd(const float* meanT, const float* v, const double* q, const float* var_u,
                          const float* eps, long long C, int L, float* F, float* Sigma, void* stream) {
   if (C < 1 || L < 1) return GPSA_EINVAL;
   dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(L, 32));

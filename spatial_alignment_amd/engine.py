@@ -57,13 +57,15 @@ class KmatFn(torch.autograd.Function):
     Replaces the built-in plugins gpsa/util/util.py:8-66."""
 
     @staticmethod
-    def forward(ctx, kind, Z, X, ls_u, var_u, jitter, dtype, same):
+    def forward(ctx, kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None):
         o = ops()
         Zc, Xc = Z.detach().to(dtype), X.detach().to(dtype)
         ls = ls_u.detach().to(dtype).reshape(1)
         var = var_u.detach().to(dtype).reshape(1)
         K = o.kmat(kind, Zc, Xc, ls, var, jitter)
         ctx.kind, ctx.same = kind, bool(same)
+        if bwd_dtype is not None and bwd_dtype != dtype:  # gradient-only precision for the backward
+            Zc, Xc, ls, var = (t.to(bwd_dtype) for t in (Zc, Xc, ls, var))
         ctx.save_for_backward(Zc, Xc, ls, var)
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, var_u.dtype, ls_u.shape, var_u.shape)
         return K
@@ -74,7 +76,7 @@ class KmatFn(torch.autograd.Function):
         Zc, Xc, ls, var = ctx.saved_tensors
         zdt, xdt, ldt, vdt, lshape, vshape = ctx.meta
         need_x = ctx.needs_input_grad[2] or ctx.same
-        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.contiguous(), need_dX=need_x)
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.to(Zc.dtype).contiguous(), need_dX=need_x)
         if ctx.same:
             dZ = dZ + dX
             dX = None
@@ -82,7 +84,7 @@ class KmatFn(torch.autograd.Function):
         gX = dX.to(xdt) if (dX is not None and ctx.needs_input_grad[2]) else None
         gl = dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None
         gv = dpar[1].to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None
-        return None, gZ, gX, gl, gv, None, None, None
+        return None, gZ, gX, gl, gv, None, None, None, None
 
 
 class OmegaFn(torch.autograd.Function):
@@ -106,36 +108,43 @@ class OmegaFn(torch.autograd.Function):
 
 
 class SGPCoreFn(torch.autograd.Function):
-    """(K_uf, dc, Omega; factor of K_uu) -> meanT [L,C], v [L,C], q [C]   (vgpsa.py:174-204)."""
+    """(K_uf, dc, Omega; factor of K_uu) -> meanT [L,C], v [L,C], q [C]   (vgpsa.py:174-204).
+
+    The whitening (beta = L^-1 K_uf, q = |beta|^2, alpha = L^-T beta) runs in K_uf's precision (fp64:
+    sigma^2 - q cancels to ~1e-3 sigma^2 when the inducing points are dense, and cond(L) ~ 1e3);
+    mean and the dominant quadratic form run in ``main_dtype`` (fp32 MFMA for the data layer) on the
+    rounded alpha.  q keeps K_uf's precision so that the sampler can form sigma^2 - q before rounding.
+    """
 
     @staticmethod
-    def forward(ctx, Kuu, Kuf, dc, Omega, fac):
+    def forward(ctx, Kuu, Kuf, dc, Omega, fac, main_dtype):
         o = ops()
-        T = Kuf.dtype
-        Li, LiT = fac.linv(T)
-        Kuf = Kuf.detach()
+        Tw, T = Kuf.dtype, main_dtype
+        Liw, LiTw = fac.linv(Tw)
+        beta, q = o.panel_mm(Liw, Kuf.detach(), want_colsq=True)
+        alpha_w, _ = o.panel_mm(LiTw, beta)
+        alpha = alpha_w.to(T)
         dcT = dc.detach().to(T).contiguous()
         Om = Omega.detach().to(T).contiguous()
-        beta, q = o.panel_mm(Li, Kuf, want_colsq=True)
-        alpha, _ = o.panel_mm(LiT, beta)
         meanT = o.gemm(dcT, alpha, transA=True)
         v = o.quadform_fwd(alpha, Om)
+        Li, LiT = fac.linv(T)
         ctx.save_for_backward(alpha, dcT, Om, Li, LiT)
-        ctx.meta = (Kuu.dtype, dc.dtype, Omega.dtype)
+        ctx.meta = (Kuu.dtype, Kuf.dtype, dc.dtype, Omega.dtype)
         return meanT, v, q
 
     @staticmethod
     def backward(ctx, dmeanT, g, qbar):
         o = ops()
         alpha, dcT, Om, Li, LiT = ctx.saved_tensors
-        kdt, ddt, odt = ctx.meta
+        kdt, fdt, ddt, odt = ctx.meta
         M, Cn = alpha.shape
         L = Om.shape[0]
         T = alpha.dtype
         zeros = lambda *s: torch.zeros(*s, dtype=T, device=alpha.device)
-        dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.contiguous()
-        g = zeros(L, Cn) if g is None else g.contiguous()
-        qbar = zeros(Cn) if qbar is None else qbar.contiguous()
+        dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.to(T).contiguous()
+        g = zeros(L, Cn) if g is None else g.to(T).contiguous()
+        qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
         abar = o.quadform_bwd_alpha(alpha, Om, g)
         o.gemm(dcT, dmeanT, beta=1.0, out=abar)
         ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
@@ -147,9 +156,10 @@ class SGPCoreFn(torch.autograd.Function):
         dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
         return (
             dKuu.to(kdt),
-            dKuf,
+            dKuf.to(fdt),
             ddc.to(ddt),
             dOm.to(odt) if dOm is not None else None,
+            None,
             None,
         )
 
@@ -187,9 +197,9 @@ class DataSampleFn(torch.autograd.Function):
     def forward(ctx, meanT, v, q, var_u, eps):
         o = ops()
         var32 = var_u.detach().float().reshape(1)
-        F, Sigma = o.data_sample_fwd(meanT.detach(), v.detach(), q.detach(), var32, eps)
+        F, Sigma = o.data_sample_fwd(meanT.detach(), v.detach(), q.detach().double(), var32, eps)
         ctx.save_for_backward(eps, Sigma, var32)
-        ctx.vmeta = (var_u.dtype, var_u.shape)
+        ctx.vmeta = (var_u.dtype, var_u.shape, q.dtype)
         return F
 
     @staticmethod
@@ -197,8 +207,8 @@ class DataSampleFn(torch.autograd.Function):
         o = ops()
         eps, Sigma, var32 = ctx.saved_tensors
         g, dmeanT, qbar, dvar = o.data_sample_bwd(dF.contiguous(), eps, Sigma, var32)
-        vdt, vshape = ctx.vmeta
-        return dmeanT, g, qbar, dvar.to(vdt).reshape(vshape), None
+        vdt, vshape, qdt = ctx.vmeta
+        return dmeanT, g, qbar.to(qdt), dvar.to(vdt).reshape(vshape), None
 
 
 class MatmulFn(torch.autograd.Function):

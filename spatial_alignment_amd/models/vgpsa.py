@@ -85,6 +85,7 @@ class VariationalGPSA(GPSA):
         }
         self.fixed_view_idx = fixed_view_idx
         self.check_numerics = True  # one host sync per forward; raises like the reference would
+        self.kl_scale = 1.0  # data-parallel ranks add 1/world of the KL each (parallel.py)
         self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
         self._cache = None
 
@@ -170,11 +171,11 @@ class VariationalGPSA(GPSA):
         """Omega = A A^T + 1e-5 I (vgpsa.py:206-210); fp64 result."""
         return E.OmegaFn.apply(Omega_sqt)
 
-    def _kmat(self, which, Z, X, ls_u, var_u, jitter, dtype, same):
+    def _kmat(self, which, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None):
         fn = self.kernel_func_warp if which == "warp" else self.kernel_func_data
         kind = builtin_kind(fn)
         if kind is not None:
-            return E.KmatFn.apply(kind, Z, X, ls_u, var_u, jitter, dtype, same)
+            return E.KmatFn.apply(kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype)
         # arbitrary plugin callable: evaluate it as the reference does (vgpsa.py:275-281, 382-388)
         K = fn(
             Z.to(dtype),
@@ -238,7 +239,7 @@ class VariationalGPSA(GPSA):
             cache.flags.append(fac.info)
             dc = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
             Om = cache.Omega_G[v * D : (v + 1) * D]  # quirk 2: forward uses rows v*D+j
-            meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac)
+            meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
             mux = Xv @ self.mean_slopes[v] + self.mean_intercepts[v]
             if noise is not None and noise["G"] is not None:
                 eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
@@ -266,8 +267,11 @@ class VariationalGPSA(GPSA):
             S_, N_ = G.shape[0], G.shape[1]
             L = self.n_latent_outputs[m]
             Gf = G.reshape(S_ * N_, D)
-            Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, torch.float32, False)
-            meanT, vq, q = E.SGPCoreFn.apply(KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF)
+            # covariance + whitening in fp64 (gradient-only fp32 backward); mean / variance form in fp32
+            Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, f64, False, torch.float32)
+            meanT, vq, q = E.SGPCoreFn.apply(
+                KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF, torch.float32
+            )
             if noise is not None and noise[eps_key] is not None:
                 eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
             else:
@@ -341,4 +345,6 @@ class VariationalGPSA(GPSA):
             Y = data_dict[m]["outputs"]
             t = E.LogLikFn.apply(F_samples[m], Y, noise_u)
             ll = t if ll is None else ll + t
+        if self.kl_scale != 1.0:
+            kl = kl * self.kl_scale
         return (-ll + kl).to(self.Xtilde.dtype)

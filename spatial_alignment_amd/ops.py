@@ -186,7 +186,7 @@ class HipOps:
 
     # ------------------------------------------------------------------ sampling
     def data_sample_fwd(self, meanT, v, q, var_u, eps):
-        meanT, v, q, eps = self._c(meanT), self._c(v), self._c(q), self._c(eps)
+        meanT, v, q, eps = self._c(meanT), self._c(v), self._c(q.double()), self._c(eps)
         L, Cn = meanT.shape
         F = torch.empty(Cn, L, dtype=torch.float32, device=meanT.device)
         Sigma = torch.empty_like(meanT)

@@ -87,7 +87,8 @@ class FakeOps:
         return out
 
     def data_sample_fwd(self, meanT, v, q, var_u, eps):
-        Sigma = torch.exp(var_u[0]) - q.unsqueeze(0) + v + JIT2
+        resid = (torch.exp(var_u[0].double()) - q.double()).to(v.dtype)
+        Sigma = resid.unsqueeze(0) + v + JIT2
         F = meanT.t() + torch.sqrt(Sigma).t() * eps
         return F.contiguous(), Sigma
 

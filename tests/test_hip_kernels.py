@@ -141,7 +141,7 @@ def test_panel_mm_col_axpy(hip, dtype, M, C):
 @pytest.mark.parametrize("C,L", [(100, 5), (4097, 50), (33, 33)])
 def test_data_sample(hip, C, L):
     meanT, v = rnd(L, C), rnd(L, C, seed=1).abs()
-    q, eps = rnd(C, seed=2).abs() * 0.1, rnd(C, L, seed=3)
+    q, eps = rnd(C, seed=2, dtype=torch.float64).abs() * 0.1, rnd(C, L, seed=3)
     var_u = torch.tensor([0.5])
     F, Sig = hip.data_sample_fwd(meanT.to(DEV), v.to(DEV), q.to(DEV), var_u.to(DEV), eps.to(DEV))
     rF, rS = FK.data_sample_fwd(meanT.double(), v.double(), q.double(), var_u.double(), eps.double())
