@@ -73,21 +73,27 @@ kmat_fwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long lo
   }
 }
 
-constexpr int KB_MCHUNK = 128;  // inducing rows per LDS pass of the backward kernel
+constexpr int KB_MCHUNK = 32;  // inducing rows per workgroup of the backward kernel
 
-// One thread per column c; loops over all M inducing rows.  Per block writes a partial row
-// part[blk][0 .. M*D) = dZ partial, part[blk][M*D] = d ls_u, part[blk][M*D+1] = d var_u.
+// grid (column blocks of 256, row chunks of KB_MCHUNK): one thread per column c, looping over the
+// chunk's inducing rows.  Deterministic partials:
+//   zpart[bx][m*D+d]      dZ contribution of column block bx (rows of chunk by only)
+//   xpart[by][c*D+d]      dX contribution of row chunk by
+//   spart[bx*ny+by][0..1] d ls_u, d var_u
 template <typename T, int KIND>
 __global__ void __launch_bounds__(256)
 kmat_bwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long long C, int D,
                 const T* __restrict__ ls_u, const T* __restrict__ var_u,
-                const T* __restrict__ Kbar, T* __restrict__ dX, T* __restrict__ part) {
+                const T* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
+                T* __restrict__ spart) {
   __shared__ T Zs[KB_MCHUNK][MAXD];
   __shared__ T acc[4][KB_MCHUNK][MAXD];
   __shared__ T red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   const bool live = c < C;
+  const int m0 = blockIdx.y * KB_MCHUNK;
+  const int mc = min(KB_MCHUNK, M - m0);
   const T ell = t_exp<T>(ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>(var_u[0]);
   T x[MAXD], dx[MAXD];
 #pragma unroll
@@ -95,45 +101,43 @@ kmat_bwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long lo
     x[d] = (live && d < D) ? X[c * D + d] : T(0);
     dx[d] = T(0);
   }
-  T s_ls = T(0), s_var = T(0);
-  const long long stride = (long long)M * D + 2;
-  T* prow = part + (long long)blockIdx.x * stride;
-  for (int m0 = 0; m0 < M; m0 += KB_MCHUNK) {
-    const int mc = min(KB_MCHUNK, M - m0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < KB_MCHUNK * MAXD; i += 256) {
-      int r = i / MAXD, d = i % MAXD;
-      Zs[r][d] = (r < mc && d < D) ? Z[(long long)(m0 + r) * D + d] : T(0);
-    }
-    __syncthreads();
-    for (int r = 0; r < mc; ++r) {
-      T k, cd, pl;
-      cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
-      T kb = live ? Kbar[(long long)(m0 + r) * C + c] : T(0);
-      s_ls += kb * pl;
-      s_var += kb * k;
-      T wgt = kb * cd;
-#pragma unroll
-      for (int d = 0; d < MAXD; ++d)
-        if (d < D) {
-          T t = wgt * (Zs[r][d] - x[d]);  // dLoss/dz_d contribution ; dLoss/dx_d = -t
-          dx[d] -= t;
-          T tz = wave_sum(t);
-          if (lane == 0) acc[w][r][d] = tz;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < mc * D; i += 256) {
-      int r = i / D, d = i % D;
-      prow[(long long)(m0 + r) * D + d] = acc[0][r][d] + acc[1][r][d] + acc[2][r][d] + acc[3][r][d];
-    }
+  if (threadIdx.x < KB_MCHUNK * MAXD) {
+    const int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
+    Zs[r][d] = (r < mc && d < D) ? Z[(long long)(m0 + r) * D + d] : T(0);
   }
-  if (dX != nullptr && live)
-    for (int d = 0; d < D; ++d) dX[c * D + d] = dx[d];
+  __syncthreads();
+  T s_ls = T(0), s_var = T(0);
+  for (int r = 0; r < mc; ++r) {
+    T k, cd, pl;
+    cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
+    T kb = live ? Kbar[(long long)(m0 + r) * C + c] : T(0);
+    s_ls += kb * pl;
+    s_var += kb * k;
+    T wgt = kb * cd;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < D) {
+        T t = wgt * (Zs[r][d] - x[d]);  // dLoss/dz_d contribution ; dLoss/dx_d = -t
+        dx[d] -= t;
+        T tz = wave_sum(t);
+        if (lane == 0) acc[w][r][d] = tz;
+      }
+  }
+  __syncthreads();
+  T* zrow = zpart + (long long)blockIdx.x * M * D;
+  for (int i = threadIdx.x; i < mc * D; i += 256) {
+    const int r = i / D, d = i % D;
+    zrow[(long long)(m0 + r) * D + d] = acc[0][r][d] + acc[1][r][d] + acc[2][r][d] + acc[3][r][d];
+  }
+  if (xpart != nullptr && live) {
+    T* xr = xpart + (long long)blockIdx.y * C * D;
+    for (int d = 0; d < D; ++d) xr[c * D + d] = dx[d];
+  }
+  T* sp = spart + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
   T a = block_sum(s_ls, red);
-  if (threadIdx.x == 0) prow[(long long)M * D] = a;
-  T b = block_sum(s_var, red);
-  if (threadIdx.x == 0) prow[(long long)M * D + 1] = b;
+  if (threadIdx.x == 0) sp[0] = a;
+  T b2 = block_sum(s_var, red);
+  if (threadIdx.x == 0) sp[1] = b2;
 }
 
 template <typename T>
@@ -161,26 +165,32 @@ template <typename T>
 int kmat_bwd_launch(int kind, const T* Z, int M, const T* X, long long C, int D, const T* ls_u,
                     const T* var_u, const T* Kbar, T* dZ, T* dX, T* dparams, void* ws,
                     long long ws_bytes, hipStream_t st) {
-  const long long nblk = cdiv(C, 256), stride = (long long)M * D + 2;
-  if (ws_bytes < nblk * stride * (long long)sizeof(T)) return GPSA_EWORKSPACE;
-  T* part = reinterpret_cast<T*>(ws);
+  const long long nbx = cdiv(C, 256), nby = cdiv(M, KB_MCHUNK);
+  const long long nz = (long long)M * D, nx = C * D;
+  const long long need = (nbx * nz + nby * nx + nbx * nby * 2) * (long long)sizeof(T);
+  if (ws_bytes < need) return GPSA_EWORKSPACE;
+  T* zpart = reinterpret_cast<T*>(ws);
+  T* xpart = zpart + nbx * nz;
+  T* spart = xpart + nby * nx;
+  dim3 grid((unsigned)nbx, (unsigned)nby);
+  T* xp = dX ? xpart : nullptr;
   switch (kind) {
     case GPSA_K_RBF:
-      kmat_bwd_kernel<T, GPSA_K_RBF><<<(unsigned)nblk, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, dX, part);
+      kmat_bwd_kernel<T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
       break;
     case GPSA_K_MATERN12:
-      kmat_bwd_kernel<T, GPSA_K_MATERN12><<<(unsigned)nblk, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, dX, part);
+      kmat_bwd_kernel<T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
       break;
     case GPSA_K_MATERN32:
-      kmat_bwd_kernel<T, GPSA_K_MATERN32><<<(unsigned)nblk, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, dX, part);
+      kmat_bwd_kernel<T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
       break;
     default:
       return GPSA_EINVAL;
   }
   GPSA_LAUNCH_CHECK();
-  const long long nz = (long long)M * D;
-  reduce_rows_kernel<T, T><<<(unsigned)cdiv(nz, 256), 256, 0, st>>>(part, nblk, stride, nz, dZ, 1.0);
-  reduce_rows_kernel<T, T><<<1, 64, 0, st>>>(part + nz, nblk, stride, 2, dparams, 1.0);
+  reduce_rows_kernel<T, T><<<(unsigned)cdiv(nz, 256), 256, 0, st>>>(zpart, nbx, nz, nz, dZ, 1.0);
+  if (dX) reduce_rows_kernel<T, T><<<(unsigned)cdiv(nx, 256), 256, 0, st>>>(xpart, nby, nx, nx, dX, 1.0);
+  reduce_rows_kernel<T, T><<<1, 64, 0, st>>>(spart, nbx * nby, 2, 2, dparams, 1.0);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -204,7 +214,8 @@ int gpsa_kmat(int dtype, int kind, const void* Z, int M, const void* X, long lon
 }
 
 long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D) {
-  return cdiv(C, 256) * ((long long)M * D + 2) * (dtype == GPSA_F64 ? 8 : 4);
+  const long long nbx = cdiv(C, 256), nby = cdiv(M, gpsa::KB_MCHUNK);
+  return (nbx * M * D + nby * C * D + nbx * nby * 2) * (dtype == GPSA_F64 ? 8 : 4);
 }
 
 int gpsa_kmat_bwd(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,

@@ -100,17 +100,21 @@ int generic_quadform_bwd_alpha(const T* alpha, const T* Omega, const T* g, int M
   return 0;
 }
 
-static inline int gram_splitk(long long C) {
-  long long s = C / 2048;
+static inline int gram_splitk(long long C, int M) {
+  // enough K-splits that a single M x M product still fills the chip (tiles of 64 x 64)
+  const long long tiles = cdiv(M, 64) * cdiv(M, 64);
+  long long s = cdiv(512, tiles);
+  const long long cap = C / 256 > 1 ? C / 256 : 1;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
   return (int)s;
 }
 
 template <typename T>
 int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, int L, T* dOmega,
                                void* ws, long long ws_bytes, hipStream_t st) {
-  const int sk = gram_splitk(C);
+  const int sk = gram_splitk(C, M);
   const long long tmp_b = (long long)M * C * (long long)sizeof(T);
   const long long part_b = (sk > 1) ? (long long)sk * M * M * (long long)sizeof(T) : 0;
   if (ws_bytes < tmp_b + part_b) return GPSA_EWORKSPACE;
@@ -145,10 +149,12 @@ __global__ void colsq_kernel(const T* __restrict__ Y, int M, long long C, T* __r
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
-constexpr int PK_LDS_STRIDE = 20;  // dwords per LDS row of a 16-deep K chunk (16 + 4 pad)
 
-// src [L][M][M] (row-major) -> dst [L][MB][MP][16] fp32, zero padded; chunk kc holds columns
-// 16kc..16kc+15 of every row, so that one K chunk is one contiguous block.
+// src [L][M][M] (row-major) -> dst fp32, zero padded, in MFMA-fragment order:
+//   dst[l][kc][rt][kq][j][r] = P_l[16 rt + j][16 kc + 4 kq + r]
+// so that K chunk kc of matrix l is one contiguous MP*64-byte block made of MB 1-KiB pieces, and
+// piece rt, copied lane-linearly into LDS (global_load_lds, lane = j + 16 kq), is read back as the
+// A fragment of row tile rt by one conflict-free ds_read_b128 at lane*16 bytes.
 template <typename TS>
 __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, int L, int transpose,
                                    float* __restrict__ dst) {
@@ -157,18 +163,44 @@ __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, in
   const long long idx = blockIdx.x * 256LL + threadIdx.x;
   if (idx >= per * L) return;
   const int l = (int)(idx / per);
-  const long long e = idx % per;
-  const int kc = (int)(e / (MP * 16));
-  const int rem = (int)(e % (MP * 16));
-  const int i = rem / 16, kk = rem % 16, k = kc * 16 + kk;
+  const int e = (int)(idx % per);
+  const int kc = e / (MP * 16);
+  const int rem = e % (MP * 16);
+  const int rt = rem / 256, lane = (rem % 256) / 4, r = rem % 4;
+  const int i = rt * 16 + (lane & 15), k = kc * 16 + (lane >> 4) * 4 + r;
   float v = 0.f;
   if (i < M && k < M) {
-    const TS* s = src + (long long)l * M * M;
-    v = (float)(transpose ? s[(long long)k * M + i] : s[(long long)i * M + k]);
+    const TS* sp = src + (long long)l * M * M;
+    v = (float)(transpose ? sp[(long long)k * M + i] : sp[(long long)i * M + k]);
   }
   dst[idx] = v;
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// 16-byte-per-lane LDS-DMA: lane i copies 16 B from its own global address to LDS byte address
+// lds_base + 16 i (lds_base wave-uniform).  Issued from inline asm on purpose: hipcc then neither
+// counts it in its vmcnt bookkeeping nor orders later ds_reads of the OTHER buffer behind it (with the
+// builtin it drains vmcnt(0) before every fragment read, serialising the prefetch).  The issuing
+// code waits with GPSA_DMA_DRAIN() before the barrier that publishes the buffer.
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+#define GPSA_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(lds_ptr_t)(p);
+}
+
+// Persistent, balanced schedule: the work is the list of items (column tile, l) in column-tile-major
+// order; workgroup b of G processes the contiguous item range [b*T/G, (b+1)*T/G).  The wave's slab of
+// X is (re)loaded only when the column tile changes (at most ~T/G/L + 2 times).  In ACCUM mode a column
+// tile whose l-range is split between two workgroups is combined with float atomics into a
+// pre-zeroed output (at most two contributors per element => order-independent result).
 template <int MB, int NCT, int MODE>
 __global__ void __launch_bounds__(256, (MB * NCT >= 24) ? 1 : 2)
 panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
@@ -179,136 +211,321 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
                   float* __restrict__ colsq,      // STORE: optional [C]
                   float out_scale) {
   constexpr int MP = MB * 16;
-  constexpr int CHUNK_F4 = MP * 4;                  // float4 per K chunk
-  constexpr int NST = (CHUNK_F4 + 255) / 256;       // staging float4 per thread
-  __shared__ __attribute__((aligned(16))) float lds[2][MP * PK_LDS_STRIDE];
+  constexpr int WGCOLS = 64 * NCT;
+  constexpr int CHUNK = MP * 16;                    // floats per K chunk (MB pieces of 256 floats)
+  __shared__ __attribute__((aligned(16))) float lds[2][CHUNK];
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const long long cw = (long long)blockIdx.x * (64 * NCT) + (long long)w * (16 * NCT);  // wave's first column
 
-  // ---- B operand: this wave's slab of X, resident in registers -------------------------------
+  const long long ntiles = (C + WGCOLS - 1) / WGCOLS;
+  const long long T = ntiles * L;
+  const long long it0 = (long long)blockIdx.x * T / gridDim.x;
+  const long long it1 = (long long)(blockIdx.x + 1) * T / gridDim.x;
+  if (it0 >= it1) return;
+
   float xb[NCT][MB][4];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const long long c = cw + ct * 16 + j;
-#pragma unroll
-    for (int t = 0; t < MB; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = t * 16 + kq * 4 + r;
-        xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
-      }
-  }
-
   f32x4 acc[MB][NCT];
-#pragma unroll
-  for (int rt = 0; rt < MB; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float4 stage[NST];
-#define GPSA_STAGE_LOAD(Q)                                                                  \
+  // K chunk Q of the packed left operand -> LDS buffer BUF by LDS-DMA (no VGPR staging, no ds_write):
+  // wave w moves pieces w, w+4, ... (1 KiB each, lane-linear)
+#define GPSA_STAGE(Q, BUF)                                                                     \
+  {                                                                                            \
+    const float* src__ = Ppk + (long long)(Q) * CHUNK + lane * 4;                              \
+    _Pragma("unroll") for (int pc = 0; pc < (MB + 3) / 4; ++pc) {                              \
+      const int piece = pc * 4 + w;                                                            \
+      if (piece < MB)                                                                          \
+        glds16(src__ + piece * 256,                                                            \
+               __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));              \
+    }                                                                                          \
+  }
+  // flush the accumulators of column tile TILE (ACCUM / STORE); PLAIN: this workgroup covered all l
+  // of the tile, otherwise its partial sum is combined atomically
+#define GPSA_FLUSH(TILE, PLAIN)                                                             \
   {                                                                                         \
-    const float4* src__ = reinterpret_cast<const float4*>(Ppk) + (long long)(Q) * CHUNK_F4; \
-    _Pragma("unroll") for (int u = 0; u < NST; ++u) {                                       \
-      const int f = tid + u * 256;                                                          \
-      stage[u] = src__[f < CHUNK_F4 ? f : CHUNK_F4 - 1];                                    \
+    const long long cw__ = (TILE) * WGCOLS + (long long)w * (16 * NCT);                     \
+    _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                    \
+      const long long c = cw__ + ct * 16 + j;                                               \
+      float s = 0.f;                                                                        \
+      _Pragma("unroll") for (int rt = 0; rt < MB; ++rt)                                     \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                     \
+          const int row = rt * 16 + kq * 4 + r;                                             \
+          const float y = acc[rt][ct][r] * out_scale;                                       \
+          s += y * y;                                                                       \
+          if (c < C && row < M) {                                                           \
+            if (PLAIN) out[(long long)row * C + c] = y;                                     \
+            else atomicAdd(&out[(long long)row * C + c], y);                                \
+          }                                                                                 \
+        }                                                                                   \
+      if (MODE == MODE_STORE && colsq != nullptr) {                                         \
+        s += __shfl_xor(s, 16, 64);                                                         \
+        s += __shfl_xor(s, 32, 64);                                                         \
+        if (kq == 0 && c < C) colsq[c] = s;                                                 \
+      }                                                                                     \
     }                                                                                       \
   }
-#define GPSA_STAGE_WRITE(BUF)                                                               \
-  {                                                                                         \
-    _Pragma("unroll") for (int u = 0; u < NST; ++u) {                                       \
-      const int f = tid + u * 256;                                                          \
-      if (f < CHUNK_F4)                                                                     \
-        *reinterpret_cast<float4*>(&lds[BUF][(f >> 2) * PK_LDS_STRIDE + (f & 3) * 4]) =     \
-            stage[u];                                                                       \
-    }                                                                                       \
-  }
 
-  const long long NQ = (long long)L * MB;
-  GPSA_STAGE_LOAD(0)
-  GPSA_STAGE_WRITE(0)
+  const long long tile0 = it0 / L, tile1 = (it1 - 1) / L;
+  int buf = 0;
+  GPSA_STAGE((long long)(it0 % L) * MB, 0)
+  GPSA_DMA_DRAIN();
   __syncthreads();
 
-  for (int l = 0; l < L; ++l) {
-    float gv[NCT];
-    if (MODE == MODE_ACCUM) {
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const long long c = cw + ct * 16 + j;
-        gv[ct] = (c < C) ? g[(long long)l * C + c] : 0.f;
-      }
-    }
-    if (MODE == MODE_QUAD) {
-#pragma unroll
-      for (int rt = 0; rt < MB; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int kc = 0; kc < MB; ++kc) {
-      const long long q = (long long)l * MB + kc;
-      const int buf = (int)(q & 1);
-      GPSA_STAGE_LOAD((q + 1 < NQ) ? q + 1 : q)  // last prefetch is a harmless re-read
-      // B values of this chunk (scaled by g in ACCUM mode)
-      float bv[NCT][4];
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          bv[ct][r] = (MODE == MODE_ACCUM) ? xb[ct][kc][r] * gv[ct] : xb[ct][kc][r];
-      const float* base = &lds[buf][(kq * 4)];
-#pragma unroll
-      for (int rt = 0; rt < MB; ++rt) {
-        const float4 a4 = *reinterpret_cast<const float4*>(base + (rt * 16 + j) * PK_LDS_STRIDE);
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
-      }
-      GPSA_STAGE_WRITE(buf ^ 1)
-      __syncthreads();
-    }
-    if (MODE == MODE_QUAD) {
-      // v[l,c] = sum over the rows this lane holds of acc * alpha, then across the 4 lane quarters
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        float s = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < MB; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s += acc[rt][ct][r] * xb[ct][rt][r];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const long long c = cw + ct * 16 + j;
-        if (kq == 0 && c < C) out[(long long)l * C + c] = s;
-      }
-    }
-  }
-  if (MODE != MODE_QUAD) {
+  for (long long tile = tile0; tile <= tile1; ++tile) {
+    const int l_lo = (tile == tile0) ? (int)(it0 - tile0 * L) : 0;
+    const int l_hi = (tile == tile1) ? (int)(it1 - 1 - tile1 * L) : L - 1;  // inclusive
+    const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const long long c = cw + ct * 16 + j;
-      float s = 0.f;
 #pragma unroll
-      for (int rt = 0; rt < MB; ++rt)
+      for (int t = 0; t < MB; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + kq * 4 + r;
-          const float y = acc[rt][ct][r] * out_scale;
-          s += y * y;
-          if (c < C && row < M) out[(long long)row * C + c] = y;
+          const int row = t * 16 + kq * 4 + r;
+          xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
-      if (MODE == MODE_STORE && colsq != nullptr) {
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (kq == 0 && c < C) colsq[c] = s;
+    }
+#pragma unroll
+    for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int l = l_lo; l <= l_hi; ++l) {
+      float gv[NCT];
+      if (MODE == MODE_ACCUM) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const long long c = cw + ct * 16 + j;
+          gv[ct] = (c < C) ? g[(long long)l * C + c] : 0.f;
+        }
+      }
+      // chunk stream successor of (l, last chunk): next l of this tile, else the next tile's first l
+      const bool last_item = (tile == tile1) && (l == l_hi);
+      const int lnext = (l < l_hi) ? l + 1 : 0;
+#pragma unroll
+      for (int kc = 0; kc < MB; ++kc) {
+        long long nq;
+        if (kc + 1 < MB) nq = (long long)l * MB + kc + 1;
+        else nq = last_item ? (long long)l * MB + kc : (long long)lnext * MB;  // last: harmless re-read
+        GPSA_STAGE(nq, buf ^ 1)
+        float bv[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            bv[ct][r] = (MODE == MODE_ACCUM) ? xb[ct][kc][r] * gv[ct] : xb[ct][kc][r];
+        const float* base = &lds[buf][lane * 4];
+        // A fragments are read one row tile ahead of the MFMAs that consume them (LDS latency
+        // hides under the previous tile's 4*NCT MFMAs instead of stalling the matrix pipe)
+        float4 a_nxt = *reinterpret_cast<const float4*>(base);
+#pragma unroll
+        for (int rt = 0; rt < MB; ++rt) {
+          const float4 a4 = a_nxt;
+          if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
+          __builtin_amdgcn_sched_barrier(0);
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        GPSA_DMA_DRAIN();
+        __syncthreads();
+        buf ^= 1;
+      }
+      if (MODE == MODE_QUAD) {
+        // v[l,c] = sum over the rows this lane holds of acc * alpha, then across the 4 lane quarters
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          float s = 0.f;
+#pragma unroll
+          for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s += acc[rt][ct][r] * xb[ct][rt][r];
+              acc[rt][ct][r] = 0.f;
+            }
+          s += __shfl_xor(s, 16, 64);
+          s += __shfl_xor(s, 32, 64);
+          const long long c = cw + ct * 16 + j;
+          if (kq == 0 && c < C) out[(long long)l * C + c] = s;
+        }
       }
     }
+    if (MODE != MODE_QUAD) {
+      const bool plain = (l_lo == 0) && (l_hi == L - 1);
+      GPSA_FLUSH(tile, plain)
+    }
   }
+#undef GPSA_STAGE
+#undef GPSA_FLUSH
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA Gram kernel:  dOmega_l = sum_c g[l,c] alpha_c alpha_c^T   (lower-triangle 16x16 tiles)
+// grid (L, nsplit): workgroup (l, s) sweeps its share of the columns in 32-column chunks staged in
+// LDS; the NT = MB(MB+1)/2 lower tiles are dealt round-robin to the 4 waves (slot s <-> tile 4s+w).
+// Both MFMA operands of a tile are rows of the same LDS image (A: rows of tile-row, scaled by g;
+// B: rows of tile-column); the K index (columns c) is permuted as in the panel kernel so that one
+// ds_read_b128 feeds four MFMAs.  Partials [L][nsplit][MP][MP] are summed + mirrored by a second
+// kernel (deterministic).
+// ------------------------------------------------------------------------------------------------
+constexpr int GR_KC = 32;  // columns per staged chunk (two 16-deep MFMA k-blocks)
+
+template <int MB, bool ALIGNED>
+__global__ void __launch_bounds__(256, (MB >= 13) ? 1 : 2)
+gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C,
+                 int nsplit, float* __restrict__ part) {
+  constexpr int MP = MB * 16, NT = MB * (MB + 1) / 2, NSLOT = (NT + 3) / 4;
+  constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;  // 1-KiB pieces (16 rows x 16 cols) per chunk
+  // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
+  // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
+  // conflict-free ds_read_b128 at lane*16 bytes.
+  __shared__ __attribute__((aligned(16))) float sA[2][NPIECE * 256];
+  __shared__ __attribute__((aligned(16))) float sG[2][GR_KC];
+  __shared__ int sOff[NSLOT * 4][2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int l = blockIdx.x, sp = blockIdx.y;
+  const long long nch = (C + GR_KC - 1) / GR_KC;
+  const long long ch0 = (long long)sp * nch / nsplit, ch1 = (long long)(sp + 1) * nch / nsplit;
+
+  for (int t = tid; t < NSLOT * 4; t += 256) {  // tile t -> (rt, ct), rt >= ct; dummy tiles -> (0,0)
+    int rt = 0, ct = 0;
+    if (t < NT) {
+      while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
+      ct = t - rt * (rt + 1) / 2;
+    }
+    sOff[t][0] = rt;
+    sOff[t][1] = ct;
+  }
+  __syncthreads();
+  int oa[NSLOT], ob[NSLOT];  // LDS float offsets of this wave's tiles' row / column pieces
+  f32x4 acc[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    oa[s] = sOff[s * 4 + w][0] * (NKB * 256);
+    ob[s] = sOff[s * 4 + w][1] * (NKB * 256);
+    acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // staging: rows >= M are clamped to row M-1 and columns >= C to the last aligned group; the clamped
+  // rows only feed output rows/cols >= M (never read back) and the clamped columns meet g == 0.
+  float gstage = 0.f;
+  auto col_of = [&](long long cb, int kb) -> long long {
+    long long col = cb + kb * 16 + kq * 4;
+    if (ALIGNED) return col < C - 4 ? col : C - 4;
+    return col;
+  };
+#define GPSA_GR_G(CH)                                                                        \
+  {                                                                                          \
+    const long long cb__ = (long long)(CH) * GR_KC;                                          \
+    if (tid < GR_KC) gstage = (cb__ + tid < C) ? g[(long long)l * C + cb__ + tid] : 0.f;     \
+  }
+#define GPSA_GR_STAGE(CH, BUF)                                                               \
+  {                                                                                          \
+    const long long cb__ = (long long)(CH) * GR_KC;                                          \
+    if (ALIGNED) {                                                                           \
+      _Pragma("unroll") for (int pc = 0; pc < (NPIECE + 3) / 4; ++pc) {                      \
+        const int piece = pc * 4 + w;                                                        \
+        if (piece < NPIECE) {                                                                \
+          const int rb = piece / NKB, kb = piece % NKB;                                      \
+          int row = rb * 16 + j;                                                             \
+          row = row < M ? row : M - 1;                                                       \
+          glds16(alpha + (long long)row * C + col_of(cb__, kb),                              \
+                 __builtin_amdgcn_readfirstlane(lds_addr(&sA[BUF][piece * 256])));           \
+        }                                                                                    \
+      }                                                                                      \
+    } else {                                                                                 \
+      for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
+        const int piece = e >> 8, ln = (e >> 2) & 63, r = e & 3;                             \
+        const int rb = piece / NKB, kb = piece % NKB;                                        \
+        const int row = rb * 16 + (ln & 15);                                                 \
+        const long long col = cb__ + kb * 16 + (ln >> 4) * 4 + r;                            \
+        sA[BUF][e] = (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;           \
+      }                                                                                      \
+    }                                                                                        \
+  }
+
+  if (ch0 < ch1) {
+    GPSA_GR_G(ch0)
+    GPSA_GR_STAGE(ch0, 0)
+    if (tid < GR_KC) sG[0][tid] = gstage;
+  }
+  GPSA_DMA_DRAIN();
+  __syncthreads();
+  int buf = 0;
+  for (long long ch = ch0; ch < ch1; ++ch) {
+    const long long nxt = (ch + 1 < ch1) ? ch + 1 : ch;  // last prefetch: harmless re-read
+    GPSA_GR_G(nxt)
+    GPSA_GR_STAGE(nxt, buf ^ 1)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
+      const float* base = &sA[buf][kb * 256 + lane * 4];
+      // operand fragments are fetched two tiles ahead of their MFMAs (4 MFMAs = 128 cycles per
+      // tile would not cover the LDS latency)
+      float4 fa[NSLOT + 2], fb[NSLOT + 2];
+#pragma unroll
+      for (int s = 0; s < 2 && s < NSLOT; ++s) {
+        fa[s] = *reinterpret_cast<const float4*>(base + oa[s]);
+        fb[s] = *reinterpret_cast<const float4*>(base + ob[s]);
+      }
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        if (s + 2 < NSLOT) {
+          fa[s + 2] = *reinterpret_cast<const float4*>(base + oa[s + 2]);
+          fb[s + 2] = *reinterpret_cast<const float4*>(base + ob[s + 2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float4 a4 = fa[s];
+        const float4 b4 = fb[s];
+        a4.x *= g4.x; a4.y *= g4.y; a4.z *= g4.z; a4.w *= g4.w;
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (tid < GR_KC) sG[buf ^ 1][tid] = gstage;
+    GPSA_DMA_DRAIN();
+    __syncthreads();
+    buf ^= 1;
+  }
+#undef GPSA_GR_G
+#undef GPSA_GR_STAGE
+  float* P = part + ((long long)l * nsplit + sp) * MP * MP;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int t = s * 4 + w;
+    if (t < NT) {
+      const int rt = sOff[t][0], ct = sOff[t][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        P[(long long)(rt * 16 + kq * 4 + r) * MP + ct * 16 + j] = acc[s][r];
+    }
+  }
+}
+
+// out[l][i][j] = sum_s part[l][s][max(i,j)][min(i,j)]
+__global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit,
+                                   float* __restrict__ out) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)L * M * M) return;
+  const int l = (int)(idx / ((long long)M * M));
+  const int rem = (int)(idx % ((long long)M * M));
+  const int i = rem / M, jj = rem % M;
+  const int hi = i > jj ? i : jj, lo = i > jj ? jj : i;
+  const float* p = part + (long long)l * nsplit * MP * MP + (long long)hi * MP + lo;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * MP * MP];
+  out[idx] = s;
 }
 
 static inline int mfma_mb_for(int M) {
@@ -330,13 +547,33 @@ static inline bool force_generic() {
   return v == 1;
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 template <int MODE>
 int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* g, int M,
                       long long C, int L, float* out, float* colsq, float scale, hipStream_t st) {
+  if (MODE == MODE_ACCUM) {  // partial column tiles are combined with atomics
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
   case MBV: {                                                                                   \
-    const unsigned grid = (unsigned)cdiv(C, 64 * NCTV);                                         \
-    panel_mfma_kernel<MBV, NCTV, MODE><<<grid, 256, 0, st>>>(Ppk, X, g, M, C, L, out, colsq, scale); \
+    const long long T = cdiv(C, 64 * NCTV) * L;                                                 \
+    const int wgs_per_cu = (MBV * NCTV >= 24) ? 1 : 2;                                          \
+    long long grid = (long long)num_cus() * wgs_per_cu;                                         \
+    if (MODE == MODE_STORE) grid = T;              /* L == 1: one item per tile */              \
+    if (grid > T) grid = T;                                                                     \
+    panel_mfma_kernel<MBV, NCTV, MODE><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, g, M, C, L, out, \
+                                                                       colsq, scale);           \
   } break;
   switch (MBsel) {
     GPSA_PANEL_CASE(2, 4)
@@ -348,6 +585,41 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
       return GPSA_EUNSUPPORTED;
   }
 #undef GPSA_PANEL_CASE
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int gram_nsplit(long long C, int L) {
+  long long ns = cdiv(768, L);
+  const long long nch = cdiv(C, GR_KC);
+  if (ns > nch) ns = nch;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
+                            float* dOmega, float* part, hipStream_t st) {
+  const int ns = gram_nsplit(C, L);
+  dim3 grid((unsigned)L, (unsigned)ns);
+  const bool al = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0);
+#define GPSA_GRAM_CASE(MBV)                                                                   \
+  case MBV:                                                                                   \
+    if (al) gram_mfma_kernel<MBV, true><<<grid, 256, 0, st>>>(alpha, g, M, C, ns, part);      \
+    else gram_mfma_kernel<MBV, false><<<grid, 256, 0, st>>>(alpha, g, M, C, ns, part);        \
+    break;
+  switch (MBsel) {
+    GPSA_GRAM_CASE(2)
+    GPSA_GRAM_CASE(4)
+    GPSA_GRAM_CASE(7)
+    GPSA_GRAM_CASE(13)
+    GPSA_GRAM_CASE(16)
+    default:
+      return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_GRAM_CASE
+  GPSA_LAUNCH_CHECK();
+  const long long tot = (long long)L * M * M;
+  gram_reduce_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(part, M, MBsel * 16, L, ns, dOmega);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -368,10 +640,11 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   const long long sz = (dtype == GPSA_F64) ? 8 : 4;
   const int MB = gpsa::mfma_mb_for(M);
   long long mfma = 0;
-  if (dtype == GPSA_F32 && MB) mfma = (long long)L * MB * 16 * MB * 16 * 4;
+  if (dtype == GPSA_F32 && MB)
+    mfma = (long long)L * MB * 16 * MB * 16 * 4 * (1 + (long long)gpsa::gram_nsplit(C, L));
   int lc = L < 4 ? L : 4;
   long long generic = (long long)M * C * sz * lc;                         // fwd: lc slabs of T
-  long long bo = (long long)M * C * sz + (long long)gpsa::gram_splitk(C) * M * M * sz;  // bwd_omega
+  long long bo = (long long)M * C * sz + (long long)gpsa::gram_splitk(C, M) * M * M * sz;  // bwd_omega
   long long r = generic > bo ? generic : bo;
   return (r > mfma ? r : mfma) + 256;
 }
@@ -432,9 +705,17 @@ int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, 
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (dtype == GPSA_F32)
+  if (dtype == GPSA_F32) {
+    const int MB = mfma_mb_for(M);
+    if (MB && !force_generic()) {
+      const long long need = (long long)L * gram_nsplit(C, L) * MB * 16 * MB * 16 * 4;
+      if (workspace_bytes < need) return GPSA_EWORKSPACE;
+      return gram_mfma_launch(MB, (const float*)alpha, (const float*)g, M, C, L, (float*)dOmega,
+                              (float*)workspace, st);
+    }
     return generic_quadform_bwd_omega<float>((const float*)alpha, (const float*)g, M, C, L,
                                              (float*)dOmega, workspace, workspace_bytes, st);
+  }
   if (dtype == GPSA_F64)
     return generic_quadform_bwd_omega<double>((const double*)alpha, (const double*)g, M, C, L,
                                               (double*)dOmega, workspace, workspace_bytes, st);

@@ -30,16 +30,17 @@ def ops():
 
 
 class Factor:
-    """fp64 factorisation of one prior covariance K_uu (shared by the layer and its KL term)."""
+    """fp64 factorisation of one symmetric positive-definite M x M matrix (a prior covariance K_uu,
+    shared by the layer and its KL term, or a variational covariance Omega_l)."""
 
     __slots__ = ("Linv", "Kinv", "logdet", "info", "_cast")
 
-    def __init__(self, Kuu64):
-        o = ops()
-        L, logdet, info = o.chol(Kuu64.detach().unsqueeze(0))
-        Linv = o.tri_inv(L)
-        self.Linv = Linv[0]
-        self.Kinv = o.gemm(self.Linv, self.Linv, transA=True)
+    def __init__(self, Kuu64=None, parts=None):
+        if parts is None:
+            parts = factor_batch([Kuu64.detach().unsqueeze(0)])[0]
+        Linv, Kinv, logdet, info = parts
+        self.Linv = Linv[0] if Linv.dim() == 3 and Linv.shape[0] == 1 else Linv
+        self.Kinv = Kinv[0] if Kinv.dim() == 3 and Kinv.shape[0] == 1 else Kinv
         self.logdet = logdet
         self.info = info
         self._cast = {}
@@ -50,6 +51,32 @@ class Factor:
             a = self.Linv.to(dtype)
             self._cast[dtype] = (a, self.Linv.t().contiguous().to(dtype))
         return self._cast[dtype]
+
+
+def factor_batch(mats):
+    """Factorise many SPD matrices with as few launches as possible.
+
+    ``mats``: list of fp64 tensors [b_i, M_i, M_i].  Matrices of equal size share ONE batched Cholesky,
+    ONE batched triangular inverse and ONE batched L^-T L^-1 product (one workgroup per matrix), so the
+    launch-latency-bound factorisations of a whole step cost one kernel's latency.
+    Returns, per input, (Linv [b,M,M], inverse [b,M,M], logdet [b], info [b]).
+    """
+    o = ops()
+    out = [None] * len(mats)
+    by_size = {}
+    for i, m in enumerate(mats):
+        by_size.setdefault(m.shape[-1], []).append(i)
+    for M, idxs in by_size.items():
+        stack = torch.cat([mats[i].detach().reshape(-1, M, M) for i in idxs], 0)
+        L, logdet, info = o.chol(stack)
+        Linv = o.tri_inv(L)
+        inv = o.gemm(Linv, Linv, transA=True)
+        off = 0
+        for i in idxs:
+            b = mats[i].reshape(-1, M, M).shape[0]
+            out[i] = (Linv[off : off + b], inv[off : off + b], logdet[off : off + b], info[off : off + b])
+            off += b
+    return out
 
 
 class KmatFn(torch.autograd.Function):
@@ -257,16 +284,15 @@ class LogLikFn(torch.autograd.Function):
 class MvnKLFn(torch.autograd.Function):
     """KL( N(delta_l, Omega_l) || N(mu_l, K) ) for l = 1..L, fp64 (vgpsa.py:498-530; torch's MVN-MVN
     formula): 0.5 [ logdet K - logdet Omega_l + tr(K^-1 Omega_l) + d_l^T K^-1 d_l - M ], d = delta - mu.
-    Inputs: Kuu [M,M] (for the gradient path), Dm [M,L], Omega [L,M,M]; ``fac`` = Factor(Kuu)."""
+    Inputs: Kuu [M,M] (for the gradient path), Dm [M,L], Omega [L,M,M]; ``fac`` = Factor(Kuu);
+    ``ofac`` = (Omega^-1 [L,M,M], logdet Omega [L]) from factor_batch."""
 
     @staticmethod
-    def forward(ctx, Kuu, Dm, Omega, fac):
+    def forward(ctx, Kuu, Dm, Omega, fac, ofac):
         o = ops()
         Om = Omega.detach().contiguous()
         D64 = Dm.detach().double().contiguous()
-        Lo, logdetO, info = o.chol(Om)
-        Loinv = o.tri_inv(Lo)
-        Oinv = o.gemm(Loinv, Loinv, transA=True)
+        Oinv, logdetO = ofac
         tr = o.bdot(fac.Kinv, Om)
         KD = o.gemm(fac.Kinv, D64)
         maha = (D64 * KD).sum(0)
@@ -274,7 +300,6 @@ class MvnKLFn(torch.autograd.Function):
         kl = 0.5 * (fac.logdet - logdetO + tr + maha - M)
         ctx.save_for_backward(Om, Oinv, KD, fac.Kinv)
         ctx.meta = (Dm.dtype,)
-        ctx.info = info
         return kl
 
     @staticmethod
@@ -288,4 +313,4 @@ class MvnKLFn(torch.autograd.Function):
         inner = o.gemm(o.gemm(Kinv, Ssum.contiguous()), Kinv)
         outer = o.gemm((KD * gkl.unsqueeze(0)).contiguous(), KD, transB=True)
         dK = 0.5 * (gkl.sum() * Kinv - inner - outer)
-        return dK, dDm.to(ctx.meta[0]), dOm, None
+        return dK, dDm.to(ctx.meta[0]), dOm, None, None

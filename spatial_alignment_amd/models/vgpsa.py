@@ -36,6 +36,8 @@ class _StepCache:
         self.data = None  # (Kuu_F, Factor)
         self.Omega_G = None  # [V*D, M, M] fp64
         self.Omega_F = {}  # mod -> [L, M, M] fp64
+        self.Omega_G_fac = None  # (Omega_G^-1 [V*D,M,M], logdet [V*D])
+        self.Omega_F_fac = {}  # mod -> (Omega_F^-1, logdet)
         self.flags = []  # device int tensors: Cholesky info / non-positive variance flags
 
 
@@ -211,7 +213,31 @@ class VariationalGPSA(GPSA):
             mu_z.append(mz)
         self.mu_z_G = torch.stack(mu_z)
 
+        # ---- everything M x M first: all prior covariances and variational covariances of the step
+        #      are factorised by ONE batched Cholesky / triangular-inverse launch per matrix size
         cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list)
+        for m in mods:
+            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m])
+        rows_of = {v: {m: _as_index(view_idx[m][v], dev) for m in mods} for v in range(V)}
+        free = [v for v in range(V)
+                if not self._is_fixed(v) and sum(rows_of[v][m][1] for m in mods) > 0]
+        Kuu_w = {}
+        for v in free:
+            Z = self.Xtilde[v]
+            Kuu_w[v] = self._kmat("warp", Z, Z, self.warp_kernel_lengthscales[v],
+                                  self.warp_kernel_variances[v], self.diagonal_offset, f64, True)
+        KuuF = self._kmat("data", self.Gtilde, self.Gtilde, self.data_kernel_lengthscale,
+                          self.data_kernel_variance, self.diagonal_offset, f64, True)
+        mats = [Kuu_w[v].unsqueeze(0) for v in free] + [KuuF.unsqueeze(0), cache.Omega_G] + \
+               [cache.Omega_F[m] for m in mods]
+        parts = E.factor_batch(mats)
+        for i, v in enumerate(free):
+            cache.warp[v] = (Kuu_w[v], E.Factor(parts=parts[i]))
+        nf = len(free)
+        cache.data = (KuuF, E.Factor(parts=parts[nf]))
+        cache.Omega_G_fac = (parts[nf + 1][1], parts[nf + 1][2])
+        cache.Omega_F_fac = {m: (parts[nf + 2 + i][1], parts[nf + 2 + i][2]) for i, m in enumerate(mods)}
+        cache.flags.extend(p[3] for p in parts)
 
         nan = float("nan")
         G_means = {m: torch.full([int(Ns[m]), D], nan, device=dev) for m in mods}
@@ -219,7 +245,7 @@ class VariationalGPSA(GPSA):
 
         draw = 0
         for v in range(V):
-            rows = {m: _as_index(view_idx[m][v], dev) for m in mods}
+            rows = rows_of[v]
             if self._is_fixed(v):  # vgpsa.py:262-273
                 for m in mods:
                     r, _ = rows[m]
@@ -232,11 +258,8 @@ class VariationalGPSA(GPSA):
                 continue  # outputs stay NaN (vgpsa.py:296-297)
             Z = self.Xtilde[v]
             ls_u, var_u = self.warp_kernel_lengthscales[v], self.warp_kernel_variances[v]
-            Kuu = self._kmat("warp", Z, Z, ls_u, var_u, self.diagonal_offset, f64, True)
+            Kuu, fac = cache.warp[v]
             Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
-            fac = E.Factor(Kuu)
-            cache.warp[v] = (Kuu, fac)
-            cache.flags.append(fac.info)
             dc = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
             Om = cache.Omega_G[v * D : (v + 1) * D]  # quirk 2: forward uses rows v*D+j
             meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
@@ -258,10 +281,7 @@ class VariationalGPSA(GPSA):
 
         # ---- data GP (vgpsa.py:353-477) ----------------------------------------------------------
         ls_u, var_u = self.data_kernel_lengthscale, self.data_kernel_variance
-        KuuF = self._kmat("data", self.Gtilde, self.Gtilde, ls_u, var_u, self.diagonal_offset, f64, True)
-        facF = E.Factor(KuuF)
-        cache.data = (KuuF, facF)
-        cache.flags.append(facF.info)
+        KuuF, facF = cache.data
 
         def data_layer(G, eps_key, m):
             S_, N_ = G.shape[0], G.shape[1]
@@ -285,7 +305,6 @@ class VariationalGPSA(GPSA):
         if G_test is not None:
             self.F_latent_samples_test, self.F_observed_samples_test = {}, {}
         for m in mods:
-            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m])
             self.F_latent_samples[m], self.F_observed_samples[m] = data_layer(G_samples[m], "F", m)
             if G_test is not None:
                 Gt = G_test[m].to(device=dev, dtype=torch.float32)
@@ -334,12 +353,14 @@ class VariationalGPSA(GPSA):
             Kuu, fac = cache.warp[v]
             Dm = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
             Om = cache.Omega_G[v::V]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
-            term = E.MvnKLFn.apply(Kuu, Dm, Om, fac).sum()
+            ofac = (cache.Omega_G_fac[0][v::V].contiguous(), cache.Omega_G_fac[1][v::V])
+            term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()
             kl = term if kl is None else kl + term
         KuuF, facF = cache.data
         ll = None
         for i, m in enumerate(self.modality_names):
-            term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF).sum()
+            term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF,
+                                   cache.Omega_F_fac[m]).sum()
             kl = term if kl is None else kl + term
             noise_u = self.noise_variance[-self.n_modalities + i]  # quirk 5 (used as a std)
             Y = data_dict[m]["outputs"]
