@@ -567,10 +567,13 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
   }
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
   case MBV: {                                                                                   \
-    const long long T = cdiv(C, 64 * NCTV) * L;                                                 \
+    const long long ntiles = cdiv(C, 64 * NCTV), T = ntiles * L;                                \
     const int wgs_per_cu = (MBV * NCTV >= 24) ? 1 : 2;                                          \
-    long long grid = (long long)num_cus() * wgs_per_cu;                                         \
+    const long long G = (long long)num_cus() * wgs_per_cu;                                      \
+    long long grid = G;                                                                         \
     if (MODE == MODE_STORE) grid = T;              /* L == 1: one item per tile */              \
+    if (MODE == MODE_ACCUM && T < G * L)           /* keep <= 2 atomic contributors/element */  \
+      grid = ntiles * ((2 * ntiles <= G && L >= 2) ? 2 : 1);                                    \
     if (grid > T) grid = T;                                                                     \
     panel_mfma_kernel<MBV, NCTV, MODE><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, g, M, C, L, out, \
                                                                        colsq, scale);           \

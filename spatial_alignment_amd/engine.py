@@ -244,7 +244,7 @@ class MatmulFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, W):
         o = ops()
-        F2 = F.detach().reshape(-1, F.shape[-1])
+        F2 = F.detach().reshape(-1, F.shape[-1]).contiguous()
         Wc = W.detach().contiguous()
         ctx.save_for_backward(F2, Wc)
         ctx.fshape = F.shape
@@ -255,8 +255,10 @@ class MatmulFn(torch.autograd.Function):
         o = ops()
         F2, Wc = ctx.saved_tensors
         dO2 = dO.contiguous().reshape(-1, dO.shape[-1])
-        dF = o.gemm(dO2, Wc, transB=True).reshape(ctx.fshape)
-        dW = o.gemm(F2, dO2, transA=True, splitk=o.pick_splitk(F2.shape[0], Wc.shape[0], Wc.shape[1]))
+        dF = o.gemm(dO2, Wc, transB=True).reshape(ctx.fshape) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = o.gemm(F2, dO2, transA=True, splitk=o.pick_splitk(F2.shape[0], Wc.shape[0], Wc.shape[1]))
         return dF, dW
 
 

@@ -207,7 +207,7 @@ class VariationalGPSA(GPSA):
         self.noise_variance_pos = torch.exp(self.noise_variance) + self.diagonal_offset  # vgpsa.py:217
         mu_z = []
         for v in range(V):
-            mz = self.Xtilde[v] @ self.mean_slopes[v] + self.mean_intercepts[v]
+            mz = E.MatmulFn.apply(self.Xtilde[v], self.mean_slopes[v]) + self.mean_intercepts[v]
             if self._is_fixed(v):
                 mz = mz * 100.0  # inert (quirk 7)
             mu_z.append(mz)
@@ -263,7 +263,7 @@ class VariationalGPSA(GPSA):
             dc = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
             Om = cache.Omega_G[v * D : (v + 1) * D]  # quirk 2: forward uses rows v*D+j
             meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
-            mux = Xv @ self.mean_slopes[v] + self.mean_intercepts[v]
+            mux = E.MatmulFn.apply(Xv, self.mean_slopes[v]) + self.mean_intercepts[v]
             if noise is not None and noise["G"] is not None:
                 eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
             else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
