@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--M", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="disable the per-forward numerics sync")
+    ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay timing")
+    ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -140,9 +142,28 @@ def main():
         model.check_numerics = False
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     Xs = {m: d["spatial_coords"] for m, d in dd.items()}
+    torch.manual_seed(1000 + rank)
+    if args.graph_only:
+        from spatial_alignment_amd.train import GraphedTrainStep
+
+        gopt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        gs = GraphedTrainStep(model, gopt, dd, view_idx, Ns, S=args.S, warmup=3)
+        for _ in range(2):
+            gs.step()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for _ in range(args.steps):
+            gs.step()
+        torch.cuda.synchronize()
+        gdt = time.perf_counter() - g0
+        gs.check()
+        print(json.dumps(dict(value=args.steps / gdt, unit="steps/s", ms_per_step=1e3 * gdt / args.steps,
+                              final_loss=float(gs.loss.item()),
+                              note="same step (forward+ELBO+backward+Adam) as ONE hipGraph replay")),
+              flush=True)
+        return
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     reducer = GradAllReducer(model.parameters())
-    torch.manual_seed(1000 + rank)
     timer = KernelTimer(ops_mod.get_ops())
 
     def step():
@@ -174,15 +195,40 @@ def main():
     dt = float(t.item())
     final_loss = float(loss.item())
 
+    graph_info = None
+    if world == 1 and not args.no_graph and not args.graph_only:
+        # extra: the SAME step captured into a hipGraph and replayed (train.GraphedTrainStep); run in a
+        # child process so that nothing it does can take the contract line down with it
+        import subprocess
+
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps),
+               "--S", str(args.S), "--side", str(args.side), "--views", str(args.views),
+               "--outputs", str(args.outputs), "--M", str(args.M)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            graph_info = json.loads(last[-1]) if last else dict(error=f"rc={r.returncode}", stderr=r.stderr[-300:])
+        except Exception as e:
+            graph_info = dict(error=f"{type(e).__name__}: {e}"[:300])
+
     if rank == 0:
         ks = timer.summary()
         dom = ks.get("quadform_fwd")
         N = int(sum(dd_full["expression"]["n_samples_list"]))
         roof = None
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+            except Exception:
+                pmc = None
         if dom:
             roof = dict(bound="mfma", kernel="panel_mfma_kernel<MODE_QUAD> (gpsa_quadform_fwd)",
                         achieved=dom["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=dom["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                        frac=dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                        traffic=(pmc or {}).get("quadform_fwd_hbm_bytes_per_launch"),
+                        traffic_note=(pmc or {}).get("note"),
                         avg_launch_ms=dom["avg_ms"], flops_per_launch=dom["flops"],
                         other_kernels={k: dict(avg_ms=v["avg_ms"], tflops=v["tflops"]) for k, v in ks.items()
                                        if k != "quadform_fwd"})
@@ -209,6 +255,7 @@ def main():
                 "final_loss": final_loss,
             },
             "roofline": roof,
+            "graph_replay": graph_info,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, state, dd_full)

@@ -130,3 +130,38 @@ def test_full_size_properties():
         p.add_(h * d)
     fd = float(lp - lm) / (2 * h)
     assert abs(fd - gdir) <= 2e-2 * max(abs(gdir), 1.0), (fd, gdir)
+
+
+def test_graphed_step_equals_eager_step():
+    """the hipGraph-captured step does the same work as the eager step (same params, same noise):
+    3 eager + 1 replayed step must land on the parameters of 4 eager steps"""
+    from spatial_alignment_amd.train import GraphedTrainStep, train_step
+
+    g = Golden("c2_three_free_views")
+    res = []
+    for mode in ("eager", "graph"):
+        model, dd = build_model(g, device=DEV)
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        eps_G = [e.to(DEV) for e in g.eps_G]
+        eps_F = {m: e.to(DEV) for m, e in g.eps_F.items()}
+        orig = model.forward
+
+        def fwd(*a, _orig=orig, _m=model, **k):  # same injected noise on every call
+            _m.inject_noise(eps_G, eps_F)
+            return _orig(*a, **k)
+
+        model.forward = fwd
+        if mode == "eager":
+            for _ in range(4):
+                loss = train_step(model, opt, dd, view_idx, Ns, S=g.S)
+        else:
+            gs = GraphedTrainStep(model, opt, dd, view_idx, Ns, S=g.S, warmup=3)
+            loss = gs.step()
+            gs.check()
+        torch.cuda.synchronize()
+        res.append((float(loss), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[0][0]), (res[0][0], res[1][0])
+    for k in res[0][1]:
+        a, b = res[0][1][k].double(), res[1][1][k].double()
+        assert (a - b).norm() <= 1e-5 * max(a.norm().item(), 1e-6), k
