@@ -468,28 +468,49 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
     for (int kb = 0; kb < NKB; ++kb) {
       const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
       const float* base = &sA[buf][kb * 256 + lane * 4];
-      // operand fragments are fetched two tiles ahead of their MFMAs (4 MFMAs = 128 cycles per
-      // tile would not cover the LDS latency)
-      float4 fa[NSLOT + 2], fb[NSLOT + 2];
+      // tiles are processed in pairs with their MFMAs interleaved (a 16x16x4 MFMA has a 40-cycle
+      // dependent latency but a 32-cycle issue interval: two independent accumulators keep the pipe
+      // full); the operand fragments of the next pair are fetched while this pair computes.
+      constexpr int NPAIR = (NSLOT + 1) / 2;
+      float4 fa[2][2], fb[2][2];
 #pragma unroll
-      for (int s = 0; s < 2 && s < NSLOT; ++s) {
-        fa[s] = *reinterpret_cast<const float4*>(base + oa[s]);
-        fb[s] = *reinterpret_cast<const float4*>(base + ob[s]);
+      for (int u = 0; u < 2; ++u) {
+        const int s = u < NSLOT ? u : NSLOT - 1;
+        fa[0][u] = *reinterpret_cast<const float4*>(base + oa[s]);
+        fb[0][u] = *reinterpret_cast<const float4*>(base + ob[s]);
       }
 #pragma unroll
-      for (int s = 0; s < NSLOT; ++s) {
-        if (s + 2 < NSLOT) {
-          fa[s + 2] = *reinterpret_cast<const float4*>(base + oa[s + 2]);
-          fb[s + 2] = *reinterpret_cast<const float4*>(base + ob[s + 2]);
+      for (int pr = 0; pr < NPAIR; ++pr) {
+        const int cur = pr & 1, nxt = cur ^ 1;
+        if (pr + 1 < NPAIR) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int s = (2 * pr + 2 + u) < NSLOT ? (2 * pr + 2 + u) : NSLOT - 1;
+            fa[nxt][u] = *reinterpret_cast<const float4*>(base + oa[s]);
+            fb[nxt][u] = *reinterpret_cast<const float4*>(base + ob[s]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
-        float4 a4 = fa[s];
-        const float4 b4 = fb[s];
-        a4.x *= g4.x; a4.y *= g4.y; a4.z *= g4.z; a4.w *= g4.w;
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[s], 0, 0, 0);
+        const int s0 = 2 * pr, s1 = (2 * pr + 1 < NSLOT) ? 2 * pr + 1 : -1;
+        float4 a0 = fa[cur][0], a1 = fa[cur][1];
+        const float4 b0 = fb[cur][0], b1 = fb[cur][1];
+        a0.x *= g4.x; a0.y *= g4.y; a0.z *= g4.z; a0.w *= g4.w;
+        a1.x *= g4.x; a1.y *= g4.y; a1.z *= g4.z; a1.w *= g4.w;
+        if (s1 >= 0) {
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
+          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
+          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
+          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
+          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+        } else {
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
+          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -191,6 +191,79 @@ class SGPCoreFn(torch.autograd.Function):
         )
 
 
+class SGPLayerFn(torch.autograd.Function):
+    """Built-in-covariance version of SGPCoreFn with the K_uf generation fused in: the N-scaled fp64
+    covariance never crosses an autograd edge (no dtype round trips, nothing of size M x C saved
+    besides alpha), and its gradient goes straight from the whitening backward into the covariance
+    backward kernel in ``bwd_dtype``.
+
+    (kind, Z, X, ls_u, var_u ; K_uu, dc, Omega ; factor) -> meanT [L,C], v [L,C], q [C] (white dtype)
+    """
+
+    @staticmethod
+    def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, white_dtype, main_dtype, bwd_dtype):
+        o = ops()
+        Tw, T = white_dtype, main_dtype
+        cast = lambda t, d: t.detach().to(d)
+        Zw, Xw = cast(Z, Tw), cast(X, Tw)
+        lsw, varw = cast(ls_u, Tw).reshape(1), cast(var_u, Tw).reshape(1)
+        Kuf = o.kmat(kind, Zw, Xw, lsw, varw, 0.0)
+        Liw, LiTw = fac.linv(Tw)
+        beta, q = o.panel_mm(Liw, Kuf, want_colsq=True)
+        del Kuf
+        alpha_w, _ = o.panel_mm(LiTw, beta)
+        del beta
+        alpha = alpha_w if T == Tw else alpha_w.to(T)
+        dcT = dc.detach().to(T).contiguous()
+        Om = Omega.detach().to(T).contiguous()
+        meanT = o.gemm(dcT, alpha, transA=True)
+        v = o.quadform_fwd(alpha, Om)
+        Li, LiT = fac.linv(T)
+        Tb = bwd_dtype
+        ctx.save_for_backward(alpha, dcT, Om, Li, LiT, cast(Z, Tb), cast(X, Tb),
+                              cast(ls_u, Tb).reshape(1), cast(var_u, Tb).reshape(1))
+        ctx.kind = kind
+        ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
+                    dc.dtype, Omega.dtype)
+        return meanT, v, q
+
+    @staticmethod
+    def backward(ctx, dmeanT, g, qbar):
+        o = ops()
+        alpha, dcT, Om, Li, LiT, Zb, Xb, lsb, varb = ctx.saved_tensors
+        zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt = ctx.meta
+        M, Cn = alpha.shape
+        L = Om.shape[0]
+        T = alpha.dtype
+        zeros = lambda *s: torch.zeros(*s, dtype=T, device=alpha.device)
+        dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.to(T).contiguous()
+        g = zeros(L, Cn) if g is None else g.to(T).contiguous()
+        qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
+        abar = o.quadform_bwd_alpha(alpha, Om, g)
+        o.gemm(dcT, dmeanT, beta=1.0, out=abar)
+        ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
+        dOm = o.quadform_bwd_omega(alpha, g) if ctx.needs_input_grad[7] else None
+        t, _ = o.panel_mm(Li, abar)
+        gamma, _ = o.panel_mm(LiT, t)
+        W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
+        dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
+        dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
+        need_x = ctx.needs_input_grad[2]
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, varb,
+                                  dKuf if dKuf.dtype == Zb.dtype else dKuf.to(Zb.dtype), need_dX=need_x)
+        return (
+            None,
+            dZ.to(zdt) if ctx.needs_input_grad[1] else None,
+            dX.to(xdt) if (need_x and dX is not None) else None,
+            dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None,
+            dpar[1].to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None,
+            dKuu.to(kdt),
+            ddc.to(ddt),
+            dOm.to(odt) if dOm is not None else None,
+            None, None, None, None,
+        )
+
+
 class WarpSampleFn(torch.autograd.Function):
     """G_mean, G_samples of the warp GP (vgpsa.py:186-191, 334-351).  var is used as the std
     (SURVEY quirk 1).  Outputs fp32; internals fp64."""

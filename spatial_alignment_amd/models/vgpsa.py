@@ -259,10 +259,14 @@ class VariationalGPSA(GPSA):
             Z = self.Xtilde[v]
             ls_u, var_u = self.warp_kernel_lengthscales[v], self.warp_kernel_variances[v]
             Kuu, fac = cache.warp[v]
-            Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
             dc = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
             Om = cache.Omega_G[v * D : (v + 1) * D]  # quirk 2: forward uses rows v*D+j
-            meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
+            kind = builtin_kind(self.kernel_func_warp)
+            if kind is not None:  # fused covariance + layer, all fp64
+                meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
+            else:
+                Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
+                meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
             mux = E.MatmulFn.apply(Xv, self.mean_slopes[v]) + self.mean_intercepts[v]
             if noise is not None and noise["G"] is not None:
                 eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
@@ -288,10 +292,17 @@ class VariationalGPSA(GPSA):
             L = self.n_latent_outputs[m]
             Gf = G.reshape(S_ * N_, D)
             # covariance + whitening in fp64 (gradient-only fp32 backward); mean / variance form in fp32
-            Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, f64, False, torch.float32)
-            meanT, vq, q = E.SGPCoreFn.apply(
-                KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF, torch.float32
-            )
+            kind = builtin_kind(self.kernel_func_data)
+            if kind is not None:
+                meanT, vq, q = E.SGPLayerFn.apply(
+                    kind, self.Gtilde, Gf, ls_u, var_u, KuuF, self.delta_F_dict[m], cache.Omega_F[m],
+                    facF, f64, torch.float32, torch.float32,
+                )
+            else:
+                Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, f64, False, torch.float32)
+                meanT, vq, q = E.SGPCoreFn.apply(
+                    KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF, torch.float32
+                )
             if noise is not None and noise[eps_key] is not None:
                 eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
             else:

@@ -96,7 +96,8 @@ def test_chol_flags_indefinite(hip):
     assert info.cpu().tolist() == [0, 8]
 
 
-QF = [(10, 100, 3), (25, 1000, 5), (50, 333, 2), (100, 500, 4), (200, 2100, 7), (256, 300, 2), (16, 64, 1)]
+QF = [(10, 100, 3), (25, 1000, 5), (50, 333, 2), (100, 500, 4), (200, 2100, 7), (256, 300, 2), (16, 64, 1),
+      (300, 130, 2), (200, 50001, 3), (13, 7, 1)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])

@@ -165,3 +165,31 @@ def test_graphed_step_equals_eager_step():
     for k in res[0][1]:
         a, b = res[0][1][k].double(), res[1][1][k].double()
         assert (a - b).norm() <= 1e-5 * max(a.norm().item(), 1e-6), k
+
+
+def _custom_m32(x1, x2, lengthscale_unconstrained, output_variance_unconstrained, diag=False):
+    import spatial_alignment_amd as gp
+
+    return gp.matern32_kernel(x1, x2, lengthscale_unconstrained, output_variance_unconstrained, diag)
+
+
+def test_custom_callable_plugin_on_gpu():
+    """an arbitrary plug-in callable is evaluated as-is and its matrices feed the HIP layer kernels"""
+    g = Golden("c5_two_modalities")  # rbf warp, matern32 data
+    model, dd = build_model(g, device=DEV)
+    model.kernel_func_data = _custom_m32
+    res = run_step(model, dd, g, device=DEV)
+    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=5e-3)
+    assert not bad, bad
+
+
+def test_prediction_mode_and_no_grad_forward():
+    g = Golden("c4_3d_gtest")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Gt = {m: g.G_test[m].to(DEV) for m in g.mods}
+    with torch.no_grad():
+        out = model.forward({m: dd[m]["spatial_coords"] for m in g.mods}, view_idx, Ns, S=3,
+                            prediction_mode=True, G_test=Gt)
+    assert len(out) == 6 and not model.training
+    assert out[4]["expression"].shape == (1, 17, 5) and torch.isfinite(out[4]["expression"]).all()
