@@ -9,7 +9,7 @@ namespace gpsa {
 constexpr int GB_M = 64, GB_N = 64, GB_K = 16;
 
 template <typename T, bool TA, bool TB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long long lda,
             long long sA, const T* __restrict__ B, long long ldb, long long sB, T beta,
             T* __restrict__ C, long long ldc, long long sC, int splitk, T* __restrict__ part) {
@@ -30,7 +30,10 @@ gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long lo
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
 
-  for (long long k0 = kbeg; k0 < kend; k0 += GB_K) {
+  // register-staged software pipeline: the global loads of K tile t+1 are in flight while tile t is
+  // multiplied out of LDS (the small M x M products of the step are latency-, not throughput-bound)
+  T ra[4], rb[4];
+  auto fetch = [&](long long k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256;
@@ -39,16 +42,36 @@ gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long lo
       const long long gr = m0 + r, gk = k0 + kk;
       T v = T(0);
       if (gr < m && gk < kend) v = TA ? Ab[gk * lda + gr] : Ab[gr * lda + gk];
-      As[kk][r] = v;
+      ra[i] = v;
       int c, kb;
       if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }
       const long long gc = n0 + c, gk2 = k0 + kb;
       T u = T(0);
       if (gc < n && gk2 < kend) u = TB ? Bb[gc * ldb + gk2] : Bb[gk2 * ldb + gc];
-      Bs[kb][c] = u;
+      rb[i] = u;
     }
-    __syncthreads();
+  };
+  auto stash = [&]() {
 #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int r, kk;
+      if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }
+      As[kk][r] = ra[i];
+      int c, kb;
+      if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }
+      Bs[kb][c] = rb[i];
+    }
+  };
+  if (kbeg < kend) {
+    fetch(kbeg);
+    stash();
+  }
+  __syncthreads();
+  for (long long k0 = kbeg; k0 < kend; k0 += GB_K) {
+    const bool more = k0 + GB_K < kend;
+    if (more) fetch(k0 + GB_K);
+#pragma unroll 4
     for (int kk = 0; kk < GB_K; ++kk) {
       T a[4], bb[4];
 #pragma unroll
@@ -60,6 +83,8 @@ gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long lo
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
     }
+    __syncthreads();
+    if (more) stash();
     __syncthreads();
   }
   if (splitk == 1) {

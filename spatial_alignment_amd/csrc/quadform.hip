@@ -614,11 +614,25 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
 }
 
 static inline int gram_nsplit(long long C, int L) {
-  long long ns = cdiv(768, L);
+  // grid = L x nsplit workgroups, one per CU at a time: pick the split (roughly 2-4 waves of the chip)
+  // that leaves the last wave of workgroups fullest
   const long long nch = cdiv(C, GR_KC);
-  if (ns > nch) ns = nch;
-  if (ns < 1) ns = 1;
-  return (int)ns;
+  const int cus = num_cus();
+  long long best = 1;
+  double best_u = -1.0;
+  for (long long ns = 1; ns <= 64; ++ns) {
+    if (ns > nch) break;
+    const long long wgs = (long long)L * ns;
+    if (wgs > 4LL * cus + cus / 2 && best_u >= 0.0) break;
+    const double u = (double)wgs / (double)(cdiv(wgs, cus) * cus);
+    // prefer >= 2 waves of workgroups (amortises the prologue) unless the problem is tiny
+    const double score = u - (wgs < 2LL * cus ? 0.05 : 0.0);
+    if (score > best_u + 1e-9) {
+      best_u = score;
+      best = ns;
+    }
+  }
+  return (int)best;
 }
 
 static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
