@@ -157,7 +157,7 @@ enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
 // A fragment of row tile rt by one conflict-free ds_read_b128 at lane*16 bytes.
 template <typename TS>
 __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, int L, int transpose,
-                                   float* __restrict__ dst) {
+                                   float* __restrict__ dst, int sym_lower) {
   const int MP = MB * 16;
   const long long per = (long long)MP * MP;
   const long long idx = blockIdx.x * 256LL + threadIdx.x;
@@ -173,6 +173,8 @@ __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, in
     const TS* sp = src + (long long)l * M * M;
     v = (float)(transpose ? sp[(long long)k * M + i] : sp[(long long)i * M + k]);
   }
+  // symmetric quadratic form: only tiles rt >= kc are used; off-diagonal ones count twice
+  if (sym_lower) v = (rt > kc) ? 2.f * v : (rt == kc ? v : 0.f);
   dst[idx] = v;
 }
 
@@ -192,6 +194,9 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
       : "memory");
 }
 #define GPSA_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// wait until at most N of this wave's vector-memory operations are outstanding (N = the LDS-DMA
+// operations of the newest stage: everything older, i.e. the stage about to be read, has landed)
+#define GPSA_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(lds_ptr_t)(p);
 }
@@ -213,7 +218,9 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   constexpr int MP = MB * 16;
   constexpr int WGCOLS = 64 * NCT;
   constexpr int CHUNK = MP * 16;                    // floats per K chunk (MB pieces of 256 floats)
-  __shared__ __attribute__((aligned(16))) float lds[2][CHUNK];
+  constexpr int NPW = (MB + 3) / 4;                 // LDS-DMA pieces per wave per stage (uniform)
+  constexpr int BUFF = NPW * 4 * 256;               // floats per LDS buffer (incl. dummy slots)
+  __shared__ __attribute__((aligned(16))) float lds[3][BUFF];  // 3-deep ring, 2 stages in flight
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,15 +235,31 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   float xb[NCT][MB][4];
   f32x4 acc[MB][NCT];
   // K chunk Q of the packed left operand -> LDS buffer BUF by LDS-DMA (no VGPR staging, no ds_write):
-  // wave w moves pieces w, w+4, ... (1 KiB each, lane-linear)
+  // wave w moves pieces w, w+4, ... (1 KiB each, lane-linear); every wave issues exactly NPW
+  // operations per stage (the surplus ones re-load the last piece into an unused slot) so that a
+  // counted vmcnt(NPW) means "everything but the newest stage has landed".
 #define GPSA_STAGE(Q, BUF)                                                                     \
   {                                                                                            \
     const float* src__ = Ppk + (long long)(Q) * CHUNK + lane * 4;                              \
-    _Pragma("unroll") for (int pc = 0; pc < (MB + 3) / 4; ++pc) {                              \
+    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
       const int piece = pc * 4 + w;                                                            \
-      if (piece < MB)                                                                          \
-        glds16(src__ + piece * 256,                                                            \
-               __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));              \
+      glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                      \
+             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                \
+    }                                                                                          \
+  }
+  // the chunk stream of this workgroup: position -> (l, kc); staged two chunks ahead of the compute
+  const long long NQ = (it1 - it0) * MB;
+  long long sidx = 0;
+  int sl = (int)(it0 % L), skc = 0;
+#define GPSA_STAGE_NEXT(BUF)                                                                   \
+  {                                                                                            \
+    GPSA_STAGE((long long)sl * MB + skc, BUF)                                                  \
+    if (sidx + 1 < NQ) {                                                                       \
+      ++sidx;                                                                                  \
+      if (++skc == MB) {                                                                       \
+        skc = 0;                                                                               \
+        sl = (sl + 1 == L) ? 0 : sl + 1;                                                       \
+      }                                                                                        \
     }                                                                                          \
   }
   // flush the accumulators of column tile TILE (ACCUM / STORE); PLAIN: this workgroup covered all l
@@ -266,9 +289,10 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   }
 
   const long long tile0 = it0 / L, tile1 = (it1 - 1) / L;
-  int buf = 0;
-  GPSA_STAGE((long long)(it0 % L) * MB, 0)
-  GPSA_DMA_DRAIN();
+  int buf = 0;  // ring slot being computed; slot (buf+2)%3 receives the stage issued now
+  GPSA_STAGE_NEXT(0)
+  GPSA_STAGE_NEXT(1)
+  GPSA_DMA_WAIT(NPW);
   __syncthreads();
 
   for (long long tile = tile0; tile <= tile1; ++tile) {
@@ -300,15 +324,9 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
           gv[ct] = (c < C) ? g[(long long)l * C + c] : 0.f;
         }
       }
-      // chunk stream successor of (l, last chunk): next l of this tile, else the next tile's first l
-      const bool last_item = (tile == tile1) && (l == l_hi);
-      const int lnext = (l < l_hi) ? l + 1 : 0;
 #pragma unroll
       for (int kc = 0; kc < MB; ++kc) {
-        long long nq;
-        if (kc + 1 < MB) nq = (long long)l * MB + kc + 1;
-        else nq = last_item ? (long long)l * MB + kc : (long long)lnext * MB;  // last: harmless re-read
-        GPSA_STAGE(nq, buf ^ 1)
+        GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
         float bv[NCT][4];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -332,9 +350,9 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
               acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        GPSA_DMA_DRAIN();
+        GPSA_DMA_WAIT(NPW);
         __syncthreads();
-        buf ^= 1;
+        buf = (buf == 2) ? 0 : buf + 1;
       }
       if (MODE == MODE_QUAD) {
         // v[l,c] = sum over the rows this lane holds of acc * alpha, then across the 4 lane quarters
@@ -360,8 +378,152 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
       GPSA_FLUSH(tile, plain)
     }
   }
+  GPSA_DMA_DRAIN();  // nothing may still be writing this workgroup's LDS when it exits
 #undef GPSA_STAGE
+#undef GPSA_STAGE_NEXT
 #undef GPSA_FLUSH
+}
+
+// ------------------------------------------------------------------------------------------------
+// Symmetric quadratic form:  v[l,c] = alpha_c^T Omega_l alpha_c  using only the lower-triangle tiles
+//   v = sum_rt alpha_rt . ( Omega[rt,rt] alpha_rt + 2 sum_{kc<rt} Omega[rt,kc] alpha_kc )
+// (the factor 2 and the zero upper tiles are baked into the packed operand, pack_panels sym_lower).
+// 91 instead of 169 tile products at M = 200.  K chunks are processed in pairs (kc, MB-1-kc) so that
+// every step between two barriers has the same MB+1 row-tile products.  Same register-resident alpha
+// slab, LDS-DMA staging, persistent balanced items and in-register closing as panel_mfma_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NCT>
+__global__ void __launch_bounds__(256, (MB * NCT >= 24) ? 1 : 2)
+quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_lower-packed
+                     const float* __restrict__ X, int M, long long C, int L,
+                     float* __restrict__ out) {
+  constexpr int WGCOLS = 64 * NCT;
+  constexpr int PER_L = MB * MB * 256;              // floats per packed matrix
+  constexpr int NSTEP = (MB + 1) / 2;               // chunk pairs (the middle chunk stands alone)
+  constexpr int NPW = (MB + 1 + 3) / 4;             // LDS-DMA pieces per wave per step (uniform)
+  constexpr int BUFP = NPW * 4;                     // piece slots per LDS buffer
+  __shared__ __attribute__((aligned(16))) float lds[3][BUFP * 256];  // ring, 2 stages in flight
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const long long ntiles = (C + WGCOLS - 1) / WGCOLS;
+  const long long T = ntiles * L;
+  const long long it0 = (long long)blockIdx.x * T / gridDim.x;
+  const long long it1 = (long long)(blockIdx.x + 1) * T / gridDim.x;
+  if (it0 >= it1) return;
+
+  float xb[NCT][MB][4];
+  f32x4 acc[MB][NCT];
+  // step P of matrix LL: pieces (rt, kc=P) for rt = P..MB-1 go to LDS slots 0..MB-1-P, then pieces
+  // (rt, kc=MB-1-P) for rt = MB-1-P..MB-1 to slots MB-P..MB   (second group absent when 2P == MB-1).
+  // Every wave issues exactly NPW operations (surplus slots re-load the step's first piece).
+#define GPSA_QS_STAGE(LL, P, BUF)                                                              \
+  {                                                                                            \
+    const float* m__ = Ppk + (long long)(LL) * PER_L + lane * 4;                               \
+    const int p__ = (P), q__ = MB - 1 - p__;                                                   \
+    const int n1__ = MB - p__, n2__ = (q__ != p__) ? p__ + 1 : 0;                              \
+    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
+      const int sl = pc * 4 + w;                                                               \
+      const int se = sl < n1__ + n2__ ? sl : 0;                                                \
+      const int kc__ = se < n1__ ? p__ : q__;                                                  \
+      const int rt__ = se < n1__ ? p__ + se : q__ + (se - n1__);                               \
+      glds16(m__ + (kc__ * MB + rt__) * 256,                                                   \
+             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][sl * 256])));                   \
+    }                                                                                          \
+  }
+  // step stream of this workgroup, staged two steps ahead of the compute
+  const long long NQ = (it1 - it0) * NSTEP;
+  long long sidx = 0;
+  int sl_ = (int)(it0 % L), sp_ = 0;
+#define GPSA_QS_STAGE_NEXT(BUF)                                                                \
+  {                                                                                            \
+    GPSA_QS_STAGE(sl_, sp_, BUF)                                                               \
+    if (sidx + 1 < NQ) {                                                                       \
+      ++sidx;                                                                                  \
+      if (++sp_ == NSTEP) {                                                                    \
+        sp_ = 0;                                                                               \
+        sl_ = (sl_ + 1 == L) ? 0 : sl_ + 1;                                                    \
+      }                                                                                        \
+    }                                                                                          \
+  }
+
+  const long long tile0 = it0 / L, tile1 = (it1 - 1) / L;
+  int buf = 0;
+  GPSA_QS_STAGE_NEXT(0)
+  GPSA_QS_STAGE_NEXT(1)
+  GPSA_DMA_WAIT(NPW);
+  __syncthreads();
+
+  for (long long tile = tile0; tile <= tile1; ++tile) {
+    const int l_lo = (tile == tile0) ? (int)(it0 - tile0 * L) : 0;
+    const int l_hi = (tile == tile1) ? (int)(it1 - 1 - tile1 * L) : L - 1;
+    const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const long long c = cw + ct * 16 + j;
+#pragma unroll
+      for (int t = 0; t < MB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = t * 16 + kq * 4 + r;
+          xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int l = l_lo; l <= l_hi; ++l) {
+#pragma unroll
+      for (int p = 0; p < NSTEP; ++p) {
+        GPSA_QS_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
+        const float* base = &lds[buf][lane * 4];
+        const int q = MB - 1 - p;
+        const int n1 = MB - p, n2 = (q != p) ? p + 1 : 0;
+        float4 a_nxt = *reinterpret_cast<const float4*>(base);
+#pragma unroll
+        for (int sl = 0; sl < MB + 1; ++sl) {
+          if (sl < n1 + n2) {
+            const int kc = sl < n1 ? p : q;
+            const int rt = sl < n1 ? p + sl : q + (sl - n1);
+            const float4 a4 = a_nxt;
+            if (sl + 1 < n1 + n2) a_nxt = *reinterpret_cast<const float4*>(base + (sl + 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xb[ct][kc][r], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        GPSA_DMA_WAIT(NPW);
+        __syncthreads();
+        buf = (buf == 2) ? 0 : buf + 1;
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sacc += acc[rt][ct][r] * xb[ct][rt][r];
+            acc[rt][ct][r] = 0.f;
+          }
+        sacc += __shfl_xor(sacc, 16, 64);
+        sacc += __shfl_xor(sacc, 32, 64);
+        const long long c = cw + ct * 16 + j;
+        if (kq == 0 && c < C) out[(long long)l * C + c] = sacc;
+      }
+    }
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_QS_STAGE
+#undef GPSA_QS_STAGE_NEXT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -384,8 +546,9 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
   // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
   // conflict-free ds_read_b128 at lane*16 bytes.
-  __shared__ __attribute__((aligned(16))) float sA[2][NPIECE * 256];
-  __shared__ __attribute__((aligned(16))) float sG[2][GR_KC];
+  constexpr int NPW = (NPIECE + 3) / 4;  // LDS-DMA pieces per wave per stage (uniform; + 1 for g)
+  __shared__ __attribute__((aligned(16))) float sA[3][NPW * 4 * 256];  // ring, 2 stages in flight
+  __shared__ __attribute__((aligned(16))) float sG[3][GR_KC];
   __shared__ int sOff[NSLOT * 4][2];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -414,33 +577,31 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
     acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // staging: rows >= M are clamped to row M-1 and columns >= C to the last aligned group; the clamped
-  // rows only feed output rows/cols >= M (never read back) and the clamped columns meet g == 0.
-  float gstage = 0.f;
-  auto col_of = [&](long long cb, int kb) -> long long {
-    long long col = cb + kb * 16 + kq * 4;
-    if (ALIGNED) return col < C - 4 ? col : C - 4;
-    return col;
-  };
-#define GPSA_GR_G(CH)                                                                        \
-  {                                                                                          \
-    const long long cb__ = (long long)(CH) * GR_KC;                                          \
-    if (tid < GR_KC) gstage = (cb__ + tid < C) ? g[(long long)l * C + cb__ + tid] : 0.f;     \
-  }
+  // staging (LDS-DMA, ALIGNED): rows >= M are clamped to row M-1 and columns >= C to the last aligned
+  // group; the clamped rows only feed output rows/cols >= M (never read back) and the clamped columns
+  // meet g == 0 (g is zero-padded to a multiple of GR_KC columns by the launcher: gpad, row stride
+  // Cpad).  Every wave issues exactly NPW + 1 operations per stage (surplus pieces re-load piece 0 into
+  // an unused slot; all four waves DMA the same 128 bytes of g) so that a counted vmcnt(NPW+1) means
+  // "everything but the newest stage has landed".
+  const long long Cpad = nch * GR_KC;
 #define GPSA_GR_STAGE(CH, BUF)                                                               \
   {                                                                                          \
     const long long cb__ = (long long)(CH) * GR_KC;                                          \
     if (ALIGNED) {                                                                           \
-      _Pragma("unroll") for (int pc = 0; pc < (NPIECE + 3) / 4; ++pc) {                      \
-        const int piece = pc * 4 + w;                                                        \
-        if (piece < NPIECE) {                                                                \
-          const int rb = piece / NKB, kb = piece % NKB;                                      \
-          int row = rb * 16 + j;                                                             \
-          row = row < M ? row : M - 1;                                                       \
-          glds16(alpha + (long long)row * C + col_of(cb__, kb),                              \
-                 __builtin_amdgcn_readfirstlane(lds_addr(&sA[BUF][piece * 256])));           \
-        }                                                                                    \
+      _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                   \
+        const int slot = pc * 4 + w;                                                         \
+        const int piece = slot < NPIECE ? slot : 0;                                          \
+        const int rb = piece / NKB, kb = piece % NKB;                                        \
+        int row = rb * 16 + j;                                                               \
+        row = row < M ? row : M - 1;                                                         \
+        long long col = cb__ + kb * 16 + kq * 4;                                             \
+        col = col < C - 4 ? col : C - 4;                                                     \
+        glds16(alpha + (long long)row * C + col,                                             \
+               __builtin_amdgcn_readfirstlane(lds_addr(&sA[BUF][slot * 256])));              \
       }                                                                                      \
+      if (lane < GR_KC / 4)                                                                  \
+        glds16(g + (long long)l * Cpad + cb__ + lane * 4,                                    \
+               __builtin_amdgcn_readfirstlane(lds_addr(&sG[BUF][0])));                       \
     } else {                                                                                 \
       for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
         const int piece = e >> 8, ln = (e >> 2) & 63, r = e & 3;                             \
@@ -449,21 +610,23 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
         const long long col = cb__ + kb * 16 + (ln >> 4) * 4 + r;                            \
         sA[BUF][e] = (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;           \
       }                                                                                      \
+      if (tid < GR_KC) sG[BUF][tid] = g[(long long)l * Cpad + cb__ + tid];                   \
     }                                                                                        \
   }
 
-  if (ch0 < ch1) {
-    GPSA_GR_G(ch0)
+  const long long nmine = ch1 - ch0;
+  if (nmine > 0) {
     GPSA_GR_STAGE(ch0, 0)
-    if (tid < GR_KC) sG[0][tid] = gstage;
+    GPSA_GR_STAGE(nmine > 1 ? ch0 + 1 : ch0, 1)
   }
-  GPSA_DMA_DRAIN();
+  GPSA_DMA_WAIT(NPW + 1);
   __syncthreads();
   int buf = 0;
   for (long long ch = ch0; ch < ch1; ++ch) {
-    const long long nxt = (ch + 1 < ch1) ? ch + 1 : ch;  // last prefetch: harmless re-read
-    GPSA_GR_G(nxt)
-    GPSA_GR_STAGE(nxt, buf ^ 1)
+    {
+      const long long nx = (ch + 2 < ch1) ? ch + 2 : ch1 - 1;  // tail: harmless re-reads
+      GPSA_GR_STAGE(nx, buf == 0 ? 2 : buf - 1)
+    }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
@@ -491,20 +654,24 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int s0 = 2 * pr, s1 = (2 * pr + 1 < NSLOT) ? 2 * pr + 1 : -1;
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int s0 = 2 * pr;
+        const bool two = (2 * pr + 1 < NSLOT);
+        const int s1 = two ? 2 * pr + 1 : 0;
         float4 a0 = fa[cur][0], a1 = fa[cur][1];
         const float4 b0 = fb[cur][0], b1 = fb[cur][1];
         a0.x *= g4.x; a0.y *= g4.y; a0.z *= g4.z; a0.w *= g4.w;
         a1.x *= g4.x; a1.y *= g4.y; a1.z *= g4.z; a1.w *= g4.w;
-        if (s1 >= 0) {
+        if (two) {
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
-          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[s1], 0, 0, 0);
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
-          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[s1], 0, 0, 0);
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
-          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[s1], 0, 0, 0);
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
-          acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[2 * pr + 1 < NSLOT ? 2 * pr + 1 : 0], 0, 0, 0);
+          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[s1], 0, 0, 0);
         } else {
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
@@ -514,12 +681,11 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (tid < GR_KC) sG[buf ^ 1][tid] = gstage;
-    GPSA_DMA_DRAIN();
+    GPSA_DMA_WAIT(NPW + 1);
     __syncthreads();
-    buf ^= 1;
+    buf = (buf == 2) ? 0 : buf + 1;
   }
-#undef GPSA_GR_G
+  GPSA_DMA_DRAIN();
 #undef GPSA_GR_STAGE
   float* P = part + ((long long)l * nsplit + sp) * MP * MP;
 #pragma unroll
@@ -613,6 +779,29 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
   return 0;
 }
 
+static int quad_sym_launch(int MBsel, const float* Ppk, const float* X, int M, long long C, int L,
+                           float* out, hipStream_t st) {
+#define GPSA_QS_CASE(MBV, NCTV)                                                                  \
+  case MBV: {                                                                                    \
+    const long long T = cdiv(C, 64 * NCTV) * L;                                                  \
+    long long grid = (long long)num_cus() * ((MBV * NCTV >= 24) ? 1 : 2);                        \
+    if (grid > T) grid = T;                                                                      \
+    quad_sym_mfma_kernel<MBV, NCTV><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, M, C, L, out);       \
+  } break;
+  switch (MBsel) {
+    GPSA_QS_CASE(2, 4)
+    GPSA_QS_CASE(4, 4)
+    GPSA_QS_CASE(7, 4)
+    GPSA_QS_CASE(13, 3)
+    GPSA_QS_CASE(16, 2)
+    default:
+      return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_QS_CASE
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
 static inline int gram_nsplit(long long C, int L) {
   // grid = L x nsplit workgroups, one per CU at a time: pick the split (roughly 2-4 waves of the chip)
   // that leaves the last wave of workgroups fullest
@@ -635,15 +824,31 @@ static inline int gram_nsplit(long long C, int L) {
   return (int)best;
 }
 
+// gpad[l][c] = g[l][c] for c < C, 0 for C <= c < Cpad
+__global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
+                                float* __restrict__ gpad) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)L * Cpad) return;
+  const long long l = idx / Cpad, c = idx % Cpad;
+  gpad[idx] = c < C ? g[l * C + c] : 0.f;
+}
+
+static inline long long gram_gpad_floats(long long C, int L) { return (long long)L * cdiv(C, GR_KC) * GR_KC; }
+
 static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
-                            float* dOmega, float* part, hipStream_t st) {
+                            float* dOmega, float* ws, hipStream_t st) {
   const int ns = gram_nsplit(C, L);
+  const long long Cpad = cdiv(C, GR_KC) * GR_KC;
+  float* gpad = ws;
+  float* part = ws + ((gram_gpad_floats(C, L) + 63) / 64) * 64;
+  pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, gpad);
+  GPSA_LAUNCH_CHECK();
   dim3 grid((unsigned)L, (unsigned)ns);
-  const bool al = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0);
+  const bool al = (C % 4 == 0) && (C >= 8) && ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0);
 #define GPSA_GRAM_CASE(MBV)                                                                   \
   case MBV:                                                                                   \
-    if (al) gram_mfma_kernel<MBV, true><<<grid, 256, 0, st>>>(alpha, g, M, C, ns, part);      \
-    else gram_mfma_kernel<MBV, false><<<grid, 256, 0, st>>>(alpha, g, M, C, ns, part);        \
+    if (al) gram_mfma_kernel<MBV, true><<<grid, 256, 0, st>>>(alpha, gpad, M, C, ns, part);   \
+    else gram_mfma_kernel<MBV, false><<<grid, 256, 0, st>>>(alpha, gpad, M, C, ns, part);     \
     break;
   switch (MBsel) {
     GPSA_GRAM_CASE(2)
@@ -662,10 +867,15 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
   return 0;
 }
 
+static inline long long gram_ws_bytes(int MB, long long C, int L) {
+  return (((gram_gpad_floats(C, L) + 63) / 64) * 64 + (long long)L * gram_nsplit(C, L) * MB * 16 * MB * 16) * 4;
+}
+
 static int pack_f32(const float* src, int M, int MB, int L, int transpose, float* dst,
-                    hipStream_t st) {
+                    hipStream_t st, int sym_lower = 0) {
   const long long tot = (long long)L * MB * 16 * MB * 16;
-  pack_panels_kernel<float><<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(src, M, MB, L, transpose, dst);
+  pack_panels_kernel<float><<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(src, M, MB, L, transpose, dst,
+                                                                      sym_lower);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -678,8 +888,11 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   const long long sz = (dtype == GPSA_F64) ? 8 : 4;
   const int MB = gpsa::mfma_mb_for(M);
   long long mfma = 0;
-  if (dtype == GPSA_F32 && MB)
-    mfma = (long long)L * MB * 16 * MB * 16 * 4 * (1 + (long long)gpsa::gram_nsplit(C, L));
+  if (dtype == GPSA_F32 && MB) {
+    mfma = (long long)L * MB * 16 * MB * 16 * 4;
+    const long long gw = gpsa::gram_ws_bytes(MB, C, L);
+    if (gw > mfma) mfma = gw;
+  }
   int lc = L < 4 ? L : 4;
   long long generic = (long long)M * C * sz * lc;                         // fwd: lc slabs of T
   long long bo = (long long)M * C * sz + (long long)gpsa::gram_splitk(C, M) * M * M * sz;  // bwd_omega
@@ -697,8 +910,10 @@ int gpsa_quadform_fwd(int dtype, const void* alpha, const void* Omega, int M, lo
     if (MB && !force_generic()) {
       if (workspace_bytes < (long long)L * MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_f32((const float*)Omega, M, MB, L, 0, Ppk, st);
+      static const bool full = [] { const char* e = getenv("GPSA_QUAD_FULL"); return e && e[0] == '1'; }();
+      int rc = pack_f32((const float*)Omega, M, MB, L, 0, Ppk, st, full ? 0 : 1);
       if (rc) return rc;
+      if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
                                           nullptr, 1.f, st);
     }
@@ -746,8 +961,7 @@ int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, 
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
     if (MB && !force_generic()) {
-      const long long need = (long long)L * gram_nsplit(C, L) * MB * 16 * MB * 16 * 4;
-      if (workspace_bytes < need) return GPSA_EWORKSPACE;
+      if (workspace_bytes < gram_ws_bytes(MB, C, L)) return GPSA_EWORKSPACE;
       return gram_mfma_launch(MB, (const float*)alpha, (const float*)g, M, C, L, (float*)dOmega,
                               (float*)workspace, st);
     }
