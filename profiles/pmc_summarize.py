@@ -33,8 +33,13 @@ def main():
         fb = 2.0 * 1024.0 * sum(fetch[k]) / len(fetch[k])
         wb = 1024.0 * sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
         out["kernels"][k[:120]] = {"launches": len(fetch[k]), "fetch_bytes": fb, "write_bytes": wb}
-        if "panel_mfma_kernel<13, 3, 0>" in k:
-            out["quadform_fwd_hbm_bytes_per_launch"] = fb + wb
+        bl = out.setdefault("hbm_bytes_per_launch", {})
+        if "quad_sym_mfma_kernel" in k or ("panel_mfma_kernel" in k and ", 0>" in k):
+            bl["quadform_fwd"] = fb + wb
+        elif "panel_mfma_kernel" in k and ", 1>" in k:
+            bl["quadform_bwd_alpha"] = fb + wb
+        elif "gram_mfma_kernel" in k:
+            bl["quadform_bwd_omega"] = fb + wb
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json"), "w"), indent=1)
     for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["fetch_bytes"])[:12]:
         print("%-100s fetch %9.1f MB write %9.1f MB" % (k[:100], v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6))
