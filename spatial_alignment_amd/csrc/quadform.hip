@@ -548,6 +548,7 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   // conflict-free ds_read_b128 at lane*16 bytes.
   constexpr int NPW = (NPIECE + 3) / 4;  // LDS-DMA pieces per wave per stage (uniform; + 1 for g)
   __shared__ __attribute__((aligned(16))) float sA[3][NPW * 4 * 256];  // ring, 2 stages in flight
+  __shared__ __attribute__((aligned(16))) float sAs[NPW * 4 * 256];    // g-scaled copy of the chunk in use
   __shared__ __attribute__((aligned(16))) float sG[3][GR_KC];
   __shared__ int sOff[NSLOT * 4][2];
 
@@ -627,10 +628,25 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
       const long long nx = (ch + 2 < ch1) ? ch + 2 : ch1 - 1;  // tail: harmless re-reads
       GPSA_GR_STAGE(nx, buf == 0 ? 2 : buf - 1)
     }
+    // phase A: every fragment of the chunk is scaled by g ONCE into sAs (the A-side image); a multiply
+    // per MFMA inside the tile loop cost 33 % of the kernel (measured), this costs ~7 per wave per chunk
+#pragma unroll
+    for (int pc = 0; pc < NPW; ++pc) {
+      const int piece = pc * 4 + w;
+      if (piece < NPIECE) {
+        const int kb = piece % NKB;
+        const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
+        const float4 t = *reinterpret_cast<const float4*>(&sA[buf][piece * 256 + lane * 4]);
+        *reinterpret_cast<float4*>(&sAs[piece * 256 + lane * 4]) =
+            make_float4(t.x * g4.x, t.y * g4.y, t.z * g4.z, t.w * g4.w);
+      }
+    }
+    __syncthreads();
+    // phase B: tile products, A from the scaled image, B from the raw one, no VALU in the loop
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
       const float* base = &sA[buf][kb * 256 + lane * 4];
+      const float* bases = &sAs[kb * 256 + lane * 4];
       // tiles are processed in pairs with their MFMAs interleaved (a 16x16x4 MFMA has a 40-cycle
       // dependent latency but a 32-cycle issue interval: two independent accumulators keep the pipe
       // full); the operand fragments of the next pair are fetched while this pair computes.
@@ -639,7 +655,7 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int s = u < NSLOT ? u : NSLOT - 1;
-        fa[0][u] = *reinterpret_cast<const float4*>(base + oa[s]);
+        fa[0][u] = *reinterpret_cast<const float4*>(bases + oa[s]);
         fb[0][u] = *reinterpret_cast<const float4*>(base + ob[s]);
       }
 #pragma unroll
@@ -649,20 +665,16 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int s = (2 * pr + 2 + u) < NSLOT ? (2 * pr + 2 + u) : NSLOT - 1;
-            fa[nxt][u] = *reinterpret_cast<const float4*>(base + oa[s]);
+            fa[nxt][u] = *reinterpret_cast<const float4*>(bases + oa[s]);
             fb[nxt][u] = *reinterpret_cast<const float4*>(base + ob[s]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int dummy = 0;
-        (void)dummy;
         const int s0 = 2 * pr;
         const bool two = (2 * pr + 1 < NSLOT);
         const int s1 = two ? 2 * pr + 1 : 0;
-        float4 a0 = fa[cur][0], a1 = fa[cur][1];
+        const float4 a0 = fa[cur][0], a1 = fa[cur][1];
         const float4 b0 = fb[cur][0], b1 = fb[cur][1];
-        a0.x *= g4.x; a0.y *= g4.y; a0.z *= g4.z; a0.w *= g4.w;
-        a1.x *= g4.x; a1.y *= g4.y; a1.z *= g4.z; a1.w *= g4.w;
         if (two) {
           acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
           acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[s1], 0, 0, 0);
