@@ -21,7 +21,7 @@ struct DenseGlobal {  // global row-major [M][M]
 };
 
 // Right-looking Cholesky on accessor `a`; sdiag[M] scratch receives the diagonal of L.
-template <typename Acc>
+template <bool FAST, typename Acc>
 __device__ void chol_body(Acc a, int M, double* sdiag, double* logdet_out, int* info_out) {
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;  // 32 x 32
   double ld = 0.0;
@@ -37,9 +37,39 @@ __device__ void chol_body(Acc a, int M, double* sdiag, double* logdet_out, int* 
     if (tid == 0) sdiag[j] = s;
     for (int i = j + 1 + tid; i < M; i += LA_THREADS) a.at(i, j) *= inv;
     __syncthreads();
-    for (int i = j + 1 + ty; i < M; i += 32) {
-      const double lij = a.at(i, j);
-      for (int k = j + 1 + tx; k <= i; k += 32) a.at(i, k) -= lij * a.at(k, j);
+    const int R = (M - j - 1 + 31) >> 5;  // 32 x 32 blocks of the trailing matrix (uniform)
+    if (FAST && R <= 7) {
+      // all operands of a thread's updates are fetched before the FMAs (independent elements): the
+      // update is bound by LDS bandwidth instead of one LDS round trip per element
+      double li[7], lk[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int i = j + 1 + ty + 32 * q, k = j + 1 + tx + 32 * q;
+        li[q] = (q < R && i < M) ? a.at(i, j) : 0.0;
+        lk[q] = (q < R && k < M) ? a.at(k, j) : 0.0;
+      }
+#pragma unroll
+      for (int qa = 0; qa < 7; ++qa) {
+        if (qa < R) {
+          const int i = j + 1 + ty + 32 * qa;
+          double e[7];
+#pragma unroll
+          for (int qb = 0; qb <= qa; ++qb) {
+            const int k = j + 1 + tx + 32 * qb;
+            e[qb] = (i < M && k <= i) ? a.at(i, k) : 0.0;
+          }
+#pragma unroll
+          for (int qb = 0; qb <= qa; ++qb) {
+            const int k = j + 1 + tx + 32 * qb;
+            if (i < M && k <= i) a.at(i, k) = e[qb] - li[qa] * lk[qb];
+          }
+        }
+      }
+    } else {
+      for (int i = j + 1 + ty; i < M; i += 32) {
+        const double lij = a.at(i, j);
+        for (int k = j + 1 + tx; k <= i; k += 32) a.at(i, k) -= lij * a.at(k, j);
+      }
     }
     __syncthreads();
   }
@@ -65,7 +95,7 @@ chol_packed_kernel(double* __restrict__ A, int M, double* __restrict__ logdet,
     if (j <= i) a.at(i, j) = G[e];
   }
   __syncthreads();
-  chol_body(a, M, sdiag, logdet + blockIdx.x, info + blockIdx.x);
+  chol_body<false>(a, M, sdiag, logdet + blockIdx.x, info + blockIdx.x);  // <true>: measured slower (0.56 vs 0.41 ms)
   for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
     const int i = e / M, j = e - i * M;
     G[e] = (j <= i) ? a.at(i, j) : 0.0;
@@ -78,7 +108,7 @@ chol_global_kernel(double* __restrict__ A, int M, double* __restrict__ logdet,
                    int* __restrict__ info) {
   __shared__ double sdiag[LA_GLOBAL_MAX];
   DenseGlobal a{A + (long long)blockIdx.x * M * M, M};
-  chol_body(a, M, sdiag, logdet + blockIdx.x, info + blockIdx.x);
+  chol_body<false>(a, M, sdiag, logdet + blockIdx.x, info + blockIdx.x);
   for (int e = threadIdx.x; e < M * M; e += LA_THREADS) {
     const int i = e / M, j = e - i * M;
     if (j > i) a.p[e] = 0.0;
@@ -90,19 +120,29 @@ chol_global_kernel(double* __restrict__ A, int M, double* __restrict__ logdet,
 // row.  256 columns x 4-way split of the inner sum per pass; the 4 partial sums meet by shuffles.
 template <typename Acc>
 __device__ void tri_inv_body(Acc a, int M, double* rowL) {
-  const int tid = threadIdx.x, ks = tid & 3, cl = tid >> 2;
+  // lane = (column within a 16-column group, k-split 0..3): the 16 lanes of one k-split read 16
+  // CONSECUTIVE elements of one packed row (conflict-free); the 4 partial sums meet by shuffles
+  const int tid = threadIdx.x;
+  const int ks = (tid >> 4) & 3, cl = (tid & 15) + ((tid >> 6) << 4);
   for (int i = 0; i < M; ++i) {
     for (int k = tid; k <= i; k += LA_THREADS) rowL[k] = a.at(i, k);
     __syncthreads();
     const double inv = 1.0 / rowL[i];
     for (int c0 = 0; c0 < i; c0 += LA_THREADS / 4) {
       const int c = c0 + cl;
-      double s = 0.0;
-      if (c < i)
-        for (int k = c + ks; k < i; k += 4) s += rowL[k] * a.at(k, c);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      if (c < i && ks == 0) a.at(i, c) = -s * inv;
+      double s0 = 0.0, s1 = 0.0;
+      if (c < i) {
+        int k = c + ks;
+        for (; k + 4 < i; k += 8) {
+          s0 += rowL[k] * a.at(k, c);
+          s1 += rowL[k + 4] * a.at(k + 4, c);
+        }
+        if (k < i) s0 += rowL[k] * a.at(k, c);
+      }
+      double sum = s0 + s1;
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (c < i && ks == 0) a.at(i, c) = -sum * inv;
     }
     if (tid == 0) a.at(i, i) = inv;
     __syncthreads();
