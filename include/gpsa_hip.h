@@ -127,7 +127,8 @@ int gpsa_loglik_bwd(const float* F, const float* Y, const float* noise_u, const 
 /* ---- small helpers used by the KL terms (vgpsa.py:498-530) -------------------------------------
  * out[b] = sum_i A[b,i]*B[b,i] (strideA/strideB in elements; 0 broadcasts) */
 int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long long strideB,
-              long long n, int batch, void* out, void* stream);
+              long long n, int batch, void* out, void* workspace, long long workspace_bytes,
+              void* stream);  /* workspace >= 8*32*batch bytes */
 /* A[b] += s * I  (A [batch,M,M]) */
 int gpsa_add_diag(int dtype, void* A, int M, int batch, double s, void* stream);
 

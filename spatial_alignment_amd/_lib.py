@@ -36,7 +36,7 @@ SIGNATURES = {
     "gpsa_warp_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_loglik_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_loglik_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
-    "gpsa_bdot": (_i, [_i, _vp, _ll, _vp, _ll, _ll, _i, _vp, _vp]),
+    "gpsa_bdot": (_i, [_i, _vp, _ll, _vp, _ll, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_add_diag": (_i, [_i, _vp, _i, _i, _d, _vp]),
 }
 

@@ -181,16 +181,27 @@ tri_inv_global_kernel(const double* __restrict__ L, double* __restrict__ Linv, i
   tri_inv_body(a, M, rowL);
 }
 
+// out[b] = sum_i A[b,i]*B[b,i]; grid (batch, nsplit): partial sums per split in part[b*nsplit+s], then summed
 template <typename T>
 __global__ void bdot_kernel(const T* __restrict__ A, long long sA, const T* __restrict__ B,
-                            long long sB, long long n, T* __restrict__ out) {
+                            long long sB, long long n, double* __restrict__ part) {
   __shared__ double red[4];
   const T* a = A + (long long)blockIdx.x * sA;
   const T* b = B + (long long)blockIdx.x * sB;
   double s = 0.0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) s += (double)a[i] * (double)b[i];
+  for (long long i = blockIdx.y * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.y * blockDim.x)
+    s += (double)a[i] * (double)b[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = (T)s;
+  if (threadIdx.x == 0) part[(long long)blockIdx.x * gridDim.y + blockIdx.y] = s;
+}
+
+template <typename T>
+__global__ void bdot_finish_kernel(const double* __restrict__ part, int nsplit, int batch, T* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double s = 0.0;
+  for (int i = 0; i < nsplit; ++i) s += part[(long long)b * nsplit + i];
+  out[b] = (T)s;
 }
 
 template <typename T>
@@ -250,17 +261,24 @@ int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream) 
 }
 
 int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long long strideB,
-              long long n, int batch, void* out, void* stream) {
+              long long n, int batch, void* out, void* workspace, long long workspace_bytes,
+              void* stream) {
   if (n < 1 || batch < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (dtype == GPSA_F32)
-    gpsa::bdot_kernel<float><<<batch, 256, 0, st>>>((const float*)A, strideA, (const float*)B,
-                                                    strideB, n, (float*)out);
-  else if (dtype == GPSA_F64)
-    gpsa::bdot_kernel<double><<<batch, 256, 0, st>>>((const double*)A, strideA, (const double*)B,
-                                                     strideB, n, (double*)out);
-  else
+  int ns = (int)((n + 2047) / 2048);
+  if (ns > 32) ns = 32;
+  if (workspace_bytes < (long long)batch * ns * 8) return GPSA_EWORKSPACE;
+  double* part = (double*)workspace;
+  dim3 grid((unsigned)batch, (unsigned)ns);
+  if (dtype == GPSA_F32) {
+    gpsa::bdot_kernel<float><<<grid, 256, 0, st>>>((const float*)A, strideA, (const float*)B, strideB, n, part);
+    gpsa::bdot_finish_kernel<float><<<(batch + 63) / 64, 64, 0, st>>>(part, ns, batch, (float*)out);
+  } else if (dtype == GPSA_F64) {
+    gpsa::bdot_kernel<double><<<grid, 256, 0, st>>>((const double*)A, strideA, (const double*)B, strideB, n, part);
+    gpsa::bdot_finish_kernel<double><<<(batch + 63) / 64, 64, 0, st>>>(part, ns, batch, (double*)out);
+  } else {
     return GPSA_EINVAL;
+  }
   GPSA_LAUNCH_CHECK();
   return 0;
 }

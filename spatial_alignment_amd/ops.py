@@ -89,6 +89,8 @@ class HipOps:
         if out is None:
             assert beta == 0.0
             out = torch.empty((nb, m, n) if batched else (m, n), dtype=A.dtype, device=A.device)
+        if splitk == 1 and nb == 1 and 128 <= k <= 1024 and ((m + 63) // 64) * ((n + 63) // 64) <= 32:
+            splitk = min(4, k // 48)  # small M x M x M products are latency-bound: spread the k loop
         sA = A.stride(0) if A.dim() == 3 else 0
         sB = B.stride(0) if B.dim() == 3 else 0
         sC = out.stride(0) if out.dim() == 3 else 0
@@ -271,7 +273,9 @@ class HipOps:
         sA = n if A2.dim() == 3 else 0
         sB = n if B2.dim() == 3 else 0
         out = torch.empty(nb, dtype=A2.dtype, device=A2.device)
-        rc = self.lib.gpsa_bdot(_dt(A2), _p(A2), sA, _p(B2), sB, n, nb, _p(out), self._stream(A2))
+        ws = self._ws(8 * 32 * nb, A2)
+        rc = self.lib.gpsa_bdot(_dt(A2), _p(A2), sA, _p(B2), sB, n, nb, _p(out), _p(ws), ws.numel(),
+                                self._stream(A2))
         _lib.check(rc, "gpsa_bdot")
         return out
 
