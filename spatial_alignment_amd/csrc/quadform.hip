@@ -201,6 +201,45 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(lds_ptr_t)(p);
 }
 
+// Visiting order of a workgroup's column tiles.  The item range [it0, it1) covers tiles tile0..tile1;
+// the first and the last may be partial in l.  Full tiles are visited first, so that every workgroup
+// sweeps l = 0..L-1 in step with all the others (they start together and run at the MFMA rate): the 32
+// workgroups of an XCD then stream the SAME packed Omega_l chunk within microseconds of each other
+// and share it through their L2 instead of each pulling it over the fabric.  Then the partial last
+// tile (l from 0, still in phase) and the partial first tile.
+struct TileOrder {
+  long long tile0, tile1, nfull, n;
+  int lo0, hi1, L, fp, lp;
+  __device__ TileOrder(long long it0, long long it1, int L_) {
+    L = L_;
+    tile0 = it0 / L;
+    tile1 = (it1 - 1) / L;
+    lo0 = (int)(it0 - tile0 * L);
+    hi1 = (int)(it1 - 1 - tile1 * L);
+    if (tile0 == tile1) {
+      fp = lp = 0;
+      nfull = 0;
+      n = 1;
+    } else {
+      fp = lo0 != 0;
+      lp = hi1 != L - 1;
+      nfull = (tile1 - lp) - (tile0 + fp) + 1;
+      n = nfull + fp + lp;
+    }
+  }
+  __device__ void get(long long step, long long& tile, int& a, int& b) const {
+    if (tile0 == tile1) {
+      tile = tile0; a = lo0; b = hi1;
+    } else if (step < nfull) {
+      tile = tile0 + fp + step; a = 0; b = L - 1;
+    } else if (lp && step == nfull) {
+      tile = tile1; a = 0; b = hi1;
+    } else {
+      tile = tile0; a = lo0; b = L - 1;
+    }
+  }
+};
+
 // Persistent, balanced schedule: the work is the list of items (column tile, l) in column-tile-major
 // order; workgroup b of G processes the contiguous item range [b*T/G, (b+1)*T/G).  The wave's slab of
 // X is (re)loaded only when the column tile changes (at most ~T/G/L + 2 times).  In ACCUM mode a column
@@ -247,19 +286,21 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
              __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                \
     }                                                                                          \
   }
-  // the chunk stream of this workgroup: position -> (l, kc); staged two chunks ahead of the compute
-  const long long NQ = (it1 - it0) * MB;
-  long long sidx = 0;
-  int sl = (int)(it0 % L), skc = 0;
+  // the chunk stream of this workgroup follows the tile visiting order; staged two chunks ahead
+  const TileOrder ord(it0, it1, L);
+  long long sstep = 0, stile_;
+  int sa_, sb_, skc = 0;
+  ord.get(0, stile_, sa_, sb_);
+  int sl = sa_;
+  bool sdone = false;
 #define GPSA_STAGE_NEXT(BUF)                                                                   \
   {                                                                                            \
     GPSA_STAGE((long long)sl * MB + skc, BUF)                                                  \
-    if (sidx + 1 < NQ) {                                                                       \
-      ++sidx;                                                                                  \
-      if (++skc == MB) {                                                                       \
-        skc = 0;                                                                               \
-        sl = (sl + 1 == L) ? 0 : sl + 1;                                                       \
-      }                                                                                        \
+    if (!sdone) {                                                                              \
+      if (skc + 1 < MB) ++skc;                                                                 \
+      else if (sl < sb_) { skc = 0; ++sl; }                                                    \
+      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl = sa_; skc = 0; } \
+      else sdone = true;                                                                       \
     }                                                                                          \
   }
   // flush the accumulators of column tile TILE (ACCUM / STORE); PLAIN: this workgroup covered all l
@@ -288,16 +329,16 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
     }                                                                                       \
   }
 
-  const long long tile0 = it0 / L, tile1 = (it1 - 1) / L;
   int buf = 0;  // ring slot being computed; slot (buf+2)%3 receives the stage issued now
   GPSA_STAGE_NEXT(0)
   GPSA_STAGE_NEXT(1)
   GPSA_DMA_WAIT(NPW);
   __syncthreads();
 
-  for (long long tile = tile0; tile <= tile1; ++tile) {
-    const int l_lo = (tile == tile0) ? (int)(it0 - tile0 * L) : 0;
-    const int l_hi = (tile == tile1) ? (int)(it1 - 1 - tile1 * L) : L - 1;  // inclusive
+  for (long long step = 0; step < ord.n; ++step) {
+    long long tile;
+    int l_lo, l_hi;  // inclusive
+    ord.get(step, tile, l_lo, l_hi);
     const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -432,32 +473,34 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
              __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][sl * 256])));                   \
     }                                                                                          \
   }
-  // step stream of this workgroup, staged two steps ahead of the compute
-  const long long NQ = (it1 - it0) * NSTEP;
-  long long sidx = 0;
-  int sl_ = (int)(it0 % L), sp_ = 0;
+  // step stream of this workgroup (follows the tile visiting order), staged two steps ahead
+  const TileOrder ord(it0, it1, L);
+  long long sstep = 0, stile_;
+  int sa_, sb_, sp_ = 0;
+  ord.get(0, stile_, sa_, sb_);
+  int sl_ = sa_;
+  bool sdone = false;
 #define GPSA_QS_STAGE_NEXT(BUF)                                                                \
   {                                                                                            \
     GPSA_QS_STAGE(sl_, sp_, BUF)                                                               \
-    if (sidx + 1 < NQ) {                                                                       \
-      ++sidx;                                                                                  \
-      if (++sp_ == NSTEP) {                                                                    \
-        sp_ = 0;                                                                               \
-        sl_ = (sl_ + 1 == L) ? 0 : sl_ + 1;                                                    \
-      }                                                                                        \
+    if (!sdone) {                                                                              \
+      if (sp_ + 1 < NSTEP) ++sp_;                                                              \
+      else if (sl_ < sb_) { sp_ = 0; ++sl_; }                                                  \
+      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl_ = sa_; sp_ = 0; } \
+      else sdone = true;                                                                       \
     }                                                                                          \
   }
 
-  const long long tile0 = it0 / L, tile1 = (it1 - 1) / L;
   int buf = 0;
   GPSA_QS_STAGE_NEXT(0)
   GPSA_QS_STAGE_NEXT(1)
   GPSA_DMA_WAIT(NPW);
   __syncthreads();
 
-  for (long long tile = tile0; tile <= tile1; ++tile) {
-    const int l_lo = (tile == tile0) ? (int)(it0 - tile0 * L) : 0;
-    const int l_hi = (tile == tile1) ? (int)(it1 - 1 - tile1 * L) : L - 1;
+  for (long long step = 0; step < ord.n; ++step) {
+    long long tile;
+    int l_lo, l_hi;
+    ord.get(step, tile, l_lo, l_hi);
     const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
