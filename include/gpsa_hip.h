@@ -132,6 +132,17 @@ int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long l
 /* A[b] += s * I  (A [batch,M,M]) */
 int gpsa_add_diag(int dtype, void* A, int M, int batch, double s, void* stream);
 
+/* ---- inducing-point initialisation: Lloyd's k-means on the device ----------
+ * replaces sklearn.cluster.KMeans at gpsa/models/vgpsa.py:74-76, 90-92.  X [N,D] fp32, centres [K,D].
+ * gpsa_kmeans_assign: assign[n] = nearest centre (ties -> lowest index), d2[n] (may be NULL) its
+ *   squared distance.   gpsa_kmeans_update: centres[k] = mean of its points (empty cluster: unchanged),
+ *   counts[k] (may be NULL).  Deterministic (no atomics). */
+long long gpsa_kmeans_workspace(long long N, int D, int K);
+int gpsa_kmeans_assign(const float* X, long long N, int D, const float* centres, int K, int* assign,
+                       float* d2, void* stream);
+int gpsa_kmeans_update(const float* X, const int* assign, long long N, int D, int K, float* centres,
+                       int* counts, void* workspace, long long workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

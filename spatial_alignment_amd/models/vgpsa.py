@@ -94,22 +94,31 @@ class VariationalGPSA(GPSA):
         V, D = self.n_views, self.n_spatial_dims
         mods = self.modality_names
         if data_init:
-            # inducing locations = k-means centres of the data (vgpsa.py:61-92)
-            from sklearn.cluster import KMeans
+            # inducing locations = k-means centres of the data (vgpsa.py:61-92).  Coordinates that
+            # already live in HBM are clustered there (init.kmeans, HIP Lloyd iterations); CPU tensors
+            # take the reference's scikit-learn path.
+            first = data_dict[mods[0]]["spatial_coords"]
+            on_device = bool(getattr(first, "is_cuda", False))
+            if on_device:
+                from ..init import kmeans as _kmeans
+
+                def centres(X, k):
+                    return _kmeans(X, k, seed=int(np.random.randint(0, 2**31 - 1))).cpu()
+            else:
+                from sklearn.cluster import KMeans
+
+                def centres(X, k):
+                    return torch.tensor(KMeans(n_clusters=k).fit(X.detach().cpu().numpy()).cluster_centers_)
 
             Xt = torch.zeros([V, self.m_X_per_view, D])
             for v in range(V):
                 Xv = torch.cat([data_dict[m]["spatial_coords"][self.view_idx[m][v], :] for m in mods], 0)
-                km = KMeans(n_clusters=self.m_X_per_view).fit(Xv.detach().cpu().numpy())
-                Xt[v] = torch.tensor(km.cluster_centers_)
+                Xt[v] = centres(Xv, self.m_X_per_view)
             self.Xtilde = nn.Parameter(Xt.clone())
             # the reference draws (and discards) a subset here: raises if m_G > spots of the last view
             np.random.choice(np.arange(Xv.shape[0]), size=self.m_G, replace=False)
             allX = torch.cat([data_dict[m]["spatial_coords"] for m in mods])
-            km = KMeans(n_clusters=self.m_G).fit(allX.detach().cpu().numpy())
-            self.Gtilde = nn.Parameter(torch.tensor(km.cluster_centers_))
-            if self.Gtilde.dtype != self.Xtilde.dtype:
-                self.Gtilde = nn.Parameter(self.Gtilde.data.to(self.Xtilde.dtype))
+            self.Gtilde = nn.Parameter(centres(allX, self.m_G).to(self.Xtilde.dtype))
         elif grid_init:
             if D == 2:  # lattice over the bounding box of the first modality (vgpsa.py:94-121)
                 xy = data_dict[mods[0]]["spatial_coords"].detach().cpu().numpy()

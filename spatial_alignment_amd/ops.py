@@ -279,6 +279,30 @@ class HipOps:
         _lib.check(rc, "gpsa_bdot")
         return out
 
+    # ------------------------------------------------------------------ k-means (initialisation)
+    def kmeans_assign(self, X, centres, want_d2=False):
+        X, centres = self._c(X), self._c(centres)
+        N, D = X.shape
+        K = centres.shape[0]
+        assign = torch.empty(N, dtype=torch.int32, device=X.device)
+        d2 = torch.empty(N, dtype=torch.float32, device=X.device) if want_d2 else None
+        rc = self.lib.gpsa_kmeans_assign(_p(X), N, D, _p(centres), K, _p(assign), _p(d2), self._stream(X))
+        _lib.check(rc, "gpsa_kmeans_assign")
+        return assign, d2
+
+    def kmeans_update(self, X, assign, centres):
+        """in place: centres[k] <- mean of the points assigned to k; returns counts [K] (int32)"""
+        X = self._c(X)
+        assert centres.is_contiguous()
+        N, D = X.shape
+        K = centres.shape[0]
+        counts = torch.empty(K, dtype=torch.int32, device=X.device)
+        ws = self._ws(self.lib.gpsa_kmeans_workspace(N, D, K), X)
+        rc = self.lib.gpsa_kmeans_update(_p(X), _p(assign), N, D, K, _p(centres), _p(counts), _p(ws),
+                                         ws.numel(), self._stream(X))
+        _lib.check(rc, "gpsa_kmeans_update")
+        return counts
+
     def add_diag(self, A, s):
         assert A.is_contiguous()
         M = A.shape[-1]
