@@ -39,6 +39,8 @@ class _StepCache:
         self.Omega_G_fac = None  # (Omega_G^-1 [V*D,M,M], logdet [V*D])
         self.Omega_F_fac = {}  # mod -> (Omega_F^-1, logdet)
         self.flags = []  # device int tensors: Cholesky info / non-positive variance flags
+        self.mu_z = self.dG_v = None  # per-view prior means / variational means of this forward
+        self.Om_fwd = self.Om_kl = None  # per-view row groups of Omega_G
 
 
 class VariationalGPSA(GPSA):
@@ -214,17 +216,27 @@ class VariationalGPSA(GPSA):
         cache = _StepCache()
 
         self.noise_variance_pos = torch.exp(self.noise_variance) + self.diagonal_offset  # vgpsa.py:217
+        # per-view slices of the parameters, unbound once (one autograd node per parameter instead of
+        # a zero-fill + copy + add per slice in the backward)
+        Xt_v = self.Xtilde.unbind(0)
+        dG_v = self.delta_G_list.unbind(0)
+        wls_v = self.warp_kernel_lengthscales.unbind(0)
+        wvar_v = self.warp_kernel_variances.unbind(0)
         mu_z = []
         for v in range(V):
-            mz = E.MatmulFn.apply(self.Xtilde[v], self.mean_slopes[v]) + self.mean_intercepts[v]
+            mz = E.MatmulFn.apply(Xt_v[v], self.mean_slopes[v]) + self.mean_intercepts[v]
             if self._is_fixed(v):
                 mz = mz * 100.0  # inert (quirk 7)
             mu_z.append(mz)
         self.mu_z_G = torch.stack(mu_z)
+        cache.mu_z, cache.dG_v = mu_z, dG_v
 
         # ---- everything M x M first: all prior covariances and variational covariances of the step
         #      are factorised by ONE batched Cholesky / triangular-inverse launch per matrix size
         cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list)
+        M_X = cache.Omega_G.shape[-1]
+        cache.Om_fwd = cache.Omega_G.split(D, 0)                      # rows v*D+j  (forward, quirk 2)
+        cache.Om_kl = cache.Omega_G.view(D, V, M_X, M_X).unbind(1)    # rows j*V+v  (KL, quirk 2)
         for m in mods:
             cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m])
         rows_of = {v: {m: _as_index(view_idx[m][v], dev) for m in mods} for v in range(V)}
@@ -232,9 +244,8 @@ class VariationalGPSA(GPSA):
                 if not self._is_fixed(v) and sum(rows_of[v][m][1] for m in mods) > 0]
         Kuu_w = {}
         for v in free:
-            Z = self.Xtilde[v]
-            Kuu_w[v] = self._kmat("warp", Z, Z, self.warp_kernel_lengthscales[v],
-                                  self.warp_kernel_variances[v], self.diagonal_offset, f64, True)
+            Z = Xt_v[v]
+            Kuu_w[v] = self._kmat("warp", Z, Z, wls_v[v], wvar_v[v], self.diagonal_offset, f64, True)
         KuuF = self._kmat("data", self.Gtilde, self.Gtilde, self.data_kernel_lengthscale,
                           self.data_kernel_variance, self.diagonal_offset, f64, True)
         mats = [Kuu_w[v].unsqueeze(0) for v in free] + [KuuF.unsqueeze(0), cache.Omega_G] + \
@@ -265,11 +276,11 @@ class VariationalGPSA(GPSA):
             n = Xv.shape[0]
             if n == 0:
                 continue  # outputs stay NaN (vgpsa.py:296-297)
-            Z = self.Xtilde[v]
-            ls_u, var_u = self.warp_kernel_lengthscales[v], self.warp_kernel_variances[v]
+            Z = Xt_v[v]
+            ls_u, var_u = wls_v[v], wvar_v[v]
             Kuu, fac = cache.warp[v]
-            dc = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
-            Om = cache.Omega_G[v * D : (v + 1) * D]  # quirk 2: forward uses rows v*D+j
+            dc = dG_v[v].to(f64) - mu_z[v].to(f64)
+            Om = cache.Om_fwd[v]  # quirk 2: forward uses rows v*D+j
             kind = builtin_kind(self.kernel_func_warp)
             if kind is not None:  # fused covariance + layer, all fp64
                 meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
@@ -371,8 +382,8 @@ class VariationalGPSA(GPSA):
             if self._is_fixed(v) or v not in cache.warp:
                 continue
             Kuu, fac = cache.warp[v]
-            Dm = self.delta_G_list[v].to(f64) - self.mu_z_G[v].to(f64)
-            Om = cache.Omega_G[v::V]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
+            Dm = cache.dG_v[v].to(f64) - cache.mu_z[v].to(f64)
+            Om = cache.Om_kl[v]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
             ofac = (cache.Omega_G_fac[0][v::V].contiguous(), cache.Omega_G_fac[1][v::V])
             term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()
             kl = term if kl is None else kl + term
