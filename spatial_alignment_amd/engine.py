@@ -365,27 +365,18 @@ class MvnKLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Kuu, Dm, Omega, fac, ofac):
         o = ops()
-        Om = Omega.detach().contiguous()
+        Om = Omega.detach()
         D64 = Dm.detach().double().contiguous()
         Oinv, logdetO = ofac
-        tr = o.bdot(fac.Kinv, Om)
-        KD = o.gemm(fac.Kinv, D64)
-        maha = (D64 * KD).sum(0)
-        M = Om.shape[-1]
-        kl = 0.5 * (fac.logdet - logdetO + tr + maha - M)
-        ctx.save_for_backward(Om, Oinv, KD, fac.Kinv)
+        kl, KD = o.mvn_kl_fwd(fac.Kinv, fac.logdet, Om, logdetO, D64)
+        ctx.save_for_backward(Kuu.detach(), Om, Oinv, KD, fac.Kinv, D64)
         ctx.meta = (Dm.dtype,)
         return kl
 
     @staticmethod
     def backward(ctx, gkl):
         o = ops()
-        Om, Oinv, KD, Kinv = ctx.saved_tensors
-        gkl = gkl.double()
-        dOm = (0.5 * gkl)[:, None, None] * (Kinv.unsqueeze(0) - Oinv)
-        dDm = KD * gkl.unsqueeze(0)
-        Ssum = (gkl[:, None, None] * Om).sum(0)
-        inner = o.gemm(o.gemm(Kinv, Ssum.contiguous()), Kinv)
-        outer = o.gemm((KD * gkl.unsqueeze(0)).contiguous(), KD, transB=True)
-        dK = 0.5 * (gkl.sum() * Kinv - inner - outer)
+        Kuu, Om, Oinv, KD, Kinv, D64 = ctx.saved_tensors
+        dOm, dDm, Sp = o.mvn_kl_bwd(Kuu, Kinv, Om, Oinv, D64, KD, gkl.double().contiguous())
+        dK = o.gemm(o.gemm(Kinv, Sp), Kinv, alpha=0.5)  # 0.5 K^-1 [(sum g) K - sum_l g_l (Omega_l + d d^T)] K^-1
         return dK, dDm.to(ctx.meta[0]), dOm, None, None

@@ -384,7 +384,7 @@ class VariationalGPSA(GPSA):
             Kuu, fac = cache.warp[v]
             Dm = cache.dG_v[v].to(f64) - cache.mu_z[v].to(f64)
             Om = cache.Om_kl[v]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
-            ofac = (cache.Omega_G_fac[0][v::V].contiguous(), cache.Omega_G_fac[1][v::V])
+            ofac = (cache.Omega_G_fac[0][v::V], cache.Omega_G_fac[1][v::V])
             term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()
             kl = term if kl is None else kl + term
         KuuF, facF = cache.data

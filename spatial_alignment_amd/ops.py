@@ -279,6 +279,41 @@ class HipOps:
         _lib.check(rc, "gpsa_bdot")
         return out
 
+    # ------------------------------------------------------------------ KL terms (fp64)
+    @staticmethod
+    def _lstride(t):
+        """(tensor usable as [L, M, M] with row-major M x M blocks, stride between blocks)"""
+        M = t.shape[-1]
+        if t.stride(-1) == 1 and t.stride(-2) == M:
+            return t, t.stride(0)
+        t = t.contiguous()
+        return t, M * M
+
+    def mvn_kl_fwd(self, Kinv, logdetK, Omega, logdetO, Dm):
+        Omega, so = self._lstride(Omega)
+        L, M = Omega.shape[0], Omega.shape[-1]
+        Kinv, Dm = self._c(Kinv), self._c(Dm)
+        kl = torch.empty(L, dtype=torch.float64, device=Kinv.device)
+        KD = torch.empty(M, L, dtype=torch.float64, device=Kinv.device)
+        rc = self.lib.gpsa_mvn_kl_fwd(_p(Kinv), _p(logdetK), _p(Omega), so, _p(logdetO), logdetO.stride(0),
+                                      _p(Dm), M, L, _p(kl), _p(KD), self._stream(Kinv))
+        _lib.check(rc, "gpsa_mvn_kl_fwd")
+        return kl, KD
+
+    def mvn_kl_bwd(self, Kuu, Kinv, Omega, Oinv, Dm, KD, g):
+        Omega, so = self._lstride(Omega)
+        Oinv, si = self._lstride(Oinv)
+        L, M = Omega.shape[0], Omega.shape[-1]
+        Kuu, Kinv, Dm, KD, g = self._c(Kuu), self._c(Kinv), self._c(Dm), self._c(KD), self._c(g)
+        dev = Kinv.device
+        dOm = torch.empty(L, M, M, dtype=torch.float64, device=dev)
+        dDm = torch.empty(M, L, dtype=torch.float64, device=dev)
+        Sp = torch.empty(M, M, dtype=torch.float64, device=dev)
+        rc = self.lib.gpsa_mvn_kl_bwd(_p(Kuu), _p(Kinv), _p(Omega), so, _p(Oinv), si, _p(Dm), _p(KD), _p(g),
+                                      M, L, _p(dOm), _p(dDm), _p(Sp), self._stream(Kinv))
+        _lib.check(rc, "gpsa_mvn_kl_bwd")
+        return dOm, dDm, Sp
+
     # ------------------------------------------------------------------ k-means (initialisation)
     def kmeans_assign(self, X, centres, want_d2=False):
         X, centres = self._c(X), self._c(centres)

@@ -126,6 +126,19 @@ class FakeOps:
         ds = ((r * r) / s**3 - 1.0 / s).sum() / S
         return dF.float(), (gout[0] * ds * e).float().reshape(1)
 
+    def mvn_kl_fwd(self, Kinv, logdetK, Omega, logdetO, Dm):
+        M = Omega.shape[-1]
+        tr = (Kinv.unsqueeze(0) * Omega).sum((-1, -2))
+        KD = Kinv @ Dm
+        kl = 0.5 * (logdetK[0] - logdetO + tr + (Dm * KD).sum(0) - M)
+        return kl, KD
+
+    def mvn_kl_bwd(self, Kuu, Kinv, Omega, Oinv, Dm, KD, g):
+        dOm = (0.5 * g)[:, None, None] * (Kinv.unsqueeze(0) - Oinv)
+        dDm = KD * g.unsqueeze(0)
+        S = (g[:, None, None] * Omega).sum(0) + (Dm * g.unsqueeze(0)) @ Dm.t()
+        return dOm, dDm, g.sum() * Kuu - S
+
     def bdot(self, A, B):
         return (A * B).sum((-1, -2)).reshape(-1)
 

@@ -193,3 +193,29 @@ def test_bdot_add_diag(hip):
     X = B.clone().to(DEV)
     hip.add_diag(X, 0.25)
     close(X, FK.add_diag(B.clone(), 0.25), 1e-15)
+
+
+@pytest.mark.parametrize("M,L,strided", [(12, 3, False), (200, 50, False), (40, 2, True)])
+def test_mvn_kl_fwd_bwd(hip, M, L, strided):
+    f64 = torch.float64
+    A = rnd(M, M, dtype=f64)
+    K = A @ A.t() + 0.5 * torch.eye(M, dtype=f64)
+    Kinv = torch.linalg.inv(K)
+    V = 3 if strided else 1
+    B = rnd(L * V, M, M, dtype=f64, seed=1)
+    Om_all = B @ B.transpose(1, 2) + 0.1 * torch.eye(M, dtype=f64)
+    Oinv_all = torch.linalg.inv(Om_all)
+    ld_all = torch.logdet(Om_all)
+    Dm, g = rnd(M, L, dtype=f64, seed=2), rnd(L, dtype=f64, seed=3)
+    ldK = torch.logdet(K).reshape(1)
+    sel = slice(1 if strided else 0, None, V)
+    d = lambda t: t.to(DEV)
+    Om_d, Oi_d, ld_d = d(Om_all)[sel], d(Oinv_all)[sel], d(ld_all)[sel]
+    kl, KD = hip.mvn_kl_fwd(d(Kinv), d(ldK), Om_d, ld_d, d(Dm))
+    rkl, rKD = FK.mvn_kl_fwd(Kinv, ldK, Om_all[sel], ld_all[sel], Dm)
+    close(kl, rkl, 1e-11)
+    close(KD, rKD, 1e-11)
+    got = hip.mvn_kl_bwd(d(K), d(Kinv), Om_d, Oi_d, d(Dm), KD, d(g))
+    want = FK.mvn_kl_bwd(K, Kinv, Om_all[sel], Oinv_all[sel], Dm, rKD, g)
+    for a, b in zip(got, want):
+        close(a, b, 1e-10)
