@@ -162,7 +162,7 @@ def main():
                               note="same step (forward+ELBO+backward+Adam) as ONE hipGraph replay")),
               flush=True)
         return
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)  # same update, one fused launch
     reducer = GradAllReducer(model.parameters())
     timer = KernelTimer(ops_mod.get_ops())
 

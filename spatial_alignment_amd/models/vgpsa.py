@@ -259,23 +259,13 @@ class VariationalGPSA(GPSA):
         cache.Omega_F_fac = {m: (parts[nf + 2 + i][1], parts[nf + 2 + i][2]) for i, m in enumerate(mods)}
         cache.flags.extend(p[3] for p in parts)
 
-        nan = float("nan")
-        G_means = {m: torch.full([int(Ns[m]), D], nan, device=dev) for m in mods}
-        G_samples = {m: torch.full([S, int(Ns[m]), D], nan, device=dev) for m in mods}
-
-        draw = 0
-        for v in range(V):
+        # ---- warp GP per view (vgpsa.py:259-351) ---------------------------------------------------
+        warp_out = {}
+        for draw, v in enumerate(free):
             rows = rows_of[v]
-            if self._is_fixed(v):  # vgpsa.py:262-273
-                for m in mods:
-                    r, _ = rows[m]
-                    G_means[m][r] = X_spatial[m][r]
-                    G_samples[m][:, r, :] = X_spatial[m][r]
-                continue
-            Xv = torch.cat([X_spatial[m][rows[m][0]] for m in mods], 0)
+            Xv = torch.cat([X_spatial[m][rows[m][0]] for m in mods], 0) if len(mods) > 1 else \
+                X_spatial[mods[0]][rows[mods[0]][0]]
             n = Xv.shape[0]
-            if n == 0:
-                continue  # outputs stay NaN (vgpsa.py:296-297)
             Z = Xt_v[v]
             ls_u, var_u = wls_v[v], wvar_v[v]
             Kuu, fac = cache.warp[v]
@@ -293,15 +283,52 @@ class VariationalGPSA(GPSA):
             else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
                 eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
                     torch.empty(0, n, D, device=dev)
-            draw += 1
             Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, mux, eps)  # quirk 1 inside
             cache.flags.append(bad)
-            a = 0
-            for m in mods:
-                r, cnt = rows[m]
-                G_means[m][r] = Gm[a : a + cnt]
-                G_samples[m][:, r, :] = Gs[:, a : a + cnt]
-                a += cnt
+            warp_out[v] = (Gm, Gs)
+
+        # ---- assemble G_means [N,D] / G_samples [S,N,D] per modality --------------------------------
+        G_means, G_samples = {}, {}
+        for mi, m in enumerate(mods):
+            # fast path: the views are consecutive row blocks covering 0..N (what create_view_idx_dict
+            # produces): concatenate (its backward is a set of views, no zero-fill / copy / add)
+            edges, ok = 0, True
+            for v in range(V):
+                r, cnt = rows_of[v][m]
+                ok = ok and isinstance(r, slice) and r.start == edges and (self._is_fixed(v) or v in warp_out or cnt == 0)
+                edges += cnt
+            ok = ok and edges == int(Ns[m])
+            if ok:
+                pm, ps = [], []
+                for v in range(V):
+                    r, cnt = rows_of[v][m]
+                    if cnt == 0:
+                        continue
+                    if self._is_fixed(v):  # vgpsa.py:262-273
+                        xv = X_spatial[m][r]
+                        pm.append(xv)
+                        ps.append(xv.unsqueeze(0).expand(S, -1, -1))
+                    else:
+                        a = sum(rows_of[v][mm][1] for mm in mods[:mi])
+                        Gm, Gs = warp_out[v]
+                        pm.append(Gm[a : a + cnt])
+                        ps.append(Gs[:, a : a + cnt])
+                G_means[m] = torch.cat(pm, 0) if len(pm) > 1 else pm[0].clone()
+                G_samples[m] = torch.cat(ps, 1) if len(ps) > 1 else ps[0].clone()
+                continue
+            nan = float("nan")  # general index sets / empty views: NaN-filled scatter like the reference
+            G_means[m] = torch.full([int(Ns[m]), D], nan, device=dev)
+            G_samples[m] = torch.full([S, int(Ns[m]), D], nan, device=dev)
+            for v in range(V):
+                r, cnt = rows_of[v][m]
+                if self._is_fixed(v):
+                    G_means[m][r] = X_spatial[m][r]
+                    G_samples[m][:, r, :] = X_spatial[m][r]
+                elif v in warp_out:
+                    a = sum(rows_of[v][mm][1] for mm in mods[:mi])
+                    Gm, Gs = warp_out[v]
+                    G_means[m][r] = Gm[a : a + cnt]
+                    G_samples[m][:, r, :] = Gs[:, a : a + cnt]
 
         # ---- data GP (vgpsa.py:353-477) ----------------------------------------------------------
         ls_u, var_u = self.data_kernel_lengthscale, self.data_kernel_variance
