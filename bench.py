@@ -216,7 +216,8 @@ def main():
         N = int(sum(dd_full["expression"]["n_samples_list"]))
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        default_cfg = (args.S, args.side, args.views, args.outputs, args.M, world) == (5, 100, 2, 50, 200, 1)
+        if os.path.exists(pmc_path) and default_cfg:  # the counters were collected on the default workload
             try:
                 pmc = json.load(open(pmc_path))
             except Exception:
