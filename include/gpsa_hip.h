@@ -133,11 +133,11 @@ int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long l
 int gpsa_add_diag(int dtype, void* A, int M, int batch, double s, void* stream);
 
 /* ---- KL terms (vgpsa.py:498-530: kl_divergence(MVN(delta_l, Omega_tril_l), MVN(mu_l, Kuu_chol))), fp64 --------
- * kl[l] = 0.5 (logdet K - logdet Omega_l + <K^-1, Omega_l> + d_l^T K^-1 d_l - M),  d = delta - mu  [M,L];
- * also returns KD = K^-1 d [M,L].  omega_stride / logdet_stride: elements between consecutive l. */
+ * kl[l] = 0.5 (logdet K - logdet Omega_l + <K^-1, Omega_l> + d_l^T KD_l - M),  d = delta - mu  [M,L],
+ * KD = K^-1 d [M,L] (from gpsa_gemm).  omega_stride / logdet_stride: elements between consecutive l. */
 int gpsa_mvn_kl_fwd(const double* Kinv, const double* logdetK, const double* Omega,
                     long long omega_stride, const double* logdetO, long long logdet_stride,
-                    const double* Dm, int M, int L, double* kl, double* KD, void* stream);
+                    const double* Dm, const double* KD, int M, int L, double* kl, void* stream);
 /* backward for upstream g[l]:  dOmega[l] = 0.5 g_l (K^-1 - Omega_l^-1) [L,M,M];  dDm = KD diag(g) [M,L];
  * Sp = (sum g) K - sum_l g_l (Omega_l + d_l d_l^T)  [M,M], so that dLoss/dK = 0.5 K^-1 Sp K^-1. */
 int gpsa_mvn_kl_bwd(const double* Kuu, const double* Kinv, const double* Omega, long long omega_stride,

@@ -38,7 +38,7 @@ SIGNATURES = {
     "gpsa_loglik_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_bdot": (_i, [_i, _vp, _ll, _vp, _ll, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_add_diag": (_i, [_i, _vp, _i, _i, _d, _vp]),
-    "gpsa_mvn_kl_fwd": (_i, [_vp, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _vp, _vp, _vp]),
+    "gpsa_mvn_kl_fwd": (_i, [_vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _vp, _vp]),
     "gpsa_mvn_kl_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "gpsa_kmeans_workspace": (_ll, [_ll, _i, _i]),
     "gpsa_kmeans_assign": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _vp]),

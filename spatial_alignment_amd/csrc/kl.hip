@@ -7,30 +7,23 @@
 
 namespace gpsa {
 
-// one block per l:  kl[l] = 0.5 (logdetK - logdetO[l] + <Kinv, Omega_l> + d_l^T Kinv d_l - M),
-//                   KD[m,l] = (Kinv d_l)[m]           (Kinv symmetric)
-__global__ void __launch_bounds__(256)
+// one 1024-thread block per l:  kl[l] = 0.5 (logdetK - logdetO[l] + <Kinv, Omega_l> + d_l^T KD_l - M)
+// with KD = Kinv d (computed by the caller with the dense-product kernel)
+__global__ void __launch_bounds__(1024)
 mvn_kl_fwd_kernel(const double* __restrict__ Kinv, const double* __restrict__ logdetK,
                   const double* __restrict__ Omega, long long omega_stride,
                   const double* __restrict__ logdetO, long long logdet_stride,
-                  const double* __restrict__ Dm, int M, int L, double* __restrict__ kl,
-                  double* __restrict__ KD) {
-  __shared__ double red[4];
+                  const double* __restrict__ Dm, const double* __restrict__ KD, int M, int L,
+                  double* __restrict__ kl) {
+  __shared__ double red[16];
   const int l = blockIdx.x;
   const double* Om = Omega + (long long)l * omega_stride;
-  double tr = 0.0;
-  for (int e = threadIdx.x; e < M * M; e += 256) tr += Kinv[e] * Om[e];
-  double maha = 0.0;
-  for (int m = threadIdx.x; m < M; m += 256) {
-    double s = 0.0;
-    for (int k = 0; k < M; ++k) s += Kinv[(long long)k * M + m] * Dm[(long long)k * L + l];
-    KD[(long long)m * L + l] = s;
-    maha += s * Dm[(long long)m * L + l];
-  }
-  const double t = block_sum(tr, red);
-  const double h = block_sum(maha, red);
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < M * M; e += 1024) acc += Kinv[e] * Om[e];
+  for (int m = threadIdx.x; m < M; m += 1024) acc += KD[(long long)m * L + l] * Dm[(long long)m * L + l];
+  const double t = block_sum(acc, red);
   if (threadIdx.x == 0)
-    kl[l] = 0.5 * (logdetK[0] - logdetO[(long long)l * logdet_stride] + t + h - (double)M);
+    kl[l] = 0.5 * (logdetK[0] - logdetO[(long long)l * logdet_stride] + t - (double)M);
 }
 
 // thread per (i,j):  dOmega[l][i][j] = 0.5 g_l (Kinv - Oinv_l)[i][j]
@@ -66,10 +59,10 @@ extern "C" {
 
 int gpsa_mvn_kl_fwd(const double* Kinv, const double* logdetK, const double* Omega,
                     long long omega_stride, const double* logdetO, long long logdet_stride,
-                    const double* Dm, int M, int L, double* kl, double* KD, void* stream) {
+                    const double* Dm, const double* KD, int M, int L, double* kl, void* stream) {
   if (M < 1 || L < 1) return GPSA_EINVAL;
-  gpsa::mvn_kl_fwd_kernel<<<L, 256, 0, as_stream(stream)>>>(Kinv, logdetK, Omega, omega_stride, logdetO,
-                                                            logdet_stride, Dm, M, L, kl, KD);
+  gpsa::mvn_kl_fwd_kernel<<<L, 1024, 0, as_stream(stream)>>>(Kinv, logdetK, Omega, omega_stride, logdetO,
+                                                             logdet_stride, Dm, KD, M, L, kl);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

@@ -51,16 +51,21 @@ __global__ void col_axpy_kernel(const T* __restrict__ Y, const T* __restrict__ X
   }
 }
 
-// v[b,c] = sum_m X[m,c] * Tm[b,m,c]
+// v[b,c] = sum_m X[m,c] * Tm[b,m,c]; block = 64 columns x 4 row quarters (summed through LDS)
 template <typename T>
-__global__ void coldot_kernel(const T* __restrict__ X, const T* __restrict__ Tm, int M, long long C,
-                              T* __restrict__ v, long long vstride) {
-  const long long c = blockIdx.x * 256LL + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256)
+coldot_kernel(const T* __restrict__ X, const T* __restrict__ Tm, int M, long long C,
+              T* __restrict__ v, long long vstride) {
+  __shared__ T red[4][64];
+  const int lane = threadIdx.x & 63, qr = threadIdx.x >> 6;
+  const long long c = blockIdx.x * 64LL + lane;
   const T* t = Tm + (long long)blockIdx.y * M * C;
   T s = T(0);
-  for (int m = 0; m < M; ++m) s += X[(long long)m * C + c] * t[(long long)m * C + c];
-  v[(long long)blockIdx.y * vstride + c] = s;
+  if (c < C)
+    for (int m = qr; m < M; m += 4) s += X[(long long)m * C + c] * t[(long long)m * C + c];
+  red[qr][lane] = s;
+  __syncthreads();
+  if (qr == 0 && c < C) v[(long long)blockIdx.y * vstride + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 template <typename T>
@@ -77,7 +82,7 @@ int generic_quadform_fwd(const T* alpha, const T* Omega, int M, long long C, int
                             (long long)M * M, alpha, C, 0, 0.0, Tm, C, (long long)M * C, nb, 1,
                             nullptr, 0, st);
     if (rc) return rc;
-    dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)nb);
     coldot_kernel<T><<<grid, 256, 0, st>>>(alpha, Tm, M, C, v + (long long)l0 * C, C);
     GPSA_LAUNCH_CHECK();
   }
@@ -131,16 +136,22 @@ int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, i
   return 0;
 }
 
+// q[c] = sum_m Y[m,c]^2; block = 64 columns x 4 row quarters
 template <typename T>
-__global__ void colsq_kernel(const T* __restrict__ Y, int M, long long C, T* __restrict__ q) {
-  const long long c = blockIdx.x * 256LL + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256)
+colsq_kernel(const T* __restrict__ Y, int M, long long C, T* __restrict__ q) {
+  __shared__ T red[4][64];
+  const int lane = threadIdx.x & 63, qr = threadIdx.x >> 6;
+  const long long c = blockIdx.x * 64LL + lane;
   T s = T(0);
-  for (int m = 0; m < M; ++m) {
-    T y = Y[(long long)m * C + c];
-    s += y * y;
-  }
-  q[c] = s;
+  if (c < C)
+    for (int m = qr; m < M; m += 4) {
+      const T y = Y[(long long)m * C + c];
+      s += y * y;
+    }
+  red[qr][lane] = s;
+  __syncthreads();
+  if (qr == 0 && c < C) q[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,7 +264,8 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
                   int M, long long C, int L,
                   float* __restrict__ out,        // QUAD: v [L][C]; ACCUM/STORE: Y [M][C]
                   float* __restrict__ colsq,      // STORE: optional [C]
-                  float out_scale) {
+                  float out_scale,
+                  float* __restrict__ slab) {     // ACCUM: [gridDim.x][2][MP][WGCOLS] partial tiles
   constexpr int MP = MB * 16;
   constexpr int WGCOLS = 64 * NCT;
   constexpr int CHUNK = MP * 16;                    // floats per K chunk (MB pieces of 256 floats)
@@ -303,23 +315,28 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
       else sdone = true;                                                                       \
     }                                                                                          \
   }
-  // flush the accumulators of column tile TILE (ACCUM / STORE); PLAIN: this workgroup covered all l
-  // of the tile, otherwise its partial sum is combined atomically
-#define GPSA_FLUSH(TILE, PLAIN)                                                             \
+  // flush the accumulators of column tile TILE (ACCUM / STORE).  PLAIN: this workgroup covered all l of
+  // the tile -> straight to the output.  Otherwise the partial sum goes to one of this workgroup's two
+  // slabs (WHICH = 0: its first tile, 1: its last tile) and panel_slab_reduce_kernel adds the slabs of
+  // a tile in workgroup order: no atomics, any number of contributors, bitwise reproducible.
+#define GPSA_FLUSH(TILE, PLAIN, WHICH)                                                      \
   {                                                                                         \
     const long long cw__ = (TILE) * WGCOLS + (long long)w * (16 * NCT);                     \
+    const bool pl__ = (PLAIN);                                                              \
+    float* dst__ = pl__ ? out : slab + ((long long)blockIdx.x * 2 + (WHICH)) * MP * WGCOLS; \
+    const long long rs__ = pl__ ? C : (long long)WGCOLS;                                    \
+    const int mlim__ = pl__ ? M : MP;                                                       \
     _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                    \
       const long long c = cw__ + ct * 16 + j;                                               \
+      const long long col__ = pl__ ? c : (long long)(w * (16 * NCT) + ct * 16 + j);         \
+      const bool okc__ = pl__ ? (c < C) : true;                                             \
       float s = 0.f;                                                                        \
       _Pragma("unroll") for (int rt = 0; rt < MB; ++rt)                                     \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                     \
           const int row = rt * 16 + kq * 4 + r;                                             \
           const float y = acc[rt][ct][r] * out_scale;                                       \
           s += y * y;                                                                       \
-          if (c < C && row < M) {                                                           \
-            if (PLAIN) out[(long long)row * C + c] = y;                                     \
-            else atomicAdd(&out[(long long)row * C + c], y);                                \
-          }                                                                                 \
+          if (okc__ && row < mlim__) dst__[(long long)row * rs__ + col__] = y;              \
         }                                                                                   \
       if (MODE == MODE_STORE && colsq != nullptr) {                                         \
         s += __shfl_xor(s, 16, 64);                                                         \
@@ -416,7 +433,7 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
     }
     if (MODE != MODE_QUAD) {
       const bool plain = (l_lo == 0) && (l_hi == L - 1);
-      GPSA_FLUSH(tile, plain)
+      GPSA_FLUSH(tile, plain, (tile == ord.tile0) ? 0 : 1)
     }
   }
   GPSA_DMA_DRAIN();  // nothing may still be writing this workgroup's LDS when it exits
@@ -800,25 +817,53 @@ static int num_cus() {
   return n;
 }
 
+// Adds, in workgroup order, the partial-tile slabs that panel_mfma_kernel<ACCUM> wrote: tile t is
+// shared by the workgroups whose item ranges [b*T/G, (b+1)*T/G) cut into [t*L, (t+1)*L).
+__global__ void __launch_bounds__(256)
+panel_slab_reduce_kernel(const float* __restrict__ slab, int M, int MP, int wgcols, long long C, int L,
+                         long long ntiles, int G, float* __restrict__ out) {
+  const long long t = blockIdx.x;
+  const long long T = ntiles * L, lo = t * L, hi = lo + L;
+  long long b0 = lo * G / T;
+  while (b0 > 0 && (b0 * T / G) > lo) --b0;
+  while (((b0 + 1) * T / G) <= lo) ++b0;
+  long long b1 = b0;
+  while (b1 + 1 < G && ((b1 + 1) * T / G) < hi) ++b1;
+  if (b0 == b1) return;  // a single workgroup owned the whole tile: it stored straight to `out`
+  const long long cbase = t * wgcols;
+  for (int e = threadIdx.x + blockIdx.y * 256; e < M * wgcols; e += 256 * gridDim.y) {
+    const int row = e / wgcols, cl = e % wgcols;
+    const long long c = cbase + cl;
+    if (c >= C) continue;
+    float s = 0.f;
+    for (long long b = b0; b <= b1; ++b) {
+      const long long i0 = b * T / G, i1 = (b + 1) * T / G;
+      if (i1 <= i0) continue;
+      const int which = ((i0 / L) == t) ? 0 : 1;  // the tile is this workgroup's first tile, else its last
+      s += slab[((b * 2 + which) * MP + row) * (long long)wgcols + cl];
+    }
+    out[(long long)row * C + c] = s;
+  }
+}
+
 template <int MODE>
 int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* g, int M,
-                      long long C, int L, float* out, float* colsq, float scale, hipStream_t st) {
-  if (MODE == MODE_ACCUM) {  // partial column tiles are combined with atomics
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-  }
+                      long long C, int L, float* out, float* colsq, float scale, float* slab,
+                      hipStream_t st) {
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
   case MBV: {                                                                                   \
     const long long ntiles = cdiv(C, 64 * NCTV), T = ntiles * L;                                \
     const int wgs_per_cu = (MBV * NCTV >= 24) ? 1 : 2;                                          \
-    const long long G = (long long)num_cus() * wgs_per_cu;                                      \
-    long long grid = G;                                                                         \
+    long long grid = (long long)num_cus() * wgs_per_cu;                                         \
     if (MODE == MODE_STORE) grid = T;              /* L == 1: one item per tile */              \
-    if (MODE == MODE_ACCUM && T < G * L)           /* keep <= 2 atomic contributors/element */  \
-      grid = ntiles * ((2 * ntiles <= G && L >= 2) ? 2 : 1);                                    \
     if (grid > T) grid = T;                                                                     \
     panel_mfma_kernel<MBV, NCTV, MODE><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, g, M, C, L, out, \
-                                                                       colsq, scale);           \
+                                                                       colsq, scale, slab);     \
+    if (MODE == MODE_ACCUM) {                                                                   \
+      dim3 rg((unsigned)ntiles, 8);                                                             \
+      panel_slab_reduce_kernel<<<rg, 256, 0, st>>>(slab, M, MBV * 16, 64 * NCTV, C, L, ntiles,  \
+                                                   (int)grid, out);                             \
+    }                                                                                           \
   } break;
   switch (MBsel) {
     GPSA_PANEL_CASE(2, 4)
@@ -832,6 +877,13 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
 #undef GPSA_PANEL_CASE
   GPSA_LAUNCH_CHECK();
   return 0;
+}
+
+// floats of slab space behind the packed operand: 2 partial tiles per workgroup of the persistent grid
+static inline long long accum_slab_floats(int MB) {
+  const int nct = (MB == 16) ? 2 : (MB == 13 ? 3 : 4);
+  const long long G = (long long)num_cus() * ((MB * nct >= 24) ? 1 : 2);
+  return G * 2 * (long long)MB * 16 * 64 * nct;
 }
 
 static int quad_sym_launch(int MBsel, const float* Ppk, const float* X, int M, long long C, int L,
@@ -944,7 +996,7 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   const int MB = gpsa::mfma_mb_for(M);
   long long mfma = 0;
   if (dtype == GPSA_F32 && MB) {
-    mfma = (long long)L * MB * 16 * MB * 16 * 4;
+    mfma = ((long long)L * MB * 16 * MB * 16 + gpsa::accum_slab_floats(MB)) * 4;
     const long long gw = gpsa::gram_ws_bytes(MB, C, L);
     if (gw > mfma) mfma = gw;
   }
@@ -970,7 +1022,7 @@ int gpsa_quadform_fwd(int dtype, const void* alpha, const void* Omega, int M, lo
       if (rc) return rc;
       if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
-                                          nullptr, 1.f, st);
+                                          nullptr, 1.f, nullptr, st);
     }
     return generic_quadform_fwd<float>((const float*)alpha, (const float*)Omega, M, C, L, (float*)v,
                                        workspace, workspace_bytes, st);
@@ -990,12 +1042,13 @@ int gpsa_quadform_bwd_alpha(int dtype, const void* alpha, const void* Omega, con
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
     if (MB && !force_generic()) {
-      if (workspace_bytes < (long long)L * MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
+      const long long pk = (long long)L * MB * 16 * MB * 16;
+      if (workspace_bytes < (pk + accum_slab_floats(MB)) * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
       int rc = pack_f32((const float*)Omega, M, MB, L, 0, Ppk, st);
       if (rc) return rc;
       return panel_mfma_launch<MODE_ACCUM>(MB, Ppk, (const float*)alpha, (const float*)g, M, C, L,
-                                           (float*)dalpha, nullptr, 2.f, st);
+                                           (float*)dalpha, nullptr, 2.f, Ppk + pk, st);
     }
     return generic_quadform_bwd_alpha<float>((const float*)alpha, (const float*)Omega,
                                              (const float*)g, M, C, L, (float*)dalpha, workspace,
@@ -1060,13 +1113,13 @@ int gpsa_panel_mm(int dtype, const void* P, const void* X, int M, long long C, v
       int rc = pack_f32((const float*)P, M, MB, 1, 0, Ppk, st);
       if (rc) return rc;
       return panel_mfma_launch<MODE_STORE>(MB, Ppk, (const float*)X, nullptr, M, C, 1, (float*)Y,
-                                           (float*)colsq, 1.f, st);
+                                           (float*)colsq, 1.f, nullptr, st);
     }
     int rc = gemm_launch<float>(0, 0, M, (int)C, M, 1.0, (const float*)P, M, 0, (const float*)X, C,
                                 0, 0.0, (float*)Y, C, 0, 1, 1, nullptr, 0, st);
     if (rc) return rc;
     if (colsq) {
-      colsq_kernel<float><<<(unsigned)cdiv(C, 256), 256, 0, st>>>((const float*)Y, M, C, (float*)colsq);
+      colsq_kernel<float><<<(unsigned)cdiv(C, 64), 256, 0, st>>>((const float*)Y, M, C, (float*)colsq);
       GPSA_LAUNCH_CHECK();
     }
     return 0;
@@ -1076,7 +1129,7 @@ int gpsa_panel_mm(int dtype, const void* P, const void* X, int M, long long C, v
                                  C, 0, 0.0, (double*)Y, C, 0, 1, 1, nullptr, 0, st);
     if (rc) return rc;
     if (colsq) {
-      colsq_kernel<double><<<(unsigned)cdiv(C, 256), 256, 0, st>>>((const double*)Y, M, C, (double*)colsq);
+      colsq_kernel<double><<<(unsigned)cdiv(C, 64), 256, 0, st>>>((const double*)Y, M, C, (double*)colsq);
       GPSA_LAUNCH_CHECK();
     }
     return 0;

@@ -294,9 +294,9 @@ class HipOps:
         L, M = Omega.shape[0], Omega.shape[-1]
         Kinv, Dm = self._c(Kinv), self._c(Dm)
         kl = torch.empty(L, dtype=torch.float64, device=Kinv.device)
-        KD = torch.empty(M, L, dtype=torch.float64, device=Kinv.device)
+        KD = self.gemm(Kinv, Dm)
         rc = self.lib.gpsa_mvn_kl_fwd(_p(Kinv), _p(logdetK), _p(Omega), so, _p(logdetO), logdetO.stride(0),
-                                      _p(Dm), M, L, _p(kl), _p(KD), self._stream(Kinv))
+                                      _p(Dm), _p(KD), M, L, _p(kl), self._stream(Kinv))
         _lib.check(rc, "gpsa_mvn_kl_fwd")
         return kl, KD
 
