@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 sys.path.insert(0, GOLDEN_DIR)
 import recipes  # noqa: E402
 
-CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(GOLDEN_DIR + "/*.npz"))
+CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(GOLDEN_DIR + "/c*.npz"))
 SMALL_CASES = [c for c in CASES if "m200" not in c]
 
 

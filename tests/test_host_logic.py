@@ -90,3 +90,26 @@ def test_constructor_errors_match_reference():
     small = {"a": {"spatial_coords": X, "outputs": Y, "n_samples_list": [10, 10]}}
     with pytest.raises(ValueError):  # m_G > spots of the last view (np.random.choice, vgpsa.py:81-85)
         gp.VariationalGPSA(small, 4, 15, data_init=True, n_latent_gps={"a": None})
+
+
+def test_initial_parameters_match_reference_rng_order():
+    """same torch seed => the same freshly initialised parameters as the reference (the constructor
+    consumes the RNG in the reference's order); fixture from tests/golden/make_init_golden.py"""
+    import os
+
+    import spatial_alignment_amd as gp
+    from golden_io import GOLDEN_DIR
+
+    z = np.load(os.path.join(GOLDEN_DIR, "init_state_seed1234.npz"))
+    dd = {
+        "rna": {"spatial_coords": torch.tensor(z["Xa"]), "outputs": torch.tensor(z["Ya"]), "n_samples_list": [25, 15]},
+        "protein": {"spatial_coords": torch.tensor(z["Xb"]), "outputs": torch.tensor(z["Yb"]), "n_samples_list": [10, 20]},
+    }
+    torch.manual_seed(1234)
+    model = gp.VariationalGPSA(dd, m_X_per_view=7, m_G=9, data_init=False, grid_init=False,
+                               n_latent_gps={"rna": None, "protein": 2})
+    sd = model.state_dict()
+    ref = {k[6:]: z[k] for k in z.files if k.startswith("state/")}
+    assert set(sd) == set(ref)
+    for k, v in ref.items():
+        assert np.array_equal(sd[k].numpy(), v), k
