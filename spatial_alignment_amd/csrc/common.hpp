@@ -47,15 +47,29 @@ template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 
-// out[j] = sum_i part[i*stride + j]   (deterministic second pass of two-pass reductions)
+// out[j] = sum_i part[i*stride + j]   (deterministic second pass of two-pass reductions).
+// Launch with 256 threads: 64 columns x 4 row groups; each group keeps 4 independent partial sums so
+// that a tall, narrow partial array (hundreds of rows) is not a chain of dependent loads.
 template <typename TI, typename TO>
 __global__ void reduce_rows_kernel(const TI* __restrict__ part, long long rows, long long stride,
                                    long long n, TO* __restrict__ out, double scale) {
-  long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double acc = 0.0;
-  for (long long i = 0; i < rows; ++i) acc += (double)part[i * stride + j];
-  out[j] = (TO)(acc * scale);
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long j = blockIdx.x * 64LL + lane;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (j < n) {
+    long long i = grp;
+    for (; i + 12 < rows; i += 16) {
+      a0 += (double)part[i * stride + j];
+      a1 += (double)part[(i + 4) * stride + j];
+      a2 += (double)part[(i + 8) * stride + j];
+      a3 += (double)part[(i + 12) * stride + j];
+    }
+    for (; i < rows; i += 4) a0 += (double)part[i * stride + j];
+  }
+  red[grp][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && j < n) out[j] = (TO)(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale);
 }
 
 }  // namespace gpsa

@@ -188,9 +188,9 @@ int kmat_bwd_launch(int kind, const T* Z, int M, const T* X, long long C, int D,
       return GPSA_EINVAL;
   }
   GPSA_LAUNCH_CHECK();
-  reduce_rows_kernel<T, T><<<(unsigned)cdiv(nz, 256), 256, 0, st>>>(zpart, nbx, nz, nz, dZ, 1.0);
-  if (dX) reduce_rows_kernel<T, T><<<(unsigned)cdiv(nx, 256), 256, 0, st>>>(xpart, nby, nx, nx, dX, 1.0);
-  reduce_rows_kernel<T, T><<<1, 64, 0, st>>>(spart, nbx * nby, 2, 2, dparams, 1.0);
+  reduce_rows_kernel<T, T><<<(unsigned)cdiv(nz, 64), 256, 0, st>>>(zpart, nbx, nz, nz, dZ, 1.0);
+  if (dX) reduce_rows_kernel<T, T><<<(unsigned)cdiv(nx, 64), 256, 0, st>>>(xpart, nby, nx, nx, dX, 1.0);
+  reduce_rows_kernel<T, T><<<1, 256, 0, st>>>(spart, nbx * nby, 2, 2, dparams, 1.0);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

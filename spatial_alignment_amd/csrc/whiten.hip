@@ -1,0 +1,178 @@
+// fp64 projection of the cross-covariance onto the inducing points on the fp64 matrix cores:
+//     alpha = K_uu^-1 K_uf ,   q[c] = k_c^T K_uu^-1 k_c = sum_m K_uf[m,c] alpha[m,c]
+// (gpsa/models/vgpsa.py:179-183, 194-196: the K_fu K_uu^-1 factors of the conditional mean and
+// covariance of both GP layers).  The M x M inverse comes from the fp64 Cholesky factor
+// (linalg.hip); this kernel is the only N-scaled fp64 product of a step, so it is written against
+// v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s dense on MI355X - the same peak as the fp64 vector pipe, but
+// reachable, and it leaves the vector pipe to the address arithmetic).
+//
+// One workgroup = 4 waves = 64 columns.  Each wave keeps its 16 columns of K_uf (the B operand, one
+// fp64 per lane and K step) and all MB row tiles of the result in registers; the packed inverse
+// streams through a 2-deep LDS ring in chunks of 16 K values by LDS-DMA, shared by the 4 waves.  The
+// C/D layout of the fp64 MFMA (row = (lane>>4) + 4*reg) coincides with the B operand's K layout
+// (k = 4*step + (lane>>4)), so q closes in registers: q = sum acc[rt][reg] * xb[4*rt + reg], then two
+// cross-lane adds.
+#include "common.hpp"
+
+namespace gpsa {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr64_t;
+
+__device__ __forceinline__ void glds16_f64(const double* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
+// Kinv [M][M] row-major -> Apk[kc][ks][rt][lane] = Kinv[16 rt + (lane&15)][16 kc + 4 ks + (lane>>4)]
+// (zero padded to MP = 16 MB): the A-operand fragment of every MFMA is one lane-linear 512-byte row.
+__global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int MB, double* __restrict__ Apk) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long tot = (long long)MB * 4 * MB * 64;
+  if (idx >= tot) return;
+  const int lane = (int)(idx & 63);
+  long long t = idx >> 6;
+  const int rt = (int)(t % MB);
+  t /= MB;
+  const int ks = (int)(t & 3);
+  const int kc = (int)(t >> 2);
+  const int row = rt * 16 + (lane & 15), k = kc * 16 + ks * 4 + (lane >> 4);
+  Apk[idx] = (row < M && k < M) ? Kinv[(long long)row * M + k] : 0.0;
+}
+
+template <int MB, typename TO>
+__global__ void __launch_bounds__(256, (MB >= 13) ? 1 : 2)
+whiten_mfma_kernel(const double* __restrict__ Apk, const double* __restrict__ X, int M, long long C,
+                   TO* __restrict__ alpha, double* __restrict__ q) {
+  constexpr int CHUNK = 4 * MB * 64;          // doubles per K chunk (2*MB pieces of 1 KiB)
+  constexpr int NPIECE = 2 * MB;
+  constexpr int NPW = (NPIECE + 3) / 4;       // LDS-DMA operations per wave per stage (uniform)
+  constexpr int BUFD = NPW * 4 * 128;         // doubles per ring slot (incl. dummy pieces)
+  __shared__ __attribute__((aligned(16))) double lds[2][BUFD];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const long long c = blockIdx.x * 64LL + w * 16 + j;
+  const bool okc = c < C;
+
+#define GPSA_WSTAGE(Q, BUF)                                                                    \
+  {                                                                                            \
+    const double* src__ = Apk + (long long)(Q) * CHUNK + lane * 2;                             \
+    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
+      const int piece = pc * 4 + w;                                                            \
+      glds16_f64(src__ + (piece < NPIECE ? piece : NPIECE - 1) * 128,                          \
+                 __builtin_amdgcn_readfirstlane(                                               \
+                     (unsigned)(unsigned long long)(lds_ptr64_t)(&lds[BUF][piece * 128])));    \
+    }                                                                                          \
+  }
+  GPSA_WSTAGE(0, 0)
+
+  double xb[4 * MB];
+#pragma unroll
+  for (int s = 0; s < 4 * MB; ++s) {
+    const int row = 4 * s + kq;
+    xb[s] = (okc && row < M) ? X[(long long)row * C + c] : 0.0;
+  }
+  f64x4 acc[MB];
+#pragma unroll
+  for (int rt = 0; rt < MB; ++rt) acc[rt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+#pragma unroll
+  for (int kc = 0; kc < MB; ++kc) {
+    // chunk kc has landed (this wave's share; the barrier publishes everyone's) and every wave is
+    // done with chunk kc-1, whose slot the next stage overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kc + 1 < MB) GPSA_WSTAGE(kc + 1, (kc + 1) & 1)
+    const double* base = &lds[kc & 1][lane];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double b = xb[4 * kc + ks];
+#pragma unroll
+      for (int rt = 0; rt < MB; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[(ks * MB + rt) * 64], b, acc[rt], 0, 0, 0);
+    }
+  }
+#undef GPSA_WSTAGE
+
+  double s = 0.0;
+#pragma unroll
+  for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * 16 + 4 * r + kq;
+      const double y = acc[rt][r];
+      s += y * xb[4 * rt + r];
+      if (okc && row < M) alpha[(long long)row * C + c] = (TO)y;
+    }
+  if (q != nullptr) {
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (kq == 0 && okc) q[c] = s;
+  }
+}
+
+static inline int whiten_mb_for(int M) {
+  const int mb = (M + 15) / 16;
+  if (mb <= 2) return 2;
+  if (mb <= 4) return 4;
+  if (mb <= 7) return 7;
+  if (mb <= 13) return 13;
+  if (mb <= 16) return 16;
+  return 0;
+}
+
+template <typename TO>
+static int whiten_launch(int MB, const double* Apk, const double* X, int M, long long C, TO* alpha,
+                         double* q, hipStream_t st) {
+  const unsigned grid = (unsigned)cdiv(C, 64);
+#define GPSA_WCASE(V)                                                                     \
+  case V:                                                                                 \
+    whiten_mfma_kernel<V, TO><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);              \
+    break;
+  switch (MB) {
+    GPSA_WCASE(2)
+    GPSA_WCASE(4)
+    GPSA_WCASE(7)
+    GPSA_WCASE(13)
+    GPSA_WCASE(16)
+    default:
+      return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_WCASE
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gpsa
+
+extern "C" {
+
+long long gpsa_whiten_workspace(int M) {
+  const int MB = gpsa::whiten_mb_for(M);
+  return MB ? (long long)MB * 16 * MB * 16 * 8 : 0;
+}
+
+int gpsa_whiten_f64(const double* Kinv, const double* Kuf, int M, long long C, int alpha_dtype,
+                    void* alpha, double* q, void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || Kinv == nullptr || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
+  if (alpha_dtype != GPSA_F32 && alpha_dtype != GPSA_F64) return GPSA_EINVAL;
+  const int MB = whiten_mb_for(M);
+  if (MB == 0) return GPSA_EUNSUPPORTED;
+  if (workspace_bytes < gpsa_whiten_workspace(M)) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* Apk = (double*)workspace;
+  const long long tot = (long long)MB * 4 * MB * 64;
+  pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk);
+  GPSA_LAUNCH_CHECK();
+  if (alpha_dtype == GPSA_F32) return whiten_launch<float>(MB, Apk, Kuf, M, C, (float*)alpha, q, st);
+  return whiten_launch<double>(MB, Apk, Kuf, M, C, (double*)alpha, q, st);
+}
+
+}  // extern "C"

@@ -208,12 +208,17 @@ class SGPLayerFn(torch.autograd.Function):
         Zw, Xw = cast(Z, Tw), cast(X, Tw)
         lsw, varw = cast(ls_u, Tw).reshape(1), cast(var_u, Tw).reshape(1)
         Kuf = o.kmat(kind, Zw, Xw, lsw, varw, 0.0)
-        Liw, LiTw = fac.linv(Tw)
-        beta, q = o.panel_mm(Liw, Kuf, want_colsq=True)
-        del Kuf
-        alpha_w, _ = o.panel_mm(LiTw, beta)
-        del beta
-        alpha = alpha_w if T == Tw else alpha_w.to(T)
+        fused = o.whiten(fac.Kinv, Kuf, T) if Tw == torch.float64 else None
+        if fused is not None:
+            alpha, q = fused
+            del Kuf
+        else:
+            Liw, LiTw = fac.linv(Tw)
+            beta, q = o.panel_mm(Liw, Kuf, want_colsq=True)
+            del Kuf
+            alpha_w, _ = o.panel_mm(LiTw, beta)
+            del beta
+            alpha = alpha_w if T == Tw else alpha_w.to(T)
         dcT = dc.detach().to(T).contiguous()
         Om = Omega.detach().to(T).contiguous()
         meanT = o.gemm(dcT, alpha, transA=True)

@@ -139,6 +139,27 @@ def test_panel_mm_col_axpy(hip, dtype, M, C):
     close(hip.col_axpy(Y, X.to(DEV), d.to(DEV), 0.5), FK.col_axpy(rY, X.double(), d.double(), 0.5), TOL[dtype] * 2)
 
 
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129)])
+def test_whiten_f64_mfma(hip, out_dtype, M, C):
+    """alpha = Kinv Kuf and q = diag(Kuf^T alpha) on the fp64 matrix cores vs a CPU fp64 product."""
+    f64 = torch.float64
+    Kinv, Kuf = rnd(M, M, dtype=f64), rnd(M, C, dtype=f64, seed=1)
+    Kinv = Kinv + Kinv.t()
+    a, q = hip.whiten(Kinv.to(DEV), Kuf.to(DEV), out_dtype)
+    ra, rq = FK.whiten(Kinv, Kuf, f64)
+    assert a.dtype == out_dtype and q.dtype == f64
+    close(a, ra, 1e-13 if out_dtype == f64 else 1e-6)
+    close(q, rq, 1e-13)
+    a2, q2 = hip.whiten(Kinv.to(DEV), Kuf.to(DEV), out_dtype, want_q=False)
+    assert q2 is None and torch.equal(a2, a)
+
+
+def test_whiten_unsupported_size_is_reported(hip):
+    f64 = torch.float64
+    assert hip.whiten(torch.eye(300, dtype=f64, device=DEV), torch.ones(300, 8, dtype=f64, device=DEV), f64) is None
+
+
 @pytest.mark.parametrize("C,L", [(100, 5), (4097, 50), (33, 33)])
 def test_data_sample(hip, C, L):
     meanT, v = rnd(L, C), rnd(L, C, seed=1).abs()
