@@ -63,6 +63,11 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
  *   inside torch.cholesky_solve, vgpsa.py:177). */
 int gpsa_chol_f64(void* A, int M, int batch, void* logdet, int* info, void* stream);
 int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream);
+/* gpsa_chol_inv_f64: Linv[b] = chol(A[b])^-1 with logdet / info as gpsa_chol_f64, in one register-
+ *   resident sweep (A is not modified; M <= 256, GPSA_EUNSUPPORTED above: chain the two calls above).
+ *   Same reference lines as the pair it fuses. */
+int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
+                      void* stream);
 
 /* ---- the dominant contraction: variational variance term --------------------------------------
  * v[l,c] = alpha[:,c]^T Omega[l] alpha[:,c]            (vgpsa.py:192-196 a_t_Omega_tril, square, sum;

@@ -181,6 +181,118 @@ tri_inv_global_kernel(const double* __restrict__ L, double* __restrict__ Linv, i
   tri_inv_body(a, M, rowL);
 }
 
+// Fused factorisation: Linv = chol(A)^-1, logdet, info in ONE pass with the matrix held in registers.
+// 1024 threads own the lower triangle 2-D cyclically: thread (ty, tx) holds t[qa][qb] = element
+// (32 qa + ty, 32 qb + tx), qb <= qa.  Step j of the right-looking factorisation publishes column j
+// (rows >= j) and, for the forward substitution that runs in the same sweep, row j of the inverse
+// (columns < j) through a double-buffered LDS vector: ONE barrier per column, no LDS read-modify-
+// write.  The register position (i,k) holds A(i,k) while k > j and X(i,k) = L^-1(i,k) once k <= j
+// (L(:,k) itself is dead after step k), so both updates are the same rank-1 FMA
+//     t(i,k) -= L(i,j) * w(k),   w(k) = L(k,j) for k > j,   X(j,k)/L(j,j) for k < j,   1/L(j,j) at k = j
+// over the rows i > j.  The outer loop over the 32-column tile index is unrolled at compile time so
+// that every register index is static and dead tiles cost nothing.
+template <int NT>
+__global__ void __launch_bounds__(1024)
+chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Linv,
+                    double* __restrict__ logdet, int* __restrict__ info) {
+  __shared__ double col[2][NT * 32];
+  __shared__ double xrow[2][NT * 32];
+  __shared__ double sdiag[NT * 32];
+  __shared__ double red[16];
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const double* G = A + (long long)blockIdx.x * M * M;
+  double* O = Linv + (long long)blockIdx.x * M * M;
+  double t[NT][NT];
+#pragma unroll
+  for (int qa = 0; qa < NT; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+      const int i = 32 * qa + ty, k = 32 * qb + tx;
+      t[qa][qb] = (qb <= qa && i < M && k < M) ? G[(long long)i * M + k] : 0.0;
+    }
+  int bad = 0;
+#pragma unroll
+  for (int q0 = 0; q0 < NT; ++q0) {
+#pragma unroll 1
+    for (int r0 = 0; r0 < 32; ++r0) {
+      const int j = 32 * q0 + r0;
+      if (j >= M || bad) break;  // uniform
+      const int b = j & 1;
+      if (tx == r0) {
+#pragma unroll
+        for (int qa = q0; qa < NT; ++qa) {
+          const int i = 32 * qa + ty;
+          if (i >= j) col[b][i] = t[qa][q0];
+        }
+      }
+      if (ty == r0) {
+#pragma unroll
+        for (int qb = 0; qb <= q0; ++qb) {
+          const int k = 32 * qb + tx;
+          if (k < j) xrow[b][k] = t[q0][qb];
+        }
+      }
+      __syncthreads();
+      const double d = col[b][j];
+      if (!(d > 0.0)) {  // uniform: everyone read the same value
+        bad = j + 1;
+        break;
+      }
+      const double s = sqrt(d), inv = 1.0 / s;
+      if (tid == 0) sdiag[j] = s;
+      double w[NT], li[NT];
+#pragma unroll
+      for (int qb = 0; qb < NT; ++qb) {
+        const int k = 32 * qb + tx;
+        if (qb > q0) w[qb] = col[b][k] * inv;
+        else if (qb < q0) w[qb] = xrow[b][k] * inv;
+        else w[qb] = (k > j) ? col[b][k] * inv : ((k == j) ? inv : xrow[b][k] * inv);
+      }
+#pragma unroll
+      for (int qa = q0; qa < NT; ++qa) {
+        const int i = 32 * qa + ty;
+        li[qa] = (i > j) ? col[b][i] * inv : 0.0;
+      }
+#pragma unroll
+      for (int qa = q0; qa < NT; ++qa)
+#pragma unroll
+        for (int qb = 0; qb <= qa; ++qb) {
+          if (qb == q0) {
+            const double base = (tx == r0) ? 0.0 : t[qa][qb];  // column j: L(i,j) leaves, X(i,j) enters
+            t[qa][qb] = base - li[qa] * w[qb];
+          } else {
+            t[qa][qb] -= li[qa] * w[qb];
+          }
+        }
+      if (ty == r0) {  // row j of the inverse is final: scale by 1/L(j,j), diagonal = 1/L(j,j)
+#pragma unroll
+        for (int qb = 0; qb <= q0; ++qb) {
+          const int k = 32 * qb + tx;
+          if (k < j) t[q0][qb] *= inv;
+          else if (k == j) t[q0][qb] = inv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // logdet = 2 sum log L(j,j), reduced in a fixed order
+  double lg = 0.0;
+  if (!bad)
+    for (int j = tid; j < M; j += 1024) lg += log(sdiag[j]);
+  lg = block_sum(lg, red);
+  if (tid == 0) {
+    logdet[blockIdx.x] = bad ? __builtin_nan("") : 2.0 * lg;
+    info[blockIdx.x] = bad;
+  }
+#pragma unroll
+  for (int qa = 0; qa < NT; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+      const int i = 32 * qa + ty, k = 32 * qb + tx;
+      if (i < M && k < M) O[(long long)i * M + k] = (qb <= qa && k <= i) ? t[qa][qb] : 0.0;
+    }
+}
+
 // out[b] = sum_i A[b,i]*B[b,i]; grid (batch, nsplit): partial sums per split in part[b*nsplit+s], then summed
 template <typename T>
 __global__ void bdot_kernel(const T* __restrict__ A, long long sA, const T* __restrict__ B,
@@ -256,6 +368,25 @@ int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream) 
     if (M > LA_GLOBAL_MAX) return GPSA_EUNSUPPORTED;
     tri_inv_global_kernel<<<batch, LA_THREADS, 0, st>>>((const double*)L, (double*)Linv, M);
   }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
+                      void* stream) {
+  using namespace gpsa;
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nt = (M + 31) / 32;
+#define GPSA_CI_CASE(V)                                                                            \
+  chol_inv_reg_kernel<V><<<batch, 1024, 0, st>>>((const double*)A, M, (double*)Linv, (double*)logdet, info)
+  if (nt <= 1) GPSA_CI_CASE(1);
+  else if (nt <= 2) GPSA_CI_CASE(2);
+  else if (nt <= 4) GPSA_CI_CASE(4);
+  else if (nt <= 7) GPSA_CI_CASE(7);
+  else if (nt <= 8) GPSA_CI_CASE(8);
+  else return GPSA_EUNSUPPORTED;
+#undef GPSA_CI_CASE
   GPSA_LAUNCH_CHECK();
   return 0;
 }

@@ -56,8 +56,8 @@ class Factor:
 def factor_batch(mats):
     """Factorise many SPD matrices with as few launches as possible.
 
-    ``mats``: list of fp64 tensors [b_i, M_i, M_i].  Matrices of equal size share ONE batched Cholesky,
-    ONE batched triangular inverse and ONE batched L^-T L^-1 product (one workgroup per matrix), so the
+    ``mats``: list of fp64 tensors [b_i, M_i, M_i].  Matrices of equal size share ONE batched fused
+    Cholesky + triangular inverse and ONE batched L^-T L^-1 product (one workgroup per matrix), so the
     launch-latency-bound factorisations of a whole step cost one kernel's latency.
     Returns, per input, (Linv [b,M,M], inverse [b,M,M], logdet [b], info [b]).
     """
@@ -68,8 +68,7 @@ def factor_batch(mats):
         by_size.setdefault(m.shape[-1], []).append(i)
     for M, idxs in by_size.items():
         stack = torch.cat([mats[i].detach().reshape(-1, M, M) for i in idxs], 0)
-        L, logdet, info = o.chol(stack)
-        Linv = o.tri_inv(L)
+        Linv, logdet, info = o.chol_inv(stack)
         inv = o.gemm(Linv, Linv, transA=True)
         off = 0
         for i in idxs:

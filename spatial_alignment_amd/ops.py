@@ -128,6 +128,21 @@ class HipOps:
         _lib.check(rc, "gpsa_tri_inv_f64")
         return out
 
+    def chol_inv(self, A):
+        """A [B,M,M] fp64 (not modified) -> L^-1 [B,M,M], logdet [B], info [B]; one fused sweep for
+        M <= 256, the chol + tri_inv pair above that."""
+        A = self._c(A)
+        Bn, M = A.shape[0], A.shape[-1]
+        if M > 256:
+            L, logdet, info = self.chol(A)
+            return self.tri_inv(L), logdet, info
+        Linv = torch.empty_like(A)
+        logdet = torch.empty(Bn, dtype=torch.float64, device=A.device)
+        info = torch.empty(Bn, dtype=torch.int32, device=A.device)
+        rc = self.lib.gpsa_chol_inv_f64(_p(A), _p(Linv), M, Bn, _p(logdet), _p(info), self._stream(A))
+        _lib.check(rc, "gpsa_chol_inv_f64")
+        return Linv, logdet, info
+
     # ------------------------------------------------------------------ quadratic forms
     def _qf_ws(self, alpha, L):
         M, Cn = alpha.shape

@@ -66,6 +66,10 @@ class FakeOps:
         eye = torch.eye(L.shape[-1], dtype=L.dtype).expand_as(L)
         return torch.linalg.solve_triangular(L, eye, upper=False)
 
+    def chol_inv(self, A):
+        L, logdet, info = self.chol(A)
+        return self.tri_inv(L), logdet, info
+
     def quadform_fwd(self, alpha, Omega):
         return torch.einsum("mc,lmk,kc->lc", alpha, Omega, alpha)
 

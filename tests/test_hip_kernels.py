@@ -89,6 +89,46 @@ def test_chol_and_tri_inv(hip, M, B):
     close(hip.tri_inv(L), FK.tri_inv(rL), 1e-9)
 
 
+@pytest.mark.parametrize("M,B", [(1, 2), (5, 3), (31, 2), (32, 2), (33, 2), (50, 4), (64, 1), (100, 3), (128, 2),
+                                 (200, 57), (224, 2), (225, 2), (256, 3), (300, 2)])
+def test_chol_inv_fused(hip, M, B):
+    """register-resident Cholesky + inverse of the factor vs LAPACK (and the unfused pair's results)."""
+    A = rnd(B, M, M, dtype=torch.float64, seed=M)
+    K = A @ A.transpose(1, 2) / M + 0.05 * torch.eye(M, dtype=torch.float64)
+    Kd = K.to(DEV)
+    Linv, logdet, info = hip.chol_inv(Kd)
+    assert torch.equal(Kd.cpu(), K)  # input untouched
+    rL, rld, _ = FK.chol(K)
+    assert int(info.abs().max()) == 0
+    close(logdet, rld, 1e-12)
+    close(Linv, FK.tri_inv(rL), 1e-9)
+    assert float(Linv.cpu().triu(1).abs().max()) == 0.0 if M > 1 else True
+    eye = torch.eye(M, dtype=torch.float64)
+    resid = Linv.cpu() @ K @ Linv.cpu().transpose(1, 2) - eye
+    assert float(resid.abs().max()) < 1e-9
+
+
+def test_chol_inv_on_covariance_conditioning(hip):
+    """K_uu of the warp GP at init (RBF on a grid + 1e-5 jitter, cond ~ 1e7): fp64 residual stays small."""
+    g = torch.linspace(0, 10, 15, dtype=torch.float64)
+    Z = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)[:200]
+    K = torch.exp(-0.5 * torch.cdist(Z, Z) ** 2) + 1e-5 * torch.eye(200, dtype=torch.float64)
+    Linv, logdet, info = hip.chol_inv(K.unsqueeze(0).to(DEV))
+    assert int(info[0]) == 0
+    X = Linv[0].cpu()
+    assert float((X @ K @ X.t() - torch.eye(200, dtype=torch.float64)).abs().max()) < 1e-7
+    close(logdet, torch.logdet(K).reshape(1), 1e-9)
+
+
+def test_chol_inv_flags_indefinite(hip):
+    K = torch.eye(40, dtype=torch.float64).repeat(3, 1, 1)
+    K[1, 7, 7] = -1.0
+    K[2, 39, 39] = 0.0
+    _, logdet, info = hip.chol_inv(K.to(DEV))
+    assert info.cpu().tolist() == [0, 8, 40]
+    assert bool(torch.isnan(logdet[1])) and bool(torch.isnan(logdet[2])) and float(logdet[0]) == 0.0
+
+
 def test_chol_flags_indefinite(hip):
     K = torch.eye(20, dtype=torch.float64).repeat(2, 1, 1)
     K[1, 7, 7] = -1.0
