@@ -238,8 +238,12 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
         bad = j + 1;
         break;
       }
-      const double s = sqrt(d), inv = 1.0 / s;
-      if (tid == 0) sdiag[j] = s;
+      // 1/sqrt(d) from the hardware estimate plus one third-order correction (error ~ e^3 with
+      // e ~ 2^-26): ~10 dependent fp64 operations on the critical path instead of sqrt + divide
+      const double y0 = __builtin_amdgcn_rsq(d);
+      const double e = fma(-(d * y0), y0, 1.0);
+      const double inv = fma(y0 * e, fma(0.375, e, 0.5), y0);
+      if (tid == 0) sdiag[j] = inv;
       double w[NT], li[NT];
 #pragma unroll
       for (int qb = 0; qb < NT; ++qb) {
@@ -278,7 +282,7 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   // logdet = 2 sum log L(j,j), reduced in a fixed order
   double lg = 0.0;
   if (!bad)
-    for (int j = tid; j < M; j += 1024) lg += log(sdiag[j]);
+    for (int j = tid; j < M; j += 1024) lg -= log(sdiag[j]);  // sdiag = 1 / L(j,j)
   lg = block_sum(lg, red);
   if (tid == 0) {
     logdet[blockIdx.x] = bad ? __builtin_nan("") : 2.0 * lg;

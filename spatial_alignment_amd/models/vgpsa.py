@@ -273,7 +273,10 @@ class VariationalGPSA(GPSA):
             Om = cache.Om_fwd[v]  # quirk 2: forward uses rows v*D+j
             kind = builtin_kind(self.kernel_func_warp)
             if kind is not None:  # fused covariance + layer, all fp64
-                meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
+                wm = getattr(self, "_warp_main_dtype", f64)
+                meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, wm, wm)
+                if wm != f64:
+                    meanT, vq = meanT.double(), vq.double()
             else:
                 Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
                 meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)

@@ -1,0 +1,61 @@
+"""Micro-benchmarks of single C-ABI entry points on one GPU (HIP-event timed).  Diagnostic tool.
+usage: python tools/bench_kernels.py chol_inv|gram|kmat_bwd|gemm64 ...
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+ge.build()
+from spatial_alignment_amd import ops as ops_mod  # noqa: E402
+
+o = ops_mod.get_ops()
+dev = "cuda"
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+
+def spd(B, M, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(B, M, M, generator=g, dtype=torch.float64)
+    return (A @ A.transpose(1, 2) / M + 0.05 * torch.eye(M, dtype=torch.float64)).to(dev)
+
+
+what = sys.argv[1:] or ["chol_inv"]
+if "chol_inv" in what:
+    for B, M in [(57, 200), (7, 200), (57, 100), (57, 256), (51, 50)]:
+        K = spd(B, M)
+        print(f"chol_inv B={B} M={M}: {timeit(lambda: o.chol_inv(K)):.1f} us", flush=True)
+if "gram" in what:
+    for C in (100000, 12500):
+        a = torch.randn(200, C, device=dev)
+        g = torch.randn(50, C, device=dev)
+        print(f"quadform_bwd_omega C={C}: {timeit(lambda: o.quadform_bwd_omega(a, g), n=10, warm=2):.1f} us", flush=True)
+if "kmat_bwd" in what:
+    for M, C, dt in [(200, 200, torch.float64), (200, 1250, torch.float64), (200, 10000, torch.float64),
+                     (200, 12500, torch.float32), (200, 100000, torch.float32)]:
+        Z = torch.rand(M, 2, device=dev, dtype=dt) * 10
+        X = torch.rand(C, 2, device=dev, dtype=dt) * 10
+        ls, var = torch.zeros(1, device=dev, dtype=dt), torch.zeros(1, device=dev, dtype=dt)
+        Kb = torch.randn(M, C, device=dev, dtype=dt)
+        print(f"kmat_bwd {dt} M={M} C={C}: {timeit(lambda: o.kmat_bwd('rbf', Z, X, ls, var, Kb, need_dX=True)):.1f} us", flush=True)
+if "gemm64" in what:
+    for B in (4, 50, 57):
+        A = torch.randn(B, 200, 200, device=dev, dtype=torch.float64)
+        print(f"gemm f64 NT batch={B} 200^3: {timeit(lambda: o.gemm(A, A, transB=True)):.1f} us", flush=True)
+        print(f"gemm f64 TN batch={B} 200^3: {timeit(lambda: o.gemm(A, A, transA=True)):.1f} us", flush=True)
