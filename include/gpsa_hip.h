@@ -33,16 +33,19 @@ const char* gpsa_build_arch(void);    /* "gfx950" */
  * K[m,c] = k(Z[m,:], X[c,:]) (+ jitter on the diagonal m==c, used for K_uu).
  * replaces gpsa/util/util.py:8-23 (rbf_kernel), :33-47 (matern12_kernel), :50-66 (matern32_kernel)
  * as called from gpsa/models/vgpsa.py:314-318, 390-392, 409.
- * Z [M,D], X [C,D], K [M,C]; ls_u / var_u: device scalars (log lengthscale, log variance). D <= 4. */
-int gpsa_kmat(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
-              const void* ls_u, const void* var_u, double jitter, void* K, void* stream);
+ * Z [M,D], X [C,D], K [M,C]; ls_u / var_u: device scalars (log lengthscale, log variance). D <= 4.
+ * dtype = type K is computed and stored in; in_dtype = storage type of Z, X, ls_u, var_u (the fp32
+ * parameters are read as they are).  Supported (dtype, in_dtype): (F32,F32), (F64,F64), (F64,F32). */
+int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
+              int D, const void* ls_u, const void* var_u, double jitter, void* K, void* stream);
 
-/* Backward of gpsa_kmat: given Kbar = dLoss/dK [M,C] produce
+/* Backward of gpsa_kmat: given Kbar = dLoss/dK [M,C] (dtype) produce, in in_dtype,
  *   dZ [M,D], dX [C,D] (may be NULL), dparams[2] = {dLoss/d ls_u, dLoss/d var_u}.
- * (autograd of util.py:8-66 in the reference).  Deterministic (two-pass reduction in workspace). */
+ * (autograd of util.py:8-66 in the reference).  Deterministic (two-pass reduction in workspace,
+ * partial sums in dtype). */
 long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D);
-int gpsa_kmat_bwd(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
-                  const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
+int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
+                  int D, const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
                   void* dparams, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- dense products ---------------------------------------------------------------------------

@@ -16,9 +16,9 @@ _vp, _i, _ll, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_double
 SIGNATURES = {
     "gpsa_version": (_i, []),
     "gpsa_build_arch": (C.c_char_p, []),
-    "gpsa_kmat": (_i, [_i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _d, _vp, _vp]),
+    "gpsa_kmat": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _d, _vp, _vp]),
     "gpsa_kmat_bwd_workspace": (_ll, [_i, _i, _ll, _i]),
-    "gpsa_kmat_bwd": (_i, [_i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_kmat_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_gemm_workspace": (_ll, [_i, _i, _i, _i, _i]),
     "gpsa_gemm": (_i, [_i, _i, _i, _i, _i, _ll, _d, _vp, _ll, _ll, _vp, _ll, _ll, _d, _vp, _ll, _ll,
                        _i, _i, _vp, _ll, _vp]),

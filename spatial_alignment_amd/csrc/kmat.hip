@@ -46,24 +46,26 @@ __device__ __forceinline__ void cov_eval(const T* z, const T* x, int D, T ell, T
 
 constexpr int KM_ROWS = 16;
 
-template <typename T, int KIND>
+// TI: storage type of the coordinates and hyper-parameters (the fp32 parameters are read as they are,
+// no cast launches); T: type the covariance is computed and stored in.
+template <typename TI, typename T, int KIND>
 __global__ void __launch_bounds__(256)
-kmat_fwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long long C, int D,
-                const T* __restrict__ ls_u, const T* __restrict__ var_u, T jitter,
+kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long long C, int D,
+                const TI* __restrict__ ls_u, const TI* __restrict__ var_u, T jitter,
                 T* __restrict__ K) {
   __shared__ T Zs[KM_ROWS][MAXD];
   const int m0 = blockIdx.y * KM_ROWS;
   if (threadIdx.x < KM_ROWS * MAXD) {
     int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
-    Zs[r][d] = (m0 + r < M && d < D) ? Z[(long long)(m0 + r) * D + d] : T(0);
+    Zs[r][d] = (m0 + r < M && d < D) ? (T)Z[(long long)(m0 + r) * D + d] : T(0);
   }
   __syncthreads();
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   if (c >= C) return;
-  const T ell = t_exp<T>(ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>(var_u[0]);
+  const T ell = t_exp<T>((T)ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>((T)var_u[0]);
   T x[MAXD];
 #pragma unroll
-  for (int d = 0; d < MAXD; ++d) x[d] = (d < D) ? X[c * D + d] : T(0);
+  for (int d = 0; d < MAXD; ++d) x[d] = (d < D) ? (T)X[c * D + d] : T(0);
   const int mend = min(KM_ROWS, M - m0);
   for (int r = 0; r < mend; ++r) {
     T k, cd, pl;
@@ -80,10 +82,10 @@ constexpr int KB_MCHUNK = 32;  // inducing rows per workgroup of the backward ke
 //   zpart[bx][m*D+d]      dZ contribution of column block bx (rows of chunk by only)
 //   xpart[by][c*D+d]      dX contribution of row chunk by
 //   spart[bx*ny+by][0..1] d ls_u, d var_u
-template <typename T, int KIND>
+template <typename TI, typename T, int KIND>
 __global__ void __launch_bounds__(256)
-kmat_bwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long long C, int D,
-                const T* __restrict__ ls_u, const T* __restrict__ var_u,
+kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long long C, int D,
+                const TI* __restrict__ ls_u, const TI* __restrict__ var_u,
                 const T* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
                 T* __restrict__ spart) {
   __shared__ T Zs[KB_MCHUNK][MAXD];
@@ -94,16 +96,16 @@ kmat_bwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long lo
   const bool live = c < C;
   const int m0 = blockIdx.y * KB_MCHUNK;
   const int mc = min(KB_MCHUNK, M - m0);
-  const T ell = t_exp<T>(ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>(var_u[0]);
+  const T ell = t_exp<T>((T)ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>((T)var_u[0]);
   T x[MAXD], dx[MAXD];
 #pragma unroll
   for (int d = 0; d < MAXD; ++d) {
-    x[d] = (live && d < D) ? X[c * D + d] : T(0);
+    x[d] = (live && d < D) ? (T)X[c * D + d] : T(0);
     dx[d] = T(0);
   }
   if (threadIdx.x < KB_MCHUNK * MAXD) {
     const int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
-    Zs[r][d] = (r < mc && d < D) ? Z[(long long)(m0 + r) * D + d] : T(0);
+    Zs[r][d] = (r < mc && d < D) ? (T)Z[(long long)(m0 + r) * D + d] : T(0);
   }
   __syncthreads();
   T s_ls = T(0), s_var = T(0);
@@ -140,19 +142,19 @@ kmat_bwd_kernel(const T* __restrict__ Z, int M, const T* __restrict__ X, long lo
   if (threadIdx.x == 0) sp[1] = b2;
 }
 
-template <typename T>
-int kmat_launch(int kind, const T* Z, int M, const T* X, long long C, int D, const T* ls_u,
-                const T* var_u, double jitter, T* K, hipStream_t st) {
+template <typename TI, typename T>
+int kmat_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
+                const TI* var_u, double jitter, T* K, hipStream_t st) {
   dim3 grid((unsigned)cdiv(C, 256), (unsigned)cdiv(M, KM_ROWS));
   switch (kind) {
     case GPSA_K_RBF:
-      kmat_fwd_kernel<T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
       break;
     case GPSA_K_MATERN12:
-      kmat_fwd_kernel<T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
       break;
     case GPSA_K_MATERN32:
-      kmat_fwd_kernel<T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
       break;
     default:
       return GPSA_EINVAL;
@@ -161,9 +163,9 @@ int kmat_launch(int kind, const T* Z, int M, const T* X, long long C, int D, con
   return 0;
 }
 
-template <typename T>
-int kmat_bwd_launch(int kind, const T* Z, int M, const T* X, long long C, int D, const T* ls_u,
-                    const T* var_u, const T* Kbar, T* dZ, T* dX, T* dparams, void* ws,
+template <typename TI, typename T>
+int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
+                    const TI* var_u, const T* Kbar, TI* dZ, TI* dX, TI* dparams, void* ws,
                     long long ws_bytes, hipStream_t st) {
   const long long nbx = cdiv(C, 256), nby = cdiv(M, KB_MCHUNK);
   const long long nz = (long long)M * D, nx = C * D;
@@ -176,21 +178,21 @@ int kmat_bwd_launch(int kind, const T* Z, int M, const T* X, long long C, int D,
   T* xp = dX ? xpart : nullptr;
   switch (kind) {
     case GPSA_K_RBF:
-      kmat_bwd_kernel<T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
+      kmat_bwd_kernel<TI, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
       break;
     case GPSA_K_MATERN12:
-      kmat_bwd_kernel<T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
+      kmat_bwd_kernel<TI, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
       break;
     case GPSA_K_MATERN32:
-      kmat_bwd_kernel<T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
+      kmat_bwd_kernel<TI, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
       break;
     default:
       return GPSA_EINVAL;
   }
   GPSA_LAUNCH_CHECK();
-  reduce_rows_kernel<T, T><<<(unsigned)cdiv(nz, 64), 256, 0, st>>>(zpart, nbx, nz, nz, dZ, 1.0);
-  if (dX) reduce_rows_kernel<T, T><<<(unsigned)cdiv(nx, 64), 256, 0, st>>>(xpart, nby, nx, nx, dX, 1.0);
-  reduce_rows_kernel<T, T><<<1, 256, 0, st>>>(spart, nbx * nby, 2, 2, dparams, 1.0);
+  reduce_rows_kernel<T, TI><<<(unsigned)cdiv(nz, 64), 256, 0, st>>>(zpart, nbx, nz, nz, dZ, 1.0);
+  if (dX) reduce_rows_kernel<T, TI><<<(unsigned)cdiv(nx, 64), 256, 0, st>>>(xpart, nby, nx, nx, dX, 1.0);
+  reduce_rows_kernel<T, TI><<<1, 256, 0, st>>>(spart, nbx * nby, 2, 2, dparams, 1.0);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -199,17 +201,19 @@ int kmat_bwd_launch(int kind, const T* Z, int M, const T* X, long long C, int D,
 
 extern "C" {
 
-int gpsa_kmat(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
-              const void* ls_u, const void* var_u, double jitter, void* K, void* stream) {
+int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
+              int D, const void* ls_u, const void* var_u, double jitter, void* K, void* stream) {
   if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
-  if (dtype == GPSA_F32)
-    return gpsa::kmat_launch<float>(kind, (const float*)Z, M, (const float*)X, C, D,
-                                    (const float*)ls_u, (const float*)var_u, jitter, (float*)K,
-                                    as_stream(stream));
-  if (dtype == GPSA_F64)
-    return gpsa::kmat_launch<double>(kind, (const double*)Z, M, (const double*)X, C, D,
-                                     (const double*)ls_u, (const double*)var_u, jitter, (double*)K,
-                                     as_stream(stream));
+  hipStream_t st = as_stream(stream);
+  if (dtype == GPSA_F32 && in_dtype == GPSA_F32)
+    return gpsa::kmat_launch<float, float>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                           (const float*)ls_u, (const float*)var_u, jitter, (float*)K, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F64)
+    return gpsa::kmat_launch<double, double>(kind, (const double*)Z, M, (const double*)X, C, D,
+                                             (const double*)ls_u, (const double*)var_u, jitter, (double*)K, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F32)
+    return gpsa::kmat_launch<float, double>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                            (const float*)ls_u, (const float*)var_u, jitter, (double*)K, st);
   return GPSA_EINVAL;
 }
 
@@ -218,22 +222,26 @@ long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D) {
   return (nbx * M * D + nby * C * D + nbx * nby * 2) * (dtype == GPSA_F64 ? 8 : 4);
 }
 
-int gpsa_kmat_bwd(int dtype, int kind, const void* Z, int M, const void* X, long long C, int D,
-                  const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
+int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
+                  int D, const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
                   void* dparams, void* workspace, long long workspace_bytes, void* stream) {
   if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
-  if (dtype == GPSA_F32)
-    return gpsa::kmat_bwd_launch<float>(kind, (const float*)Z, M, (const float*)X, C, D,
-                                        (const float*)ls_u, (const float*)var_u,
-                                        (const float*)Kbar, (float*)dZ, (float*)dX,
-                                        (float*)dparams, workspace, workspace_bytes,
-                                        as_stream(stream));
-  if (dtype == GPSA_F64)
-    return gpsa::kmat_bwd_launch<double>(kind, (const double*)Z, M, (const double*)X, C, D,
-                                         (const double*)ls_u, (const double*)var_u,
-                                         (const double*)Kbar, (double*)dZ, (double*)dX,
-                                         (double*)dparams, workspace, workspace_bytes,
-                                         as_stream(stream));
+  hipStream_t st = as_stream(stream);
+  if (dtype == GPSA_F32 && in_dtype == GPSA_F32)
+    return gpsa::kmat_bwd_launch<float, float>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                               (const float*)ls_u, (const float*)var_u, (const float*)Kbar,
+                                               (float*)dZ, (float*)dX, (float*)dparams, workspace,
+                                               workspace_bytes, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F64)
+    return gpsa::kmat_bwd_launch<double, double>(kind, (const double*)Z, M, (const double*)X, C, D,
+                                                 (const double*)ls_u, (const double*)var_u,
+                                                 (const double*)Kbar, (double*)dZ, (double*)dX,
+                                                 (double*)dparams, workspace, workspace_bytes, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F32)
+    return gpsa::kmat_bwd_launch<float, double>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                                (const float*)ls_u, (const float*)var_u,
+                                                (const double*)Kbar, (float*)dZ, (float*)dX,
+                                                (float*)dparams, workspace, workspace_bytes, st);
   return GPSA_EINVAL;
 }
 

@@ -78,6 +78,16 @@ def factor_batch(mats):
     return out
 
 
+def _cov_inputs(Z, X, ls_u, var_u, dtype):
+    """Detached covariance inputs in one storage dtype the kernels accept next to compute dtype
+    ``dtype``: (fp32 | fp64 storage, fp64 compute) or (fp32, fp32)."""
+    sd = Z.dtype if Z.dtype in (torch.float32, torch.float64) else torch.float32
+    if dtype == torch.float32:
+        sd = torch.float32
+    fix = lambda t: t.detach() if t.dtype == sd else t.detach().to(sd)
+    return fix(Z), fix(X), fix(ls_u).reshape(1), fix(var_u).reshape(1)
+
+
 class KmatFn(torch.autograd.Function):
     """K = k(Z, X) (+ jitter on the diagonal), computed in ``dtype``; fused HIP forward and backward.
     Replaces the built-in plugins gpsa/util/util.py:8-66."""
@@ -85,13 +95,13 @@ class KmatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None):
         o = ops()
-        Zc, Xc = Z.detach().to(dtype), X.detach().to(dtype)
-        ls = ls_u.detach().to(dtype).reshape(1)
-        var = var_u.detach().to(dtype).reshape(1)
-        K = o.kmat(kind, Zc, Xc, ls, var, jitter)
+        # the kernels read the (fp32) parameters as stored and compute in ``dtype``: no cast launches
+        Zc, Xc, ls, var = _cov_inputs(Z, X, ls_u, var_u, dtype)
+        K = o.kmat(kind, Zc, Xc, ls, var, jitter, dtype=dtype)
         ctx.kind, ctx.same = kind, bool(same)
-        if bwd_dtype is not None and bwd_dtype != dtype:  # gradient-only precision for the backward
-            Zc, Xc, ls, var = (t.to(bwd_dtype) for t in (Zc, Xc, ls, var))
+        ctx.bwd_dtype = bwd_dtype or dtype  # gradient-only precision for the backward
+        if ctx.bwd_dtype == torch.float32 and Zc.dtype != torch.float32:
+            Zc, Xc, ls, var = (t.float() for t in (Zc, Xc, ls, var))
         ctx.save_for_backward(Zc, Xc, ls, var)
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, var_u.dtype, ls_u.shape, var_u.shape)
         return K
@@ -102,7 +112,7 @@ class KmatFn(torch.autograd.Function):
         Zc, Xc, ls, var = ctx.saved_tensors
         zdt, xdt, ldt, vdt, lshape, vshape = ctx.meta
         need_x = ctx.needs_input_grad[2] or ctx.same
-        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.to(Zc.dtype).contiguous(), need_dX=need_x)
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.to(ctx.bwd_dtype), need_dX=need_x)
         if ctx.same:
             dZ = dZ + dX
             dX = None
@@ -203,10 +213,8 @@ class SGPLayerFn(torch.autograd.Function):
     def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, white_dtype, main_dtype, bwd_dtype):
         o = ops()
         Tw, T = white_dtype, main_dtype
-        cast = lambda t, d: t.detach().to(d)
-        Zw, Xw = cast(Z, Tw), cast(X, Tw)
-        lsw, varw = cast(ls_u, Tw).reshape(1), cast(var_u, Tw).reshape(1)
-        Kuf = o.kmat(kind, Zw, Xw, lsw, varw, 0.0)
+        Zs, Xs, lss, vars_ = _cov_inputs(Z, X, ls_u, var_u, Tw)
+        Kuf = o.kmat(kind, Zs, Xs, lss, vars_, 0.0, dtype=Tw)
         fused = o.whiten(fac.Kinv, Kuf, T) if Tw == torch.float64 else None
         if fused is not None:
             alpha, q = fused
@@ -223,9 +231,10 @@ class SGPLayerFn(torch.autograd.Function):
         meanT = o.gemm(dcT, alpha, transA=True)
         v = o.quadform_fwd(alpha, Om)
         Li, LiT = fac.linv(T)
-        Tb = bwd_dtype
-        ctx.save_for_backward(alpha, dcT, Om, Li, LiT, cast(Z, Tb), cast(X, Tb),
-                              cast(ls_u, Tb).reshape(1), cast(var_u, Tb).reshape(1))
+        if bwd_dtype == torch.float32 and Zs.dtype != torch.float32:
+            Zs, Xs, lss, vars_ = (t.float() for t in (Zs, Xs, lss, vars_))
+        ctx.bwd_dtype = bwd_dtype
+        ctx.save_for_backward(alpha, dcT, Om, Li, LiT, Zs, Xs, lss, vars_)
         ctx.kind = kind
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
                     dc.dtype, Omega.dtype)
@@ -254,7 +263,8 @@ class SGPLayerFn(torch.autograd.Function):
         dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
         need_x = ctx.needs_input_grad[2]
         dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, varb,
-                                  dKuf if dKuf.dtype == Zb.dtype else dKuf.to(Zb.dtype), need_dX=need_x)
+                                  dKuf if dKuf.dtype == ctx.bwd_dtype else dKuf.to(ctx.bwd_dtype),
+                                  need_dX=need_x)
         return (
             None,
             dZ.to(zdt) if ctx.needs_input_grad[1] else None,

@@ -283,6 +283,8 @@ class VariationalGPSA(GPSA):
             mux = E.MatmulFn.apply(Xv, self.mean_slopes[v]) + self.mean_intercepts[v]
             if noise is not None and noise["G"] is not None:
                 eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
+            elif dev.type == "cuda":  # one launch; the device generator never reproduces the CPU stream anyway
+                eps = self._draw([S, n, D], dev)
             else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
                 eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
                     torch.empty(0, n, D, device=dev)

@@ -48,27 +48,38 @@ class HipOps:
         return t if t.is_contiguous() else t.contiguous()
 
     # ------------------------------------------------------------------ covariance matrices
-    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0):
-        Z, X = self._c(Z), self._c(X)
+    @staticmethod
+    def _cov_args(Z, X, ls_u, var_u):
+        """coordinates and hyper-parameters in ONE storage dtype (fp32 parameters pass through)"""
+        dt = Z.dtype
+        fix = lambda t: t if t.dtype == dt else t.to(dt)
+        return HipOps._c(Z), HipOps._c(fix(X)), fix(ls_u), fix(var_u)
+
+    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None):
+        """K = k(Z, X) computed and stored in ``dtype`` (default: Z's) from inputs of Z's dtype"""
+        Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
+        dtype = dtype or Z.dtype
         M, D = Z.shape
         Cn = X.shape[0]
-        K = torch.empty(M, Cn, dtype=Z.dtype, device=Z.device)
-        rc = self.lib.gpsa_kmat(_dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
+        K = torch.empty(M, Cn, dtype=dtype, device=Z.device)
+        rc = self.lib.gpsa_kmat(_dt(K), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
                                 float(jitter), _p(K), self._stream(Z))
         _lib.check(rc, "gpsa_kmat")
         return K
 
     def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True):
-        Z, X, Kbar = self._c(Z), self._c(X), self._c(Kbar)
+        """gradients in Z's dtype; the arithmetic and partial sums run in Kbar's dtype"""
+        Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
+        Kbar = self._c(Kbar)
         M, D = Z.shape
         Cn = X.shape[0]
         dZ = torch.empty_like(Z)
         dX = torch.empty_like(X) if need_dX else None
         dpar = torch.empty(2, dtype=Z.dtype, device=Z.device)
-        wsb = self.lib.gpsa_kmat_bwd_workspace(_dt(Z), M, Cn, D)
+        wsb = self.lib.gpsa_kmat_bwd_workspace(_dt(Kbar), M, Cn, D)
         ws = self._ws(wsb, Z)
-        rc = self.lib.gpsa_kmat_bwd(_dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
-                                    _p(Kbar), _p(dZ), _p(dX), _p(dpar), _p(ws), ws.numel(),
+        rc = self.lib.gpsa_kmat_bwd(_dt(Kbar), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u),
+                                    _p(var_u), _p(Kbar), _p(dZ), _p(dX), _p(dpar), _p(ws), ws.numel(),
                                     self._stream(Z))
         _lib.check(rc, "gpsa_kmat_bwd")
         return dZ, dX, dpar

@@ -28,8 +28,9 @@ def _cov(kind, Z, X, ls_u, var_u):
 class FakeOps:
     name = "fake-cpu"
 
-    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0):
-        K = _cov(kind, Z, X, ls_u, var_u)
+    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None):
+        dtype = dtype or Z.dtype
+        K = _cov(kind, Z.to(dtype), X.to(dtype), ls_u.to(dtype), var_u.to(dtype))
         if jitter:
             n = min(K.shape)
             K = K.clone()
@@ -37,12 +38,14 @@ class FakeOps:
         return K
 
     def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True):
+        dt = Kbar.dtype
         with torch.enable_grad():
-            Zr, Xr = Z.clone().requires_grad_(True), X.clone().requires_grad_(True)
-            lr, vr = ls_u.clone().requires_grad_(True), var_u.clone().requires_grad_(True)
+            Zr, Xr = Z.to(dt).clone().requires_grad_(True), X.to(dt).clone().requires_grad_(True)
+            lr, vr = ls_u.to(dt).clone().requires_grad_(True), var_u.to(dt).clone().requires_grad_(True)
             K = _cov(kind, Zr, Xr, lr, vr)
             gz, gx, gl, gv = torch.autograd.grad(K, [Zr, Xr, lr, vr], Kbar)
-        return gz, (gx if need_dX else None), torch.cat([gl.reshape(1), gv.reshape(1)])
+        o = Z.dtype
+        return gz.to(o), (gx.to(o) if need_dX else None), torch.cat([gl.reshape(1), gv.reshape(1)]).to(o)
 
     def gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, splitk=1):
         a = A.transpose(-1, -2) if transA else A

@@ -52,6 +52,25 @@ def test_kmat_fwd_bwd(hip, dtype, kind, M, C, D):
     close(dp, rp, t)
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32"])
+@pytest.mark.parametrize("M,C,D", [(25, 1000, 1), (200, 777, 2), (200, 200, 2)])
+def test_kmat_fp32_storage_fp64_compute(hip, kind, M, C, D):
+    """fp32 coordinates / hyper-parameters read as stored, covariance and its backward in fp64,
+    gradients handed back in fp32 (= the fp64 result rounded once)."""
+    f32, f64 = torch.float32, torch.float64
+    Z, X = rnd(M, D, dtype=f32, scale=3), rnd(C, D, dtype=f32, seed=1, scale=3)
+    ls, var = torch.tensor([0.4], dtype=f32), torch.tensor([-0.3], dtype=f32)
+    Kb = rnd(M, C, dtype=f64, seed=2)
+    K = hip.kmat(kind, Z.to(DEV), X.to(DEV), ls.to(DEV), var.to(DEV), 1e-5, dtype=f64)
+    assert K.dtype == f64
+    close(K, FK.kmat(kind, Z.double(), X.double(), ls.double(), var.double(), 1e-5), 1e-11)
+    dZ, dX, dp = hip.kmat_bwd(kind, Z.to(DEV), X.to(DEV), ls.to(DEV), var.to(DEV), Kb.to(DEV))
+    assert dZ.dtype == f32 and dX.dtype == f32 and dp.dtype == f32
+    rZ, rX, rp = FK.kmat_bwd(kind, Z.double(), X.double(), ls.double(), var.double(), Kb)
+    for a, b in ((dZ, rZ), (dX, rX), (dp, rp)):
+        close(a, b, 2e-7)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 def test_gemm(hip, dtype, ta, tb):
