@@ -76,13 +76,16 @@ int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet,
  * v[l,c] = alpha[:,c]^T Omega[l] alpha[:,c]            (vgpsa.py:192-196 a_t_Omega_tril, square, sum;
  *                                                        Omega_tril Omega_tril^T == Omega exactly)
  * alpha [M,C], Omega [L,M,M] symmetric, v [L,C].  Never materialises the [S,L,N,M] tensor.
- * fp32 + M <= 256 runs on the MFMA (v_mfma_f32_16x16x4_f32) path; otherwise a tiled generic path. */
+ * fp32 + M <= 256 runs on the MFMA (v_mfma_f32_16x16x4_f32) path; otherwise a tiled generic path.
+ * omega_dtype: storage type of Omega (the fp64 Omega = A A^T + 1e-5 I is read as stored and rounded
+ * to the compute type while it is packed for the matrix cores). */
 long long gpsa_quadform_workspace(int dtype, int M, long long C, int L);
-int gpsa_quadform_fwd(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
-                      void* v, void* workspace, long long workspace_bytes, void* stream);
+int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void* Omega, int M,
+                      long long C, int L, void* v, void* workspace, long long workspace_bytes,
+                      void* stream);
 /* dalpha[:,c] = 2 * sum_l g[l,c] * Omega[l] alpha[:,c]      (autograd of the above wrt alpha) */
-int gpsa_quadform_bwd_alpha(int dtype, const void* alpha, const void* Omega, const void* g, int M,
-                            long long C, int L, void* dalpha, void* workspace,
+int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const void* Omega,
+                            const void* g, int M, long long C, int L, void* dalpha, void* workspace,
                             long long workspace_bytes, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]) */
 int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, long long C, int L,
@@ -98,10 +101,11 @@ long long gpsa_whiten_workspace(int M);
 int gpsa_whiten_f64(const double* Kinv, const double* Kuf, int M, long long C, int alpha_dtype,
                     void* alpha, double* q, void* workspace, long long workspace_bytes, void* stream);
 
-/* Y = P X with P [M,M], X [M,C]  (+ optional colsq[c] = sum_m Y[m,c]^2, may be NULL).
- * The whitening products beta = L^-1 K_uf, alpha = L^-T beta of vgpsa.py:177-180. */
-int gpsa_panel_mm(int dtype, const void* P, const void* X, int M, long long C, void* Y, void* colsq,
-                  void* workspace, long long workspace_bytes, void* stream);
+/* Y = op(P) X with P [M,M] (stored as p_dtype, op = transpose when transP), X [M,C] and Y in dtype
+ * (+ optional colsq[c] = sum_m Y[m,c]^2, may be NULL).
+ * The whitening products beta = L^-1 K_uf, alpha = L^-T beta of vgpsa.py:177-180 and their adjoints. */
+int gpsa_panel_mm(int dtype, int p_dtype, int transP, const void* P, const void* X, int M, long long C,
+                  void* Y, void* colsq, void* workspace, long long workspace_bytes, void* stream);
 
 /* out[m,c] = Y[m,c] + s * d[c] * X[m,c]   (X, Y, out [M,C]; d [C]; out may alias Y).
  * Column-scaled update used by the whitening backward (autograd of vgpsa.py:177-180). */
@@ -118,19 +122,33 @@ int gpsa_data_sample_fwd(const float* meanT, const float* v, const double* q, co
 int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, const float* var_u,
                          long long C, int L, float* g, float* dmeanT, float* qbar, float* dvar_u,
                          void* workspace, long long workspace_bytes, void* stream);
-/* warp GP (vgpsa.py:186-191, 334-351; variance used as the std), fp64 inside:
- *   var = exp(var_u) - q[c] + v[j,c] + 2e-5 ; Gmean[c,j] = mux[c,j] + meanT[j,c] ;
- *   Gs[s,c,j] = Gmean[c,j] + var * eps[s,c,j].   bad[0] is set to 1 if any var <= 0 or NaN
- *   (the reference's Normal(...) argument validation raises ValueError there). */
-int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const double* var_u,
-                         const double* mux, const float* eps, long long n, int D, int S,
-                         float* Gmean, float* Gs, double* Sigma, int* bad, void* stream);
+/* warp GP (vgpsa.py:186-191, 334-351; variance used as the std), fp64 inside, with the
+ * linear mean function of the view (vgpsa.py:283-289 mean_slopes / mean_intercepts) evaluated in place:
+ *   var = exp(var_u) - q[c] + v[j,c] + 2e-5 ; Gmean[c,j] = (X[c,:] slopes)[j] + intercept[j] + meanT[j,c] ;
+ *   Gs[s,c,j] = Gmean[c,j] + var * eps[s,c,j].
+ * X [n,D], slopes [D,D], intercept [D], var_u: fp32 as stored.  bad[ceil(n/256)]: per-block flags, 1 if
+ * any var <= 0 or NaN (the reference's Normal(...) argument validation raises ValueError there). */
+int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const float* var_u,
+                         const float* X, const float* slopes, const float* intercept,
+                         const float* eps, long long n, int D, int S, float* Gmean, float* Gs,
+                         int* bad, void* stream);
 /* given dGmean [n,D] (may be NULL), dGs [S,n,D]:  dmeanT[j,c], g[j,c] = sum_s dGs*eps, qbar[c],
- *   dvar_u (overwritten).  workspace >= 8*(n/256+2) bytes */
-int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps,
-                         const double* var_u, long long n, int D, int S, double* dmeanT, double* g,
-                         double* qbar, double* dvar_u, void* workspace, long long workspace_bytes,
-                         void* stream);
+ *   dvar_u, dslopes [D,D], dintercept [D] (overwritten).  workspace >= 8*21*ceil(n/256) bytes */
+int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps, const float* var_u,
+                         const float* X, long long n, int D, int S, double* dmeanT, double* g,
+                         double* qbar, float* dvar_u, float* dslopes, float* dintercept,
+                         void* workspace, long long workspace_bytes, void* stream);
+
+/* linear mean function at the inducing points and the variational residual (vgpsa.py:283-289, 296):
+ *   mu_z = scale * (Z slopes + intercept)  [M,D] fp32 ;  resid = delta - mu_z  [M,D] fp64
+ * (scale = 100 reproduces the reference's inert x100 on a fixed view) and its adjoint:
+ * given dresid: ddelta = dresid, dZ, dslopes, dintercept (all overwritten, fp32). */
+int gpsa_mean_resid_fwd(const float* Z, const float* slopes, const float* intercept,
+                        const float* delta, int M, int D, double scale, float* mu_z, double* resid,
+                        void* stream);
+int gpsa_mean_resid_bwd(const double* dresid, const float* Z, const float* slopes, int M, int D,
+                        double scale, float* ddelta, float* dZ, float* dslopes, float* dintercept,
+                        void* stream);
 
 /* ---- Gaussian likelihood (vgpsa.py:532-538; "variance" used as std) -----------
  * scale = exp(noise_u[0]) + 1e-5 ;  out[0] = sum_{s,n,p} log N(Y[n,p]; F[s,n,p], scale) / S.

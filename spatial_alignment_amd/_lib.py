@@ -26,17 +26,20 @@ SIGNATURES = {
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_quadform_workspace": (_ll, [_i, _i, _ll, _i]),
-    "gpsa_quadform_fwd": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
-    "gpsa_quadform_bwd_alpha": (_i, [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
+    "gpsa_quadform_fwd": (_i, [_i, _i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
+    "gpsa_quadform_bwd_alpha": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_bwd_omega": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_whiten_workspace": (_ll, [_i]),
     "gpsa_whiten_f64": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
-    "gpsa_panel_mm": (_i, [_i, _vp, _vp, _i, _ll, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_panel_mm": (_i, [_i, _i, _i, _vp, _vp, _i, _ll, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_col_axpy": (_i, [_i, _vp, _vp, _vp, _d, _i, _ll, _vp, _vp]),
     "gpsa_data_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     "gpsa_data_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
-    "gpsa_warp_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "gpsa_warp_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_warp_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
+    "gpsa_warp_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _ll, _vp]),
+    "gpsa_mean_resid_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
+    "gpsa_mean_resid_bwd": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "gpsa_loglik_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_loglik_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_bdot": (_i, [_i, _vp, _ll, _vp, _ll, _ll, _i, _vp, _vp, _ll, _vp]),

@@ -126,52 +126,169 @@ data_sample_bwd_kernel(const float* __restrict__ dF, const float* __restrict__ e
 // ---- warp GP (fp64 inside) ------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 warp_sample_fwd_kernel(const double* __restrict__ meanT, const double* __restrict__ v,
-                       const double* __restrict__ q, const double* __restrict__ var_u,
-                       const double* __restrict__ mux, const float* __restrict__ eps, long long n,
-                       int D, int S, float* __restrict__ Gmean, float* __restrict__ Gs,
-                       double* __restrict__ Sigma, int* __restrict__ bad) {
+                       const double* __restrict__ q, const float* __restrict__ var_u,
+                       const float* __restrict__ X, const float* __restrict__ slopes,
+                       const float* __restrict__ intercept, const float* __restrict__ eps,
+                       long long n, int D, int S, float* __restrict__ Gmean, float* __restrict__ Gs,
+                       int* __restrict__ bad) {
   const long long c = blockIdx.x * 256LL + threadIdx.x;
-  if (c >= n) return;
-  const double var0 = exp(var_u[0]), qc = q[c];
-  for (int j = 0; j < D; ++j) {
-    const long long o = (long long)j * n + c;
-    const double var = var0 - qc + v[o] + TWO_JITTER;
-    const double mu = mux[c * D + j] + meanT[o];
-    Sigma[o] = var;
-    if (!(var > 0.0)) bad[0] = 1;
-    Gmean[c * D + j] = (float)mu;
-    for (int s = 0; s < S; ++s) {
-      const long long e = ((long long)s * n + c) * D + j;
-      Gs[e] = (float)(mu + var * (double)eps[e]);  // variance used as the std
+  int flag = 0;
+  if (c < n) {
+    const double var0 = exp((double)var_u[0]), qc = q[c];
+    double x[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) x[d] = d < D ? (double)X[c * D + d] : 0.0;
+    for (int j = 0; j < D; ++j) {
+      const long long o = (long long)j * n + c;
+      const double var = var0 - qc + v[o] + TWO_JITTER;
+      double mu = (double)intercept[j] + meanT[o];  // linear mean function of the warp GP at x_c
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d)
+        if (d < D) mu += x[d] * (double)slopes[d * D + j];
+      if (!(var > 0.0)) flag = 1;
+      Gmean[c * D + j] = (float)mu;
+      for (int s = 0; s < S; ++s) {
+        const long long e = ((long long)s * n + c) * D + j;
+        Gs[e] = (float)(mu + var * (double)eps[e]);  // variance used as the std
+      }
     }
   }
+  flag = __syncthreads_or(flag);
+  if (threadIdx.x == 0) bad[blockIdx.x] = flag;
 }
+
+// partials per block: [0] = sum g (for d var_u), [1 + d*D + j] = sum_c x[c,d] dmu[c,j], [1 + D*D + j] = sum_c dmu[c,j]
+constexpr int WS_NPART = 1 + MAXD * MAXD + MAXD;
 
 __global__ void __launch_bounds__(256)
 warp_sample_bwd_kernel(const float* __restrict__ dGmean, const float* __restrict__ dGs,
-                       const float* __restrict__ eps, long long n, int D, int S,
-                       double* __restrict__ dmeanT, double* __restrict__ g,
+                       const float* __restrict__ eps, const float* __restrict__ X, long long n,
+                       int D, int S, double* __restrict__ dmeanT, double* __restrict__ g,
                        double* __restrict__ qbar, double* __restrict__ part) {
   __shared__ double red[4];
   const long long c = blockIdx.x * 256LL + threadIdx.x;
-  double gtot = 0.0;
+  double gtot = 0.0, dmu[MAXD], x[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) {
+    dmu[d] = 0.0;
+    x[d] = (c < n && d < D) ? (double)X[c * D + d] : 0.0;
+  }
   if (c < n) {
-    for (int j = 0; j < D; ++j) {
-      double dm = dGmean ? (double)dGmean[c * D + j] : 0.0, gj = 0.0;
-      for (int s = 0; s < S; ++s) {
-        const long long e = ((long long)s * n + c) * D + j;
-        const double d = (double)dGs[e];
-        dm += d;
-        gj += d * (double)eps[e];
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j)
+      if (j < D) {
+        double dm = dGmean ? (double)dGmean[c * D + j] : 0.0, gj = 0.0;
+        for (int s = 0; s < S; ++s) {
+          const long long e = ((long long)s * n + c) * D + j;
+          const double d = (double)dGs[e];
+          dm += d;
+          gj += d * (double)eps[e];
+        }
+        dmeanT[(long long)j * n + c] = dm;
+        g[(long long)j * n + c] = gj;
+        gtot += gj;
+        dmu[j] = dm;
       }
-      dmeanT[(long long)j * n + c] = dm;
-      g[(long long)j * n + c] = gj;
-      gtot += gj;
-    }
     qbar[c] = -gtot;
   }
-  double tot = block_sum(gtot, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  double* pb = part + (long long)blockIdx.x * WS_NPART;
+  double t = block_sum(gtot, red);
+  if (threadIdx.x == 0) pb[0] = t;
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d)
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j)
+      if (d < D && j < D) {
+        t = block_sum(x[d] * dmu[j], red);
+        if (threadIdx.x == 0) pb[1 + d * D + j] = t;
+      }
+#pragma unroll
+  for (int j = 0; j < MAXD; ++j)
+    if (j < D) {
+      t = block_sum(dmu[j], red);
+      if (threadIdx.x == 0) pb[1 + D * D + j] = t;
+    }
+}
+
+// sums the block partials in block order: dvar_u = exp(var_u) * sum g ; dslopes ; dintercept
+__global__ void __launch_bounds__(64)
+warp_sample_bwd_finish_kernel(const double* __restrict__ part, long long nb, int D,
+                              const float* __restrict__ var_u, float* __restrict__ dvar_u,
+                              float* __restrict__ dslopes, float* __restrict__ dintercept) {
+  const int k = threadIdx.x, nk = 1 + D * D + D;
+  if (k >= nk) return;
+  double s = 0.0;
+  for (long long b = 0; b < nb; ++b) s += part[b * WS_NPART + k];
+  if (k == 0) dvar_u[0] = (float)(s * exp((double)var_u[0]));
+  else if (k < 1 + D * D) dslopes[k - 1] = (float)s;
+  else dintercept[k - 1 - D * D] = (float)s;
+}
+
+// ---- linear mean function at the inducing points and the variational residual -------------------
+// mu_z = scale * (Z A + b) (fp32, kept as an attribute like the reference's self.mu_z_G);
+// resid = delta - mu_z formed in fp64 from the fp32 parameters.  One block: M x D is tiny.
+__global__ void __launch_bounds__(256)
+mean_resid_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ slopes,
+                      const float* __restrict__ intercept, const float* __restrict__ delta, int M,
+                      int D, double scale, float* __restrict__ mu_z, double* __restrict__ resid) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < M * D; i += gridDim.x * 256) {
+    const int m = i / D, j = i - m * D;
+    double mu = (double)intercept[j];
+    for (int d = 0; d < D; ++d) mu += (double)Z[m * D + d] * (double)slopes[d * D + j];
+    mu *= scale;
+    mu_z[i] = (float)mu;
+    resid[i] = (double)delta[i] - mu;
+  }
+}
+
+// r = dLoss/d resid [M,D] (fp64): ddelta = r ; dZ = -scale r A^T ; dA = -scale Z^T r ; db = -scale sum_m r
+__global__ void __launch_bounds__(256)
+mean_resid_bwd_kernel(const double* __restrict__ r, const float* __restrict__ Z,
+                      const float* __restrict__ slopes, int M, int D, double scale,
+                      float* __restrict__ ddelta, float* __restrict__ dZ,
+                      float* __restrict__ dslopes, float* __restrict__ dintercept) {
+  __shared__ double red[4];
+  double accA[MAXD][MAXD], accb[MAXD];
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d) {
+    accb[d] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j) accA[d][j] = 0.0;
+  }
+  for (int m = threadIdx.x; m < M; m += 256) {
+    double rr[MAXD], zz[MAXD];
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j) {
+      rr[j] = j < D ? r[m * D + j] : 0.0;
+      zz[j] = j < D ? (double)Z[m * D + j] : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < D) {
+        ddelta[m * D + d] = (float)rr[d];
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXD; ++j)
+          if (j < D) {
+            s += rr[j] * (double)slopes[d * D + j];
+            accA[d][j] += zz[d] * rr[j];
+          }
+        dZ[m * D + d] = (float)(-scale * s);
+        accb[d] += rr[d];
+      }
+  }
+#pragma unroll
+  for (int d = 0; d < MAXD; ++d)
+    if (d < D) {
+#pragma unroll
+      for (int j = 0; j < MAXD; ++j)
+        if (j < D) {
+          const double t = block_sum(accA[d][j], red);
+          if (threadIdx.x == 0) dslopes[d * D + j] = (float)(-scale * t);
+        }
+      const double t = block_sum(accb[d], red);
+      if (threadIdx.x == 0) dintercept[d] = (float)(-scale * t);
+    }
 }
 
 // ---- Gaussian likelihood --------------------------------------------------------------------------
@@ -278,27 +395,49 @@ int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, 
   return 0;
 }
 
-int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const double* var_u,
-                         const double* mux, const float* eps, long long n, int D, int S,
-                         float* Gmean, float* Gs, double* Sigma, int* bad, void* stream) {
-  if (n < 1 || D < 1 || S < 0) return GPSA_EINVAL;
+int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const float* var_u,
+                         const float* X, const float* slopes, const float* intercept,
+                         const float* eps, long long n, int D, int S, float* Gmean, float* Gs,
+                         int* bad, void* stream) {
+  if (n < 1 || D < 1 || D > gpsa::MAXD || S < 0) return GPSA_EINVAL;
   gpsa::warp_sample_fwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, as_stream(stream)>>>(
-      meanT, v, q, var_u, mux, eps, n, D, S, Gmean, Gs, Sigma, bad);
+      meanT, v, q, var_u, X, slopes, intercept, eps, n, D, S, Gmean, Gs, bad);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
 
-int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps,
-                         const double* var_u, long long n, int D, int S, double* dmeanT, double* g,
-                         double* qbar, double* dvar_u, void* workspace, long long workspace_bytes,
-                         void* stream) {
-  if (n < 1 || D < 1 || S < 0) return GPSA_EINVAL;
+int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps, const float* var_u,
+                         const float* X, long long n, int D, int S, double* dmeanT, double* g,
+                         double* qbar, float* dvar_u, float* dslopes, float* dintercept,
+                         void* workspace, long long workspace_bytes, void* stream) {
+  if (n < 1 || D < 1 || D > gpsa::MAXD || S < 0) return GPSA_EINVAL;
   const long long nb = cdiv(n, 256);
-  if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
+  if (workspace_bytes < nb * gpsa::WS_NPART * 8) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* part = (double*)workspace;
-  gpsa::warp_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dGmean, dGs, eps, n, D, S, dmeanT, g, qbar, part);
-  gpsa::sum_scale_kernel<double, double><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
+  gpsa::warp_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dGmean, dGs, eps, X, n, D, S, dmeanT, g,
+                                                             qbar, part);
+  gpsa::warp_sample_bwd_finish_kernel<<<1, 64, 0, st>>>(part, nb, D, var_u, dvar_u, dslopes, dintercept);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_mean_resid_fwd(const float* Z, const float* slopes, const float* intercept,
+                        const float* delta, int M, int D, double scale, float* mu_z, double* resid,
+                        void* stream) {
+  if (M < 1 || D < 1 || D > gpsa::MAXD) return GPSA_EINVAL;
+  gpsa::mean_resid_fwd_kernel<<<(unsigned)cdiv((long long)M * D, 256), 256, 0, as_stream(stream)>>>(
+      Z, slopes, intercept, delta, M, D, scale, mu_z, resid);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_mean_resid_bwd(const double* dresid, const float* Z, const float* slopes, int M, int D,
+                        double scale, float* ddelta, float* dZ, float* dslopes, float* dintercept,
+                        void* stream) {
+  if (M < 1 || D < 1 || D > gpsa::MAXD) return GPSA_EINVAL;
+  gpsa::mean_resid_bwd_kernel<<<1, 256, 0, as_stream(stream)>>>(dresid, Z, slopes, M, D, scale, ddelta,
+                                                                dZ, dslopes, dintercept);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

@@ -971,12 +971,49 @@ static inline long long gram_ws_bytes(int MB, long long C, int L) {
   return (((gram_gpad_floats(C, L) + 63) / 64) * 64 + (long long)L * gram_nsplit(C, L) * MB * 16 * MB * 16) * 4;
 }
 
-static int pack_f32(const float* src, int M, int MB, int L, int transpose, float* dst,
+// The M x M operands (Omega_l, L^-1) may arrive in either precision: the MFMA paths convert while
+// packing, the generic paths take a converted copy from the head of the workspace.
+static int pack_any(int p_dtype, const void* src, int M, int MB, int L, int transpose, float* dst,
                     hipStream_t st, int sym_lower = 0) {
   const long long tot = (long long)L * MB * 16 * MB * 16;
-  pack_panels_kernel<float><<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(src, M, MB, L, transpose, dst,
-                                                                      sym_lower);
+  const unsigned grid = (unsigned)cdiv(tot, 256);
+  if (p_dtype == GPSA_F32)
+    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, sym_lower);
+  else if (p_dtype == GPSA_F64)
+    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, sym_lower);
+  else
+    return GPSA_EINVAL;
   GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename TS, typename TD>
+__global__ void convert_kernel(const TS* __restrict__ src, long long n, TD* __restrict__ dst) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i < n) dst[i] = (TD)src[i];
+}
+
+// *out = P viewed as T: P itself when it already is, else a converted copy carved off the workspace
+template <typename T>
+static int operand_as(int p_dtype, const void* P, long long n, const T** out, void** ws,
+                      long long* ws_bytes, hipStream_t st) {
+  const int want = sizeof(T) == 8 ? GPSA_F64 : GPSA_F32;
+  if (p_dtype == want) {
+    *out = (const T*)P;
+    return 0;
+  }
+  if (p_dtype != GPSA_F32 && p_dtype != GPSA_F64) return GPSA_EINVAL;
+  const long long need = ((n * (long long)sizeof(T) + 255) / 256) * 256;
+  if (*ws_bytes < need) return GPSA_EWORKSPACE;
+  T* dst = (T*)*ws;
+  if (p_dtype == GPSA_F32)
+    convert_kernel<float, T><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)P, n, dst);
+  else
+    convert_kernel<double, T><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const double*)P, n, dst);
+  GPSA_LAUNCH_CHECK();
+  *out = dst;
+  *ws = (char*)*ws + need;
+  *ws_bytes -= need;
   return 0;
 }
 
@@ -997,11 +1034,13 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   long long generic = (long long)M * C * sz * lc;                         // fwd: lc slabs of T
   long long bo = (long long)M * C * sz + (long long)gpsa::gram_splitk(C, M) * M * M * sz;  // bwd_omega
   long long r = generic > bo ? generic : bo;
+  r += (long long)L * M * M * sz + 256;  // converted copy of Omega (generic paths, other precision)
   return (r > mfma ? r : mfma) + 256;
 }
 
-int gpsa_quadform_fwd(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
-                      void* v, void* workspace, long long workspace_bytes, void* stream) {
+int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void* Omega, int M,
+                      long long C, int L, void* v, void* workspace, long long workspace_bytes,
+                      void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
@@ -1011,23 +1050,30 @@ int gpsa_quadform_fwd(int dtype, const void* alpha, const void* Omega, int M, lo
       if (workspace_bytes < (long long)L * MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
       static const bool full = [] { const char* e = getenv("GPSA_QUAD_FULL"); return e && e[0] == '1'; }();
-      int rc = pack_f32((const float*)Omega, M, MB, L, 0, Ppk, st, full ? 0 : 1);
+      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, full ? 0 : 1);
       if (rc) return rc;
       if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
                                           nullptr, 1.f, nullptr, st);
     }
-    return generic_quadform_fwd<float>((const float*)alpha, (const float*)Omega, M, C, L, (float*)v,
-                                       workspace, workspace_bytes, st);
+    const float* Om;
+    int rc = operand_as<float>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
+    if (rc) return rc;
+    return generic_quadform_fwd<float>((const float*)alpha, Om, M, C, L, (float*)v, workspace,
+                                       workspace_bytes, st);
   }
-  if (dtype == GPSA_F64)
-    return generic_quadform_fwd<double>((const double*)alpha, (const double*)Omega, M, C, L,
-                                        (double*)v, workspace, workspace_bytes, st);
+  if (dtype == GPSA_F64) {
+    const double* Om;
+    int rc = operand_as<double>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
+    if (rc) return rc;
+    return generic_quadform_fwd<double>((const double*)alpha, Om, M, C, L, (double*)v, workspace,
+                                        workspace_bytes, st);
+  }
   return GPSA_EINVAL;
 }
 
-int gpsa_quadform_bwd_alpha(int dtype, const void* alpha, const void* Omega, const void* g, int M,
-                            long long C, int L, void* dalpha, void* workspace,
+int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const void* Omega,
+                            const void* g, int M, long long C, int L, void* dalpha, void* workspace,
                             long long workspace_bytes, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1) return GPSA_EINVAL;
@@ -1038,19 +1084,24 @@ int gpsa_quadform_bwd_alpha(int dtype, const void* alpha, const void* Omega, con
       const long long pk = (long long)L * MB * 16 * MB * 16;
       if (workspace_bytes < (pk + accum_slab_floats(MB)) * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_f32((const float*)Omega, M, MB, L, 0, Ppk, st);
+      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st);
       if (rc) return rc;
       return panel_mfma_launch<MODE_ACCUM>(MB, Ppk, (const float*)alpha, (const float*)g, M, C, L,
                                            (float*)dalpha, nullptr, 2.f, Ppk + pk, st);
     }
-    return generic_quadform_bwd_alpha<float>((const float*)alpha, (const float*)Omega,
-                                             (const float*)g, M, C, L, (float*)dalpha, workspace,
-                                             workspace_bytes, st);
+    const float* Om;
+    int rc = operand_as<float>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
+    if (rc) return rc;
+    return generic_quadform_bwd_alpha<float>((const float*)alpha, Om, (const float*)g, M, C, L,
+                                             (float*)dalpha, workspace, workspace_bytes, st);
   }
-  if (dtype == GPSA_F64)
-    return generic_quadform_bwd_alpha<double>((const double*)alpha, (const double*)Omega,
-                                              (const double*)g, M, C, L, (double*)dalpha, workspace,
-                                              workspace_bytes, st);
+  if (dtype == GPSA_F64) {
+    const double* Om;
+    int rc = operand_as<double>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
+    if (rc) return rc;
+    return generic_quadform_bwd_alpha<double>((const double*)alpha, Om, (const double*)g, M, C, L,
+                                              (double*)dalpha, workspace, workspace_bytes, st);
+  }
   return GPSA_EINVAL;
 }
 
@@ -1093,23 +1144,27 @@ int gpsa_col_axpy(int dtype, const void* Y, const void* X, const void* d, double
   return 0;
 }
 
-int gpsa_panel_mm(int dtype, const void* P, const void* X, int M, long long C, void* Y, void* colsq,
-                  void* workspace, long long workspace_bytes, void* stream) {
+int gpsa_panel_mm(int dtype, int p_dtype, int transP, const void* P, const void* X, int M, long long C,
+                  void* Y, void* colsq, void* workspace, long long workspace_bytes, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
+  const int tp = transP ? 1 : 0;
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
     if (MB && !force_generic()) {
       if (workspace_bytes < (long long)MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_f32((const float*)P, M, MB, 1, 0, Ppk, st);
+      int rc = pack_any(p_dtype, P, M, MB, 1, tp, Ppk, st);
       if (rc) return rc;
       return panel_mfma_launch<MODE_STORE>(MB, Ppk, (const float*)X, nullptr, M, C, 1, (float*)Y,
                                            (float*)colsq, 1.f, nullptr, st);
     }
-    int rc = gemm_launch<float>(0, 0, M, (int)C, M, 1.0, (const float*)P, M, 0, (const float*)X, C,
-                                0, 0.0, (float*)Y, C, 0, 1, 1, nullptr, 0, st);
+    const float* Pc;
+    int rc = operand_as<float>(p_dtype, P, (long long)M * M, &Pc, &workspace, &workspace_bytes, st);
+    if (rc) return rc;
+    rc = gemm_launch<float>(tp, 0, M, (int)C, M, 1.0, Pc, M, 0, (const float*)X, C, 0, 0.0, (float*)Y,
+                            C, 0, 1, 1, nullptr, 0, st);
     if (rc) return rc;
     if (colsq) {
       colsq_kernel<float><<<(unsigned)cdiv(C, 64), 256, 0, st>>>((const float*)Y, M, C, (float*)colsq);
@@ -1118,8 +1173,11 @@ int gpsa_panel_mm(int dtype, const void* P, const void* X, int M, long long C, v
     return 0;
   }
   if (dtype == GPSA_F64) {
-    int rc = gemm_launch<double>(0, 0, M, (int)C, M, 1.0, (const double*)P, M, 0, (const double*)X,
-                                 C, 0, 0.0, (double*)Y, C, 0, 1, 1, nullptr, 0, st);
+    const double* Pc;
+    int rc = operand_as<double>(p_dtype, P, (long long)M * M, &Pc, &workspace, &workspace_bytes, st);
+    if (rc) return rc;
+    rc = gemm_launch<double>(tp, 0, M, (int)C, M, 1.0, Pc, M, 0, (const double*)X, C, 0, 0.0,
+                             (double*)Y, C, 0, 1, 1, nullptr, 0, st);
     if (rc) return rc;
     if (colsq) {
       colsq_kernel<double><<<(unsigned)cdiv(C, 64), 256, 0, st>>>((const double*)Y, M, C, (double*)colsq);

@@ -33,7 +33,7 @@ class Factor:
     """fp64 factorisation of one symmetric positive-definite M x M matrix (a prior covariance K_uu,
     shared by the layer and its KL term, or a variational covariance Omega_l)."""
 
-    __slots__ = ("Linv", "Kinv", "logdet", "info", "_cast")
+    __slots__ = ("Linv", "Kinv", "logdet", "info")
 
     def __init__(self, Kuu64=None, parts=None):
         if parts is None:
@@ -43,14 +43,6 @@ class Factor:
         self.Kinv = Kinv[0] if Kinv.dim() == 3 and Kinv.shape[0] == 1 else Kinv
         self.logdet = logdet
         self.info = info
-        self._cast = {}
-
-    def linv(self, dtype):
-        """(L^-1, L^-T) in the layer's working precision"""
-        if dtype not in self._cast:
-            a = self.Linv.to(dtype)
-            self._cast[dtype] = (a, self.Linv.t().contiguous().to(dtype))
-        return self._cast[dtype]
 
 
 def factor_batch(mats):
@@ -143,6 +135,48 @@ class OmegaFn(torch.autograd.Function):
         return ops().gemm(sym.contiguous(), A64).to(ctx.adt)
 
 
+def _project(o, fac, Kuf, T):
+    """alpha = K_uu^-1 K_uf (stored as T) and q = k^T K_uu^-1 k in K_uf's precision.  fp64: ONE pass of
+    the fp64-MFMA kernel with the explicit inverse; otherwise the two triangular passes (their fp32
+    error grows with cond(L) = sqrt(cond(K)), not cond(K)).  The fp64 factor is read as stored."""
+    fused = o.whiten(fac.Kinv, Kuf, T) if Kuf.dtype == torch.float64 else None
+    if fused is not None:
+        return fused
+    beta, q = o.panel_mm(fac.Linv, Kuf, want_colsq=True)
+    alpha_w, _ = o.panel_mm(fac.Linv, beta, transP=True)
+    return (alpha_w if alpha_w.dtype == T else alpha_w.to(T)), q
+
+
+def _solve_K(o, Linv, Kinv, abar):
+    """gamma = K_uu^-1 abar in abar's precision (same choice of path as _project)"""
+    if abar.dtype == torch.float64:
+        fused = o.whiten(Kinv, abar, torch.float64, want_q=False)
+        if fused is not None:
+            return fused[0]
+    t, _ = o.panel_mm(Linv, abar)
+    return o.panel_mm(Linv, t, transP=True)[0]
+
+
+def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm):
+    """shared backward of the sparse-GP layer: returns dKuu, dKuf, ddc, dOm (alpha's precision)"""
+    M, Cn = alpha.shape
+    L = Om.shape[0]
+    T = alpha.dtype
+    zeros = lambda *sh: torch.zeros(*sh, dtype=T, device=alpha.device)
+    dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.to(T).contiguous()
+    g = zeros(L, Cn) if g is None else g.to(T).contiguous()
+    qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
+    abar = o.quadform_bwd_alpha(alpha, Om, g)
+    o.gemm(dcT, dmeanT, beta=1.0, out=abar)
+    ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
+    dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
+    gamma = _solve_K(o, Linv, Kinv, abar)
+    W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
+    dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
+    dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
+    return dKuu, dKuf, ddc, dOm
+
+
 class SGPCoreFn(torch.autograd.Function):
     """(K_uf, dc, Omega; factor of K_uu) -> meanT [L,C], v [L,C], q [C]   (vgpsa.py:174-204).
 
@@ -155,41 +189,23 @@ class SGPCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Kuu, Kuf, dc, Omega, fac, main_dtype):
         o = ops()
-        Tw, T = Kuf.dtype, main_dtype
-        Liw, LiTw = fac.linv(Tw)
-        beta, q = o.panel_mm(Liw, Kuf.detach(), want_colsq=True)
-        alpha_w, _ = o.panel_mm(LiTw, beta)
-        alpha = alpha_w.to(T)
+        T = main_dtype
+        alpha, q = _project(o, fac, Kuf.detach(), T)
         dcT = dc.detach().to(T).contiguous()
-        Om = Omega.detach().to(T).contiguous()
+        Om = Omega.detach()  # read as stored (fp64); rounded to T while packed for the matrix cores
         meanT = o.gemm(dcT, alpha, transA=True)
         v = o.quadform_fwd(alpha, Om)
-        Li, LiT = fac.linv(T)
-        ctx.save_for_backward(alpha, dcT, Om, Li, LiT)
+        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv)
         ctx.meta = (Kuu.dtype, Kuf.dtype, dc.dtype, Omega.dtype)
         return meanT, v, q
 
     @staticmethod
     def backward(ctx, dmeanT, g, qbar):
         o = ops()
-        alpha, dcT, Om, Li, LiT = ctx.saved_tensors
+        alpha, dcT, Om, Linv, Kinv = ctx.saved_tensors
         kdt, fdt, ddt, odt = ctx.meta
-        M, Cn = alpha.shape
-        L = Om.shape[0]
-        T = alpha.dtype
-        zeros = lambda *s: torch.zeros(*s, dtype=T, device=alpha.device)
-        dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.to(T).contiguous()
-        g = zeros(L, Cn) if g is None else g.to(T).contiguous()
-        qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
-        abar = o.quadform_bwd_alpha(alpha, Om, g)
-        o.gemm(dcT, dmeanT, beta=1.0, out=abar)
-        ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
-        dOm = o.quadform_bwd_omega(alpha, g) if ctx.needs_input_grad[3] else None
-        t, _ = o.panel_mm(Li, abar)
-        gamma, _ = o.panel_mm(LiT, t)
-        W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
-        dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
-        dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
+        dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar,
+                                               ctx.needs_input_grad[3])
         return (
             dKuu.to(kdt),
             dKuf.to(fdt),
@@ -215,26 +231,16 @@ class SGPLayerFn(torch.autograd.Function):
         Tw, T = white_dtype, main_dtype
         Zs, Xs, lss, vars_ = _cov_inputs(Z, X, ls_u, var_u, Tw)
         Kuf = o.kmat(kind, Zs, Xs, lss, vars_, 0.0, dtype=Tw)
-        fused = o.whiten(fac.Kinv, Kuf, T) if Tw == torch.float64 else None
-        if fused is not None:
-            alpha, q = fused
-            del Kuf
-        else:
-            Liw, LiTw = fac.linv(Tw)
-            beta, q = o.panel_mm(Liw, Kuf, want_colsq=True)
-            del Kuf
-            alpha_w, _ = o.panel_mm(LiTw, beta)
-            del beta
-            alpha = alpha_w if T == Tw else alpha_w.to(T)
+        alpha, q = _project(o, fac, Kuf, T)
+        del Kuf
         dcT = dc.detach().to(T).contiguous()
-        Om = Omega.detach().to(T).contiguous()
+        Om = Omega.detach()  # read as stored (fp64); rounded to T while packed for the matrix cores
         meanT = o.gemm(dcT, alpha, transA=True)
         v = o.quadform_fwd(alpha, Om)
-        Li, LiT = fac.linv(T)
         if bwd_dtype == torch.float32 and Zs.dtype != torch.float32:
             Zs, Xs, lss, vars_ = (t.float() for t in (Zs, Xs, lss, vars_))
         ctx.bwd_dtype = bwd_dtype
-        ctx.save_for_backward(alpha, dcT, Om, Li, LiT, Zs, Xs, lss, vars_)
+        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_)
         ctx.kind = kind
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
                     dc.dtype, Omega.dtype)
@@ -243,24 +249,10 @@ class SGPLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmeanT, g, qbar):
         o = ops()
-        alpha, dcT, Om, Li, LiT, Zb, Xb, lsb, varb = ctx.saved_tensors
+        alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, varb = ctx.saved_tensors
         zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt = ctx.meta
-        M, Cn = alpha.shape
-        L = Om.shape[0]
-        T = alpha.dtype
-        zeros = lambda *s: torch.zeros(*s, dtype=T, device=alpha.device)
-        dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.to(T).contiguous()
-        g = zeros(L, Cn) if g is None else g.to(T).contiguous()
-        qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
-        abar = o.quadform_bwd_alpha(alpha, Om, g)
-        o.gemm(dcT, dmeanT, beta=1.0, out=abar)
-        ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
-        dOm = o.quadform_bwd_omega(alpha, g) if ctx.needs_input_grad[7] else None
-        t, _ = o.panel_mm(Li, abar)
-        gamma, _ = o.panel_mm(LiT, t)
-        W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
-        dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
-        dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
+        dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar,
+                                               ctx.needs_input_grad[7])
         need_x = ctx.needs_input_grad[2]
         dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, varb,
                                   dKuf if dKuf.dtype == ctx.bwd_dtype else dKuf.to(ctx.bwd_dtype),
@@ -278,30 +270,56 @@ class SGPLayerFn(torch.autograd.Function):
         )
 
 
-class WarpSampleFn(torch.autograd.Function):
-    """G_mean, G_samples of the warp GP (vgpsa.py:186-191, 334-351).  var is used as the std
-    (SURVEY quirk 1).  Outputs fp32; internals fp64."""
+class MeanResidFn(torch.autograd.Function):
+    """Linear mean function at the inducing points and the variational residual of one view
+    (vgpsa.py:283-289, 296): (Z, slopes, intercept, delta) -> mu_z = scale (Z slopes + intercept)
+    [fp32, not differentiable: it is only kept as the reference's ``mu_z_G`` attribute] and
+    resid = delta - mu_z [fp64], one launch each way."""
 
     @staticmethod
-    def forward(ctx, meanT, v, q, var_u, mux, eps):
+    def forward(ctx, Z, slopes, intercept, delta, scale):
         o = ops()
-        var64 = var_u.detach().double().reshape(1)
-        Gmean, Gs, Sigma, bad = o.warp_sample_fwd(meanT.detach(), v.detach(), q.detach(), var64,
-                                                  mux.detach().double(), eps)
-        ctx.save_for_backward(eps, var64)
-        ctx.vmeta = (var_u.dtype, var_u.shape)
+        mu, resid = o.mean_resid_fwd(Z.detach(), slopes.detach(), intercept.detach(), delta.detach(), scale)
+        ctx.save_for_backward(Z.detach(), slopes.detach())
+        ctx.scale = scale
+        ctx.meta = (Z.dtype, slopes.dtype, intercept.dtype, delta.dtype)
+        ctx.mark_non_differentiable(mu)
+        return mu, resid
+
+    @staticmethod
+    def backward(ctx, _dmu, dresid):
+        o = ops()
+        Z, slopes = ctx.saved_tensors
+        zdt, sdt, idt, ddt = ctx.meta
+        ddelta, dZ, dslopes, dint = o.mean_resid_bwd(dresid, Z, slopes, ctx.scale)
+        return dZ.to(zdt), dslopes.to(sdt), dint.to(idt), ddelta.to(ddt), None
+
+
+class WarpSampleFn(torch.autograd.Function):
+    """G_mean, G_samples of the warp GP (vgpsa.py:186-191, 334-351) with the view's linear mean function
+    evaluated in the same kernel.  var is used as the std.  Outputs fp32; internals
+    fp64; the fp32 parameters are read as stored."""
+
+    @staticmethod
+    def forward(ctx, meanT, v, q, var_u, X, slopes, intercept, eps):
+        o = ops()
+        Xd, var_d = X.detach(), var_u.detach().reshape(1)
+        Gmean, Gs, bad = o.warp_sample_fwd(meanT.detach(), v.detach(), q.detach(), var_d, Xd,
+                                           slopes.detach(), intercept.detach(), eps)
+        ctx.save_for_backward(eps, var_d, Xd)
+        ctx.vmeta = (var_u.dtype, var_u.shape, slopes.dtype, intercept.dtype)
         ctx.mark_non_differentiable(bad)
         return Gmean, Gs, bad
 
     @staticmethod
     def backward(ctx, dGmean, dGs, _dbad):
         o = ops()
-        eps, var64 = ctx.saved_tensors
+        eps, var_d, Xd = ctx.saved_tensors
         if dGs is None:
             dGs = torch.zeros(eps.shape, dtype=torch.float32, device=eps.device)
-        dmeanT, g, qbar, dvar = o.warp_sample_bwd(dGmean, dGs.float(), eps, var64)
-        vdt, vshape = ctx.vmeta
-        return dmeanT, g, qbar, dvar.to(vdt).reshape(vshape), None, None
+        dmeanT, g, qbar, dvar, dslopes, dint = o.warp_sample_bwd(dGmean, dGs.float(), eps, var_d, Xd)
+        vdt, vshape, sdt, idt = ctx.vmeta
+        return (dmeanT, g, qbar, dvar.to(vdt).reshape(vshape), None, dslopes.to(sdt), dint.to(idt), None)
 
 
 class DataSampleFn(torch.autograd.Function):

@@ -39,7 +39,7 @@ class _StepCache:
         self.Omega_G_fac = None  # (Omega_G^-1 [V*D,M,M], logdet [V*D])
         self.Omega_F_fac = {}  # mod -> (Omega_F^-1, logdet)
         self.flags = []  # device int tensors: Cholesky info / non-positive variance flags
-        self.mu_z = self.dG_v = None  # per-view prior means / variational means of this forward
+        self.mu_z = self.dG_v = self.resid = None  # per-view prior means / variational means / their difference
         self.Om_fwd = self.Om_kl = None  # per-view row groups of Omega_G
 
 
@@ -222,14 +222,16 @@ class VariationalGPSA(GPSA):
         dG_v = self.delta_G_list.unbind(0)
         wls_v = self.warp_kernel_lengthscales.unbind(0)
         wvar_v = self.warp_kernel_variances.unbind(0)
-        mu_z = []
-        for v in range(V):
-            mz = E.MatmulFn.apply(Xt_v[v], self.mean_slopes[v]) + self.mean_intercepts[v]
-            if self._is_fixed(v):
-                mz = mz * 100.0  # inert (quirk 7)
+        slopes_v = self.mean_slopes.unbind(0)
+        icpt_v = self.mean_intercepts.unbind(0)
+        mu_z, resid = [], []
+        for v in range(V):  # mean function at the inducing points + variational residual, one launch
+            mz, dc = E.MeanResidFn.apply(Xt_v[v], slopes_v[v], icpt_v[v], dG_v[v],
+                                         100.0 if self._is_fixed(v) else 1.0)  # x100: inert (quirk 7)
             mu_z.append(mz)
+            resid.append(dc)
         self.mu_z_G = torch.stack(mu_z)
-        cache.mu_z, cache.dG_v = mu_z, dG_v
+        cache.mu_z, cache.dG_v, cache.resid = mu_z, dG_v, resid
 
         # ---- everything M x M first: all prior covariances and variational covariances of the step
         #      are factorised by ONE batched Cholesky / triangular-inverse launch per matrix size
@@ -269,18 +271,14 @@ class VariationalGPSA(GPSA):
             Z = Xt_v[v]
             ls_u, var_u = wls_v[v], wvar_v[v]
             Kuu, fac = cache.warp[v]
-            dc = dG_v[v].to(f64) - mu_z[v].to(f64)
+            dc = resid[v]
             Om = cache.Om_fwd[v]  # quirk 2: forward uses rows v*D+j
             kind = builtin_kind(self.kernel_func_warp)
             if kind is not None:  # fused covariance + layer, all fp64
-                wm = getattr(self, "_warp_main_dtype", f64)
-                meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, wm, wm)
-                if wm != f64:
-                    meanT, vq = meanT.double(), vq.double()
+                meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
             else:
                 Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
                 meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
-            mux = E.MatmulFn.apply(Xv, self.mean_slopes[v]) + self.mean_intercepts[v]
             if noise is not None and noise["G"] is not None:
                 eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
             elif dev.type == "cuda":  # one launch; the device generator never reproduces the CPU stream anyway
@@ -288,7 +286,7 @@ class VariationalGPSA(GPSA):
             else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
                 eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
                     torch.empty(0, n, D, device=dev)
-            Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, mux, eps)  # quirk 1 inside
+            Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
             cache.flags.append(bad)
             warp_out[v] = (Gm, Gs)
 
@@ -414,7 +412,7 @@ class VariationalGPSA(GPSA):
             if self._is_fixed(v) or v not in cache.warp:
                 continue
             Kuu, fac = cache.warp[v]
-            Dm = cache.dG_v[v].to(f64) - cache.mu_z[v].to(f64)
+            Dm = cache.resid[v]
             Om = cache.Om_kl[v]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
             ofac = (cache.Omega_G_fac[0][v::V], cache.Omega_G_fac[1][v::V])
             term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()

@@ -165,8 +165,8 @@ class HipOps:
         L = Omega.shape[0]
         v = torch.empty(L, Cn, dtype=alpha.dtype, device=alpha.device)
         ws = self._qf_ws(alpha, L)
-        rc = self.lib.gpsa_quadform_fwd(_dt(alpha), _p(alpha), _p(Omega), M, Cn, L, _p(v), _p(ws),
-                                        ws.numel(), self._stream(alpha))
+        rc = self.lib.gpsa_quadform_fwd(_dt(alpha), _dt(Omega), _p(alpha), _p(Omega), M, Cn, L, _p(v),
+                                        _p(ws), ws.numel(), self._stream(alpha))
         _lib.check(rc, "gpsa_quadform_fwd")
         return v
 
@@ -176,8 +176,8 @@ class HipOps:
         L = Omega.shape[0]
         out = torch.empty_like(alpha)
         ws = self._qf_ws(alpha, L)
-        rc = self.lib.gpsa_quadform_bwd_alpha(_dt(alpha), _p(alpha), _p(Omega), _p(g), M, Cn, L,
-                                              _p(out), _p(ws), ws.numel(), self._stream(alpha))
+        rc = self.lib.gpsa_quadform_bwd_alpha(_dt(alpha), _dt(Omega), _p(alpha), _p(Omega), _p(g), M, Cn,
+                                              L, _p(out), _p(ws), ws.numel(), self._stream(alpha))
         _lib.check(rc, "gpsa_quadform_bwd_alpha")
         return out
 
@@ -192,14 +192,15 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_bwd_omega")
         return out
 
-    def panel_mm(self, P, X, want_colsq=False):
+    def panel_mm(self, P, X, want_colsq=False, transP=False):
+        """Y = op(P) @ X in X's dtype; P [M,M] may be stored in either precision"""
         P, X = self._c(P), self._c(X)
         M, Cn = X.shape
         Y = torch.empty_like(X)
         q = torch.empty(Cn, dtype=X.dtype, device=X.device) if want_colsq else None
-        ws = self._ws(4 * 256 * 256 + 256, X)
-        rc = self.lib.gpsa_panel_mm(_dt(X), _p(P), _p(X), M, Cn, _p(Y), _p(q), _p(ws), ws.numel(),
-                                    self._stream(X))
+        ws = self._ws(max(4 * 256 * 256, 8 * M * M) + 512, X)
+        rc = self.lib.gpsa_panel_mm(_dt(X), _dt(P), int(bool(transP)), _p(P), _p(X), M, Cn, _p(Y), _p(q),
+                                    _p(ws), ws.numel(), self._stream(X))
         _lib.check(rc, "gpsa_panel_mm")
         return Y, q
 
@@ -254,35 +255,73 @@ class HipOps:
         _lib.check(rc, "gpsa_data_sample_bwd")
         return g, dmeanT, qbar, dvar
 
-    def warp_sample_fwd(self, meanT, v, q, var_u, mux, eps):
-        meanT, v, q, mux, eps = self._c(meanT), self._c(v), self._c(q), self._c(mux), self._c(eps)
+    @staticmethod
+    def _f32(t):
+        t = t if t.dtype == torch.float32 else t.float()
+        return t if t.is_contiguous() else t.contiguous()
+
+    def warp_sample_fwd(self, meanT, v, q, var_u, X, slopes, intercept, eps):
+        """-> Gmean [n,D], Gs [S,n,D] (fp32), bad [blocks] (int32 flags)"""
+        meanT, v, q, eps = self._c(meanT), self._c(v), self._c(q), self._c(eps)
+        var_u, X, slopes, intercept = (self._f32(t) for t in (var_u, X, slopes, intercept))
         D, n = meanT.shape
         S = eps.shape[0]
         Gmean = torch.empty(n, D, dtype=torch.float32, device=meanT.device)
         Gs = torch.empty(S, n, D, dtype=torch.float32, device=meanT.device)
-        Sigma = torch.empty_like(meanT)
-        bad = torch.zeros(1, dtype=torch.int32, device=meanT.device)
-        rc = self.lib.gpsa_warp_sample_fwd(_p(meanT), _p(v), _p(q), _p(var_u), _p(mux), _p(eps), n, D,
-                                           S, _p(Gmean), _p(Gs), _p(Sigma), _p(bad),
+        bad = torch.empty((n + 255) // 256, dtype=torch.int32, device=meanT.device)
+        rc = self.lib.gpsa_warp_sample_fwd(_p(meanT), _p(v), _p(q), _p(var_u), _p(X), _p(slopes),
+                                           _p(intercept), _p(eps), n, D, S, _p(Gmean), _p(Gs), _p(bad),
                                            self._stream(meanT))
         _lib.check(rc, "gpsa_warp_sample_fwd")
-        return Gmean, Gs, Sigma, bad
+        return Gmean, Gs, bad
 
-    def warp_sample_bwd(self, dGmean, dGs, eps, var_u):
+    def warp_sample_bwd(self, dGmean, dGs, eps, var_u, X):
+        """-> dmeanT, g [D,n], qbar [n] (fp64); dvar_u [1], dslopes [D,D], dintercept [D] (fp32)"""
         dGs, eps = self._c(dGs), self._c(eps)
         dGmean = None if dGmean is None else self._c(dGmean)
+        var_u, X = self._f32(var_u), self._f32(X)
         S, n, D = dGs.shape
         dev = dGs.device
-        dmeanT = torch.empty(D, n, dtype=torch.float64, device=dev)
-        g = torch.empty(D, n, dtype=torch.float64, device=dev)
-        qbar = torch.empty(n, dtype=torch.float64, device=dev)
-        dvar = torch.empty(1, dtype=torch.float64, device=dev)
-        ws = self._ws(8 * (n // 256 + 2), dGs)
-        rc = self.lib.gpsa_warp_sample_bwd(_p(dGmean), _p(dGs), _p(eps), _p(var_u), n, D, S,
-                                           _p(dmeanT), _p(g), _p(qbar), _p(dvar), _p(ws), ws.numel(),
-                                           self._stream(dGs))
+        f64, f32 = torch.float64, torch.float32
+        dmeanT = torch.empty(D, n, dtype=f64, device=dev)
+        g = torch.empty(D, n, dtype=f64, device=dev)
+        qbar = torch.empty(n, dtype=f64, device=dev)
+        dvar = torch.empty(1, dtype=f32, device=dev)
+        dslopes = torch.empty(D, D, dtype=f32, device=dev)
+        dint = torch.empty(D, dtype=f32, device=dev)
+        ws = self._ws(8 * 21 * ((n + 255) // 256) + 64, dGs)
+        rc = self.lib.gpsa_warp_sample_bwd(_p(dGmean), _p(dGs), _p(eps), _p(var_u), _p(X), n, D, S,
+                                           _p(dmeanT), _p(g), _p(qbar), _p(dvar), _p(dslopes), _p(dint),
+                                           _p(ws), ws.numel(), self._stream(dGs))
         _lib.check(rc, "gpsa_warp_sample_bwd")
-        return dmeanT, g, qbar, dvar
+        return dmeanT, g, qbar, dvar, dslopes, dint
+
+    # ------------------------------------------------------------------ mean function at Z
+    def mean_resid_fwd(self, Z, slopes, intercept, delta, scale=1.0):
+        """-> mu_z = scale (Z slopes + intercept) [M,D] fp32, resid = delta - mu_z [M,D] fp64"""
+        Z, slopes, intercept, delta = (self._f32(t) for t in (Z, slopes, intercept, delta))
+        M, D = Z.shape
+        mu = torch.empty(M, D, dtype=torch.float32, device=Z.device)
+        resid = torch.empty(M, D, dtype=torch.float64, device=Z.device)
+        rc = self.lib.gpsa_mean_resid_fwd(_p(Z), _p(slopes), _p(intercept), _p(delta), M, D, float(scale),
+                                          _p(mu), _p(resid), self._stream(Z))
+        _lib.check(rc, "gpsa_mean_resid_fwd")
+        return mu, resid
+
+    def mean_resid_bwd(self, dresid, Z, slopes, scale=1.0):
+        """-> ddelta, dZ [M,D], dslopes [D,D], dintercept [D] (fp32)"""
+        dresid = self._c(dresid if dresid.dtype == torch.float64 else dresid.double())
+        Z, slopes = self._f32(Z), self._f32(slopes)
+        M, D = Z.shape
+        f32, dev = torch.float32, Z.device
+        ddelta = torch.empty(M, D, dtype=f32, device=dev)
+        dZ = torch.empty(M, D, dtype=f32, device=dev)
+        dslopes = torch.empty(D, D, dtype=f32, device=dev)
+        dint = torch.empty(D, dtype=f32, device=dev)
+        rc = self.lib.gpsa_mean_resid_bwd(_p(dresid), _p(Z), _p(slopes), M, D, float(scale), _p(ddelta),
+                                          _p(dZ), _p(dslopes), _p(dint), self._stream(Z))
+        _lib.check(rc, "gpsa_mean_resid_bwd")
+        return ddelta, dZ, dslopes, dint
 
     # ------------------------------------------------------------------ likelihood
     def loglik_fwd(self, F, Y, noise_u):

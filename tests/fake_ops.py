@@ -74,16 +74,16 @@ class FakeOps:
         return self.tri_inv(L), logdet, info
 
     def quadform_fwd(self, alpha, Omega):
-        return torch.einsum("mc,lmk,kc->lc", alpha, Omega, alpha)
+        return torch.einsum("mc,lmk,kc->lc", alpha, Omega.to(alpha.dtype), alpha)
 
     def quadform_bwd_alpha(self, alpha, Omega, g):
-        return 2.0 * torch.einsum("lc,lmk,kc->mc", g, Omega, alpha)
+        return 2.0 * torch.einsum("lc,lmk,kc->mc", g, Omega.to(alpha.dtype), alpha)
 
     def quadform_bwd_omega(self, alpha, g):
         return torch.einsum("lc,mc,kc->lmk", g, alpha, alpha)
 
-    def panel_mm(self, P, X, want_colsq=False):
-        Y = P @ X
+    def panel_mm(self, P, X, want_colsq=False, transP=False):
+        Y = (P.t() if transP else P).to(X.dtype) @ X
         return Y, ((Y * Y).sum(0) if want_colsq else None)
 
     def whiten(self, Kinv, Kuf, out_dtype, want_q=True):
@@ -107,20 +107,31 @@ class FakeOps:
         g = (dF * eps).t() * 0.5 / torch.sqrt(Sigma)
         return g, dF.t().contiguous(), -g.sum(0), (torch.exp(var_u[0]) * g.sum()).reshape(1)
 
-    def warp_sample_fwd(self, meanT, v, q, var_u, mux, eps):
-        Sigma = torch.exp(var_u[0]) - q.unsqueeze(0) + v + JIT2  # [D,n]
-        mu = mux + meanT.t()
+    def warp_sample_fwd(self, meanT, v, q, var_u, X, slopes, intercept, eps):
+        Sigma = torch.exp(var_u.reshape(-1)[0].double()) - q.unsqueeze(0) + v + JIT2  # [D,n]
+        mu = X.double() @ slopes.double() + intercept.double() + meanT.t()
         Gs = mu.unsqueeze(0) + Sigma.t().unsqueeze(0) * eps.double()
         bad = (~(Sigma > 0)).any().to(torch.int32).reshape(1)
-        return mu.float(), Gs.float(), Sigma, bad
+        return mu.float(), Gs.float(), bad
 
-    def warp_sample_bwd(self, dGmean, dGs, eps, var_u):
+    def warp_sample_bwd(self, dGmean, dGs, eps, var_u, X):
         d = dGs.double()
         dm = d.sum(0)
         if dGmean is not None:
             dm = dm + dGmean.double()
         g = (d * eps.double()).sum(0)  # [n,D]
-        return dm.t().contiguous(), g.t().contiguous(), -g.sum(1), (torch.exp(var_u[0]) * g.sum()).reshape(1)
+        dvar = (torch.exp(var_u.reshape(-1)[0].double()) * g.sum()).reshape(1).float()
+        return (dm.t().contiguous(), g.t().contiguous(), -g.sum(1), dvar,
+                (X.double().t() @ dm).float(), dm.sum(0).float())
+
+    def mean_resid_fwd(self, Z, slopes, intercept, delta, scale=1.0):
+        mu = scale * (Z.double() @ slopes.double() + intercept.double())
+        return mu.float(), delta.double() - mu
+
+    def mean_resid_bwd(self, dresid, Z, slopes, scale=1.0):
+        r = dresid.double()
+        return (r.float(), (-scale * r @ slopes.double().t()).float(),
+                (-scale * Z.double().t() @ r).float(), (-scale * r.sum(0)).float())
 
     def loglik_fwd(self, F, Y, noise_u):
         s = torch.exp(noise_u[0].double()) + 1e-5

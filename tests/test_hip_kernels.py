@@ -198,6 +198,33 @@ def test_panel_mm_col_axpy(hip, dtype, M, C):
     close(hip.col_axpy(Y, X.to(DEV), d.to(DEV), 0.5), FK.col_axpy(rY, X.double(), d.double(), 0.5), TOL[dtype] * 2)
 
 
+@pytest.mark.parametrize("M,C", [(12, 50), (200, 1500), (300, 70)])
+@pytest.mark.parametrize("xdt", [torch.float32, torch.float64])
+def test_panel_mm_fp64_operand_and_transpose(hip, M, C, xdt):
+    """the fp64 factor is read as stored (rounded while packed / converted), optionally transposed"""
+    P = rnd(M, M, dtype=torch.float64).tril()
+    X = rnd(M, C, dtype=xdt, seed=1)
+    tol = TOL[xdt] * 2
+    for tp in (False, True):
+        Y, q = hip.panel_mm(P.to(DEV), X.to(DEV), want_colsq=True, transP=tp)
+        assert Y.dtype == xdt
+        rY = (P.t() if tp else P) @ X.double()
+        close(Y, rY, tol)
+        close(q, (rY * rY).sum(0), tol)
+
+
+@pytest.mark.parametrize("M,C,L", [(25, 1000, 5), (200, 2100, 3), (300, 130, 2)])
+def test_quadform_fp64_omega_fp32_alpha(hip, M, C, L):
+    a = rnd(M, C, dtype=torch.float32)
+    A = rnd(L, M, M, dtype=torch.float64, seed=1)
+    Om = A @ A.transpose(1, 2) / M
+    g = rnd(L, C, dtype=torch.float32, seed=2)
+    v = hip.quadform_fwd(a.to(DEV), Om.to(DEV))
+    assert v.dtype == torch.float32
+    close(v, FK.quadform_fwd(a.double(), Om), 3e-5)
+    close(hip.quadform_bwd_alpha(a.to(DEV), Om.to(DEV), g.to(DEV)), FK.quadform_bwd_alpha(a.double(), Om, g.double()), 3e-5)
+
+
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129)])
 def test_whiten_f64_mfma(hip, out_dtype, M, C):
@@ -239,21 +266,41 @@ def test_data_sample(hip, C, L):
 def test_warp_sample(hip, n, D, S):
     f64 = torch.float64
     meanT, v = rnd(D, n, dtype=f64), rnd(D, n, dtype=f64, seed=1).abs()
-    q, mux = rnd(n, dtype=f64, seed=2).abs() * 0.1, rnd(n, D, dtype=f64, seed=3)
-    eps, var_u = rnd(S, n, D, seed=4), torch.tensor([0.2], dtype=f64)
-    Gm, Gs, Sig, bad = hip.warp_sample_fwd(meanT.to(DEV), v.to(DEV), q.to(DEV), var_u.to(DEV), mux.to(DEV), eps.to(DEV))
-    rGm, rGs, rSig, rbad = FK.warp_sample_fwd(meanT, v, q, var_u, mux, eps)
+    q, X = rnd(n, dtype=f64, seed=2).abs() * 0.1, rnd(n, D, seed=3, scale=4)
+    A, b = torch.eye(D) + 0.1 * rnd(D, D, seed=7), rnd(D, seed=8)
+    eps, var_u = rnd(S, n, D, seed=4), torch.tensor([0.2])
+    dev = lambda *ts: [t.to(DEV) for t in ts]
+    Gm, Gs, bad = hip.warp_sample_fwd(*dev(meanT, v, q, var_u, X, A, b, eps))
+    rGm, rGs, rbad = FK.warp_sample_fwd(meanT, v, q, var_u, X, A, b, eps)
     close(Gm, rGm, 1e-6)
     close(Gs, rGs, 1e-6)
-    close(Sig, rSig, 1e-12)
-    assert int(bad) == 0
+    assert bad.numel() == (n + 255) // 256 and int(bad.abs().max()) == 0
     dGm, dGs = rnd(n, D, seed=5), rnd(S, n, D, seed=6)
-    got = hip.warp_sample_bwd(dGm.to(DEV), dGs.to(DEV), eps.to(DEV), var_u.to(DEV))
-    want = FK.warp_sample_bwd(dGm, dGs, eps, var_u)
-    for a, b in zip(got, want):
-        close(a, b, 1e-11)
-    _, _, _, bad = hip.warp_sample_fwd(meanT.to(DEV), (v - 100).to(DEV), q.to(DEV), var_u.to(DEV), mux.to(DEV), eps.to(DEV))
-    assert int(bad) == 1
+    got = hip.warp_sample_bwd(*dev(dGm, dGs, eps, var_u, X))
+    want = FK.warp_sample_bwd(dGm, dGs, eps, var_u, X)
+    for a, w in zip(got, want):
+        close(a, w, 1e-11 if a.dtype == f64 else 2e-6)
+    _, _, bad = hip.warp_sample_fwd(*dev(meanT, v - 100, q, var_u, X, A, b, eps))
+    assert int(bad.max()) == 1
+
+
+@pytest.mark.parametrize("M,D,scale", [(50, 2, 1.0), (200, 2, 1.0), (333, 3, 100.0), (7, 1, 1.0)])
+def test_mean_resid(hip, M, D, scale):
+    Z, delta = rnd(M, D, seed=1, scale=5), rnd(M, D, seed=2, scale=5)
+    A, b = torch.eye(D) + 0.1 * rnd(D, D, seed=3), rnd(D, seed=4)
+    mu, r = hip.mean_resid_fwd(*[t.to(DEV) for t in (Z, A, b, delta)], scale)
+    rmu, rr = FK.mean_resid_fwd(Z, A, b, delta, scale)
+    assert mu.dtype == torch.float32 and r.dtype == torch.float64
+    close(mu, rmu, 1e-6)
+    close(r, rr, 1e-13)
+    dres = rnd(M, D, dtype=torch.float64, seed=5)
+    got = hip.mean_resid_bwd(dres.to(DEV), Z.to(DEV), A.to(DEV), scale)
+    want = FK.mean_resid_bwd(dres, Z, A, scale)
+    for a, w in zip(got, want):
+        close(a, w, 2e-6)
+    # identity mean function and delta = Z (the initial state): the residual is exactly zero
+    _, r0 = hip.mean_resid_fwd(Z.to(DEV), torch.eye(D, device=DEV), torch.zeros(D, device=DEV), Z.to(DEV))
+    assert float(r0.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("S,N,P", [(1, 100, 3), (5, 2000, 50), (2, 33, 7)])
