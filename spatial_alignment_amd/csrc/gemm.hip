@@ -116,6 +116,115 @@ gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long lo
   }
 }
 
+// fp64 variant on the matrix cores (v_mfma_f64_16x16x4_f64): same 64 x 64 x 16 workgroup tile and the
+// same register-staged prefetch, but each wave owns a 32 x 32 quadrant as 2 x 2 MFMA tiles, so one K
+// step of 4 costs 4 LDS fragment reads per 4 MFMAs instead of 4 ds_read_b128 per 16 vector FMAs (the
+// vector kernel above is LDS-bandwidth-bound at twice its FMA time in fp64).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256, 4)
+gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const double* __restrict__ A,
+                     long long lda, long long sA, const double* __restrict__ B, long long ldb,
+                     long long sB, double beta, double* __restrict__ C, long long ldc, long long sC,
+                     int splitk, double* __restrict__ part) {
+  __shared__ double As[2][GB_K][GB_M + 4];  // double-buffered: one barrier per K tile
+  __shared__ double Bs[2][GB_K][GB_N + 4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32, j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.z / splitk, sp = blockIdx.z % splitk;
+  const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+  long long kchunk = (k + splitk - 1) / splitk;
+  kchunk = (kchunk + GB_K - 1) / GB_K * GB_K;
+  const long long kbeg = (long long)sp * kchunk;
+  const long long kend = (kbeg + kchunk < k) ? kbeg + kchunk : k;
+  const double* Ab = A + (long long)b * sA;
+  const double* Bb = B + (long long)b * sB;
+  f64x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+  const bool lm0 = m0 + wm < m, lm1 = m0 + wm + 16 < m, ln0 = n0 + wn < n, ln1 = n0 + wn + 16 < n;
+
+  double ra[4], rb[4];
+#define GPSA_G64_FETCH(K0)                                                                \
+  {                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+      const int e = tid + i * 256;                                                        \
+      int r, kk;                                                                          \
+      if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }      \
+      const long long gr = m0 + r, gk = (K0) + kk;                                        \
+      double va = 0.0;                                                                    \
+      if (gr < m && gk < kend) va = TA ? Ab[gk * lda + gr] : Ab[gr * lda + gk];           \
+      ra[i] = va;                                                                         \
+      int c, kb;                                                                          \
+      if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }      \
+      const long long gc = n0 + c, gk2 = (K0) + kb;                                       \
+      double vb = 0.0;                                                                    \
+      if (gc < n && gk2 < kend) vb = TB ? Bb[gc * ldb + gk2] : Bb[gk2 * ldb + gc];        \
+      rb[i] = vb;                                                                         \
+    }                                                                                     \
+  }
+#define GPSA_G64_STASH(BUF)                                                               \
+  {                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+      const int e = tid + i * 256;                                                        \
+      int r, kk;                                                                          \
+      if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }      \
+      As[BUF][kk][r] = ra[i];                                                             \
+      int c, kb;                                                                          \
+      if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }      \
+      Bs[BUF][kb][c] = rb[i];                                                             \
+    }                                                                                     \
+  }
+  if (kbeg < kend) {
+    GPSA_G64_FETCH(kbeg)
+    GPSA_G64_STASH(0)
+  }
+  __syncthreads();
+  int cur = 0;
+  for (long long k0 = kbeg; k0 < kend; k0 += GB_K) {
+    const bool more = k0 + GB_K < kend;
+    if (more) GPSA_G64_FETCH(k0 + GB_K)
+#pragma unroll
+    for (int ks = 0; ks < GB_K / 4; ++ks) {
+      const int kk = ks * 4 + kq;
+      const double a0 = As[cur][kk][wm + j], a1 = As[cur][kk][wm + 16 + j];
+      const double b0 = Bs[cur][kk][wn + j], b1 = Bs[cur][kk][wn + 16 + j];
+      // MFMA tiles that lie wholly outside the matrix are skipped (wave-uniform): M = 200 costs
+      // 3.5 x 3.5 tile units instead of 4 x 4
+      if (lm0 && ln0) acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      if (lm0 && ln1) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      if (lm1 && ln0) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      if (lm1 && ln1) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // the other buffer was last read one tile ago, before the previous barrier
+    if (more) GPSA_G64_STASH(cur ^ 1)
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef GPSA_G64_FETCH
+#undef GPSA_G64_STASH
+  // C/D layout of the fp64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15
+  double* Cb = (splitk == 1) ? C + (long long)b * sC : part + ((long long)blockIdx.z) * m * n;
+  const long long ld = (splitk == 1) ? ldc : (long long)n;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + tm * 16 + kq + 4 * r, col = n0 + wn + tn * 16 + j;
+        if (row < m && col < n) {
+          double* p = Cb + (long long)row * ld + col;
+          const double y = acc[tm][tn][r];
+          if (splitk == 1) *p = (beta == 0.0) ? alpha * y : alpha * y + beta * (*p);
+          else *p = y;
+        }
+      }
+}
+
 template <typename T>
 __global__ void splitk_reduce_kernel(const T* __restrict__ part, int batch, int splitk, int m, int n,
                                      T alpha, T beta, T* __restrict__ C, long long ldc,
@@ -130,6 +239,11 @@ __global__ void splitk_reduce_kernel(const T* __restrict__ part, int batch, int 
   for (int sp = 0; sp < splitk; ++sp) s += part[((long long)b * splitk + sp) * mn + e];
   T* p = C + (long long)b * sC + (long long)r * ldc + c;
   *p = (beta == T(0)) ? alpha * s : alpha * s + beta * (*p);
+}
+
+static inline bool gemm_force_vector() {
+  static const bool v = [] { const char* e = getenv("GPSA_GEMM_VECTOR"); return e && e[0] == '1'; }();
+  return v;
 }
 
 template <typename T>
@@ -148,11 +262,23 @@ int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha,
 #define GPSA_GEMM_CASE(TA, TB)                                                               \
   gemm_kernel<T, TA, TB><<<grid, 256, 0, st>>>(m, n, k, (T)alpha, A, lda, sA, B, ldb, sB,     \
                                                (T)beta, C, ldc, sC, splitk, part)
-  if (!transA && !transB) GPSA_GEMM_CASE(false, false);
+#define GPSA_GEMM64_CASE(TA, TB)                                                                    \
+  gemm_f64_mfma_kernel<TA, TB><<<grid, 256, 0, st>>>(m, n, k, alpha, (const double*)A, lda, sA,      \
+                                                     (const double*)B, ldb, sB, beta, (double*)C,    \
+                                                     ldc, sC, splitk, (double*)part)
+  // fp64 products with at least one MFMA tile in each direction run on the matrix cores
+  const bool mfma64 = (sizeof(T) == 8) && m >= 16 && n >= 16 && !gemm_force_vector();
+  if (mfma64) {
+    if (!transA && !transB) GPSA_GEMM64_CASE(false, false);
+    else if (transA && !transB) GPSA_GEMM64_CASE(true, false);
+    else if (!transA && transB) GPSA_GEMM64_CASE(false, true);
+    else GPSA_GEMM64_CASE(true, true);
+  } else if (!transA && !transB) GPSA_GEMM_CASE(false, false);
   else if (transA && !transB) GPSA_GEMM_CASE(true, false);
   else if (!transA && transB) GPSA_GEMM_CASE(false, true);
   else GPSA_GEMM_CASE(true, true);
 #undef GPSA_GEMM_CASE
+#undef GPSA_GEMM64_CASE
   GPSA_LAUNCH_CHECK();
   if (splitk > 1) {
     const long long tot = (long long)m * n * batch;

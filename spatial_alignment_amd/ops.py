@@ -118,7 +118,7 @@ class HipOps:
     def pick_splitk(k, m, n):
         """split the reduction dim so that a skinny product still fills the chip"""
         tiles = ((m + 63) // 64) * ((n + 63) // 64)
-        s = max(1, min(256, -(-512 // max(tiles, 1)), k // 256))
+        s = max(1, min(256, -(-512 // max(tiles, 1)), k // 64))
         return int(s)
 
     # ------------------------------------------------------------------ factorisations (fp64)

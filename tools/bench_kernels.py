@@ -54,6 +54,13 @@ if "kmat_bwd" in what:
         ls, var = torch.zeros(1, device=dev, dtype=dt), torch.zeros(1, device=dev, dtype=dt)
         Kb = torch.randn(M, C, device=dev, dtype=dt)
         print(f"kmat_bwd {dt} M={M} C={C}: {timeit(lambda: o.kmat_bwd('rbf', Z, X, ls, var, Kb, need_dX=True)):.1f} us", flush=True)
+if "gemm64w" in what:  # the warp-layer shapes (M = 200, C = columns of one view)
+    for C in (1250, 10000):
+        A = torch.randn(200, 200, device=dev, dtype=torch.float64)
+        X = torch.randn(200, C, device=dev, dtype=torch.float64)
+        print(f"gemm f64 NN 200x200x{C}: {timeit(lambda: o.gemm(A, X)):.1f} us", flush=True)
+        sk = o.pick_splitk(C, 200, 200)
+        print(f"gemm f64 NT 200x{C}x200 splitk={sk}: {timeit(lambda: o.gemm(X, X, transB=True, splitk=sk)):.1f} us", flush=True)
 if "gemm64" in what:
     for B in (4, 50, 57):
         A = torch.randn(B, 200, 200, device=dev, dtype=torch.float64)
