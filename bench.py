@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="disable the per-forward numerics sync")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay timing")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-overlap", action="store_true", help="diagnostic: warp GPs of the views on ONE stream")
     ap.add_argument("--emulate-shard", type=int, default=1,
                     help="diagnostic: time rank 0's share of a K-way row sharding on ONE GPU (no all-reduce); "
                          "the line is then NOT the contract metric")
@@ -144,6 +145,8 @@ def main():
     model.kl_scale = 1.0 / (world * emu)
     if args.no_check:
         model.check_numerics = False
+    if args.no_overlap:
+        model.overlap_views = False
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     Xs = {m: d["spatial_coords"] for m, d in dd.items()}
     torch.manual_seed(1000 + rank)
@@ -207,7 +210,7 @@ def main():
 
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps),
                "--S", str(args.S), "--side", str(args.side), "--views", str(args.views),
-               "--outputs", str(args.outputs), "--M", str(args.M), "--emulate-shard", str(emu)]
+               "--outputs", str(args.outputs), "--M", str(args.M), "--emulate-shard", str(emu)] + (["--no-overlap"] if args.no_overlap else [])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

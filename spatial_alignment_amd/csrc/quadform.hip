@@ -589,28 +589,128 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
 // ------------------------------------------------------------------------------------------------
 // MFMA Gram kernel:  dOmega_l = sum_c g[l,c] alpha_c alpha_c^T   (lower-triangle 16x16 tiles)
 // grid (L, nsplit): workgroup (l, s) sweeps its share of the columns in 32-column chunks staged in
-// LDS; the NT = MB(MB+1)/2 lower tiles are dealt round-robin to the 4 waves (slot s <-> tile 4s+w).
-// Both MFMA operands of a tile are rows of the same LDS image (A: rows of tile-row, scaled by g;
-// B: rows of tile-column); the K index (columns c) is permuted as in the panel kernel so that one
-// ds_read_b128 feeds four MFMAs.  Partials [L][nsplit][MP][MP] are summed + mirrored by a second
+// LDS; the NT = MB(MB+1)/2 lower tiles are dealt to the 4 waves by whole tile rows (GramPlan).
+// Both MFMA operands of a tile are rows of the same LDS image (A: rows of tile-row, scaled by g in
+// registers once per row and K block; B: rows of tile-column); the K index (columns c) is permuted as
+// in the panel kernel so that one ds_read_b128 feeds four MFMAs.  Partials [L][nsplit][MP][MP] are summed + mirrored by a second
 // kernel (deterministic).
 // ------------------------------------------------------------------------------------------------
 constexpr int GR_KC = 32;  // columns per staged chunk (two 16-deep MFMA k-blocks)
+
+// Ownership of the lower-triangle tiles: whole tile ROWS are dealt to the 4 waves (longest row first
+// to the least loaded wave), so that a wave loads and g-scales the A fragment of a row once per K block
+// and then only streams the B fragments of that row's columns: half the LDS fragment reads of a
+// tile-by-tile deal, and no separate scaling pass over the chunk.
+template <int MB>
+struct GramPlan {
+  static constexpr int NT = MB * (MB + 1) / 2;
+  int cnt[4];
+  int rr[4][NT], cc[4][NT];
+  constexpr GramPlan() : cnt{}, rr{}, cc{} {
+    for (int r = MB - 1; r >= 0; --r) {
+      int best = 0;
+      for (int w = 1; w < 4; ++w)
+        if (cnt[w] < cnt[best]) best = w;
+      for (int c = 0; c <= r; ++c) {
+        rr[best][cnt[best]] = r;
+        cc[best][cnt[best]] = c;
+        ++cnt[best];
+      }
+    }
+  }
+  constexpr int max_cnt() const {
+    int m = 0;
+    for (int w = 0; w < 4; ++w) m = cnt[w] > m ? cnt[w] : m;
+    return m;
+  }
+};
+
+// one K block (16 columns) of wave W's tiles: acc[s] += (g-scaled row fragment) x (column fragment)
+template <int MB, int NKB, int W, int NS>
+__device__ __forceinline__ void gram_wave_block(const float* __restrict__ img, const float4 g4,
+                                                f32x4 (&acc)[NS]) {
+  constexpr GramPlan<MB> P{};
+  constexpr int N = P.cnt[W];
+  // tiles in pairs with interleaved MFMAs (a 16x16x4 MFMA has a 40-cycle dependent latency but a
+  // 32-cycle issue interval); the fragments of the next pair are fetched while this pair computes
+  float4 fb[2][2], fa[2][2];
+  auto frag = [&](int tile_row) { return *reinterpret_cast<const float4*>(img + tile_row * (NKB * 256)); };
+  auto scaled = [&](int tile_row) {
+    const float4 t = frag(tile_row);
+    return make_float4(t.x * g4.x, t.y * g4.y, t.z * g4.z, t.w * g4.w);
+  };
+  float4 arow = make_float4(0.f, 0.f, 0.f, 0.f);
+  int arow_of = -1;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int s = u < N ? u : N - 1;
+    if (P.rr[W][s] != arow_of) { arow = scaled(P.rr[W][s]); arow_of = P.rr[W][s]; }
+    fa[0][u] = arow;
+    fb[0][u] = frag(P.cc[W][s]);
+  }
+  constexpr int NPAIR = (N + 1) / 2;
+#pragma unroll
+  for (int pr = 0; pr < NPAIR; ++pr) {
+    const int cur = pr & 1, nxt = cur ^ 1;
+    if (pr + 1 < NPAIR) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = (2 * pr + 2 + u) < N ? (2 * pr + 2 + u) : N - 1;
+        if (P.rr[W][s] != arow_of) { arow = scaled(P.rr[W][s]); arow_of = P.rr[W][s]; }
+        fa[nxt][u] = arow;
+        fb[nxt][u] = frag(P.cc[W][s]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int s0 = 2 * pr;
+    const float4 a0 = fa[cur][0], a1 = fa[cur][1];
+    const float4 b0 = fb[cur][0], b1 = fb[cur][1];
+    if (2 * pr + 1 < N) {
+      const int s1 = 2 * pr + 1;
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
+      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[s1], 0, 0, 0);
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
+      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[s1], 0, 0, 0);
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
+      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[s1], 0, 0, 0);
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
+      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[s1], 0, 0, 0);
+    } else {
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
+      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int MB, int W, int NS>
+__device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS], float* __restrict__ P_, int j,
+                                                int kq) {
+  constexpr GramPlan<MB> P{};
+  constexpr int MP = MB * 16;
+#pragma unroll
+  for (int s = 0; s < P.cnt[W]; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      P_[(long long)(P.rr[W][s] * 16 + kq * 4 + r) * MP + P.cc[W][s] * 16 + j] = acc[s][r];
+}
 
 template <int MB, bool ALIGNED>
 __global__ void __launch_bounds__(256, (MB >= 13) ? 1 : 2)
 gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C,
                  int nsplit, float* __restrict__ part) {
-  constexpr int MP = MB * 16, NT = MB * (MB + 1) / 2, NSLOT = (NT + 3) / 4;
+  constexpr int MP = MB * 16;
+  constexpr GramPlan<MB> PLAN{};
+  constexpr int NS = PLAN.max_cnt();
   constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;  // 1-KiB pieces (16 rows x 16 cols) per chunk
   // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
   // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
   // conflict-free ds_read_b128 at lane*16 bytes.
   constexpr int NPW = (NPIECE + 3) / 4;  // LDS-DMA pieces per wave per stage (uniform; + 1 for g)
   __shared__ __attribute__((aligned(16))) float sA[3][NPW * 4 * 256];  // ring, 2 stages in flight
-  __shared__ __attribute__((aligned(16))) float sAs[NPW * 4 * 256];    // g-scaled copy of the chunk in use
   __shared__ __attribute__((aligned(16))) float sG[3][GR_KC];
-  __shared__ int sOff[NSLOT * 4][2];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -619,24 +719,9 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   const long long nch = (C + GR_KC - 1) / GR_KC;
   const long long ch0 = (long long)sp * nch / nsplit, ch1 = (long long)(sp + 1) * nch / nsplit;
 
-  for (int t = tid; t < NSLOT * 4; t += 256) {  // tile t -> (rt, ct), rt >= ct; dummy tiles -> (0,0)
-    int rt = 0, ct = 0;
-    if (t < NT) {
-      while ((rt + 1) * (rt + 2) / 2 <= t) ++rt;
-      ct = t - rt * (rt + 1) / 2;
-    }
-    sOff[t][0] = rt;
-    sOff[t][1] = ct;
-  }
-  __syncthreads();
-  int oa[NSLOT], ob[NSLOT];  // LDS float offsets of this wave's tiles' row / column pieces
-  f32x4 acc[NSLOT];
+  f32x4 acc[NS];
 #pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    oa[s] = sOff[s * 4 + w][0] * (NKB * 256);
-    ob[s] = sOff[s * 4 + w][1] * (NKB * 256);
-    acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int s = 0; s < NS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // staging (LDS-DMA, ALIGNED): rows >= M are clamped to row M-1 and columns >= C to the last aligned
   // group; the clamped rows only feed output rows/cols >= M (never read back) and the clamped columns
@@ -688,69 +773,15 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
       const long long nx = (ch + 2 < ch1) ? ch + 2 : ch1 - 1;  // tail: harmless re-reads
       GPSA_GR_STAGE(nx, buf == 0 ? 2 : buf - 1)
     }
-    // phase A: every fragment of the chunk is scaled by g ONCE into sAs (the A-side image); a multiply
-    // per MFMA inside the tile loop cost 33 % of the kernel (measured), this costs ~7 per wave per chunk
-#pragma unroll
-    for (int pc = 0; pc < NPW; ++pc) {
-      const int piece = pc * 4 + w;
-      if (piece < NPIECE) {
-        const int kb = piece % NKB;
-        const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
-        const float4 t = *reinterpret_cast<const float4*>(&sA[buf][piece * 256 + lane * 4]);
-        *reinterpret_cast<float4*>(&sAs[piece * 256 + lane * 4]) =
-            make_float4(t.x * g4.x, t.y * g4.y, t.z * g4.z, t.w * g4.w);
-      }
-    }
-    __syncthreads();
-    // phase B: tile products, A from the scaled image, B from the raw one, no VALU in the loop
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      const float* base = &sA[buf][kb * 256 + lane * 4];
-      const float* bases = &sAs[kb * 256 + lane * 4];
-      // tiles are processed in pairs with their MFMAs interleaved (a 16x16x4 MFMA has a 40-cycle
-      // dependent latency but a 32-cycle issue interval: two independent accumulators keep the pipe
-      // full); the operand fragments of the next pair are fetched while this pair computes.
-      constexpr int NPAIR = (NSLOT + 1) / 2;
-      float4 fa[2][2], fb[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int s = u < NSLOT ? u : NSLOT - 1;
-        fa[0][u] = *reinterpret_cast<const float4*>(bases + oa[s]);
-        fb[0][u] = *reinterpret_cast<const float4*>(base + ob[s]);
-      }
-#pragma unroll
-      for (int pr = 0; pr < NPAIR; ++pr) {
-        const int cur = pr & 1, nxt = cur ^ 1;
-        if (pr + 1 < NPAIR) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int s = (2 * pr + 2 + u) < NSLOT ? (2 * pr + 2 + u) : NSLOT - 1;
-            fa[nxt][u] = *reinterpret_cast<const float4*>(bases + oa[s]);
-            fb[nxt][u] = *reinterpret_cast<const float4*>(base + ob[s]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int s0 = 2 * pr;
-        const bool two = (2 * pr + 1 < NSLOT);
-        const int s1 = two ? 2 * pr + 1 : 0;
-        const float4 a0 = fa[cur][0], a1 = fa[cur][1];
-        const float4 b0 = fb[cur][0], b1 = fb[cur][1];
-        if (two) {
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
-          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[s1], 0, 0, 0);
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
-          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[s1], 0, 0, 0);
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
-          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[s1], 0, 0, 0);
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
-          acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[s1], 0, 0, 0);
-        } else {
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
-          acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      const float* img = &sA[buf][kb * 256 + lane * 4];
+      const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
+      switch (w) {
+        case 0: gram_wave_block<MB, NKB, 0, NS>(img, g4, acc); break;
+        case 1: gram_wave_block<MB, NKB, 1, NS>(img, g4, acc); break;
+        case 2: gram_wave_block<MB, NKB, 2, NS>(img, g4, acc); break;
+        default: gram_wave_block<MB, NKB, 3, NS>(img, g4, acc); break;
       }
     }
     GPSA_DMA_WAIT(NPW + 1);
@@ -760,15 +791,11 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   GPSA_DMA_DRAIN();
 #undef GPSA_GR_STAGE
   float* P = part + ((long long)l * nsplit + sp) * MP * MP;
-#pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    const int t = s * 4 + w;
-    if (t < NT) {
-      const int rt = sOff[t][0], ct = sOff[t][1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        P[(long long)(rt * 16 + kq * 4 + r) * MP + ct * 16 + j] = acc[s][r];
-    }
+  switch (w) {
+    case 0: gram_wave_store<MB, 0, NS>(acc, P, j, kq); break;
+    case 1: gram_wave_store<MB, 1, NS>(acc, P, j, kq); break;
+    case 2: gram_wave_store<MB, 2, NS>(acc, P, j, kq); break;
+    default: gram_wave_store<MB, 3, NS>(acc, P, j, kq); break;
   }
 }
 

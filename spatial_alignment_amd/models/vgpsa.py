@@ -6,6 +6,7 @@ return structure — with the numerical work done by hand-written HIP kernels (s
 ../csrc).  The index and scale quirks of the reference are reproduced on purpose; they are listed in
 SURVEY.md §8a and flagged ``# quirk N`` below.
 """
+import contextlib
 from collections.abc import Iterable
 
 import numpy as np
@@ -90,6 +91,7 @@ class VariationalGPSA(GPSA):
         self.fixed_view_idx = fixed_view_idx
         self.check_numerics = True  # one host sync per forward; raises like the reference would
         self.kl_scale = 1.0  # data-parallel ranks add 1/world of the KL each (parallel.py)
+        self.overlap_views = True  # warp GPs of different views on side HIP streams (GPU only)
         self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
         self._cache = None
 
@@ -201,6 +203,12 @@ class VariationalGPSA(GPSA):
             K = K + jitter * torch.eye(K.shape[-1], dtype=dtype, device=K.device)
         return K
 
+    def _side_streams(self, n, device):
+        pool = self.__dict__.setdefault("_stream_pool", [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[:n]
+
     def _draw(self, shape, device):
         return torch.empty(shape, dtype=torch.float32, device=device).normal_()
 
@@ -263,32 +271,47 @@ class VariationalGPSA(GPSA):
 
         # ---- warp GP per view (vgpsa.py:259-351) ---------------------------------------------------
         warp_out = {}
+        # the views' warp GPs are independent and each fills only part of the chip (one view of 10k
+        # spots = 157 workgroups on 256 CUs): run them on side streams so that they overlap; autograd
+        # replays each node's backward on the stream of its forward, so the backward overlaps too
+        side = self._side_streams(len(free), dev) if (self.overlap_views and dev.type == "cuda"
+                                                      and len(free) > 1) else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
         for draw, v in enumerate(free):
-            rows = rows_of[v]
-            Xv = torch.cat([X_spatial[m][rows[m][0]] for m in mods], 0) if len(mods) > 1 else \
-                X_spatial[mods[0]][rows[mods[0]][0]]
-            n = Xv.shape[0]
-            Z = Xt_v[v]
-            ls_u, var_u = wls_v[v], wvar_v[v]
-            Kuu, fac = cache.warp[v]
-            dc = resid[v]
-            Om = cache.Om_fwd[v]  # quirk 2: forward uses rows v*D+j
-            kind = builtin_kind(self.kernel_func_warp)
-            if kind is not None:  # fused covariance + layer, all fp64
-                meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
-            else:
-                Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
-                meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
-            if noise is not None and noise["G"] is not None:
-                eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
-            elif dev.type == "cuda":  # one launch; the device generator never reproduces the CPU stream anyway
-                eps = self._draw([S, n, D], dev)
-            else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
-                eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
-                    torch.empty(0, n, D, device=dev)
-            Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
+            if side is not None:
+                side[draw].wait_stream(main)
+            with (torch.cuda.stream(side[draw]) if side is not None else contextlib.nullcontext()):
+                rows = rows_of[v]
+                Xv = torch.cat([X_spatial[m][rows[m][0]] for m in mods], 0) if len(mods) > 1 else \
+                    X_spatial[mods[0]][rows[mods[0]][0]]
+                n = Xv.shape[0]
+                Z = Xt_v[v]
+                ls_u, var_u = wls_v[v], wvar_v[v]
+                Kuu, fac = cache.warp[v]
+                dc = resid[v]
+                Om = cache.Om_fwd[v]  # quirk 2: forward uses rows v*D+j
+                kind = builtin_kind(self.kernel_func_warp)
+                if kind is not None:  # fused covariance + layer, all fp64
+                    meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
+                else:
+                    Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
+                    meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
+                if noise is not None and noise["G"] is not None:
+                    eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
+                elif dev.type == "cuda":  # one launch; the device generator never reproduces the CPU stream anyway
+                    eps = self._draw([S, n, D], dev)
+                else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
+                    eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
+                        torch.empty(0, n, D, device=dev)
+                Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
+                if side is not None:  # consumed on the main stream from here on
+                    for t in (Gm, Gs, bad):
+                        t.record_stream(main)
             cache.flags.append(bad)
             warp_out[v] = (Gm, Gs)
+        if side is not None:
+            for draw in range(len(free)):
+                main.wait_stream(side[draw])
 
         # ---- assemble G_means [N,D] / G_samples [S,N,D] per modality --------------------------------
         G_means, G_samples = {}, {}
