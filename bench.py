@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="disable the per-forward numerics sync")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay timing")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-overlap", action="store_true", help="diagnostic: warp GPs of the views on ONE stream")
+    ap.add_argument("--static-grads", action="store_true", help="diagnostic: zero_grad(set_to_none=False)")
+    ap.add_argument("--overlap", action="store_true", help="diagnostic: per-view side streams in eager mode too")
     ap.add_argument("--emulate-shard", type=int, default=1,
                     help="diagnostic: time rank 0's share of a K-way row sharding on ONE GPU (no all-reduce); "
                          "the line is then NOT the contract metric")
@@ -145,8 +146,8 @@ def main():
     model.kl_scale = 1.0 / (world * emu)
     if args.no_check:
         model.check_numerics = False
-    if args.no_overlap:
-        model.overlap_views = False
+    if args.overlap:
+        model.overlap_views = True
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     Xs = {m: d["spatial_coords"] for m, d in dd.items()}
     torch.manual_seed(1000 + rank)
@@ -176,7 +177,7 @@ def main():
     def step():
         out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=args.S)
         loss = model.loss_fn(dd, out[3])
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=not args.static_grads)
         loss.backward()
         reducer()
         opt.step()
@@ -210,7 +211,7 @@ def main():
 
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps),
                "--S", str(args.S), "--side", str(args.side), "--views", str(args.views),
-               "--outputs", str(args.outputs), "--M", str(args.M), "--emulate-shard", str(emu)] + (["--no-overlap"] if args.no_overlap else [])
+               "--outputs", str(args.outputs), "--M", str(args.M), "--emulate-shard", str(emu)]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

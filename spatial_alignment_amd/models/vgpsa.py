@@ -91,7 +91,9 @@ class VariationalGPSA(GPSA):
         self.fixed_view_idx = fixed_view_idx
         self.check_numerics = True  # one host sync per forward; raises like the reference would
         self.kl_scale = 1.0  # data-parallel ranks add 1/world of the KL each (parallel.py)
-        self.overlap_views = True  # warp GPs of different views on side HIP streams (GPU only)
+        # warp GPs of different views on side HIP streams: pays under hipGraph replay (-0.2 ms at the
+        # headline config), costs CPU time per launch in eager mode, so train.GraphedTrainStep turns it on
+        self.overlap_views = False
         self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
         self._cache = None
 

@@ -50,21 +50,12 @@ class GradAllReducer:
             return
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
-        off = 0
-        for p in self.params:
-            n = p.numel()
+            self.flat = torch.empty(self.numel, dtype=p0.dtype, device=p0.device)
+            self.views = list(self.flat.split([p.numel() for p in self.params]))
+        for p in self.params:  # a parameter the step did not touch contributes zeros
             if p.grad is None:
-                self.flat[off : off + n].zero_()
-            else:
-                self.flat[off : off + n].copy_(p.grad.reshape(-1))
-            off += n
+                p.grad = torch.zeros_like(p)
+        # pack (one batched launch), reduce, unpack (one batched launch): not one copy per parameter
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off : off + n].reshape(p.shape).clone()
-            else:
-                p.grad.copy_(self.flat[off : off + n].reshape(p.shape))
-            off += n
+        torch._foreach_copy_([p.grad.reshape(-1) for p in self.params], self.views)

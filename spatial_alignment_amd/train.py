@@ -6,12 +6,14 @@ launch-bound small configurations (config 1, S=1).
 import torch
 
 
-def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None):
-    """forward(S) + loss_fn + backward + optimizer step; returns the loss tensor (no host sync)."""
+def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None, static_grads=False):
+    """forward(S) + loss_fn + backward + optimizer step; returns the loss tensor (no host sync).
+    ``static_grads``: keep the .grad buffers (zeroed, accumulated into) instead of letting autograd hand
+    over fresh ones: needed under graph capture, ~one extra launch per parameter otherwise."""
     Xs = {m: d["spatial_coords"] for m, d in data_dict.items()}
     out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=S)
     loss = model.loss_fn(data_dict, out[3])
-    optimizer.zero_grad(set_to_none=False)
+    optimizer.zero_grad(set_to_none=not static_grads)
     loss.backward()
     if reducer is not None:
         reducer()
@@ -36,6 +38,7 @@ class GraphedTrainStep:
         self.model, self.optimizer = model, optimizer
         self._saved_check = model.check_numerics
         model.check_numerics = False
+        model.overlap_views = True  # independent views become parallel branches of the graph
         # drop every reference to an earlier autograd graph (capture needs fresh AccumulateGrad nodes
         # on the capture stream)
         model._cache = None
@@ -47,12 +50,12 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up off the default stream, as torch's capture rules ask
             for _ in range(warmup):
-                train_step(model, optimizer, data_dict, view_idx, Ns, S)
+                train_step(model, optimizer, data_dict, view_idx, Ns, S, static_grads=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = train_step(model, optimizer, data_dict, view_idx, Ns, S)
+            self.loss = train_step(model, optimizer, data_dict, view_idx, Ns, S, static_grads=True)
             flags = model._cache.flags
             self.flags = torch.cat([f.reshape(-1).to(torch.int32) for f in flags]).abs().max()
 
