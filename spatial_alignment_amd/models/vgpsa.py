@@ -358,6 +358,11 @@ class VariationalGPSA(GPSA):
                     G_means[m][r] = Gm[a : a + cnt]
                     G_samples[m][:, r, :] = Gs[:, a : a + cnt]
 
+        # every flag of this forward exists now (factorisations, warp variances): ship them to the host
+        # behind an event BEFORE the data GP is queued, so that the check at the end of forward waits for
+        # the warp GP only and the host keeps queueing while the data GP's kernels run
+        pending = self._post_flags(cache) if self.check_numerics else None
+
         # ---- data GP (vgpsa.py:353-477) ----------------------------------------------------------
         ls_u, var_u = self.data_kernel_lengthscale, self.data_kernel_variance
         KuuF, facF = cache.data
@@ -398,8 +403,8 @@ class VariationalGPSA(GPSA):
                 self.F_latent_samples_test[m], self.F_observed_samples_test[m] = lt, ot
 
         self._cache = cache
-        if self.check_numerics:
-            self._raise_on_flags(cache)
+        if pending is not None:
+            self._raise_on_flags(pending)
         if G_test is not None:
             return (
                 G_means,
@@ -411,12 +416,27 @@ class VariationalGPSA(GPSA):
             )
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
-    @staticmethod
-    def _raise_on_flags(cache):
+    def _post_flags(self, cache):
+        """max |flag| of this forward -> host, asynchronously; returns what _raise_on_flags waits on"""
         if not cache.flags:
-            return
-        flags = torch.cat([f.reshape(-1).to(torch.int32) for f in cache.flags])
-        if int(flags.abs().max().item()) != 0:  # the one host sync of forward
+            return None
+        worst = torch.cat([f.reshape(-1).to(torch.int32) for f in cache.flags]).abs().max()
+        if worst.device.type != "cuda":
+            return worst, None
+        host = self.__dict__.get("_flag_host")
+        if host is None:
+            host = self.__dict__["_flag_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(worst.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
+    @staticmethod
+    def _raise_on_flags(pending):
+        host, ev = pending
+        if ev is not None:
+            ev.synchronize()  # the one host wait of forward: up to the end of the warp GPs
+        if int(host.reshape(-1)[0].item()) != 0:
             raise torch.linalg.LinAlgError(
                 "GPSA forward: an inducing-point covariance is not positive-definite or a warp "
                 "variance is not positive (the reference raises from torch.cholesky / "
