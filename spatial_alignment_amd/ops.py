@@ -24,6 +24,9 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream  # (device index) -> hipStream_t as int
+
+
 class HipOps:
     """All ops run on the current HIP stream of the tensors' device; outputs are freshly allocated."""
 
@@ -31,17 +34,29 @@ class HipOps:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._scratch = {}
         if not torch.cuda.is_available():
             raise _lib.GpsaHipError("no HIP device visible: the GPSA hot path has no CPU fallback")
 
     # ------------------------------------------------------------------ plumbing
+    # (host time per launch matters: a 1/8 shard of the headline step is bound by the ~250 launches'
+    #  host cost, not by the GPU - so no Stream objects and no allocator round trip per call)
     @staticmethod
     def _stream(t):
-        return torch.cuda.current_stream(t.device).cuda_stream
+        """raw hipStream_t of the current stream of t's device"""
+        return _raw_stream(t.get_device())
 
-    @staticmethod
-    def _ws(nbytes, like):
-        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+    def _ws(self, nbytes, like):
+        """scratch of >= nbytes for ONE launch sequence on the current stream.  One buffer per
+        (device, stream), grown on demand: launches on a stream are ordered, scratch never outlives its
+        call, so consecutive calls can share it."""
+        dev = like.get_device()
+        key = (dev, _raw_stream(dev))
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            grow = max(int(nbytes), 1 << 20, 0 if buf is None else 2 * buf.numel())
+            buf = self._scratch[key] = torch.empty(grow, dtype=torch.uint8, device=like.device)
+        return buf
 
     @staticmethod
     def _c(t):
