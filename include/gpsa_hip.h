@@ -41,12 +41,13 @@ int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const voi
 
 /* Backward of gpsa_kmat: given Kbar = dLoss/dK [M,C] (dtype) produce, in in_dtype,
  *   dZ [M,D], dX [C,D] (may be NULL), dparams[2] = {dLoss/d ls_u, dLoss/d var_u}.
- * (autograd of util.py:8-66 in the reference).  Deterministic (two-pass reduction in workspace,
- * partial sums in dtype). */
+ * same != 0: Z and X are the same points (K_uu, C == M): the X-side sums are added into dZ and dX is
+ * not written.  (autograd of util.py:8-66 in the reference).  Deterministic: per-workgroup partial sums
+ * (in dtype) in the workspace, then ONE second launch that adds them in a fixed order. */
 long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D);
 int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
-                  int D, const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
-                  void* dparams, void* workspace, long long workspace_bytes, void* stream);
+                  int D, const void* ls_u, const void* var_u, const void* Kbar, int same, void* dZ,
+                  void* dX, void* dparams, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- dense products ---------------------------------------------------------------------------
  * C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b];  op(A): m x k, op(B): k x n, row-major, strided batch.
@@ -57,6 +58,12 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
               const void* A, long long lda, long long strideA, const void* B, long long ldb,
               long long strideB, double beta, void* C, long long ldc, long long strideC, int batch,
               int splitk, void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- variational covariances (vgpsa.py:206-210): Omega[b] = A[b] A[b]^T + jitter I ---------------
+ * A [batch,M,M] is the fp32 parameter (Omega_sqt_*), read as stored; Omega [batch,M,M] fp64 (matrix
+ * cores).  gpsa_omega_bwd is its adjoint: dA[b] = (G[b] + G[b]^T) A[b] with G = dLoss/dOmega (fp64). */
+int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omega, void* stream);
+int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, float* dA, void* stream);
 
 /* ---- inducing-point factorisations (fp64, batched, one workgroup per matrix) -----------------
  * gpsa_chol_f64: in-place lower Cholesky of A[b] (upper triangle zeroed); logdet[b] = 2*sum(log diag);

@@ -18,10 +18,12 @@ SIGNATURES = {
     "gpsa_build_arch": (C.c_char_p, []),
     "gpsa_kmat": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _d, _vp, _vp]),
     "gpsa_kmat_bwd_workspace": (_ll, [_i, _i, _ll, _i]),
-    "gpsa_kmat_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_kmat_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_gemm_workspace": (_ll, [_i, _i, _i, _i, _i]),
     "gpsa_gemm": (_i, [_i, _i, _i, _i, _i, _ll, _d, _vp, _ll, _ll, _vp, _ll, _ll, _d, _vp, _ll, _ll,
                        _i, _i, _vp, _ll, _vp]),
+    "gpsa_omega_fwd": (_i, [_vp, _i, _i, _d, _vp, _vp]),
+    "gpsa_omega_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "gpsa_chol_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

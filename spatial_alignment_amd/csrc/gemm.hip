@@ -122,12 +122,16 @@ gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long lo
 // vector kernel above is LDS-bandwidth-bound at twice its FMA time in fp64).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
-template <bool TA, bool TB>
+// TIA / TIB: storage types of the operands (fp32 parameters are read as stored and widened), TO: type of
+// C; SYMA: the left operand is A + A^T (square A); diag is added to C[i][i] (split-K == 1 only).  These
+// cover Omega = A A^T + 1e-5 I straight from the fp32 parameter and its adjoint dA = (G + G^T) A.
+template <bool TA, bool TB, typename TIA = double, typename TIB = double, typename TO = double,
+          bool SYMA = false>
 __global__ void __launch_bounds__(256, 4)
-gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const double* __restrict__ A,
-                     long long lda, long long sA, const double* __restrict__ B, long long ldb,
-                     long long sB, double beta, double* __restrict__ C, long long ldc, long long sC,
-                     int splitk, double* __restrict__ part) {
+gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const TIA* __restrict__ A,
+                     long long lda, long long sA, const TIB* __restrict__ B, long long ldb,
+                     long long sB, double beta, TO* __restrict__ C, long long ldc, long long sC,
+                     int splitk, double* __restrict__ part, double diag = 0.0) {
   __shared__ double As[2][GB_K][GB_M + 4];  // double-buffered: one barrier per K tile
   __shared__ double Bs[2][GB_K][GB_N + 4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -138,8 +142,8 @@ gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const double* __re
   kchunk = (kchunk + GB_K - 1) / GB_K * GB_K;
   const long long kbeg = (long long)sp * kchunk;
   const long long kend = (kbeg + kchunk < k) ? kbeg + kchunk : k;
-  const double* Ab = A + (long long)b * sA;
-  const double* Bb = B + (long long)b * sB;
+  const TIA* Ab = A + (long long)b * sA;
+  const TIB* Bb = B + (long long)b * sB;
   f64x4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -156,13 +160,16 @@ gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const double* __re
       if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }      \
       const long long gr = m0 + r, gk = (K0) + kk;                                        \
       double va = 0.0;                                                                    \
-      if (gr < m && gk < kend) va = TA ? Ab[gk * lda + gr] : Ab[gr * lda + gk];           \
+      if (gr < m && gk < kend) {                                                          \
+        va = TA ? (double)Ab[gk * lda + gr] : (double)Ab[gr * lda + gk];                  \
+        if (SYMA) va += TA ? (double)Ab[gr * lda + gk] : (double)Ab[gk * lda + gr];       \
+      }                                                                                   \
       ra[i] = va;                                                                         \
       int c, kb;                                                                          \
       if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }      \
       const long long gc = n0 + c, gk2 = (K0) + kb;                                       \
       double vb = 0.0;                                                                    \
-      if (gc < n && gk2 < kend) vb = TB ? Bb[gc * ldb + gk2] : Bb[gk2 * ldb + gc];        \
+      if (gc < n && gk2 < kend) vb = TB ? (double)Bb[gc * ldb + gk2] : (double)Bb[gk2 * ldb + gc]; \
       rb[i] = vb;                                                                         \
     }                                                                                     \
   }
@@ -207,8 +214,6 @@ gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const double* __re
 #undef GPSA_G64_FETCH
 #undef GPSA_G64_STASH
   // C/D layout of the fp64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15
-  double* Cb = (splitk == 1) ? C + (long long)b * sC : part + ((long long)blockIdx.z) * m * n;
-  const long long ld = (splitk == 1) ? ldc : (long long)n;
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -217,10 +222,15 @@ gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const double* __re
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm + tm * 16 + kq + 4 * r, col = n0 + wn + tn * 16 + j;
         if (row < m && col < n) {
-          double* p = Cb + (long long)row * ld + col;
           const double y = acc[tm][tn][r];
-          if (splitk == 1) *p = (beta == 0.0) ? alpha * y : alpha * y + beta * (*p);
-          else *p = y;
+          if (splitk == 1) {
+            TO* p = C + (long long)b * sC + (long long)row * ldc + col;
+            double v = (beta == 0.0) ? alpha * y : alpha * y + beta * (double)(*p);
+            if (row == col) v += diag;
+            *p = (TO)v;
+          } else {
+            part[((long long)blockIdx.z * m + row) * n + col] = y;
+          }
         }
       }
 }
@@ -320,6 +330,28 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
                                      ldc, strideC, batch, splitk, workspace, workspace_bytes,
                                      as_stream(stream));
   return GPSA_EINVAL;
+}
+
+/* Omega[b] = A[b] A[b]^T + jitter I in fp64 from the fp32 parameter, one launch */
+int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omega, void* stream) {
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  const long long mm = (long long)M * M;
+  dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
+  gpsa::gemm_f64_mfma_kernel<false, true, float, float, double, false><<<grid, 256, 0, as_stream(stream)>>>(
+      M, M, M, 1.0, A, M, mm, A, M, mm, 0.0, Omega, M, mm, 1, nullptr, jitter);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+/* dA[b] = (G[b] + G[b]^T) A[b]  (fp64 G, fp32 A, fp32 dA): adjoint of gpsa_omega_fwd, one launch */
+int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, float* dA, void* stream) {
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  const long long mm = (long long)M * M;
+  dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
+  gpsa::gemm_f64_mfma_kernel<false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
+      M, M, M, 1.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
+  GPSA_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // extern "C"

@@ -142,6 +142,43 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
   if (threadIdx.x == 0) sp[1] = b2;
 }
 
+// Second pass of the backward: ONE launch sums all three partial arrays in a fixed order
+//   dZ[i] = sum_bx zpart[bx][i]  (+ sum_by xpart[by][i] when Z and X are the same points: K_uu)
+//   dX[i] = sum_by xpart[by][i] ;  dparams[0..1] = sum spart
+// one output element per thread, 4 independent partial sums for the long columns.
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256)
+kmat_bwd_finish_kernel(const T* __restrict__ zpart, long long nbx, long long nz,
+                       const T* __restrict__ xpart, long long nby, long long nx,
+                       const T* __restrict__ spart, long long ns, int same, TO* __restrict__ dZ,
+                       TO* __restrict__ dX, TO* __restrict__ dparams) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  const T* part;
+  long long rows, stride, col;
+  TO* dst;
+  if (i < nz) { part = zpart; rows = nbx; stride = nz; col = i; dst = dZ + i; }
+  else if (i < nz + nx) { part = xpart; rows = nby; stride = nx; col = i - nz; dst = dX + (i - nz); }
+  else if (i < nz + nx + 2) { part = spart; rows = ns; stride = 2; col = i - nz - nx; dst = dparams + col; }
+  else return;
+  if (part == xpart && (xpart == nullptr || same)) return;  // folded into dZ below / not requested
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  long long r = 0;
+  for (; r + 3 < rows; r += 4) {
+    a0 += (double)part[r * stride + col];
+    a1 += (double)part[(r + 1) * stride + col];
+    a2 += (double)part[(r + 2) * stride + col];
+    a3 += (double)part[(r + 3) * stride + col];
+  }
+  for (; r < rows; ++r) a0 += (double)part[r * stride + col];
+  double tot = (a0 + a1) + (a2 + a3);
+  if (part == zpart && same) {  // K_uu: both arguments are the inducing points
+    double b = 0.0;
+    for (long long q = 0; q < nby; ++q) b += (double)xpart[q * nx + col];
+    tot += b;
+  }
+  *dst = (TO)tot;
+}
+
 template <typename TI, typename T>
 int kmat_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
                 const TI* var_u, double jitter, T* K, hipStream_t st) {
@@ -165,7 +202,7 @@ int kmat_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, c
 
 template <typename TI, typename T>
 int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
-                    const TI* var_u, const T* Kbar, TI* dZ, TI* dX, TI* dparams, void* ws,
+                    const TI* var_u, const T* Kbar, TI* dZ, TI* dX, TI* dparams, int same, void* ws,
                     long long ws_bytes, hipStream_t st) {
   const long long nbx = cdiv(C, 256), nby = cdiv(M, KB_MCHUNK);
   const long long nz = (long long)M * D, nx = C * D;
@@ -175,7 +212,7 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
   T* xpart = zpart + nbx * nz;
   T* spart = xpart + nby * nx;
   dim3 grid((unsigned)nbx, (unsigned)nby);
-  T* xp = dX ? xpart : nullptr;
+  T* xp = (dX || same) ? xpart : nullptr;  // K_uu: the X-side partials are folded into dZ
   switch (kind) {
     case GPSA_K_RBF:
       kmat_bwd_kernel<TI, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
@@ -190,9 +227,10 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
       return GPSA_EINVAL;
   }
   GPSA_LAUNCH_CHECK();
-  reduce_rows_kernel<T, TI><<<(unsigned)cdiv(nz, 64), 256, 0, st>>>(zpart, nbx, nz, nz, dZ, 1.0);
-  if (dX) reduce_rows_kernel<T, TI><<<(unsigned)cdiv(nx, 64), 256, 0, st>>>(xpart, nby, nx, nx, dX, 1.0);
-  reduce_rows_kernel<T, TI><<<1, 256, 0, st>>>(spart, nbx * nby, 2, 2, dparams, 1.0);
+  const bool fold = same != 0;
+  if (fold && (nx != nz)) return GPSA_EINVAL;
+  kmat_bwd_finish_kernel<T, TI><<<(unsigned)cdiv(nz + nx + 2, 256), 256, 0, st>>>(
+      zpart, nbx, nz, xp, nby, nx, spart, nbx * nby, fold ? 1 : 0, dZ, dX, dparams);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -223,25 +261,25 @@ long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D) {
 }
 
 int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
-                  int D, const void* ls_u, const void* var_u, const void* Kbar, void* dZ, void* dX,
-                  void* dparams, void* workspace, long long workspace_bytes, void* stream) {
+                  int D, const void* ls_u, const void* var_u, const void* Kbar, int same, void* dZ,
+                  void* dX, void* dparams, void* workspace, long long workspace_bytes, void* stream) {
   if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32 && in_dtype == GPSA_F32)
     return gpsa::kmat_bwd_launch<float, float>(kind, (const float*)Z, M, (const float*)X, C, D,
                                                (const float*)ls_u, (const float*)var_u, (const float*)Kbar,
-                                               (float*)dZ, (float*)dX, (float*)dparams, workspace,
+                                               (float*)dZ, (float*)dX, (float*)dparams, same, workspace,
                                                workspace_bytes, st);
   if (dtype == GPSA_F64 && in_dtype == GPSA_F64)
     return gpsa::kmat_bwd_launch<double, double>(kind, (const double*)Z, M, (const double*)X, C, D,
                                                  (const double*)ls_u, (const double*)var_u,
                                                  (const double*)Kbar, (double*)dZ, (double*)dX,
-                                                 (double*)dparams, workspace, workspace_bytes, st);
+                                                 (double*)dparams, same, workspace, workspace_bytes, st);
   if (dtype == GPSA_F64 && in_dtype == GPSA_F32)
     return gpsa::kmat_bwd_launch<float, double>(kind, (const float*)Z, M, (const float*)X, C, D,
                                                 (const float*)ls_u, (const float*)var_u,
                                                 (const double*)Kbar, (float*)dZ, (float*)dX,
-                                                (float*)dparams, workspace, workspace_bytes, st);
+                                                (float*)dparams, same, workspace, workspace_bytes, st);
   return GPSA_EINVAL;
 }
 

@@ -45,12 +45,13 @@ class Factor:
         self.info = info
 
 
-def factor_batch(mats):
+def factor_batch(mats, stack=None):
     """Factorise many SPD matrices with as few launches as possible.
 
     ``mats``: list of fp64 tensors [b_i, M_i, M_i].  Matrices of equal size share ONE batched fused
     Cholesky + triangular inverse and ONE batched L^-T L^-1 product (one workgroup per matrix), so the
-    launch-latency-bound factorisations of a whole step cost one kernel's latency.
+    launch-latency-bound factorisations of a whole step cost one kernel's latency.  ``stack``: the
+    matrices already laid out back to back in this [sum b_i, M, M] buffer (then nothing is copied).
     Returns, per input, (Linv [b,M,M], inverse [b,M,M], logdet [b], info [b]).
     """
     o = ops()
@@ -59,8 +60,11 @@ def factor_batch(mats):
     for i, m in enumerate(mats):
         by_size.setdefault(m.shape[-1], []).append(i)
     for M, idxs in by_size.items():
-        stack = torch.cat([mats[i].detach().reshape(-1, M, M) for i in idxs], 0)
-        Linv, logdet, info = o.chol_inv(stack)
+        if stack is not None and len(by_size) == 1:
+            batch = stack
+        else:
+            batch = torch.cat([mats[i].detach().reshape(-1, M, M) for i in idxs], 0)
+        Linv, logdet, info = o.chol_inv(batch)
         inv = o.gemm(Linv, Linv, transA=True)
         off = 0
         for i in idxs:
@@ -85,11 +89,11 @@ class KmatFn(torch.autograd.Function):
     Replaces the built-in plugins gpsa/util/util.py:8-66."""
 
     @staticmethod
-    def forward(ctx, kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None):
+    def forward(ctx, kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None, out=None):
         o = ops()
         # the kernels read the (fp32) parameters as stored and compute in ``dtype``: no cast launches
         Zc, Xc, ls, var = _cov_inputs(Z, X, ls_u, var_u, dtype)
-        K = o.kmat(kind, Zc, Xc, ls, var, jitter, dtype=dtype)
+        K = o.kmat(kind, Zc, Xc, ls, var, jitter, dtype=dtype, out=out)
         ctx.kind, ctx.same = kind, bool(same)
         ctx.bwd_dtype = bwd_dtype or dtype  # gradient-only precision for the backward
         if ctx.bwd_dtype == torch.float32 and Zc.dtype != torch.float32:
@@ -103,36 +107,30 @@ class KmatFn(torch.autograd.Function):
         o = ops()
         Zc, Xc, ls, var = ctx.saved_tensors
         zdt, xdt, ldt, vdt, lshape, vshape = ctx.meta
-        need_x = ctx.needs_input_grad[2] or ctx.same
-        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.to(ctx.bwd_dtype), need_dX=need_x)
-        if ctx.same:
-            dZ = dZ + dX
-            dX = None
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zc, Xc, ls, var, Kbar.to(ctx.bwd_dtype),
+                                  need_dX=ctx.needs_input_grad[2], same=ctx.same)
         gZ = dZ.to(zdt) if ctx.needs_input_grad[1] else None
         gX = dX.to(xdt) if (dX is not None and ctx.needs_input_grad[2]) else None
         gl = dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None
         gv = dpar[1].to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None
-        return None, gZ, gX, gl, gv, None, None, None, None
+        return None, gZ, gX, gl, gv, None, None, None, None, None
 
 
 class OmegaFn(torch.autograd.Function):
     """Omega = A A^T + 1e-5 I in fp64 (vgpsa.py:206-210).  A [B,M,M] fp32 parameter rows."""
 
     @staticmethod
-    def forward(ctx, A):
-        o = ops()
-        A64 = A.detach().double().contiguous()
-        Om = o.gemm(A64, A64, transB=True)
-        o.add_diag(Om, JITTER)
-        ctx.save_for_backward(A64)
+    def forward(ctx, A, out=None):
+        Ad = A.detach()
+        Om = ops().omega_fwd(Ad, JITTER, out=out)  # ``out``: a slice of the step's factorisation batch
+        ctx.save_for_backward(Ad)
         ctx.adt = A.dtype
         return Om
 
     @staticmethod
     def backward(ctx, dOm):
-        (A64,) = ctx.saved_tensors
-        sym = dOm + dOm.transpose(-1, -2)
-        return ops().gemm(sym.contiguous(), A64).to(ctx.adt)
+        (Ad,) = ctx.saved_tensors
+        return ops().omega_bwd(dOm, Ad).to(ctx.adt), None
 
 
 def _project(o, fac, Kuf, T):

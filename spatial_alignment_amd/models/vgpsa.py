@@ -188,11 +188,11 @@ class VariationalGPSA(GPSA):
         """Omega = A A^T + 1e-5 I (vgpsa.py:206-210); fp64 result."""
         return E.OmegaFn.apply(Omega_sqt)
 
-    def _kmat(self, which, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None):
+    def _kmat(self, which, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype=None, out=None):
         fn = self.kernel_func_warp if which == "warp" else self.kernel_func_data
         kind = builtin_kind(fn)
         if kind is not None:
-            return E.KmatFn.apply(kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype)
+            return E.KmatFn.apply(kind, Z, X, ls_u, var_u, jitter, dtype, same, bwd_dtype, out)
         # arbitrary plugin callable: evaluate it as the reference does (vgpsa.py:275-281, 382-388)
         K = fn(
             Z.to(dtype),
@@ -204,6 +204,19 @@ class VariationalGPSA(GPSA):
         if jitter:
             K = K + jitter * torch.eye(K.shape[-1], dtype=dtype, device=K.device)
         return K
+
+    # attributes the reference's forward leaves behind (vgpsa.py:217, 283-289); nothing on the hot path
+    # reads them, so they are formed on access instead of costing launches every step
+    @property
+    def noise_variance_pos(self):
+        return torch.exp(self.noise_variance.detach()) + self.diagonal_offset
+
+    @property
+    def mu_z_G(self):
+        cache = self.__dict__.get("_cache")
+        if cache is None or not cache.mu_z:
+            raise AttributeError("mu_z_G is available after forward")
+        return torch.stack(cache.mu_z)
 
     def _side_streams(self, n, device):
         pool = self.__dict__.setdefault("_stream_pool", [])
@@ -225,7 +238,6 @@ class VariationalGPSA(GPSA):
         noise, self._noise = self._noise, None
         cache = _StepCache()
 
-        self.noise_variance_pos = torch.exp(self.noise_variance) + self.diagonal_offset  # vgpsa.py:217
         # per-view slices of the parameters, unbound once (one autograd node per parameter instead of
         # a zero-fill + copy + add per slice in the backward)
         Xt_v = self.Xtilde.unbind(0)
@@ -240,29 +252,46 @@ class VariationalGPSA(GPSA):
                                          100.0 if self._is_fixed(v) else 1.0)  # x100: inert (quirk 7)
             mu_z.append(mz)
             resid.append(dc)
-        self.mu_z_G = torch.stack(mu_z)
         cache.mu_z, cache.dG_v, cache.resid = mu_z, dG_v, resid
 
         # ---- everything M x M first: all prior covariances and variational covariances of the step
         #      are factorised by ONE batched Cholesky / triangular-inverse launch per matrix size
-        cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list)
-        M_X = cache.Omega_G.shape[-1]
-        cache.Om_fwd = cache.Omega_G.split(D, 0)                      # rows v*D+j  (forward, quirk 2)
-        cache.Om_kl = cache.Omega_G.view(D, V, M_X, M_X).unbind(1)    # rows j*V+v  (KL, quirk 2)
-        for m in mods:
-            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m])
         rows_of = {v: {m: _as_index(view_idx[m][v], dev) for m in mods} for v in range(V)}
         free = [v for v in range(V)
                 if not self._is_fixed(v) and sum(rows_of[v][m][1] for m in mods) > 0]
+        M_X, nG = self.Omega_sqt_G_list.shape[-1], self.Omega_sqt_G_list.shape[0]
+        sizes_F = [self.Omega_sqt_F_dict[m].shape for m in mods]
+        builtin = builtin_kind(self.kernel_func_warp) is not None and builtin_kind(self.kernel_func_data) is not None
+        # when every matrix of the step has the same size and comes from a built-in covariance, the
+        # kernels write straight into ONE [T, M, M] batch (no concatenation before the factorisation)
+        stack, slot = None, None
+        if builtin and all(sh[-1] == M_X for sh in sizes_F) and self.Gtilde.shape[0] == M_X \
+                and all(Xt_v[v].shape[0] == M_X for v in free):
+            total = len(free) + 1 + nG + sum(sh[0] for sh in sizes_F)
+            stack = torch.empty(total, M_X, M_X, dtype=f64, device=dev)
+            cursor = [0]
+
+            def slot(n):  # independent tensors over the batch's memory (not autograd views of it)
+                a = cursor[0]
+                cursor[0] += n
+                return torch.empty(0, dtype=f64, device=dev).set_(
+                    stack.untyped_storage(), a * M_X * M_X, (n, M_X, M_X), (M_X * M_X, M_X, 1))
         Kuu_w = {}
         for v in free:
             Z = Xt_v[v]
-            Kuu_w[v] = self._kmat("warp", Z, Z, wls_v[v], wvar_v[v], self.diagonal_offset, f64, True)
+            Kuu_w[v] = self._kmat("warp", Z, Z, wls_v[v], wvar_v[v], self.diagonal_offset, f64, True,
+                                  out=slot(1)[0] if slot else None)
         KuuF = self._kmat("data", self.Gtilde, self.Gtilde, self.data_kernel_lengthscale,
-                          self.data_kernel_variance, self.diagonal_offset, f64, True)
+                          self.data_kernel_variance, self.diagonal_offset, f64, True,
+                          out=slot(1)[0] if slot else None)
+        cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list, slot(nG) if slot else None)
+        cache.Om_fwd = cache.Omega_G.split(D, 0)                      # rows v*D+j  (forward, quirk 2)
+        cache.Om_kl = cache.Omega_G.view(D, V, M_X, M_X).unbind(1)    # rows j*V+v  (KL, quirk 2)
+        for m, sh in zip(mods, sizes_F):
+            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m], slot(sh[0]) if slot else None)
         mats = [Kuu_w[v].unsqueeze(0) for v in free] + [KuuF.unsqueeze(0), cache.Omega_G] + \
                [cache.Omega_F[m] for m in mods]
-        parts = E.factor_batch(mats)
+        parts = E.factor_batch(mats, stack=stack)
         for i, v in enumerate(free):
             cache.warp[v] = (Kuu_w[v], E.Factor(parts=parts[i]))
         nf = len(free)
@@ -420,7 +449,7 @@ class VariationalGPSA(GPSA):
         """max |flag| of this forward -> host, asynchronously; returns what _raise_on_flags waits on"""
         if not cache.flags:
             return None
-        worst = torch.cat([f.reshape(-1).to(torch.int32) for f in cache.flags]).abs().max()
+        worst = torch.cat([f.reshape(-1) for f in cache.flags]).max()  # int32, all >= 0
         if worst.device.type != "cuda":
             return worst, None
         host = self.__dict__.get("_flag_host")

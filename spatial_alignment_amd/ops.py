@@ -70,32 +70,34 @@ class HipOps:
         fix = lambda t: t if t.dtype == dt else t.to(dt)
         return HipOps._c(Z), HipOps._c(fix(X)), fix(ls_u), fix(var_u)
 
-    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None):
+    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None, out=None):
         """K = k(Z, X) computed and stored in ``dtype`` (default: Z's) from inputs of Z's dtype"""
         Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
         dtype = dtype or Z.dtype
         M, D = Z.shape
         Cn = X.shape[0]
-        K = torch.empty(M, Cn, dtype=dtype, device=Z.device)
+        K = torch.empty(M, Cn, dtype=dtype, device=Z.device) if out is None else out
+        assert K.shape == (M, Cn) and K.dtype == dtype and K.is_contiguous()
         rc = self.lib.gpsa_kmat(_dt(K), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
                                 float(jitter), _p(K), self._stream(Z))
         _lib.check(rc, "gpsa_kmat")
         return K
 
-    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True):
-        """gradients in Z's dtype; the arithmetic and partial sums run in Kbar's dtype"""
+    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True, same=False):
+        """gradients in Z's dtype; the arithmetic and partial sums run in Kbar's dtype.  ``same``: Z and
+        X are the same points (K_uu): returns dZ + dX as dZ, and None for dX."""
         Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
         Kbar = self._c(Kbar)
         M, D = Z.shape
         Cn = X.shape[0]
         dZ = torch.empty_like(Z)
-        dX = torch.empty_like(X) if need_dX else None
+        dX = torch.empty_like(X) if (need_dX and not same) else None
         dpar = torch.empty(2, dtype=Z.dtype, device=Z.device)
         wsb = self.lib.gpsa_kmat_bwd_workspace(_dt(Kbar), M, Cn, D)
         ws = self._ws(wsb, Z)
         rc = self.lib.gpsa_kmat_bwd(_dt(Kbar), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u),
-                                    _p(var_u), _p(Kbar), _p(dZ), _p(dX), _p(dpar), _p(ws), ws.numel(),
-                                    self._stream(Z))
+                                    _p(var_u), _p(Kbar), int(bool(same)), _p(dZ), _p(dX), _p(dpar), _p(ws),
+                                    ws.numel(), self._stream(Z))
         _lib.check(rc, "gpsa_kmat_bwd")
         return dZ, dX, dpar
 
@@ -135,6 +137,28 @@ class HipOps:
         tiles = ((m + 63) // 64) * ((n + 63) // 64)
         s = max(1, min(256, -(-512 // max(tiles, 1)), k // 64))
         return int(s)
+
+    # ------------------------------------------------------------------ variational covariances
+    def omega_fwd(self, A, jitter, out=None):
+        """A [B,M,M] fp32 -> A A^T + jitter I [B,M,M] fp64 (written into ``out`` when given)"""
+        A = self._f32(A)
+        Bn, M = A.shape[0], A.shape[-1]
+        if out is None:
+            out = torch.empty(Bn, M, M, dtype=torch.float64, device=A.device)
+        assert out.is_contiguous() and out.dtype == torch.float64 and out.shape == (Bn, M, M)
+        rc = self.lib.gpsa_omega_fwd(_p(A), M, Bn, float(jitter), _p(out), self._stream(A))
+        _lib.check(rc, "gpsa_omega_fwd")
+        return out
+
+    def omega_bwd(self, G, A):
+        """dA = (G + G^T) A : G [B,M,M] fp64, A [B,M,M] fp32 -> fp32"""
+        G = self._c(G if G.dtype == torch.float64 else G.double())
+        A = self._f32(A)
+        Bn, M = A.shape[0], A.shape[-1]
+        dA = torch.empty(Bn, M, M, dtype=torch.float32, device=A.device)
+        rc = self.lib.gpsa_omega_bwd(_p(G), _p(A), M, Bn, _p(dA), self._stream(A))
+        _lib.check(rc, "gpsa_omega_bwd")
+        return dA
 
     # ------------------------------------------------------------------ factorisations (fp64)
     def chol(self, A):

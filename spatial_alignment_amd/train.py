@@ -43,7 +43,6 @@ class GraphedTrainStep:
         # on the capture stream)
         model._cache = None
         model.F_latent_samples, model.F_observed_samples = {}, {}
-        model.mu_z_G = model.noise_variance_pos = None
         for p in model.parameters():
             p.grad = None
         side = torch.cuda.Stream()

@@ -28,16 +28,19 @@ def _cov(kind, Z, X, ls_u, var_u):
 class FakeOps:
     name = "fake-cpu"
 
-    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None):
+    def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None, out=None):
         dtype = dtype or Z.dtype
         K = _cov(kind, Z.to(dtype), X.to(dtype), ls_u.to(dtype), var_u.to(dtype))
         if jitter:
             n = min(K.shape)
             K = K.clone()
             K[range(n), range(n)] += jitter
+        if out is not None:
+            out.copy_(K)
+            return out
         return K
 
-    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True):
+    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True, same=False):
         dt = Kbar.dtype
         with torch.enable_grad():
             Zr, Xr = Z.to(dt).clone().requires_grad_(True), X.to(dt).clone().requires_grad_(True)
@@ -45,6 +48,8 @@ class FakeOps:
             K = _cov(kind, Zr, Xr, lr, vr)
             gz, gx, gl, gv = torch.autograd.grad(K, [Zr, Xr, lr, vr], Kbar)
         o = Z.dtype
+        if same:
+            return (gz + gx).to(o), None, torch.cat([gl.reshape(1), gv.reshape(1)]).to(o)
         return gz.to(o), (gx.to(o) if need_dX else None), torch.cat([gl.reshape(1), gv.reshape(1)]).to(o)
 
     def gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None, splitk=1):
@@ -59,6 +64,18 @@ class FakeOps:
     @staticmethod
     def pick_splitk(k, m, n):
         return 1
+
+    def omega_fwd(self, A, jitter, out=None):
+        A64 = A.double()
+        Om = A64 @ A64.transpose(-1, -2) + jitter * torch.eye(A.shape[-1], dtype=torch.float64)
+        if out is not None:
+            out.copy_(Om)
+            return out
+        return Om
+
+    def omega_bwd(self, G, A):
+        G = G.double()
+        return ((G + G.transpose(-1, -2)) @ A.double()).float()
 
     def chol(self, A):
         L, info = torch.linalg.cholesky_ex(A)

@@ -69,6 +69,11 @@ def test_kmat_fp32_storage_fp64_compute(hip, kind, M, C, D):
     rZ, rX, rp = FK.kmat_bwd(kind, Z.double(), X.double(), ls.double(), var.double(), Kb)
     for a, b in ((dZ, rZ), (dX, rX), (dp, rp)):
         close(a, b, 2e-7)
+    if M == C:  # K_uu: both arguments are the same points, the two gradients arrive summed
+        sZ, sX, sp = hip.kmat_bwd(kind, Z.to(DEV), X.to(DEV), ls.to(DEV), var.to(DEV), Kb.to(DEV), same=True)
+        assert sX is None
+        close(sZ, rZ + rX, 2e-7)
+        close(sp, rp, 2e-7)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
@@ -94,6 +99,22 @@ def test_gemm_batched_broadcast_splitk(hip, dtype):
     close(got, X.double() @ Yt.double().t(), TOL[dtype] * 3)
     A3 = rnd(4, 33, 33, dtype=dtype)
     close(hip.gemm(A3.to(DEV), A3.to(DEV), transB=True), A3.double() @ A3.double().transpose(1, 2), TOL[dtype])
+
+
+@pytest.mark.parametrize("M,B", [(5, 3), (50, 4), (200, 6), (233, 2), (64, 1)])
+def test_omega_fwd_bwd(hip, M, B):
+    """Omega = A A^T + 1e-5 I from the fp32 parameter in fp64, and its adjoint dA = (G + G^T) A"""
+    A = rnd(B, M, M, seed=M).tril()
+    Om = hip.omega_fwd(A.to(DEV), 1e-5)
+    assert Om.dtype == torch.float64
+    close(Om, FK.omega_fwd(A, 1e-5), 1e-13)
+    buf = torch.full((B + 2, M, M), -1.0, dtype=torch.float64, device=DEV)
+    hip.omega_fwd(A.to(DEV), 1e-5, out=buf[1 : B + 1])
+    assert torch.equal(buf[1 : B + 1], Om) and float(buf[0].max()) == -1.0 and float(buf[-1].max()) == -1.0
+    G = rnd(B, M, M, dtype=torch.float64, seed=3)
+    dA = hip.omega_bwd(G.to(DEV), A.to(DEV))
+    assert dA.dtype == torch.float32
+    close(dA, FK.omega_bwd(G, A), 2e-6)
 
 
 @pytest.mark.parametrize("M,B", [(1, 2), (5, 3), (50, 4), (200, 6), (233, 2)])
