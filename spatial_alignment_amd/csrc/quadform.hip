@@ -166,14 +166,9 @@ enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
 // so that K chunk kc of matrix l is one contiguous MP*64-byte block made of MB 1-KiB pieces, and
 // piece rt, copied lane-linearly into LDS (global_load_lds, lane = j + 16 kq), is read back as the
 // A fragment of row tile rt by one conflict-free ds_read_b128 at lane*16 bytes.
-// kmap selects which K index element r of lane quarter kq carries within a 16-deep chunk:
-//   0: k = 4 kq + r  (MFMA step r spans k = r, 4+r, 8+r, 12+r: the C/D row layout 4 kq + r of a result
-//      tile then matches the B operand's K layout and a quadratic form closes in registers)
-//   1: k = 4 r + kq  (MFMA step r spans 4 CONSECUTIVE k: the steps of the last chunk that lie wholly
-//      beyond M are skipped - at M = 200 two of its four, 3.8 % of all MFMAs)
 template <typename TS>
 __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, int L, int transpose,
-                                   float* __restrict__ dst, int sym_lower, int kmap) {
+                                   float* __restrict__ dst, int sym_lower) {
   const int MP = MB * 16;
   const long long per = (long long)MP * MP;
   const long long idx = blockIdx.x * 256LL + threadIdx.x;
@@ -183,7 +178,7 @@ __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, in
   const int kc = e / (MP * 16);
   const int rem = e % (MP * 16);
   const int rt = rem / 256, lane = (rem % 256) / 4, r = rem % 4;
-  const int i = rt * 16 + (lane & 15), k = kc * 16 + (kmap ? r * 4 + (lane >> 4) : (lane >> 4) * 4 + r);
+  const int i = rt * 16 + (lane & 15), k = kc * 16 + (lane >> 4) * 4 + r;
   float v = 0.f;
   if (i < M && k < M) {
     const TS* sp = src + (long long)l * M * M;
@@ -281,8 +276,6 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  constexpr bool KROW = (MODE != MODE_QUAD);  // K layout of the packed operand (pack_panels kmap = 1)
-  const int rlast = (M - 16 * (MB - 1) + 3) / 4;  // live K steps of the last chunk (1..4; <= 0: none)
 
   const long long ntiles = (C + WGCOLS - 1) / WGCOLS;
   const long long T = ntiles * L;
@@ -371,7 +364,7 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
       for (int t = 0; t < MB; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = KROW ? t * 16 + r * 4 + kq : t * 16 + kq * 4 + r;  // pack_panels kmap
+          const int row = t * 16 + kq * 4 + r;
           xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
     }
@@ -409,12 +402,10 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
           __builtin_amdgcn_sched_barrier(0);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (KROW && kc == MB - 1 && r >= rlast) continue;  // K steps wholly beyond M (wave-uniform)
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
               acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
-          }
           __builtin_amdgcn_sched_barrier(0);
         }
         GPSA_DMA_WAIT(NPW);
@@ -1016,13 +1007,13 @@ static inline long long gram_ws_bytes(int MB, long long C, int L) {
 // The M x M operands (Omega_l, L^-1) may arrive in either precision: the MFMA paths convert while
 // packing, the generic paths take a converted copy from the head of the workspace.
 static int pack_any(int p_dtype, const void* src, int M, int MB, int L, int transpose, float* dst,
-                    hipStream_t st, int sym_lower = 0, int kmap = 0) {
+                    hipStream_t st, int sym_lower = 0) {
   const long long tot = (long long)L * MB * 16 * MB * 16;
   const unsigned grid = (unsigned)cdiv(tot, 256);
   if (p_dtype == GPSA_F32)
-    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, sym_lower, kmap);
+    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, sym_lower);
   else if (p_dtype == GPSA_F64)
-    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, sym_lower, kmap);
+    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, sym_lower);
   else
     return GPSA_EINVAL;
   GPSA_LAUNCH_CHECK();
@@ -1126,7 +1117,7 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
       const long long pk = (long long)L * MB * 16 * MB * 16;
       if (workspace_bytes < (pk + accum_slab_floats(MB)) * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, 0, 1);
+      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st);
       if (rc) return rc;
       return panel_mfma_launch<MODE_ACCUM>(MB, Ppk, (const float*)alpha, (const float*)g, M, C, L,
                                            (float*)dalpha, nullptr, 2.f, Ppk + pk, st);
@@ -1197,7 +1188,7 @@ int gpsa_panel_mm(int dtype, int p_dtype, int transP, const void* P, const void*
     if (MB && !force_generic()) {
       if (workspace_bytes < (long long)MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_any(p_dtype, P, M, MB, 1, tp, Ppk, st, 0, 1);
+      int rc = pack_any(p_dtype, P, M, MB, 1, tp, Ppk, st);
       if (rc) return rc;
       return panel_mfma_launch<MODE_STORE>(MB, Ppk, (const float*)X, nullptr, M, C, 1, (float*)Y,
                                            (float*)colsq, 1.f, nullptr, st);

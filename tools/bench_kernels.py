@@ -54,6 +54,14 @@ if "kmat_bwd" in what:
         ls, var = torch.zeros(1, device=dev, dtype=dt), torch.zeros(1, device=dev, dtype=dt)
         Kb = torch.randn(M, C, device=dev, dtype=dt)
         print(f"kmat_bwd {dt} M={M} C={C}: {timeit(lambda: o.kmat_bwd('rbf', Z, X, ls, var, Kb, need_dX=True)):.1f} us", flush=True)
+if "panel" in what:
+    for C in (12500, 100000):
+        P = torch.randn(200, 200, device=dev, dtype=torch.float64).tril()
+        X = torch.randn(200, C, device=dev)
+        Om = torch.randn(50, 200, 200, device=dev, dtype=torch.float64)
+        g = torch.randn(50, C, device=dev)
+        print(f"panel_mm f32 (fp64 P) C={C}: {timeit(lambda: o.panel_mm(P, X), n=20):.1f} us", flush=True)
+        print(f"quadform_bwd_alpha C={C}: {timeit(lambda: o.quadform_bwd_alpha(X, Om, g), n=10, warm=2):.1f} us", flush=True)
 if "gemm64w" in what:  # the warp-layer shapes (M = 200, C = columns of one view)
     for C in (1250, 10000):
         A = torch.randn(200, 200, device=dev, dtype=torch.float64)
