@@ -595,7 +595,7 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
 // in the panel kernel so that one ds_read_b128 feeds four MFMAs.  Partials [L][nsplit][MP][MP] are summed + mirrored by a second
 // kernel (deterministic).
 // ------------------------------------------------------------------------------------------------
-constexpr int GR_KC = 32;  // columns per staged chunk (two 16-deep MFMA k-blocks)
+constexpr int GR_KC = 64;  // columns per staged chunk (four 16-deep MFMA K blocks)
 
 // Ownership of the lower-triangle tiles: whole tile ROWS are dealt to the 4 waves (longest row first,
 // first fit: 23 / 23 / 23 / 22 tiles at MB = 13), so that a wave loads and g-scales the A fragment of a row once per K block
@@ -631,68 +631,89 @@ struct GramPlan {
   }
 };
 
-// one K block (16 columns) of wave W's tiles: acc[s] += (g-scaled row fragment) x (column fragment)
+// one staged chunk (NKB K blocks of 16 columns) of wave W's tiles:
+//     acc[s] += (g-scaled row fragment) x (column fragment)
+// Tiles go in groups of GR_G with their MFMAs interleaved, so that an accumulator is touched again only
+// every GR_G-th MFMA: with two chains the kernel ran at 2/3 of the MFMA issue rate (the back-to-back
+// dependent latency of v_mfma_f32_16x16x4_f32 is well above two issue intervals), four chains hide it.
+// The fragments of the next group - of the next K block after the last group - are fetched while this
+// group computes, so the matrix pipe only sees a cold start once per chunk.  Every wave runs the same
+// EVEN number of groups per block (the two fragment register sets then keep their roles from one trip
+// of the K-block loop to the next); surplus slots repeat the wave's last tile into scratch accumulators
+// acc[NS .. NS+GR_G-1] (never stored).
+constexpr int GR_G = 4;
+
 template <int MB, int NKB, int W, int NS>
-__device__ __forceinline__ void gram_wave_block(const float* __restrict__ img, const float4 g4,
-                                                f32x4 (&acc)[NS]) {
+__device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
+                                                const float* __restrict__ gvec, int kq,
+                                                f32x4 (&acc)[NS + GR_G]) {
   constexpr GramPlan<MB> P{};
   constexpr int N = P.cnt[W];
-  // tiles in pairs with interleaved MFMAs (a 16x16x4 MFMA has a 40-cycle dependent latency but a
-  // 32-cycle issue interval); the fragments of the next pair are fetched while this pair computes
-  float4 fb[2][2], fa[2][2];
-  auto frag = [&](int tile_row) { return *reinterpret_cast<const float4*>(img + tile_row * (NKB * 256)); };
-  auto scaled = [&](int tile_row) {
-    const float4 t = frag(tile_row);
-    return make_float4(t.x * g4.x, t.y * g4.y, t.z * g4.z, t.w * g4.w);
+  constexpr int NGRP = (((NS + GR_G - 1) / GR_G) + 1) & ~1;
+  auto frag = [&](int kb, int tile_row) {
+    return *reinterpret_cast<const float4*>(img + kb * 256 + tile_row * (NKB * 256));
   };
+  // slot s of the wave's schedule: tile (rr, cc), or a repeat of the last tile into scratch
+  auto tile_of = [](int s) { return s < N ? s : N - 1; };
+  auto new_row = [&](int s) { return s < N && (s == 0 || P.rr[W][s] != P.rr[W][s - 1]); };
+  // The raw row fragment is fetched with the group's column fragments, one group ahead; it is scaled by
+  // g when the group is CONSUMED (4 multiplies per row and K block, next to MFMAs that do not depend on
+  // them) - scaling at fetch time would wait out the LDS round trip of a read issued a moment ago.
+  float4 araw[2][GR_G], fb[2][GR_G];
+  float4 gk = *reinterpret_cast<const float4*>(gvec + kq * 4), gn = gk;
   float4 arow = make_float4(0.f, 0.f, 0.f, 0.f);
-  int arow_of = -1;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int s = u < N ? u : N - 1;
-    if (P.rr[W][s] != arow_of) { arow = scaled(P.rr[W][s]); arow_of = P.rr[W][s]; }
-    fa[0][u] = arow;
-    fb[0][u] = frag(P.cc[W][s]);
+#define GPSA_GR_FETCH(SLOT, KB, GP)                                                           \
+  _Pragma("unroll") for (int u = 0; u < GR_G; ++u) {                                          \
+    const int t__ = tile_of(GR_G * (GP) + u);                                                 \
+    if (new_row(GR_G * (GP) + u)) araw[SLOT][u] = frag(KB, P.rr[W][t__]);                     \
+    fb[SLOT][u] = frag(KB, P.cc[W][t__]);                                                     \
   }
-  constexpr int NPAIR = (N + 1) / 2;
+  GPSA_GR_FETCH(0, 0, 0)
+#pragma unroll 1
+  for (int kb = 0; kb < NKB; ++kb) {
+    gk = gn;
 #pragma unroll
-  for (int pr = 0; pr < NPAIR; ++pr) {
-    const int cur = pr & 1, nxt = cur ^ 1;
-    if (pr + 1 < NPAIR) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int s = (2 * pr + 2 + u) < N ? (2 * pr + 2 + u) : N - 1;
-        if (P.rr[W][s] != arow_of) { arow = scaled(P.rr[W][s]); arow_of = P.rr[W][s]; }
-        fa[nxt][u] = arow;
-        fb[nxt][u] = frag(P.cc[W][s]);
+    for (int gp = 0; gp < NGRP; ++gp) {
+      const int cur = gp & 1, nxt = cur ^ 1;
+      if (gp + 1 < NGRP) {
+        GPSA_GR_FETCH(nxt, kb, gp + 1)
+      } else if (kb + 1 < NKB) {  // first group of the next K block (and its g)
+        gn = *reinterpret_cast<const float4*>(gvec + (kb + 1) * 16 + kq * 4);
+        GPSA_GR_FETCH(nxt, kb + 1, 0)
       }
+      __builtin_amdgcn_sched_barrier(0);
+      float4 a[GR_G];
+      int sl[GR_G];
+#pragma unroll
+      for (int u = 0; u < GR_G; ++u) {
+        const int s_ = GR_G * gp + u;
+        sl[u] = s_ < N ? s_ : NS + u;
+        if (new_row(s_)) {
+          const float4 r_ = araw[cur][u];
+          arow = make_float4(r_.x * gk.x, r_.y * gk.y, r_.z * gk.z, r_.w * gk.w);
+        }
+        a[u] = arow;
+      }
+#pragma unroll
+      for (int u = 0; u < GR_G; ++u)
+        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, fb[cur][u].x, acc[sl[u]], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GR_G; ++u)
+        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, fb[cur][u].y, acc[sl[u]], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GR_G; ++u)
+        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, fb[cur][u].z, acc[sl[u]], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GR_G; ++u)
+        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, fb[cur][u].w, acc[sl[u]], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    const int s0 = 2 * pr;
-    const float4 a0 = fa[cur][0], a1 = fa[cur][1];
-    const float4 b0 = fb[cur][0], b1 = fb[cur][1];
-    if (2 * pr + 1 < N) {
-      const int s1 = 2 * pr + 1;
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
-      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[s1], 0, 0, 0);
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
-      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[s1], 0, 0, 0);
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
-      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[s1], 0, 0, 0);
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
-      acc[s1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[s1], 0, 0, 0);
-    } else {
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[s0], 0, 0, 0);
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[s0], 0, 0, 0);
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[s0], 0, 0, 0);
-      acc[s0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[s0], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
   }
+#undef GPSA_GR_FETCH
 }
 
 template <int MB, int W, int NS>
-__device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS], float* __restrict__ P_, int j,
+__device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS + GR_G], float* __restrict__ P_, int j,
                                                 int kq) {
   constexpr GramPlan<MB> P{};
   constexpr int MP = MB * 16;
@@ -715,8 +736,10 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
   // conflict-free ds_read_b128 at lane*16 bytes.
   constexpr int NPW = (NPIECE + 3) / 4;  // LDS-DMA pieces per wave per stage (uniform; + 1 for g)
-  __shared__ __attribute__((aligned(16))) float sA[3][NPW * 4 * 256];  // ring, 2 stages in flight
-  __shared__ __attribute__((aligned(16))) float sG[3][GR_KC];
+  // two slots: the chunk being multiplied and the next one in flight (a chunk is ~12k MFMA cycles per
+  // wave, far longer than the DMA latency, so one stage ahead is enough and the chunks can be big)
+  __shared__ __attribute__((aligned(16))) float sA[2][NPW * 4 * 256];
+  __shared__ __attribute__((aligned(16))) float sG[2][GR_KC];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -725,9 +748,9 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   const long long nch = (C + GR_KC - 1) / GR_KC;
   const long long ch0 = (long long)sp * nch / nsplit, ch1 = (long long)(sp + 1) * nch / nsplit;
 
-  f32x4 acc[NS];
+  f32x4 acc[NS + GR_G];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS + GR_G; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // staging (LDS-DMA, ALIGNED): rows >= M are clamped to row M-1 and columns >= C to the last aligned
   // group; the clamped rows only feed output rows/cols >= M (never read back) and the clamped columns
@@ -766,33 +789,23 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
     }                                                                                        \
   }
 
-  const long long nmine = ch1 - ch0;
-  if (nmine > 0) {
-    GPSA_GR_STAGE(ch0, 0)
-    GPSA_GR_STAGE(nmine > 1 ? ch0 + 1 : ch0, 1)
-  }
-  GPSA_DMA_WAIT(NPW + 1);
+  if (ch1 > ch0) GPSA_GR_STAGE(ch0, 0)
+  GPSA_DMA_DRAIN();
   __syncthreads();
   int buf = 0;
   for (long long ch = ch0; ch < ch1; ++ch) {
-    {
-      const long long nx = (ch + 2 < ch1) ? ch + 2 : ch1 - 1;  // tail: harmless re-reads
-      GPSA_GR_STAGE(nx, buf == 0 ? 2 : buf - 1)
+    // the other slot held chunk ch-1: everyone left it before the barrier that ended that iteration
+    if (ch + 1 < ch1) GPSA_GR_STAGE(ch + 1, buf ^ 1)
+    const float* img = &sA[buf][lane * 4];
+    switch (w) {
+      case 0: gram_wave_chunk<MB, NKB, 0, NS>(img, sG[buf], kq, acc); break;
+      case 1: gram_wave_chunk<MB, NKB, 1, NS>(img, sG[buf], kq, acc); break;
+      case 2: gram_wave_chunk<MB, NKB, 2, NS>(img, sG[buf], kq, acc); break;
+      default: gram_wave_chunk<MB, NKB, 3, NS>(img, sG[buf], kq, acc); break;
     }
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      const float* img = &sA[buf][kb * 256 + lane * 4];
-      const float4 g4 = *reinterpret_cast<const float4*>(&sG[buf][kb * 16 + kq * 4]);
-      switch (w) {
-        case 0: gram_wave_block<MB, NKB, 0, NS>(img, g4, acc); break;
-        case 1: gram_wave_block<MB, NKB, 1, NS>(img, g4, acc); break;
-        case 2: gram_wave_block<MB, NKB, 2, NS>(img, g4, acc); break;
-        default: gram_wave_block<MB, NKB, 3, NS>(img, g4, acc); break;
-      }
-    }
-    GPSA_DMA_WAIT(NPW + 1);
+    GPSA_DMA_DRAIN();  // chunk ch+1 (issued a whole chunk of MFMAs ago) has landed
     __syncthreads();
-    buf = (buf == 2) ? 0 : buf + 1;
+    buf ^= 1;
   }
   GPSA_DMA_DRAIN();
 #undef GPSA_GR_STAGE
