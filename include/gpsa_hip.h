@@ -188,6 +188,22 @@ int gpsa_mvn_kl_bwd(const double* Kuu, const double* Kinv, const double* Omega, 
                     const double* g, int M, int L, double* dOmega, double* dDm, double* Sp,
                     void* stream);
 
+/* Grouped form: all T KL terms of a step in one launch each way.  The step's matrices live in ONE
+ * batch mats [B,M,M] with inverses inv [B,M,M] and logdet [B] (gpsa_chol_inv_f64 + L^-T L^-1): term t
+ * pairs the variational covariance mats[om_idx[t]] with the prior mats[pr_idx[t]] (pr_idx[t] < 0: the
+ * term is absent - a fixed view - and contributes kl = 0 and zero gradients); D [T,M] holds d_t.
+ * fwd: kl [T], KD [T,M] = K_p^-1 d_t (kept for the backward).
+ * bwd: the terms are listed per prior: order[grp_off[pg] .. grp_off[pg+1]) are the terms of prior
+ *   pr_list[pg], pg < P; group P lists the absent terms.  Writes dOmega [T,M,M], dD [T,M] and
+ *   S [P,M,M] with dLoss/dK_p = 0.5 K_p^-1 S_p K_p^-1 (two batched gpsa_gemm calls by the caller). */
+int gpsa_mvn_kl_grouped_fwd(const double* mats, const double* inv, const double* logdet,
+                            const int* om_idx, const int* pr_idx, const double* D, int M, int T,
+                            double* kl, double* KD, void* stream);
+int gpsa_mvn_kl_grouped_bwd(const double* mats, const double* inv, const int* om_idx,
+                            const int* pr_list, const int* grp_off, const int* order, const double* D,
+                            const double* KD, const double* g, int M, int T, int P, double* dOmega,
+                            double* dD, double* S, void* stream);
+
 /* ---- inducing-point initialisation: Lloyd's k-means on the device ----------
  * replaces sklearn.cluster.KMeans at gpsa/models/vgpsa.py:74-76, 90-92.  X [N,D] fp32, centres [K,D].
  * gpsa_kmeans_assign: assign[n] = nearest centre (ties -> lowest index), d2[n] (may be NULL) its

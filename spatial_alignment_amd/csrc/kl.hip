@@ -53,9 +53,113 @@ mvn_kl_bwd_kernel(const double* __restrict__ Kuu, const double* __restrict__ Kin
   Sp[e] = gs * Kuu[e] - s;
 }
 
+// ---- grouped form: ALL KL terms of a step in one launch each way -----------------------------------
+// The step's M x M matrices live in one batch (priors first, then every Omega): term t pairs the
+// covariance mats[om_idx[t]] with the prior mats[pr_idx[t]] (pr_idx < 0: the term is absent, kl = 0);
+// inverses and log-determinants come from the same batch.  D [T,M]: d_t = delta_t - mu_t.
+__global__ void __launch_bounds__(1024)
+mvn_kl_grouped_fwd_kernel(const double* __restrict__ mats, const double* __restrict__ inv,
+                          const double* __restrict__ logdet, const int* __restrict__ om_idx,
+                          const int* __restrict__ pr_idx, const double* __restrict__ D, int M,
+                          double* __restrict__ kl, double* __restrict__ KD) {
+  __shared__ double red[16];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int p = pr_idx[t], o = om_idx[t];
+  if (p < 0) {  // uniform
+    if (threadIdx.x == 0) kl[t] = 0.0;
+    for (int m = threadIdx.x; m < M; m += 1024) KD[(long long)t * M + m] = 0.0;
+    return;
+  }
+  const double* Ki = inv + (long long)p * M * M;
+  const double* Om = mats + (long long)o * M * M;
+  const double* d = D + (long long)t * M;
+  double acc = 0.0;
+  for (int i = w; i < M; i += 16) {  // one wave per row: trace term and (K^-1 d)_i in the same pass
+    double tr = 0.0, kd = 0.0;
+    for (int j = lane; j < M; j += 64) {
+      const double k = Ki[(long long)i * M + j];
+      tr += k * Om[(long long)i * M + j];
+      kd += k * d[j];
+    }
+    kd = wave_sum(kd);
+    if (lane == 0) {
+      KD[(long long)t * M + i] = kd;
+      acc += kd * d[i];
+    }
+    acc += tr;
+  }
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) kl[t] = 0.5 * (logdet[p] - logdet[o] + tot - (double)M);
+}
+
+// grid (elements / 256, P): thread (e, p) walks the terms of prior p (order[grp_off[p] .. grp_off[p+1])):
+//   dOmega[t][e] = 0.5 g_t (K_p^-1 - Omega_t^-1)[e]
+//   S[p][e] = (sum g_t) K_p[e] - sum g_t (Omega_t[e] + d_t[i] d_t[j])      ( dK_p = 0.5 K_p^-1 S_p K_p^-1 )
+// blocks with blockIdx.x == 0 also write dD[t] = g_t K_p^-1 d_t; absent terms get zero gradients.
+__global__ void __launch_bounds__(256)
+mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restrict__ inv,
+                          const int* __restrict__ om_idx, const int* __restrict__ pr_list,
+                          const int* __restrict__ grp_off, const int* __restrict__ order,
+                          const double* __restrict__ D, const double* __restrict__ KD,
+                          const double* __restrict__ g, int M, int P, double* __restrict__ dOmega,
+                          double* __restrict__ dD, double* __restrict__ S) {
+  const int pg = blockIdx.y;
+  const long long mm = (long long)M * M, e = blockIdx.x * 256LL + threadIdx.x;
+  const int t0 = grp_off[pg], t1 = grp_off[pg + 1];
+  if (pg == P) {  // pseudo-group of the absent terms
+    for (int q = t0; q < t1; ++q) {
+      const int t = order[q];
+      if (e < mm) dOmega[(long long)t * mm + e] = 0.0;
+      if (blockIdx.x == 0)
+        for (int m = threadIdx.x; m < M; m += 256) dD[(long long)t * M + m] = 0.0;
+    }
+    return;
+  }
+  const int p = pr_list[pg];
+  if (blockIdx.x == 0)
+    for (int q = t0; q < t1; ++q) {
+      const int t = order[q];
+      for (int m = threadIdx.x; m < M; m += 256) dD[(long long)t * M + m] = g[t] * KD[(long long)t * M + m];
+    }
+  if (e >= mm) return;
+  const int i = (int)(e / M), j = (int)(e % M);
+  const double kin = inv[(long long)p * mm + e];
+  double s = 0.0, gs = 0.0;
+  for (int q = t0; q < t1; ++q) {
+    const int t = order[q], o = om_idx[t];
+    const double gt = g[t];
+    gs += gt;
+    dOmega[(long long)t * mm + e] = 0.5 * gt * (kin - inv[(long long)o * mm + e]);
+    s += gt * (mats[(long long)o * mm + e] + D[(long long)t * M + i] * D[(long long)t * M + j]);
+  }
+  S[(long long)pg * mm + e] = gs * mats[(long long)p * mm + e] - s;
+}
+
 }  // namespace gpsa
 
 extern "C" {
+
+int gpsa_mvn_kl_grouped_fwd(const double* mats, const double* inv, const double* logdet,
+                            const int* om_idx, const int* pr_idx, const double* D, int M, int T,
+                            double* kl, double* KD, void* stream) {
+  if (M < 1 || T < 1) return GPSA_EINVAL;
+  gpsa::mvn_kl_grouped_fwd_kernel<<<T, 1024, 0, as_stream(stream)>>>(mats, inv, logdet, om_idx, pr_idx, D,
+                                                                     M, kl, KD);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_mvn_kl_grouped_bwd(const double* mats, const double* inv, const int* om_idx,
+                            const int* pr_list, const int* grp_off, const int* order, const double* D,
+                            const double* KD, const double* g, int M, int T, int P, double* dOmega,
+                            double* dD, double* S, void* stream) {
+  if (M < 1 || T < 1 || P < 1) return GPSA_EINVAL;
+  dim3 grid((unsigned)cdiv((long long)M * M, 256), (unsigned)(P + 1));
+  gpsa::mvn_kl_grouped_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(mats, inv, om_idx, pr_list, grp_off,
+                                                                       order, D, KD, g, M, P, dOmega, dD, S);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
 
 int gpsa_mvn_kl_fwd(const double* Kinv, const double* logdetK, const double* Omega,
                     long long omega_stride, const double* logdetO, long long logdet_stride,

@@ -45,32 +45,42 @@ class Factor:
         self.info = info
 
 
+def factor_stack(stack):
+    """(Linv, inverse, logdet, info) of a [B,M,M] batch of SPD matrices: ONE fused Cholesky + triangular
+    inverse launch and ONE batched L^-T L^-1 product for the whole batch."""
+    o = ops()
+    Linv, logdet, info = o.chol_inv(stack)
+    return Linv, o.gemm(Linv, Linv, transA=True), logdet, info
+
+
 def factor_batch(mats, stack=None):
     """Factorise many SPD matrices with as few launches as possible.
 
-    ``mats``: list of fp64 tensors [b_i, M_i, M_i].  Matrices of equal size share ONE batched fused
-    Cholesky + triangular inverse and ONE batched L^-T L^-1 product (one workgroup per matrix), so the
-    launch-latency-bound factorisations of a whole step cost one kernel's latency.  ``stack``: the
-    matrices already laid out back to back in this [sum b_i, M, M] buffer (then nothing is copied).
-    Returns, per input, (Linv [b,M,M], inverse [b,M,M], logdet [b], info [b]).
+    ``mats``: list of fp64 tensors [b_i, M_i, M_i].  Matrices of equal size share one factor_stack call
+    (one workgroup per matrix), so the launch-latency-bound factorisations of a whole step cost one
+    kernel's latency.  ``stack``: the matrices already laid out back to back in this [sum b_i, M, M]
+    buffer (then nothing is copied).
+    Returns, per input, (Linv [b,M,M], inverse [b,M,M], logdet [b], info [b]); with ``stack`` also the
+    four whole-batch tensors as a second value.
     """
-    o = ops()
     out = [None] * len(mats)
     by_size = {}
     for i, m in enumerate(mats):
         by_size.setdefault(m.shape[-1], []).append(i)
+    whole = None
     for M, idxs in by_size.items():
         if stack is not None and len(by_size) == 1:
             batch = stack
         else:
             batch = torch.cat([mats[i].detach().reshape(-1, M, M) for i in idxs], 0)
-        Linv, logdet, info = o.chol_inv(batch)
-        inv = o.gemm(Linv, Linv, transA=True)
+        Linv, inv, logdet, info = whole = factor_stack(batch)
         off = 0
         for i in idxs:
             b = mats[i].reshape(-1, M, M).shape[0]
             out[i] = (Linv[off : off + b], inv[off : off + b], logdet[off : off + b], info[off : off + b])
             off += b
+    if stack is not None and len(by_size) == 1:
+        return out, whole
     return out
 
 
@@ -384,6 +394,59 @@ class LogLikFn(torch.autograd.Function):
         dF, dn = o.loglik_bwd(Fc, Yc, nu, gout.detach().double().reshape(1))
         ndt, nshape = ctx.nmeta
         return dF, None, dn.to(ndt).reshape(nshape)
+
+
+class KLPlan:
+    """Static pairing of the KL terms of a model with the matrices of its factorisation batch
+    (priors at batch positions 0..P-1, every variational covariance behind them, in forward's order).
+    ``prior_of_term[t]``: position of term t's prior in the batch, or -1 for an absent term (fixed view)."""
+
+    def __init__(self, prior_of_term, n_priors, device):
+        T = len(prior_of_term)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+        self.T, self.P = T, n_priors
+        self.om_idx = i32([n_priors + t for t in range(T)])
+        self.pr_idx = i32(list(prior_of_term))
+        order, off = [], [0]
+        for p in list(range(n_priors)) + [-1]:  # last group: the absent terms
+            order += [t for t in range(T) if prior_of_term[t] == p]
+            off.append(len(order))
+        self.pr_list, self.grp_off, self.order = i32(list(range(n_priors))), i32(off), i32(order)
+
+
+class MvnKLGroupedFn(torch.autograd.Function):
+    """Every KL term of the step in one launch each way (same formulas as MvnKLFn).  Inputs: D [T,M]
+    (d_t rows, fp64), the P prior matrices, then the variational covariance tensors in batch order;
+    ``batch`` = (mats, inv, logdet) of the whole factorisation batch.  Returns kl [T]."""
+
+    @staticmethod
+    def forward(ctx, plan, batch, D, *mats_in):
+        o = ops()
+        mats, inv, logdet = batch
+        Dc = D.detach().contiguous()
+        kl, KD = o.mvn_kl_grouped_fwd(mats, inv, logdet, plan, Dc)
+        ctx.save_for_backward(mats, inv, Dc, KD)
+        ctx.plan = plan
+        ctx.shapes = [tuple(m.shape) for m in mats_in]
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        o = ops()
+        mats, inv, Dc, KD = ctx.saved_tensors
+        plan = ctx.plan
+        dOm, dD, S = o.mvn_kl_grouped_bwd(mats, inv, plan, Dc, KD, gkl.double().contiguous())
+        Kinv = inv[: plan.P]
+        dK = o.gemm(o.gemm(Kinv, S), Kinv, alpha=0.5)
+        grads, used = [], 0
+        for i, shp in enumerate(ctx.shapes):
+            if i < plan.P:
+                grads.append(dK[i].reshape(shp))
+            else:
+                n = shp[0] if len(shp) == 3 else 1
+                grads.append(dOm[used : used + n].reshape(shp))
+                used += n
+        return (None, None, dD) + tuple(grads)
 
 
 class MvnKLFn(torch.autograd.Function):

@@ -41,6 +41,7 @@ class _StepCache:
         self.Omega_F_fac = {}  # mod -> (Omega_F^-1, logdet)
         self.flags = []  # device int tensors: Cholesky info / non-positive variance flags
         self.mu_z = self.dG_v = self.resid = None  # per-view prior means / variational means / their difference
+        self.batch = self.free = None  # (matrices, inverses, logdets) of the whole factorisation batch
         self.Om_fwd = self.Om_kl = None  # per-view row groups of Omega_G
 
 
@@ -291,14 +292,20 @@ class VariationalGPSA(GPSA):
             cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m], slot(sh[0]) if slot else None)
         mats = [Kuu_w[v].unsqueeze(0) for v in free] + [KuuF.unsqueeze(0), cache.Omega_G] + \
                [cache.Omega_F[m] for m in mods]
-        parts = E.factor_batch(mats, stack=stack)
+        cache.batch = None
+        if stack is not None:
+            parts, whole = E.factor_batch(mats, stack=stack)
+            cache.batch = (stack, whole[1], whole[2])  # matrices, inverses, logdets of the whole step
+            cache.free = tuple(free)
+        else:
+            parts = E.factor_batch(mats)
         for i, v in enumerate(free):
             cache.warp[v] = (Kuu_w[v], E.Factor(parts=parts[i]))
         nf = len(free)
         cache.data = (KuuF, E.Factor(parts=parts[nf]))
         cache.Omega_G_fac = (parts[nf + 1][1], parts[nf + 1][2])
         cache.Omega_F_fac = {m: (parts[nf + 2 + i][1], parts[nf + 2 + i][2]) for i, m in enumerate(mods)}
-        cache.flags.extend(p[3] for p in parts)
+        cache.flags.extend([whole[3]] if stack is not None else [p[3] for p in parts])
 
         # ---- warp GP per view (vgpsa.py:259-351) ---------------------------------------------------
         warp_out = {}
@@ -472,6 +479,29 @@ class VariationalGPSA(GPSA):
                 "Normal(...) argument validation here)"
             )
 
+    def _kl_grouped(self, cache):
+        """sum of all KL terms through MvnKLGroupedFn; term order = order of the variational covariances
+        in the factorisation batch: Omega_G rows r = j*V + v (quirk 2: the KL pairs row r with view
+        r % V and coordinate r // V), then every Omega_F row."""
+        V, D = self.n_views, self.n_spatial_dims
+        mods, free = self.modality_names, cache.free
+        key = (free, tuple(int(cache.Omega_F[m].shape[0]) for m in mods))
+        plan = self.__dict__.setdefault("_kl_plans", {}).get(key)
+        if plan is None:
+            pos = {v: i for i, v in enumerate(free)}
+            prior = [pos.get(r % V, -1) for r in range(V * D)]
+            for m in mods:
+                prior += [len(free)] * int(cache.Omega_F[m].shape[0])
+            plan = self._kl_plans[key] = E.KLPlan(prior, len(free) + 1, cache.Omega_G.device)
+        M = cache.Omega_G.shape[-1]
+        rows = [torch.stack(cache.resid, 0).permute(2, 0, 1).reshape(V * D, M)]  # row j*V+v = resid[v][:, j]
+        rows += [self.delta_F_dict[m].t() for m in mods]
+        Dall = torch.cat(rows, 0)  # promoted to fp64
+        priors = [cache.warp[v][0] for v in free] + [cache.data[0]]
+        kl = E.MvnKLGroupedFn.apply(plan, cache.batch, Dall, *priors, cache.Omega_G,
+                                    *[cache.Omega_F[m] for m in mods])
+        return kl.sum()
+
     # ------------------------------------------------------------------------------------------
     def loss_fn(self, data_dict, F_samples):
         """Negative (approximate) ELBO (vgpsa.py:491-540).  Valid only after ``forward`` on the same
@@ -482,8 +512,11 @@ class VariationalGPSA(GPSA):
         V, D = self.n_views, self.n_spatial_dims
         f64 = torch.float64
         kl = None
+        grouped = cache.batch is not None
+        if grouped:  # every KL term of the step (all views, all outputs) in one launch each way
+            kl = self._kl_grouped(cache)
         for v in range(V):
-            if self._is_fixed(v) or v not in cache.warp:
+            if grouped or self._is_fixed(v) or v not in cache.warp:
                 continue
             Kuu, fac = cache.warp[v]
             Dm = cache.resid[v]
@@ -494,9 +527,10 @@ class VariationalGPSA(GPSA):
         KuuF, facF = cache.data
         ll = None
         for i, m in enumerate(self.modality_names):
-            term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF,
-                                   cache.Omega_F_fac[m]).sum()
-            kl = term if kl is None else kl + term
+            if not grouped:
+                term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF,
+                                       cache.Omega_F_fac[m]).sum()
+                kl = term if kl is None else kl + term
             noise_u = self.noise_variance[-self.n_modalities + i]  # quirk 5 (used as a std)
             Y = data_dict[m]["outputs"]
             t = E.LogLikFn.apply(F_samples[m], Y, noise_u)

@@ -435,6 +435,29 @@ class HipOps:
         _lib.check(rc, "gpsa_mvn_kl_bwd")
         return dOm, dDm, Sp
 
+    def mvn_kl_grouped_fwd(self, mats, inv, logdet, plan, D):
+        """all KL terms of a step: -> kl [T], KD [T,M] (see include/gpsa_hip.h; ``plan``: KLPlan)"""
+        T, M = D.shape
+        kl = torch.empty(T, dtype=torch.float64, device=D.device)
+        KD = torch.empty(T, M, dtype=torch.float64, device=D.device)
+        rc = self.lib.gpsa_mvn_kl_grouped_fwd(_p(mats), _p(inv), _p(logdet), _p(plan.om_idx), _p(plan.pr_idx),
+                                              _p(D), M, T, _p(kl), _p(KD), self._stream(D))
+        _lib.check(rc, "gpsa_mvn_kl_grouped_fwd")
+        return kl, KD
+
+    def mvn_kl_grouped_bwd(self, mats, inv, plan, D, KD, g):
+        """-> dOmega [T,M,M], dD [T,M], S [P,M,M]  (dK_p = 0.5 K_p^-1 S_p K_p^-1)"""
+        T, M = D.shape
+        dev = D.device
+        dOm = torch.empty(T, M, M, dtype=torch.float64, device=dev)
+        dD = torch.empty(T, M, dtype=torch.float64, device=dev)
+        S = torch.empty(plan.P, M, M, dtype=torch.float64, device=dev)
+        rc = self.lib.gpsa_mvn_kl_grouped_bwd(_p(mats), _p(inv), _p(plan.om_idx), _p(plan.pr_list),
+                                              _p(plan.grp_off), _p(plan.order), _p(D), _p(KD), _p(g), M, T,
+                                              plan.P, _p(dOm), _p(dD), _p(S), self._stream(D))
+        _lib.check(rc, "gpsa_mvn_kl_grouped_bwd")
+        return dOm, dD, S
+
     # ------------------------------------------------------------------ k-means (initialisation)
     def kmeans_assign(self, X, centres, want_d2=False):
         X, centres = self._c(X), self._c(centres)

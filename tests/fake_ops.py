@@ -165,6 +165,33 @@ class FakeOps:
         ds = ((r * r) / s**3 - 1.0 / s).sum() / S
         return dF.float(), (gout[0] * ds * e).float().reshape(1)
 
+    def mvn_kl_grouped_fwd(self, mats, inv, logdet, plan, D):
+        T, M = D.shape
+        kl = torch.zeros(T, dtype=torch.float64)
+        KD = torch.zeros(T, M, dtype=torch.float64)
+        for t in range(T):
+            p, o = int(plan.pr_idx[t]), int(plan.om_idx[t])
+            if p < 0:
+                continue
+            KD[t] = inv[p] @ D[t]
+            kl[t] = 0.5 * (logdet[p] - logdet[o] + (inv[p] * mats[o]).sum() + D[t] @ KD[t] - M)
+        return kl, KD
+
+    def mvn_kl_grouped_bwd(self, mats, inv, plan, D, KD, g):
+        T, M = D.shape
+        dOm = torch.zeros(T, M, M, dtype=torch.float64)
+        dD = torch.zeros(T, M, dtype=torch.float64)
+        S = torch.zeros(plan.P, M, M, dtype=torch.float64)
+        for pg in range(plan.P):
+            p = int(plan.pr_list[pg])
+            for q in range(int(plan.grp_off[pg]), int(plan.grp_off[pg + 1])):
+                t = int(plan.order[q])
+                o = int(plan.om_idx[t])
+                dOm[t] = 0.5 * g[t] * (inv[p] - inv[o])
+                dD[t] = g[t] * KD[t]
+                S[pg] += g[t] * (mats[p] - mats[o] - torch.outer(D[t], D[t]))
+        return dOm, dD, S
+
     def mvn_kl_fwd(self, Kinv, logdetK, Omega, logdetO, Dm):
         M = Omega.shape[-1]
         tr = (Kinv.unsqueeze(0) * Omega).sum((-1, -2))

@@ -101,6 +101,31 @@ def test_gemm_batched_broadcast_splitk(hip, dtype):
     close(hip.gemm(A3.to(DEV), A3.to(DEV), transB=True), A3.double() @ A3.double().transpose(1, 2), TOL[dtype])
 
 
+@pytest.mark.parametrize("M", [7, 50, 200])
+def test_mvn_kl_grouped(hip, M):
+    """all KL terms in one launch each way vs the per-term formulas (incl. an absent term)"""
+    from spatial_alignment_amd.engine import KLPlan
+
+    f64 = torch.float64
+    P, prior = 3, [0, 1, -1, 0, 2, 2, 2, 1, 2]
+    T = len(prior)
+    A = rnd(P + T, M, M, dtype=f64, seed=M)
+    mats = A @ A.transpose(1, 2) / M + 0.1 * torch.eye(M, dtype=f64)
+    inv, logdet = torch.linalg.inv(mats), torch.logdet(mats)
+    D, g = rnd(T, M, dtype=f64, seed=1), rnd(T, dtype=f64, seed=2)
+    plan_d, plan_h = KLPlan(prior, P, DEV), KLPlan(prior, P, "cpu")
+    kl, KD = hip.mvn_kl_grouped_fwd(mats.to(DEV), inv.to(DEV), logdet.to(DEV), plan_d, D.to(DEV))
+    rkl, rKD = FK.mvn_kl_grouped_fwd(mats, inv, logdet, plan_h, D)
+    close(kl, rkl, 1e-12)
+    close(KD, rKD, 1e-12)
+    assert float(kl[2]) == 0.0
+    got = hip.mvn_kl_grouped_bwd(mats.to(DEV), inv.to(DEV), plan_d, D.to(DEV), KD, g.to(DEV))
+    want = FK.mvn_kl_grouped_bwd(mats, inv, plan_h, D, rKD, g)
+    for a, b in zip(got, want):
+        close(a, b, 1e-12)
+    assert float(got[0][2].abs().max()) == 0.0 and float(got[1][2].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,B", [(5, 3), (50, 4), (200, 6), (233, 2), (64, 1)])
 def test_omega_fwd_bwd(hip, M, B):
     """Omega = A A^T + 1e-5 I from the fp32 parameter in fp64, and its adjoint dA = (G + G^T) A"""
