@@ -182,8 +182,9 @@ tri_inv_global_kernel(const double* __restrict__ L, double* __restrict__ Linv, i
 }
 
 // Fused factorisation: Linv = chol(A)^-1, logdet, info in ONE pass with the matrix held in registers.
-// 1024 threads own the lower triangle 2-D cyclically: thread (ty, tx) holds t[qa][qb] = element
-// (32 qa + ty, 32 qb + tx), qb <= qa.  Step j of the right-looking factorisation publishes column j
+// TS x TS threads own the lower triangle 2-D cyclically: thread (ty, tx) holds t[qa][qb] = element
+// (TS qa + ty, TS qb + tx), qb <= qa.  TS = 16 (one wave per SIMD, up to 136 elements per thread) runs
+// the per-column bookkeeping once per SIMD instead of four times and is the faster shape up to M = 208; TS = 32 above (GPSA_CHOL_TS forces one).  Step j of the right-looking factorisation publishes column j
 // (rows >= j) and, for the forward substitution that runs in the same sweep, row j of the inverse
 // (columns < j) through a double-buffered LDS vector: ONE barrier per column, no LDS read-modify-
 // write.  The register position (i,k) holds A(i,k) while k > j and X(i,k) = L^-1(i,k) once k <= j
@@ -191,15 +192,16 @@ tri_inv_global_kernel(const double* __restrict__ L, double* __restrict__ Linv, i
 //     t(i,k) -= L(i,j) * w(k),   w(k) = L(k,j) for k > j,   X(j,k)/L(j,j) for k < j,   1/L(j,j) at k = j
 // over the rows i > j.  The outer loop over the 32-column tile index is unrolled at compile time so
 // that every register index is static and dead tiles cost nothing.
-template <int NT>
-__global__ void __launch_bounds__(1024)
+template <int NT, int TS>
+__global__ void __launch_bounds__(TS * TS)
 chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Linv,
                     double* __restrict__ logdet, int* __restrict__ info) {
-  __shared__ double col[2][NT * 32];
-  __shared__ double xrow[2][NT * 32];
-  __shared__ double sdiag[NT * 32];
+  constexpr int NTH = TS * TS;
+  __shared__ double col[2][NT * TS];
+  __shared__ double xrow[2][NT * TS];
+  __shared__ double sdiag[NT * TS];
   __shared__ double red[16];
-  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
   const double* G = A + (long long)blockIdx.x * M * M;
   double* O = Linv + (long long)blockIdx.x * M * M;
   double t[NT][NT];
@@ -207,28 +209,28 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   for (int qa = 0; qa < NT; ++qa)
 #pragma unroll
     for (int qb = 0; qb < NT; ++qb) {
-      const int i = 32 * qa + ty, k = 32 * qb + tx;
+      const int i = TS * qa + ty, k = TS * qb + tx;
       t[qa][qb] = (qb <= qa && i < M && k < M) ? G[(long long)i * M + k] : 0.0;
     }
   int bad = 0;
 #pragma unroll
   for (int q0 = 0; q0 < NT; ++q0) {
 #pragma unroll 1
-    for (int r0 = 0; r0 < 32; ++r0) {
-      const int j = 32 * q0 + r0;
+    for (int r0 = 0; r0 < TS; ++r0) {
+      const int j = TS * q0 + r0;
       if (j >= M || bad) break;  // uniform
       const int b = j & 1;
       if (tx == r0) {
 #pragma unroll
         for (int qa = q0; qa < NT; ++qa) {
-          const int i = 32 * qa + ty;
+          const int i = TS * qa + ty;
           if (i >= j) col[b][i] = t[qa][q0];
         }
       }
       if (ty == r0) {
 #pragma unroll
         for (int qb = 0; qb <= q0; ++qb) {
-          const int k = 32 * qb + tx;
+          const int k = TS * qb + tx;
           if (k < j) xrow[b][k] = t[q0][qb];
         }
       }
@@ -247,14 +249,14 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
       double w[NT], li[NT];
 #pragma unroll
       for (int qb = 0; qb < NT; ++qb) {
-        const int k = 32 * qb + tx;
+        const int k = TS * qb + tx;
         if (qb > q0) w[qb] = col[b][k] * inv;
         else if (qb < q0) w[qb] = xrow[b][k] * inv;
         else w[qb] = (k > j) ? col[b][k] * inv : ((k == j) ? inv : xrow[b][k] * inv);
       }
 #pragma unroll
       for (int qa = q0; qa < NT; ++qa) {
-        const int i = 32 * qa + ty;
+        const int i = TS * qa + ty;
         li[qa] = (i > j) ? col[b][i] * inv : 0.0;
       }
 #pragma unroll
@@ -271,7 +273,7 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
       if (ty == r0) {  // row j of the inverse is final: scale by 1/L(j,j), diagonal = 1/L(j,j)
 #pragma unroll
         for (int qb = 0; qb <= q0; ++qb) {
-          const int k = 32 * qb + tx;
+          const int k = TS * qb + tx;
           if (k < j) t[q0][qb] *= inv;
           else if (k == j) t[q0][qb] = inv;
         }
@@ -282,7 +284,7 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   // logdet = 2 sum log L(j,j), reduced in a fixed order
   double lg = 0.0;
   if (!bad)
-    for (int j = tid; j < M; j += 1024) lg -= log(sdiag[j]);  // sdiag = 1 / L(j,j)
+    for (int j = tid; j < M; j += NTH) lg -= log(sdiag[j]);  // sdiag = 1 / L(j,j)
   lg = block_sum(lg, red);
   if (tid == 0) {
     logdet[blockIdx.x] = bad ? __builtin_nan("") : 2.0 * lg;
@@ -292,7 +294,7 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   for (int qa = 0; qa < NT; ++qa)
 #pragma unroll
     for (int qb = 0; qb < NT; ++qb) {
-      const int i = 32 * qa + ty, k = 32 * qb + tx;
+      const int i = TS * qa + ty, k = TS * qb + tx;
       if (i < M && k < M) O[(long long)i * M + k] = (qb <= qa && k <= i) ? t[qa][qb] : 0.0;
     }
 }
@@ -381,15 +383,30 @@ int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet,
   using namespace gpsa;
   if (M < 1 || batch < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
-  const int nt = (M + 31) / 32;
-#define GPSA_CI_CASE(V)                                                                            \
-  chol_inv_reg_kernel<V><<<batch, 1024, 0, st>>>((const double*)A, M, (double*)Linv, (double*)logdet, info)
-  if (nt <= 1) GPSA_CI_CASE(1);
-  else if (nt <= 2) GPSA_CI_CASE(2);
-  else if (nt <= 4) GPSA_CI_CASE(4);
-  else if (nt <= 7) GPSA_CI_CASE(7);
-  else if (nt <= 8) GPSA_CI_CASE(8);
-  else return GPSA_EUNSUPPORTED;
+#define GPSA_CI_CASE(V, TSV)                                                                      \
+  chol_inv_reg_kernel<V, TSV><<<batch, TSV * TSV, 0, st>>>((const double*)A, M, (double*)Linv,       \
+                                                            (double*)logdet, info)
+  // 16 x 16 threads (one wave per SIMD) while a thread's share fits comfortably in registers: 166 vs
+  // 185 us at M = 200; 32 x 32 above (252 vs 287 us at M = 256)
+  static const int forced = [] { const char* e = getenv("GPSA_CHOL_TS"); return e ? atoi(e) : 0; }();
+  const int ts = forced ? forced : (M <= 208 ? 16 : 32);
+  if (ts == 32) {
+    const int nt = (M + 31) / 32;
+    if (nt <= 1) GPSA_CI_CASE(1, 32);
+    else if (nt <= 2) GPSA_CI_CASE(2, 32);
+    else if (nt <= 4) GPSA_CI_CASE(4, 32);
+    else if (nt <= 7) GPSA_CI_CASE(7, 32);
+    else if (nt <= 8) GPSA_CI_CASE(8, 32);
+    else return GPSA_EUNSUPPORTED;
+  } else {
+    const int nt = (M + 15) / 16;
+    if (nt <= 2) GPSA_CI_CASE(2, 16);
+    else if (nt <= 4) GPSA_CI_CASE(4, 16);
+    else if (nt <= 7) GPSA_CI_CASE(7, 16);
+    else if (nt <= 13) GPSA_CI_CASE(13, 16);
+    else if (nt <= 16) GPSA_CI_CASE(16, 16);
+    else return GPSA_EUNSUPPORTED;
+  }
 #undef GPSA_CI_CASE
   GPSA_LAUNCH_CHECK();
   return 0;
