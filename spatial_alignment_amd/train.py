@@ -21,6 +21,45 @@ def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None, sta
     return loss
 
 
+def fit(model, data_dict, n_epochs, lr=1e-2, S=5, optimizer=None, checker=None, sync_every=10,
+        callback=None, graphed=False):
+    """The reference's training loop (examples/grid_example.py:59-78 and the convergence test of
+    gpsa/util/util.py:257-278 used by the experiment scripts) as one call.
+
+    Runs ``n_epochs`` steps of forward(S) + loss_fn + backward + Adam on ``data_dict``; returns the loss
+    trace (a list of floats, one per step).  The loss stays on the device and is brought to the host
+    every ``sync_every`` steps only, so the queue is not drained at each iteration; ``checker`` (a
+    ``LossNotDecreasingChecker``) is evaluated on the synced values and stops the loop early;
+    ``callback(step, model, loss_trace)`` is called at every sync.  ``graphed=True`` replays the step as
+    one hipGraph (single GPU)."""
+    model.train()
+    view_idx, Ns, _, _ = model.create_view_idx_dict(data_dict)
+    if optimizer is None:
+        dev_is_gpu = next(model.parameters()).is_cuda
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr, **({"capturable": True} if graphed else
+                                                                    {"fused": True} if dev_is_gpu else {}))
+    stepper = GraphedTrainStep(model, optimizer, data_dict, view_idx, Ns, S=S) if graphed else None
+    trace, pending = [], []
+
+    def drain():
+        trace.extend(float(v) for v in torch.stack(pending).tolist())
+        pending.clear()
+
+    for it in range(n_epochs):
+        loss = stepper.step() if graphed else train_step(model, optimizer, data_dict, view_idx, Ns, S)
+        pending.append(loss.detach().clone() if graphed else loss.detach())
+        if (it + 1) % sync_every == 0 or it + 1 == n_epochs:
+            first = len(trace)
+            drain()
+            if graphed:
+                stepper.check()
+            if callback is not None:
+                callback(it, model, trace)
+            if checker is not None and any(checker.check_loss(i, trace) for i in range(first, len(trace))):
+                break
+    return trace
+
+
 class GraphedTrainStep:
     """One training step captured into a hipGraph (torch.cuda.CUDAGraph) and replayed.
 

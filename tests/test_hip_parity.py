@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import spatial_alignment_amd as gp
 from golden_io import CASES, Golden, rel
 from model_util import build_model, compare, run_step
 
@@ -57,6 +58,48 @@ def test_hip_matches_oracle_fresh_noise():
     for k, gr in ref["grads"].items():
         if gr.norm() > 0:
             assert rel(res[f"grad/{k}"], gr.numpy()) < 5e-3, k
+
+
+@pytest.mark.parametrize("M,mG", [(288, 288), (300, 96)])
+def test_large_and_mixed_inducing_counts_match_oracle(M, mG):
+    """M > 256 leaves every register-resident kernel (MFMA panels, fp64 projection, fused
+    factorisation) for the generic tiled / LDS-resident paths; m_X != m_G leaves the one-batch
+    factorisation and the grouped KL.  Same step through the CPU oracle in fp64, noise drawn here."""
+    from oracle import gpsa_oracle as orc
+    from spatial_alignment_amd.synthetic import make_grid_problem
+
+    dd = make_grid_problem(side=20, n_views=2, n_outputs=6, device="cpu")
+    m = "expression"
+    torch.manual_seed(5)
+    np.random.seed(5)
+    model = gp.VariationalGPSA(dd, m_X_per_view=M, m_G=mG, data_init=False, n_latent_gps={m: None},
+                               kernel_func_warp=gp.rbf_kernel, kernel_func_data=gp.rbf_kernel,
+                               fixed_view_idx=None)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for name in ("mean_slopes", "mean_intercepts"):  # non-persistent buffers the oracle needs
+        state.setdefault(name, getattr(model, name).detach().clone())
+    model = model.to(DEV)
+    S, n, L = 2, 400, 6
+    gen = torch.Generator().manual_seed(9)
+    eps_G = [torch.randn(S, n, 2, generator=gen) for _ in range(2)]
+    eps_F = {m: torch.randn(S, 2 * n, L, generator=gen)}
+    ddd = {m: {"spatial_coords": dd[m]["spatial_coords"].to(DEV), "outputs": dd[m]["outputs"].to(DEV),
+               "n_samples_list": dd[m]["n_samples_list"]}}
+    view_idx, Ns, _, _ = model.create_view_idx_dict(ddd)
+    model.inject_noise(eps_G, eps_F, None)
+    out = model.forward({m: ddd[m]["spatial_coords"]}, view_idx=view_idx, Ns=Ns, S=S)
+    loss = model.loss_fn(ddd, out[3])
+    loss.backward()
+    cfg = dict(modality_names=[m], n_views=2, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
+               n_latent_gps={m: None}, fixed_view_idx=None)
+    ref = orc.evaluate(state, cfg, {m: dd[m]["spatial_coords"]}, {m: dd[m]["outputs"]},
+                       {m: dd[m]["n_samples_list"]}, S, eps_G, eps_F, dtype=torch.float64)
+    assert rel(out[0][m].detach().cpu().numpy(), ref["G_means"][m].numpy()) < 1e-5
+    assert rel(out[3][m].detach().cpu().numpy(), ref["F_obs"][m].numpy()) < 1e-4
+    assert rel(loss.detach().cpu().numpy(), ref["loss"].numpy()) < 1e-5
+    grads = dict(model.named_parameters())
+    for k in ("Xtilde", "delta_G_list", f"Omega_sqt_F_dict.{m}", "data_kernel_lengthscale"):
+        assert rel(grads[k].grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-2, k
 
 
 def test_training_reduces_loss_and_is_deterministic():

@@ -113,3 +113,27 @@ def test_initial_parameters_match_reference_rng_order():
     assert set(sd) == set(ref)
     for k, v in ref.items():
         assert np.array_equal(sd[k].numpy(), v), k
+
+
+def test_fit_loop_matches_manual_steps_and_stops_on_checker():
+    """train.fit == the reference's loop body repeated; LossNotDecreasingChecker ends it early"""
+    from spatial_alignment_amd.train import fit, train_step
+
+    g = Golden("c1_example_fixed0")
+    traces = []
+    for use_fit in (True, False):
+        model, dd = build_model(g)
+        torch.manual_seed(3)
+        if use_fit:
+            traces.append(fit(model, dd, n_epochs=6, lr=1e-2, S=2, sync_every=4))
+        else:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+            traces.append([float(train_step(model, opt, dd, view_idx, Ns, S=2)) for _ in range(6)])
+    assert traces[0] == traces[1] and len(traces[0]) == 6
+    model, dd = build_model(g)
+    from spatial_alignment_amd import LossNotDecreasingChecker
+
+    chk = LossNotDecreasingChecker(max_epochs=40, atol=1e9, window_size=3)  # any decrease is "too small"
+    tr = fit(model, dd, n_epochs=40, S=1, sync_every=2, checker=chk)
+    assert 3 <= len(tr) < 40
