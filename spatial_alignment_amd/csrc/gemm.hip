@@ -120,69 +120,111 @@ gemm_kernel(int m, int n, long long k, T alpha, const T* __restrict__ A, long lo
 // same register-staged prefetch, but each wave owns a 32 x 32 quadrant as 2 x 2 MFMA tiles, so one K
 // step of 4 costs 4 LDS fragment reads per 4 MFMAs instead of 4 ds_read_b128 per 16 vector FMAs (the
 // vector kernel above is LDS-bandwidth-bound at twice its FMA time in fp64).
-typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
 // TIA / TIB: storage types of the operands (fp32 parameters are read as stored and widened), TO: type of
 // C; SYMA: the left operand is A + A^T (square A); diag is added to C[i][i] (split-K == 1 only).  These
 // cover Omega = A A^T + 1e-5 I straight from the fp32 parameter and its adjoint dA = (G + G^T) A.
-template <bool TA, bool TB, typename TIA = double, typename TIB = double, typename TO = double,
+// TC: arithmetic type (double: v_mfma_f64_16x16x4_f64, float: v_mfma_f32_16x16x4_f32 - both take one
+// element per lane and K step, lane = (row or column) + 16 * k; only the C/D row layouts differ).
+// out[i] = p[i] for i < lim (the leading in-range elements of a contiguous group of 4), else 0
+template <typename TI, typename TC>
+__device__ __forceinline__ void load4(const TI* __restrict__ p, bool vec_ok, long long lim, TC (&out)[4]) {
+  if (vec_ok && lim >= 4) {
+    if (sizeof(TI) == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      out[0] = (TC)v.x; out[1] = (TC)v.y; out[2] = (TC)v.z; out[3] = (TC)v.w;
+    } else {
+      const double2 v0 = *reinterpret_cast<const double2*>(p);
+      const double2 v1 = *reinterpret_cast<const double2*>(p + 2);
+      out[0] = (TC)v0.x; out[1] = (TC)v0.y; out[2] = (TC)v1.x; out[3] = (TC)v1.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (i < lim) ? (TC)p[i] : TC(0);
+  }
+}
+
+template <typename TC> struct MfmaTile;
+template <> struct MfmaTile<double> {
+  typedef double vec __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ vec mma(double a, double b, vec c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int kq, int r) { return kq + 4 * r; }
+};
+template <> struct MfmaTile<float> {
+  typedef float vec __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ vec mma(float a, float b, vec c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+};
+
+template <typename TC, bool TA, bool TB, typename TIA = TC, typename TIB = TC, typename TO = TC,
           bool SYMA = false>
 __global__ void __launch_bounds__(256, 4)
-gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const TIA* __restrict__ A,
-                     long long lda, long long sA, const TIB* __restrict__ B, long long ldb,
-                     long long sB, double beta, TO* __restrict__ C, long long ldc, long long sC,
-                     int splitk, double* __restrict__ part, double diag = 0.0) {
-  __shared__ double As[2][GB_K][GB_M + 4];  // double-buffered: one barrier per K tile
-  __shared__ double Bs[2][GB_K][GB_N + 4];
+gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A, long long lda,
+                 long long sA, const TIB* __restrict__ B, long long ldb, long long sB, TC beta,
+                 TO* __restrict__ C, long long ldc, long long sC, int splitk, TC* __restrict__ part,
+                 TC diag = TC(0)) {
+  typedef typename MfmaTile<TC>::vec acc_t;
+  // K tile of 16 (32 was tried: fewer resident workgroups, 20-40 % slower on every shape used here)
+  constexpr int GK = 16, NG = GK / 16;
+  __shared__ TC As[2][GK][GB_M + 4];  // double-buffered: one barrier per K tile
+  __shared__ TC Bs[2][GK][GB_N + 4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32, wn = (w & 1) * 32, j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z / splitk, sp = blockIdx.z % splitk;
   const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
   long long kchunk = (k + splitk - 1) / splitk;
-  kchunk = (kchunk + GB_K - 1) / GB_K * GB_K;
+  kchunk = (kchunk + GK - 1) / GK * GK;
   const long long kbeg = (long long)sp * kchunk;
   const long long kend = (kbeg + kchunk < k) ? kbeg + kchunk : k;
   const TIA* Ab = A + (long long)b * sA;
   const TIB* Bb = B + (long long)b * sB;
-  f64x4_t acc[2][2];
+  acc_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (acc_t){TC(0), TC(0), TC(0), TC(0)};
   const bool lm0 = m0 + wm < m, lm1 = m0 + wm + 16 < m, ln0 = n0 + wn < n, ln1 = n0 + wn + 16 < n;
 
-  double ra[4], rb[4];
+  // Staging: every thread owns 4 elements of each operand tile that are CONTIGUOUS in memory (along K
+  // for a row-major left / transposed right operand, along the row / column index otherwise) and
+  // fetches them with 16-byte loads when the whole group is in range and aligned; edge groups and
+  // unaligned operands take guarded scalar loads of the same elements.
+  TC ra[NG][4], rb[NG][4];
+  const bool va_ok = !SYMA && (lda % (16 / (int)sizeof(TIA)) == 0) && (sA % (16 / (int)sizeof(TIA)) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vb_ok = (ldb % (16 / (int)sizeof(TIB)) == 0) && (sB % (16 / (int)sizeof(TIB)) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // A: (row ar + i*ari, k ak + i*aki), i = 0..3     B: (k bk + i*bki, col bc + i*bci)
+  const int ar = TA ? (tid % 16) * 4 : tid / 4, ak = TA ? tid / 16 : (tid % 4) * 4;
+  const int bc = TB ? tid / 4 : (tid % 16) * 4, bk = TB ? (tid % 4) * 4 : tid / 16;
 #define GPSA_G64_FETCH(K0)                                                                \
-  {                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-      const int e = tid + i * 256;                                                        \
-      int r, kk;                                                                          \
-      if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }      \
-      const long long gr = m0 + r, gk = (K0) + kk;                                        \
-      double va = 0.0;                                                                    \
-      if (gr < m && gk < kend) {                                                          \
-        va = TA ? (double)Ab[gk * lda + gr] : (double)Ab[gr * lda + gk];                  \
-        if (SYMA) va += TA ? (double)Ab[gr * lda + gk] : (double)Ab[gk * lda + gr];       \
-      }                                                                                   \
-      ra[i] = va;                                                                         \
-      int c, kb;                                                                          \
-      if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }      \
-      const long long gc = n0 + c, gk2 = (K0) + kb;                                       \
-      double vb = 0.0;                                                                    \
-      if (gc < n && gk2 < kend) vb = TB ? (double)Bb[gc * ldb + gk2] : (double)Bb[gk2 * ldb + gc]; \
-      rb[i] = vb;                                                                         \
+  _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                     \
+    const long long gr = m0 + ar, gk = (K0) + ak + 16 * g_;                               \
+    const TIA* pa = TA ? Ab + gk * lda + gr : Ab + gr * lda + gk;                         \
+    const long long lim_a = TA ? ((gk < kend) ? (long long)m - gr : 0)                    \
+                               : ((gr < m) ? kend - gk : 0);                              \
+    load4<TIA, TC>(pa, va_ok, lim_a, ra[g_]);                                             \
+    if (SYMA) {                                                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
+        if (i < lim_a) ra[g_][i] += (TC)(TA ? Ab[(gr + i) * lda + gk] : Ab[(gk + i) * lda + gr]); \
     }                                                                                     \
+    const long long gc = n0 + bc, gk2 = (K0) + bk + 16 * g_;                              \
+    const TIB* pb = TB ? Bb + gc * ldb + gk2 : Bb + gk2 * ldb + gc;                       \
+    const long long lim_b = TB ? ((gc < n) ? kend - gk2 : 0)                              \
+                               : ((gk2 < kend) ? (long long)n - gc : 0);                  \
+    load4<TIB, TC>(pb, vb_ok, lim_b, rb[g_]);                                             \
   }
 #define GPSA_G64_STASH(BUF)                                                               \
-  {                                                                                       \
+  _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                     \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-      const int e = tid + i * 256;                                                        \
-      int r, kk;                                                                          \
-      if (TA) { r = e % GB_M; kk = e / GB_M; } else { r = e / GB_K; kk = e % GB_K; }      \
-      As[BUF][kk][r] = ra[i];                                                             \
-      int c, kb;                                                                          \
-      if (TB) { kb = e % GB_K; c = e / GB_K; } else { c = e % GB_N; kb = e / GB_N; }      \
-      Bs[BUF][kb][c] = rb[i];                                                             \
+      if (TA) As[BUF][ak + 16 * g_][ar + i] = ra[g_][i];                                  \
+      else As[BUF][ak + 16 * g_ + i][ar] = ra[g_][i];                                     \
+      if (TB) Bs[BUF][bk + 16 * g_ + i][bc] = rb[g_][i];                                  \
+      else Bs[BUF][bk + 16 * g_][bc + i] = rb[g_][i];                                     \
     }                                                                                     \
   }
   if (kbeg < kend) {
@@ -191,20 +233,20 @@ gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const TIA* __restr
   }
   __syncthreads();
   int cur = 0;
-  for (long long k0 = kbeg; k0 < kend; k0 += GB_K) {
-    const bool more = k0 + GB_K < kend;
-    if (more) GPSA_G64_FETCH(k0 + GB_K)
+  for (long long k0 = kbeg; k0 < kend; k0 += GK) {
+    const bool more = k0 + GK < kend;
+    if (more) GPSA_G64_FETCH(k0 + GK)
 #pragma unroll
-    for (int ks = 0; ks < GB_K / 4; ++ks) {
+    for (int ks = 0; ks < GK / 4; ++ks) {
       const int kk = ks * 4 + kq;
-      const double a0 = As[cur][kk][wm + j], a1 = As[cur][kk][wm + 16 + j];
-      const double b0 = Bs[cur][kk][wn + j], b1 = Bs[cur][kk][wn + 16 + j];
+      const TC a0 = As[cur][kk][wm + j], a1 = As[cur][kk][wm + 16 + j];
+      const TC b0 = Bs[cur][kk][wn + j], b1 = Bs[cur][kk][wn + 16 + j];
       // MFMA tiles that lie wholly outside the matrix are skipped (wave-uniform): M = 200 costs
       // 3.5 x 3.5 tile units instead of 4 x 4
-      if (lm0 && ln0) acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      if (lm0 && ln1) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      if (lm1 && ln0) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      if (lm1 && ln1) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      if (lm0 && ln0) acc[0][0] = MfmaTile<TC>::mma(a0, b0, acc[0][0]);
+      if (lm0 && ln1) acc[0][1] = MfmaTile<TC>::mma(a0, b1, acc[0][1]);
+      if (lm1 && ln0) acc[1][0] = MfmaTile<TC>::mma(a1, b0, acc[1][0]);
+      if (lm1 && ln1) acc[1][1] = MfmaTile<TC>::mma(a1, b1, acc[1][1]);
     }
     // the other buffer was last read one tile ago, before the previous barrier
     if (more) GPSA_G64_STASH(cur ^ 1)
@@ -213,19 +255,19 @@ gemm_f64_mfma_kernel(int m, int n, long long k, double alpha, const TIA* __restr
   }
 #undef GPSA_G64_FETCH
 #undef GPSA_G64_STASH
-  // C/D layout of the fp64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15
+  // C/D layout: col = lane & 15; row = (lane >> 4) + 4 * reg (fp64) or 4 * (lane >> 4) + reg (fp32)
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm + tm * 16 + kq + 4 * r, col = n0 + wn + tn * 16 + j;
+        const int row = m0 + wm + tm * 16 + MfmaTile<TC>::row(kq, r), col = n0 + wn + tn * 16 + j;
         if (row < m && col < n) {
-          const double y = acc[tm][tn][r];
+          const TC y = acc[tm][tn][r];
           if (splitk == 1) {
             TO* p = C + (long long)b * sC + (long long)row * ldc + col;
-            double v = (beta == 0.0) ? alpha * y : alpha * y + beta * (double)(*p);
+            TC v = (beta == TC(0)) ? alpha * y : alpha * y + beta * (TC)(*p);
             if (row == col) v += diag;
             *p = (TO)v;
           } else {
@@ -272,23 +314,22 @@ int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha,
 #define GPSA_GEMM_CASE(TA, TB)                                                               \
   gemm_kernel<T, TA, TB><<<grid, 256, 0, st>>>(m, n, k, (T)alpha, A, lda, sA, B, ldb, sB,     \
                                                (T)beta, C, ldc, sC, splitk, part)
-#define GPSA_GEMM64_CASE(TA, TB)                                                                    \
-  gemm_f64_mfma_kernel<TA, TB><<<grid, 256, 0, st>>>(m, n, k, alpha, (const double*)A, lda, sA,      \
-                                                     (const double*)B, ldb, sB, beta, (double*)C,    \
-                                                     ldc, sC, splitk, (double*)part)
-  // fp64 products with at least one MFMA tile in each direction run on the matrix cores
-  const bool mfma64 = (sizeof(T) == 8) && m >= 16 && n >= 16 && !gemm_force_vector();
-  if (mfma64) {
-    if (!transA && !transB) GPSA_GEMM64_CASE(false, false);
-    else if (transA && !transB) GPSA_GEMM64_CASE(true, false);
-    else if (!transA && transB) GPSA_GEMM64_CASE(false, true);
-    else GPSA_GEMM64_CASE(true, true);
+#define GPSA_GEMMX_CASE(TA, TB)                                                                     \
+  gemm_mfma_kernel<T, TA, TB><<<grid, 256, 0, st>>>(m, n, k, (T)alpha, A, lda, sA, B, ldb, sB, (T)beta, \
+                                                    C, ldc, sC, splitk, part)
+  // products with at least one MFMA tile in each direction run on the matrix cores
+  const bool mfma = m >= 16 && n >= 16 && !gemm_force_vector();
+  if (mfma) {
+    if (!transA && !transB) GPSA_GEMMX_CASE(false, false);
+    else if (transA && !transB) GPSA_GEMMX_CASE(true, false);
+    else if (!transA && transB) GPSA_GEMMX_CASE(false, true);
+    else GPSA_GEMMX_CASE(true, true);
   } else if (!transA && !transB) GPSA_GEMM_CASE(false, false);
   else if (transA && !transB) GPSA_GEMM_CASE(true, false);
   else if (!transA && transB) GPSA_GEMM_CASE(false, true);
   else GPSA_GEMM_CASE(true, true);
 #undef GPSA_GEMM_CASE
-#undef GPSA_GEMM64_CASE
+#undef GPSA_GEMMX_CASE
   GPSA_LAUNCH_CHECK();
   if (splitk > 1) {
     const long long tot = (long long)m * n * batch;
@@ -337,7 +378,7 @@ int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omeg
   if (M < 1 || batch < 1) return GPSA_EINVAL;
   const long long mm = (long long)M * M;
   dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
-  gpsa::gemm_f64_mfma_kernel<false, true, float, float, double, false><<<grid, 256, 0, as_stream(stream)>>>(
+  gpsa::gemm_mfma_kernel<double, false, true, float, float, double, false><<<grid, 256, 0, as_stream(stream)>>>(
       M, M, M, 1.0, A, M, mm, A, M, mm, 0.0, Omega, M, mm, 1, nullptr, jitter);
   GPSA_LAUNCH_CHECK();
   return 0;
@@ -348,7 +389,7 @@ int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, float* dA,
   if (M < 1 || batch < 1) return GPSA_EINVAL;
   const long long mm = (long long)M * M;
   dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
-  gpsa::gemm_f64_mfma_kernel<false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
+  gpsa::gemm_mfma_kernel<double, false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
       M, M, M, 1.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
   GPSA_LAUNCH_CHECK();
   return 0;

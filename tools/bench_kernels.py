@@ -62,6 +62,19 @@ if "panel" in what:
         g = torch.randn(50, C, device=dev)
         print(f"panel_mm f32 (fp64 P) C={C}: {timeit(lambda: o.panel_mm(P, X), n=20):.1f} us", flush=True)
         print(f"quadform_bwd_alpha C={C}: {timeit(lambda: o.quadform_bwd_alpha(X, Om, g), n=10, warm=2):.1f} us", flush=True)
+if "gemm32" in what:  # the data layer's fp32 products (M = 200, L = 50, C columns)
+    for C in (12500, 100000):
+        al = torch.randn(200, C, device=dev)
+        W = torch.randn(200, C, device=dev)
+        dm = torch.randn(50, C, device=dev)
+        dc = torch.randn(200, 50, device=dev)
+        out = torch.randn(200, C, device=dev)
+        sk = o.pick_splitk(C, 200, 200)
+        print(f"f32 dKuu NT 200x{C}x200 splitk={sk}: {timeit(lambda: o.gemm(W, al, transB=True, alpha=-1.0, splitk=sk), n=20):.1f} us", flush=True)
+        sk2 = o.pick_splitk(C, 200, 50)
+        print(f"f32 ddc NT 200x{C}x50 splitk={sk2}: {timeit(lambda: o.gemm(al, dm, transB=True, splitk=sk2), n=20):.1f} us", flush=True)
+        print(f"f32 meanT TN 50x200x{C}: {timeit(lambda: o.gemm(dc, al, transA=True), n=20):.1f} us", flush=True)
+        print(f"f32 abar += dc dmean NN 200x50x{C}: {timeit(lambda: o.gemm(dc, dm, beta=1.0, out=out), n=20):.1f} us", flush=True)
 if "gemm64w" in what:  # the warp-layer shapes (M = 200, C = columns of one view)
     for C in (1250, 10000):
         A = torch.randn(200, 200, device=dev, dtype=torch.float64)
