@@ -165,20 +165,37 @@ def _solve_K(o, Linv, Kinv, abar):
     return o.panel_mm(Linv, t, transP=True)[0]
 
 
-def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm):
-    """shared backward of the sparse-GP layer: returns dKuu, dKuf, ddc, dOm (alpha's precision)"""
+def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_ext=None):
+    """shared backward of the sparse-GP layer: returns dKuu, dKuf, ddc, dOm (alpha's precision, dKuu
+    possibly fp64).  ``g_ext`` [L+1, C] = g rows followed by the qbar row in ONE buffer (the fused data
+    layer): qbar then rides through the Gram kernel as one more weight row, Q = sum_c qbar_c a_c a_c^T."""
     M, Cn = alpha.shape
     L = Om.shape[0]
     T = alpha.dtype
     zeros = lambda *sh: torch.zeros(*sh, dtype=T, device=alpha.device)
     dmeanT = zeros(L, Cn) if dmeanT is None else dmeanT.to(T).contiguous()
-    g = zeros(L, Cn) if g is None else g.to(T).contiguous()
-    qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
+    if g_ext is not None:
+        g, qbar = g_ext[:L], g_ext[L]
+    else:
+        g = zeros(L, Cn) if g is None else g.to(T).contiguous()
+        qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
     abar = o.quadform_bwd_alpha(alpha, Om, g)
     o.gemm(dcT, dmeanT, beta=1.0, out=abar)
     ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
-    dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
     gamma = _solve_K(o, Linv, Kinv, abar)
+    if g_ext is not None and need_dOm and Cn >= 4 * L * M:
+        # dK_uu = -(gamma + qbar a) a^T without a second C-long product:
+        #   gamma a^T = K^-1 (abar a^T),   abar a^T = dc ddc^T + 2 sum_l Omega_l dOmega_l,   dOmega_l = sum_c g a a^T
+        # i.e. one product with K = L M (fp64, on what the Gram kernel already produced) instead of K = C
+        f64 = torch.float64
+        dOm64 = o.quadform_bwd_omega(alpha, g_ext).to(f64)  # [L+1, M, M]; the caller wants fp64 anyway
+        P = o.gemm(Om.reshape(L * M, M), dOm64[:L].reshape(L * M, M), transA=True, alpha=2.0,
+                   splitk=o.pick_splitk(L * M, M, M))
+        o.gemm(dcT.to(f64), ddc.to(f64), transB=True, beta=1.0, out=P)
+        dKuu = o.gemm(Kinv, P, alpha=-1.0, beta=-1.0, out=dOm64[L])  # -(K^-1 P) - Q, in Q's buffer
+        dKuf = o.col_axpy(gamma, alpha, qbar, 2.0, out=gamma)
+        return dKuu, dKuf, ddc, dOm64[:L]
+    dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
     W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
     dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
     dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
@@ -278,6 +295,58 @@ class SGPLayerFn(torch.autograd.Function):
         )
 
 
+class SGPDataLayerFn(torch.autograd.Function):
+    """The whole data GP of one modality as ONE node: covariance, projection, mean / variance forms and
+    the reparameterised draw F = mean + sqrt(var) eps (SGPLayerFn + DataSampleFn without the autograd
+    edges between them: no fp64 <-> fp32 round trip of q and its gradient, g and qbar in one buffer).
+    fp64 covariance + projection, fp32 MFMA contractions, fp32 backward.  Returns F [C, L] fp32."""
+
+    @staticmethod
+    def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, eps):
+        o = ops()
+        f64, T = torch.float64, torch.float32
+        Zs, Xs, lss, vars_ = _cov_inputs(Z, X, ls_u, var_u, f64)
+        Kuf = o.kmat(kind, Zs, Xs, lss, vars_, 0.0, dtype=f64)
+        alpha, q = _project(o, fac, Kuf, T)
+        del Kuf
+        dcT = dc.detach().to(T).contiguous()
+        Om = Omega.detach()
+        meanT = o.gemm(dcT, alpha, transA=True)
+        v = o.quadform_fwd(alpha, Om)
+        var32 = vars_ if vars_.dtype == T else vars_.float()
+        F, Sigma = o.data_sample_fwd(meanT, v, q, var32, eps)
+        if Zs.dtype != T:
+            Zs, Xs, lss = Zs.float(), Xs.float(), lss.float()
+        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, var32, eps, Sigma)
+        ctx.kind = kind
+        ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
+                    dc.dtype, Omega.dtype)
+        return F
+
+    @staticmethod
+    def backward(ctx, dF):
+        o = ops()
+        alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, var32, eps, Sigma = ctx.saved_tensors
+        zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt = ctx.meta
+        g_ext, dmeanT, dvar_s = o.data_sample_bwd(dF.contiguous(), eps, Sigma, var32)
+        dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, None, None,
+                                               ctx.needs_input_grad[7], g_ext=g_ext)
+        need_x = ctx.needs_input_grad[2]
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, var32, dKuf, need_dX=need_x)
+        dvar = dpar[1:2] + dvar_s  # sigma^2 enters through the covariance and through var = sigma^2 - q + v
+        return (
+            None,
+            dZ.to(zdt) if ctx.needs_input_grad[1] else None,
+            dX.to(xdt) if (need_x and dX is not None) else None,
+            dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None,
+            dvar.to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None,
+            dKuu.to(kdt),
+            ddc.to(ddt),
+            dOm.to(odt) if dOm is not None else None,
+            None, None,
+        )
+
+
 class MeanResidFn(torch.autograd.Function):
     """Linear mean function at the inducing points and the variational residual of one view
     (vgpsa.py:283-289, 296): (Z, slopes, intercept, delta) -> mu_z = scale (Z slopes + intercept)
@@ -346,9 +415,9 @@ class DataSampleFn(torch.autograd.Function):
     def backward(ctx, dF):
         o = ops()
         eps, Sigma, var32 = ctx.saved_tensors
-        g, dmeanT, qbar, dvar = o.data_sample_bwd(dF.contiguous(), eps, Sigma, var32)
+        g_ext, dmeanT, dvar = o.data_sample_bwd(dF.contiguous(), eps, Sigma, var32)
         vdt, vshape, qdt = ctx.vmeta
-        return dmeanT, g, qbar.to(qdt), dvar.to(vdt).reshape(vshape), None
+        return dmeanT, g_ext[:-1], g_ext[-1].to(qdt), dvar.to(vdt).reshape(vshape), None
 
 
 class MatmulFn(torch.autograd.Function):

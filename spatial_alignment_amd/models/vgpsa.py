@@ -408,22 +408,20 @@ class VariationalGPSA(GPSA):
             L = self.n_latent_outputs[m]
             Gf = G.reshape(S_ * N_, D)
             # covariance + whitening in fp64 (gradient-only fp32 backward); mean / variance form in fp32
+            if noise is not None and noise[eps_key] is not None:
+                eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
+            else:
+                eps = torch.randn([S_, N_, L], device=dev).reshape(S_ * N_, L)
             kind = builtin_kind(self.kernel_func_data)
-            if kind is not None:
-                meanT, vq, q = E.SGPLayerFn.apply(
-                    kind, self.Gtilde, Gf, ls_u, var_u, KuuF, self.delta_F_dict[m], cache.Omega_F[m],
-                    facF, f64, torch.float32, torch.float32,
-                )
+            if kind is not None:  # covariance, projection, contractions and the draw as one node
+                Fl = E.SGPDataLayerFn.apply(kind, self.Gtilde, Gf, ls_u, var_u, KuuF, self.delta_F_dict[m],
+                                            cache.Omega_F[m], facF, eps).reshape(S_, N_, L)
             else:
                 Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, f64, False, torch.float32)
                 meanT, vq, q = E.SGPCoreFn.apply(
                     KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF, torch.float32
                 )
-            if noise is not None and noise[eps_key] is not None:
-                eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
-            else:
-                eps = torch.randn([S_, N_, L], device=dev).reshape(S_ * N_, L)
-            Fl = E.DataSampleFn.apply(meanT, vq, q, var_u, eps).reshape(S_, N_, L)
+                Fl = E.DataSampleFn.apply(meanT, vq, q, var_u, eps).reshape(S_, N_, L)
             if self.n_latent_gps[m] is not None:
                 return Fl, E.MatmulFn.apply(Fl, self.W_dict[m])
             return Fl, Fl  # same tensor object when there is no LMC (quirk 10)

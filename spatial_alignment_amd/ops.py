@@ -281,18 +281,19 @@ class HipOps:
         return F, Sigma
 
     def data_sample_bwd(self, dF, eps, Sigma, var_u):
+        """-> g_ext [L+1, C] (rows 0..L-1: g[l,c]; row L: qbar[c] = -sum_l g), dmeanT [L,C], dvar [1].
+        g and qbar share one buffer so that the Gram kernel can take qbar as one more weight row."""
         dF, eps = self._c(dF), self._c(eps)
         L, Cn = Sigma.shape
-        g = torch.empty_like(Sigma)
+        g_ext = torch.empty(L + 1, Cn, dtype=torch.float32, device=Sigma.device)
         dmeanT = torch.empty_like(Sigma)
-        qbar = torch.empty(Cn, dtype=torch.float32, device=Sigma.device)
         dvar = torch.empty(1, dtype=torch.float32, device=Sigma.device)
         ws = self._ws(8 * (Cn // 32 + 2), Sigma)
-        rc = self.lib.gpsa_data_sample_bwd(_p(dF), _p(eps), _p(Sigma), _p(var_u), Cn, L, _p(g),
-                                           _p(dmeanT), _p(qbar), _p(dvar), _p(ws), ws.numel(),
-                                           self._stream(Sigma))
+        rc = self.lib.gpsa_data_sample_bwd(_p(dF), _p(eps), _p(Sigma), _p(var_u), Cn, L, _p(g_ext),
+                                           _p(dmeanT), g_ext.data_ptr() + 4 * L * Cn, _p(dvar), _p(ws),
+                                           ws.numel(), self._stream(Sigma))
         _lib.check(rc, "gpsa_data_sample_bwd")
-        return g, dmeanT, qbar, dvar
+        return g_ext, dmeanT, dvar
 
     @staticmethod
     def _f32(t):

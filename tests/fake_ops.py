@@ -122,7 +122,8 @@ class FakeOps:
 
     def data_sample_bwd(self, dF, eps, Sigma, var_u):
         g = (dF * eps).t() * 0.5 / torch.sqrt(Sigma)
-        return g, dF.t().contiguous(), -g.sum(0), (torch.exp(var_u[0]) * g.sum()).reshape(1)
+        g_ext = torch.cat([g, -g.sum(0, keepdim=True)], 0)
+        return g_ext, dF.t().contiguous(), (torch.exp(var_u[0]) * g.sum()).reshape(1)
 
     def warp_sample_fwd(self, meanT, v, q, var_u, X, slopes, intercept, eps):
         Sigma = torch.exp(var_u.reshape(-1)[0].double()) - q.unsqueeze(0) + v + JIT2  # [D,n]

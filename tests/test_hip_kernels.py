@@ -304,6 +304,7 @@ def test_data_sample(hip, C, L):
     dF = rnd(C, L, seed=4)
     got = hip.data_sample_bwd(dF.to(DEV), eps.to(DEV), Sig, var_u.to(DEV))
     want = FK.data_sample_bwd(dF.double(), eps.double(), rS, var_u.double())
+    assert got[0].shape == (L + 1, C)  # g rows, then the qbar row
     for a, b in zip(got, want):
         close(a, b, 2e-6)
 
