@@ -76,6 +76,7 @@ kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
 }
 
 constexpr int KB_MCHUNK = 32;  // inducing rows per workgroup of the backward kernel
+constexpr int KB_MAXBX = 1024;  // column-block workgroups per row chunk (beyond: each walks several blocks)
 
 // grid (column blocks of 256, row chunks of KB_MCHUNK): one thread per column c, looping over the
 // chunk's inducing rows.  Deterministic partials:
@@ -92,48 +93,54 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
   __shared__ T acc[4][KB_MCHUNK][MAXD];
   __shared__ T red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long c = blockIdx.x * 256LL + threadIdx.x;
-  const bool live = c < C;
   const int m0 = blockIdx.y * KB_MCHUNK;
   const int mc = min(KB_MCHUNK, M - m0);
   const T ell = t_exp<T>((T)ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>((T)var_u[0]);
-  T x[MAXD], dx[MAXD];
-#pragma unroll
-  for (int d = 0; d < MAXD; ++d) {
-    x[d] = (live && d < D) ? (T)X[c * D + d] : T(0);
-    dx[d] = T(0);
-  }
   if (threadIdx.x < KB_MCHUNK * MAXD) {
     const int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
     Zs[r][d] = (r < mc && d < D) ? (T)Z[(long long)(m0 + r) * D + d] : T(0);
   }
+  for (int i = threadIdx.x; i < 4 * KB_MCHUNK * MAXD; i += 256) (&acc[0][0][0])[i] = T(0);
   __syncthreads();
   T s_ls = T(0), s_var = T(0);
-  for (int r = 0; r < mc; ++r) {
-    T k, cd, pl;
-    cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
-    T kb = live ? Kbar[(long long)(m0 + r) * C + c] : T(0);
-    s_ls += kb * pl;
-    s_var += kb * k;
-    T wgt = kb * cd;
+  // a workgroup walks column blocks bx, bx + gridDim.x, ...: the per-row sums of all of them meet in
+  // LDS, so zpart has gridDim.x (<= 128) rows however many columns K has
+  const long long ncb = (C + 255) / 256;
+  for (long long cb = blockIdx.x; cb < ncb; cb += gridDim.x) {
+    const long long c = cb * 256 + threadIdx.x;
+    const bool live = c < C;
+    T x[MAXD], dx[MAXD];
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d)
-      if (d < D) {
-        T t = wgt * (Zs[r][d] - x[d]);  // dLoss/dz_d contribution ; dLoss/dx_d = -t
-        dx[d] -= t;
-        T tz = wave_sum(t);
-        if (lane == 0) acc[w][r][d] = tz;
-      }
+    for (int d = 0; d < MAXD; ++d) {
+      x[d] = (live && d < D) ? (T)X[c * D + d] : T(0);
+      dx[d] = T(0);
+    }
+    for (int r = 0; r < mc; ++r) {
+      T k, cd, pl;
+      cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
+      T kb = live ? Kbar[(long long)(m0 + r) * C + c] : T(0);
+      s_ls += kb * pl;
+      s_var += kb * k;
+      T wgt = kb * cd;
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d)
+        if (d < D) {
+          T t = wgt * (Zs[r][d] - x[d]);  // dLoss/dz_d contribution ; dLoss/dx_d = -t
+          dx[d] -= t;
+          T tz = wave_sum(t);
+          if (lane == 0) acc[w][r][d] += tz;
+        }
+    }
+    if (xpart != nullptr && live) {
+      T* xr = xpart + (long long)blockIdx.y * C * D;
+      for (int d = 0; d < D; ++d) xr[c * D + d] = dx[d];
+    }
   }
   __syncthreads();
   T* zrow = zpart + (long long)blockIdx.x * M * D;
   for (int i = threadIdx.x; i < mc * D; i += 256) {
     const int r = i / D, d = i % D;
     zrow[(long long)(m0 + r) * D + d] = acc[0][r][d] + acc[1][r][d] + acc[2][r][d] + acc[3][r][d];
-  }
-  if (xpart != nullptr && live) {
-    T* xr = xpart + (long long)blockIdx.y * C * D;
-    for (int d = 0; d < D; ++d) xr[c * D + d] = dx[d];
   }
   T* sp = spart + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
   T a = block_sum(s_ls, red);
@@ -145,38 +152,56 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
 // Second pass of the backward: ONE launch sums all three partial arrays in a fixed order
 //   dZ[i] = sum_bx zpart[bx][i]  (+ sum_by xpart[by][i] when Z and X are the same points: K_uu)
 //   dX[i] = sum_by xpart[by][i] ;  dparams[0..1] = sum spart
-// one output element per thread, 4 independent partial sums for the long columns.
+// A block serves consecutive outputs of ONE of the three arrays: 16 outputs x 16 row groups for the tall,
+// narrow zpart (one row per 256 columns of K: 391 rows x 400 outputs at the headline size), 64 outputs x
+// 4 row groups for the short, wide xpart; 4 independent partial sums per thread either way.
 template <typename T, typename TO>
 __global__ void __launch_bounds__(256)
 kmat_bwd_finish_kernel(const T* __restrict__ zpart, long long nbx, long long nz,
                        const T* __restrict__ xpart, long long nby, long long nx,
                        const T* __restrict__ spart, long long ns, int same, TO* __restrict__ dZ,
                        TO* __restrict__ dX, TO* __restrict__ dparams) {
-  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  __shared__ double red[256];
+  const long long zb = (nz + 15) / 16, xb = (nx + 63) / 64;
   const T* part;
-  long long rows, stride, col;
+  long long rows, stride, n, col;
+  int ng, grp, sub;  // row groups, this thread's group, its output within the block
   TO* dst;
-  if (i < nz) { part = zpart; rows = nbx; stride = nz; col = i; dst = dZ + i; }
-  else if (i < nz + nx) { part = xpart; rows = nby; stride = nx; col = i - nz; dst = dX + (i - nz); }
-  else if (i < nz + nx + 2) { part = spart; rows = ns; stride = 2; col = i - nz - nx; dst = dparams + col; }
-  else return;
-  if (part == xpart && (xpart == nullptr || same)) return;  // folded into dZ below / not requested
+  long long blk = blockIdx.x;
+  bool fold = false;
+  if (blk < zb) {
+    ng = 16; grp = threadIdx.x >> 4; sub = threadIdx.x & 15;
+    part = zpart; rows = nbx; stride = nz; n = nz; col = blk * 16 + sub; dst = dZ; fold = same != 0;
+  } else if (blk < zb + xb) {
+    blk -= zb;
+    if (xpart == nullptr || dX == nullptr || same) return;  // not requested / folded into dZ (uniform)
+    ng = 4; grp = threadIdx.x >> 6; sub = threadIdx.x & 63;
+    part = xpart; rows = nby; stride = nx; n = nx; col = blk * 64 + sub; dst = dX;
+  } else {
+    ng = 16; grp = threadIdx.x >> 4; sub = threadIdx.x & 15;
+    part = spart; rows = ns; stride = 2; n = 2; col = sub; dst = dparams;
+  }
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  long long r = 0;
-  for (; r + 3 < rows; r += 4) {
-    a0 += (double)part[r * stride + col];
-    a1 += (double)part[(r + 1) * stride + col];
-    a2 += (double)part[(r + 2) * stride + col];
-    a3 += (double)part[(r + 3) * stride + col];
+  if (col < n) {
+    long long r = grp;
+    for (; r + 3 * ng < rows; r += 4 * ng) {
+      a0 += (double)part[r * stride + col];
+      a1 += (double)part[(r + ng) * stride + col];
+      a2 += (double)part[(r + 2 * ng) * stride + col];
+      a3 += (double)part[(r + 3 * ng) * stride + col];
+    }
+    for (; r < rows; r += ng) a0 += (double)part[r * stride + col];
+    if (fold)  // K_uu: both arguments are the inducing points (nx == nz)
+      for (long long q = grp; q < nby; q += ng) a1 += (double)xpart[q * nx + col];
   }
-  for (; r < rows; ++r) a0 += (double)part[r * stride + col];
-  double tot = (a0 + a1) + (a2 + a3);
-  if (part == zpart && same) {  // K_uu: both arguments are the inducing points
-    double b = 0.0;
-    for (long long q = 0; q < nby; ++q) b += (double)xpart[q * nx + col];
-    tot += b;
+  const int width = 256 / ng;
+  red[grp * width + sub] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && col < n) {
+    double t = 0.0;
+    for (int q = 0; q < ng; ++q) t += red[q * width + sub];
+    dst[col] = (TO)t;
   }
-  *dst = (TO)tot;
 }
 
 template <typename TI, typename T>
@@ -204,7 +229,7 @@ template <typename TI, typename T>
 int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
                     const TI* var_u, const T* Kbar, TI* dZ, TI* dX, TI* dparams, int same, void* ws,
                     long long ws_bytes, hipStream_t st) {
-  const long long nbx = cdiv(C, 256), nby = cdiv(M, KB_MCHUNK);
+  const long long ncb = cdiv(C, 256), nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX, nby = cdiv(M, KB_MCHUNK);
   const long long nz = (long long)M * D, nx = C * D;
   const long long need = (nbx * nz + nby * nx + nbx * nby * 2) * (long long)sizeof(T);
   if (ws_bytes < need) return GPSA_EWORKSPACE;
@@ -229,7 +254,7 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
   GPSA_LAUNCH_CHECK();
   const bool fold = same != 0;
   if (fold && (nx != nz)) return GPSA_EINVAL;
-  kmat_bwd_finish_kernel<T, TI><<<(unsigned)cdiv(nz + nx + 2, 256), 256, 0, st>>>(
+  kmat_bwd_finish_kernel<T, TI><<<(unsigned)(cdiv(nz, 16) + cdiv(nx, 64) + 1), 256, 0, st>>>(
       zpart, nbx, nz, xp, nby, nx, spart, nbx * nby, fold ? 1 : 0, dZ, dX, dparams);
   GPSA_LAUNCH_CHECK();
   return 0;
