@@ -82,6 +82,14 @@ if "gemm64w" in what:  # the warp-layer shapes (M = 200, C = columns of one view
         print(f"gemm f64 NN 200x200x{C}: {timeit(lambda: o.gemm(A, X)):.1f} us", flush=True)
         sk = o.pick_splitk(C, 200, 200)
         print(f"gemm f64 NT 200x{C}x200 splitk={sk}: {timeit(lambda: o.gemm(X, X, transB=True, splitk=sk)):.1f} us", flush=True)
+if "splitk" in what:
+    for dt in (torch.float64, torch.float32):
+        for K in (10000, 100000, 1250):
+            X = torch.randn(200, K, device=dev, dtype=dt)
+            for sk in (4, 8, 16, 32, 64):
+                if K // sk < 64:
+                    continue
+                print(f"{dt} NT 200x{K}x200 splitk={sk}: {timeit(lambda: o.gemm(X, X, transB=True, splitk=sk), n=20):.1f} us", flush=True)
 if "gemm64" in what:
     for B in (4, 50, 57):
         A = torch.randn(B, 200, 200, device=dev, dtype=torch.float64)
