@@ -241,64 +241,10 @@ class SGPCoreFn(torch.autograd.Function):
         )
 
 
-class SGPLayerFn(torch.autograd.Function):
-    """Built-in-covariance version of SGPCoreFn with the K_uf generation fused in: the N-scaled fp64
-    covariance never crosses an autograd edge (no dtype round trips, nothing of size M x C saved
-    besides alpha), and its gradient goes straight from the whitening backward into the covariance
-    backward kernel in ``bwd_dtype``.
-
-    (kind, Z, X, ls_u, var_u ; K_uu, dc, Omega ; factor) -> meanT [L,C], v [L,C], q [C] (white dtype)
-    """
-
-    @staticmethod
-    def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, white_dtype, main_dtype, bwd_dtype):
-        o = ops()
-        Tw, T = white_dtype, main_dtype
-        Zs, Xs, lss, vars_ = _cov_inputs(Z, X, ls_u, var_u, Tw)
-        Kuf = o.kmat(kind, Zs, Xs, lss, vars_, 0.0, dtype=Tw)
-        alpha, q = _project(o, fac, Kuf, T)
-        del Kuf
-        dcT = dc.detach().to(T).contiguous()
-        Om = Omega.detach()  # read as stored (fp64); rounded to T while packed for the matrix cores
-        meanT = o.gemm(dcT, alpha, transA=True)
-        v = o.quadform_fwd(alpha, Om)
-        if bwd_dtype == torch.float32 and Zs.dtype != torch.float32:
-            Zs, Xs, lss, vars_ = (t.float() for t in (Zs, Xs, lss, vars_))
-        ctx.bwd_dtype = bwd_dtype
-        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_)
-        ctx.kind = kind
-        ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
-                    dc.dtype, Omega.dtype)
-        return meanT, v, q
-
-    @staticmethod
-    def backward(ctx, dmeanT, g, qbar):
-        o = ops()
-        alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, varb = ctx.saved_tensors
-        zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt = ctx.meta
-        dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar,
-                                               ctx.needs_input_grad[7])
-        need_x = ctx.needs_input_grad[2]
-        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, varb,
-                                  dKuf if dKuf.dtype == ctx.bwd_dtype else dKuf.to(ctx.bwd_dtype),
-                                  need_dX=need_x)
-        return (
-            None,
-            dZ.to(zdt) if ctx.needs_input_grad[1] else None,
-            dX.to(xdt) if (need_x and dX is not None) else None,
-            dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None,
-            dpar[1].to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None,
-            dKuu.to(kdt),
-            ddc.to(ddt),
-            dOm.to(odt) if dOm is not None else None,
-            None, None, None, None,
-        )
-
-
 class SGPDataLayerFn(torch.autograd.Function):
     """The whole data GP of one modality as ONE node: covariance, projection, mean / variance forms and
-    the reparameterised draw F = mean + sqrt(var) eps (SGPLayerFn + DataSampleFn without the autograd
-    edges between them: no fp64 <-> fp32 round trip of q and its gradient, g and qbar in one buffer).
+    the reparameterised draw F = mean + sqrt(var) eps (SGPCoreFn + DataSampleFn with the covariance fused in
+    and without the autograd edges between them: no fp64 <-> fp32 round trip of q and its gradient, g and qbar in one buffer).
     fp64 covariance + projection, fp32 MFMA contractions, fp32 backward.  Returns F [C, L] fp32."""
 
     @staticmethod
@@ -344,6 +290,62 @@ class SGPDataLayerFn(torch.autograd.Function):
             ddc.to(ddt),
             dOm.to(odt) if dOm is not None else None,
             None, None,
+        )
+
+
+class SGPWarpLayerFn(torch.autograd.Function):
+    """The warp GP of one view as ONE node, all fp64: covariance, projection, mean / variance forms, the
+    view's linear mean function and the reparameterised draws G = mean + var eps (SGPCoreFn + WarpSampleFn
+    with the covariance fused in and without the autograd edges between them).  Returns G_mean [n,D], G_samples [S,n,D]
+    (fp32) and the per-block variance flags."""
+
+    @staticmethod
+    def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, slopes, intercept, eps):
+        o = ops()
+        f64 = torch.float64
+        Zs, Xs, lss, vars_ = _cov_inputs(Z, X, ls_u, var_u, f64)
+        Kuf = o.kmat(kind, Zs, Xs, lss, vars_, 0.0, dtype=f64)
+        alpha, q = _project(o, fac, Kuf, f64)
+        del Kuf
+        dcT = dc.detach().to(f64).contiguous()
+        Om = Omega.detach()
+        meanT = o.gemm(dcT, alpha, transA=True)
+        v = o.quadform_fwd(alpha, Om)
+        sl, ic = slopes.detach(), intercept.detach()
+        Gmean, Gs, bad = o.warp_sample_fwd(meanT, v, q, vars_, Xs, sl, ic, eps)
+        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_, eps)
+        ctx.kind = kind
+        ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
+                    dc.dtype, Omega.dtype, slopes.dtype, intercept.dtype)
+        ctx.mark_non_differentiable(bad)
+        return Gmean, Gs, bad
+
+    @staticmethod
+    def backward(ctx, dGmean, dGs, _dbad):
+        o = ops()
+        alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, varb, eps = ctx.saved_tensors
+        zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt, sdt, idt = ctx.meta
+        if dGs is None:
+            dGs = torch.zeros(eps.shape, dtype=torch.float32, device=eps.device)
+        dmeanT, g, qbar, dvar_s, dslopes, dint = o.warp_sample_bwd(dGmean, dGs.float(), eps, varb, Xb)
+        dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar,
+                                               ctx.needs_input_grad[7])
+        need_x = ctx.needs_input_grad[2]
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, varb, dKuf, need_dX=need_x)
+        dvar = dpar[1:2] + dvar_s.to(dpar.dtype)  # variance enters the covariance and the sampler
+        return (
+            None,
+            dZ.to(zdt) if ctx.needs_input_grad[1] else None,
+            dX.to(xdt) if (need_x and dX is not None) else None,
+            dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None,
+            dvar.to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None,
+            dKuu.to(kdt),
+            ddc.to(ddt),
+            dOm.to(odt) if dOm is not None else None,
+            None,
+            dslopes.to(sdt),
+            dint.to(idt),
+            None,
         )
 
 

@@ -328,12 +328,6 @@ class VariationalGPSA(GPSA):
                 Kuu, fac = cache.warp[v]
                 dc = resid[v]
                 Om = cache.Om_fwd[v]  # quirk 2: forward uses rows v*D+j
-                kind = builtin_kind(self.kernel_func_warp)
-                if kind is not None:  # fused covariance + layer, all fp64
-                    meanT, vq, q = E.SGPLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac, f64, f64, f64)
-                else:
-                    Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
-                    meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
                 if noise is not None and noise["G"] is not None:
                     eps = noise["G"][draw].to(device=dev, dtype=torch.float32)
                 elif dev.type == "cuda":  # one launch; the device generator never reproduces the CPU stream anyway
@@ -341,7 +335,14 @@ class VariationalGPSA(GPSA):
                 else:  # S successive [n, D] draws, as Normal.rsample() in the reference's loop
                     eps = torch.stack([self._draw([n, D], dev) for _ in range(S)]) if S > 0 else \
                         torch.empty(0, n, D, device=dev)
-                Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
+                kind = builtin_kind(self.kernel_func_warp)
+                if kind is not None:  # covariance, projection, contractions and the draws as one fp64 node
+                    Gm, Gs, bad = E.SGPWarpLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac,
+                                                         slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
+                else:
+                    Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
+                    meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
+                    Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)
                 if side is not None:  # consumed on the main stream from here on
                     for t in (Gm, Gs, bad):
                         t.record_stream(main)
