@@ -195,7 +195,13 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
         dKuu = o.gemm(Kinv, P, alpha=-1.0, beta=-1.0, out=dOm64[L])  # -(K^-1 P) - Q, in Q's buffer
         dKuf = o.col_axpy(gamma, alpha, qbar, 2.0, out=gamma)
         return dKuu, dKuf, ddc, dOm64[:L]
-    dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
+    if need_dOm and T == torch.float64 and M <= 256:
+        # fp64 layer (the warp GP): dOmega is a plain gradient (it takes no part in the sigma^2
+        # cancellation that forces fp64 on dK_uu / dK_uf), so it runs on the fp32 MFMA Gram kernel on the
+        # rounded alpha: 3 launches instead of L x (scale + C-long fp64 product + split-K reduce)
+        dOm = o.quadform_bwd_omega(alpha.float(), g.float()).to(T)
+    else:
+        dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
     W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
     dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
     dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
