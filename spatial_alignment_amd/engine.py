@@ -195,10 +195,11 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
         dKuu = o.gemm(Kinv, P, alpha=-1.0, beta=-1.0, out=dOm64[L])  # -(K^-1 P) - Q, in Q's buffer
         dKuf = o.col_axpy(gamma, alpha, qbar, 2.0, out=gamma)
         return dKuu, dKuf, ddc, dOm64[:L]
-    if need_dOm and T == torch.float64 and M <= 256:
+    if need_dOm and T == torch.float64 and M <= 256 and Cn % 4 == 0 and Cn >= 4096:
         # fp64 layer (the warp GP): dOmega is a plain gradient (it takes no part in the sigma^2
         # cancellation that forces fp64 on dK_uu / dK_uf), so it runs on the fp32 MFMA Gram kernel on the
-        # rounded alpha: 3 launches instead of L x (scale + C-long fp64 product + split-K reduce)
+        # rounded alpha: 3 launches instead of L x (scale + C-long fp64 product + split-K reduce).  Only
+        # where it pays: the LDS-DMA staging needs 16-byte aligned rows, and a small C is latency either way
         dOm = o.quadform_bwd_omega(alpha.float(), g.float()).to(T)
     else:
         dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
