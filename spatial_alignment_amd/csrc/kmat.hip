@@ -75,7 +75,13 @@ kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
   }
 }
 
-constexpr int KB_MCHUNK = 32;  // inducing rows per workgroup of the backward kernel
+constexpr int KB_MCHUNK = 32;  // inducing rows per workgroup of the backward kernel ...
+constexpr int KB_MCHUNK_SMALL = 8;  // ... and for problems that would otherwise leave most CUs idle
+static inline int kb_rows(int M, long long C) {
+  // K_uu (200 x 200) or one view's K_uf at a 1/8 shard are 7 - 35 workgroups with 32 rows each: a long
+  // serial exp / reduce chain per thread on a nearly empty chip; 8 rows per workgroup quarter it
+  return (cdiv(C, 256) * cdiv(M, KB_MCHUNK) < 1024) ? KB_MCHUNK_SMALL : KB_MCHUNK;
+}
 constexpr int KB_MAXBX = 1024;  // column-block workgroups per row chunk (beyond: each walks several blocks)
 
 // grid (column blocks of 256, row chunks of KB_MCHUNK): one thread per column c, looping over the
@@ -83,28 +89,28 @@ constexpr int KB_MAXBX = 1024;  // column-block workgroups per row chunk (beyond
 //   zpart[bx][m*D+d]      dZ contribution of column block bx (rows of chunk by only)
 //   xpart[by][c*D+d]      dX contribution of row chunk by
 //   spart[bx*ny+by][0..1] d ls_u, d var_u
-template <typename TI, typename T, int KIND>
+template <typename TI, typename T, int KIND, int MCH>
 __global__ void __launch_bounds__(256)
 kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long long C, int D,
                 const TI* __restrict__ ls_u, const TI* __restrict__ var_u,
                 const T* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
                 T* __restrict__ spart) {
-  __shared__ T Zs[KB_MCHUNK][MAXD];
-  __shared__ T acc[4][KB_MCHUNK][MAXD];
+  __shared__ T Zs[MCH][MAXD];
+  __shared__ T acc[4][MCH][MAXD];
   __shared__ T red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int m0 = blockIdx.y * KB_MCHUNK;
-  const int mc = min(KB_MCHUNK, M - m0);
+  const int m0 = blockIdx.y * MCH;
+  const int mc = min(MCH, M - m0);
   const T ell = t_exp<T>((T)ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>((T)var_u[0]);
-  if (threadIdx.x < KB_MCHUNK * MAXD) {
+  if (threadIdx.x < MCH * MAXD) {
     const int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
     Zs[r][d] = (r < mc && d < D) ? (T)Z[(long long)(m0 + r) * D + d] : T(0);
   }
-  for (int i = threadIdx.x; i < 4 * KB_MCHUNK * MAXD; i += 256) (&acc[0][0][0])[i] = T(0);
+  for (int i = threadIdx.x; i < 4 * MCH * MAXD; i += 256) (&acc[0][0][0])[i] = T(0);
   __syncthreads();
   T s_ls = T(0), s_var = T(0);
   // a workgroup walks column blocks bx, bx + gridDim.x, ...: the per-row sums of all of them meet in
-  // LDS, so zpart has gridDim.x (<= 128) rows however many columns K has
+  // LDS, so zpart has gridDim.x (<= KB_MAXBX) rows however many columns K has
   const long long ncb = (C + 255) / 256;
   for (long long cb = blockIdx.x; cb < ncb; cb += gridDim.x) {
     const long long c = cb * 256 + threadIdx.x;
@@ -229,7 +235,8 @@ template <typename TI, typename T>
 int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
                     const TI* var_u, const T* Kbar, TI* dZ, TI* dX, TI* dparams, int same, void* ws,
                     long long ws_bytes, hipStream_t st) {
-  const long long ncb = cdiv(C, 256), nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX, nby = cdiv(M, KB_MCHUNK);
+  const int mch = kb_rows(M, C);
+  const long long ncb = cdiv(C, 256), nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX, nby = cdiv(M, mch);
   const long long nz = (long long)M * D, nx = C * D;
   const long long need = (nbx * nz + nby * nx + nbx * nby * 2) * (long long)sizeof(T);
   if (ws_bytes < need) return GPSA_EWORKSPACE;
@@ -238,19 +245,21 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
   T* spart = xpart + nby * nx;
   dim3 grid((unsigned)nbx, (unsigned)nby);
   T* xp = (dX || same) ? xpart : nullptr;  // K_uu: the X-side partials are folded into dZ
+#define GPSA_KB_CASE(KIND)                                                                          \
+  if (mch == KB_MCHUNK)                                                                             \
+    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar,  \
+                                                                  zpart, xp, spart);                \
+  else                                                                                              \
+    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK_SMALL><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u,  \
+                                                                        Kbar, zpart, xp, spart);
   switch (kind) {
-    case GPSA_K_RBF:
-      kmat_bwd_kernel<TI, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
-      break;
-    case GPSA_K_MATERN12:
-      kmat_bwd_kernel<TI, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
-      break;
-    case GPSA_K_MATERN32:
-      kmat_bwd_kernel<TI, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar, zpart, xp, spart);
-      break;
+    case GPSA_K_RBF: GPSA_KB_CASE(GPSA_K_RBF) break;
+    case GPSA_K_MATERN12: GPSA_KB_CASE(GPSA_K_MATERN12) break;
+    case GPSA_K_MATERN32: GPSA_KB_CASE(GPSA_K_MATERN32) break;
     default:
       return GPSA_EINVAL;
   }
+#undef GPSA_KB_CASE
   GPSA_LAUNCH_CHECK();
   const bool fold = same != 0;
   if (fold && (nx != nz)) return GPSA_EINVAL;
@@ -281,7 +290,7 @@ int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const voi
 }
 
 long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D) {
-  const long long nbx = cdiv(C, 256), nby = cdiv(M, gpsa::KB_MCHUNK);
+  const long long nbx = cdiv(C, 256), nby = cdiv(M, gpsa::kb_rows(M, C));
   return (nbx * M * D + nby * C * D + nbx * nby * 2) * (dtype == GPSA_F64 ? 8 : 4);
 }
 
