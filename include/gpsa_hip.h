@@ -61,9 +61,11 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
 
 /* ---- variational covariances (vgpsa.py:206-210): Omega[b] = A[b] A[b]^T + jitter I ---------------
  * A [batch,M,M] is the fp32 parameter (Omega_sqt_*), read as stored; Omega [batch,M,M] fp64 (matrix
- * cores).  gpsa_omega_bwd is its adjoint: dA[b] = (G[b] + G[b]^T) A[b] with G = dLoss/dOmega (fp64). */
+ * cores).  gpsa_omega_bwd is its adjoint: dA[b] = (G[b] + G[b]^T) A[b] with G = dLoss/dOmega (fp64);
+ * symmetric != 0 promises G = G^T and computes 2 G A (no strided reads of G^T). */
 int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omega, void* stream);
-int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, float* dA, void* stream);
+int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, int symmetric, float* dA,
+                   void* stream);
 
 /* ---- inducing-point factorisations (fp64, batched, one workgroup per matrix) -----------------
  * gpsa_chol_f64: in-place lower Cholesky of A[b] (upper triangle zeroed); logdet[b] = 2*sum(log diag);

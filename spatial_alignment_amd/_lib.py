@@ -23,7 +23,7 @@ SIGNATURES = {
     "gpsa_gemm": (_i, [_i, _i, _i, _i, _i, _ll, _d, _vp, _ll, _ll, _vp, _ll, _ll, _d, _vp, _ll, _ll,
                        _i, _i, _vp, _ll, _vp]),
     "gpsa_omega_fwd": (_i, [_vp, _i, _i, _d, _vp, _vp]),
-    "gpsa_omega_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "gpsa_omega_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "gpsa_chol_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

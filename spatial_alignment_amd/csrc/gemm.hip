@@ -384,13 +384,21 @@ int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omeg
   return 0;
 }
 
-/* dA[b] = (G[b] + G[b]^T) A[b]  (fp64 G, fp32 A, fp32 dA): adjoint of gpsa_omega_fwd, one launch */
-int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, float* dA, void* stream) {
+/* dA[b] = (G[b] + G[b]^T) A[b]  (fp64 G, fp32 A, fp32 dA): adjoint of gpsa_omega_fwd, one launch.
+ * symmetric != 0: the caller guarantees G = G^T (every gradient this package produces for Omega is:
+ * mirrored Gram sums, differences of inverses of symmetric matrices) and dA = 2 G A skips the strided
+ * reads of G^T. */
+int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, int symmetric, float* dA,
+                   void* stream) {
   if (M < 1 || batch < 1) return GPSA_EINVAL;
   const long long mm = (long long)M * M;
   dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
-  gpsa::gemm_mfma_kernel<double, false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
-      M, M, M, 1.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
+  if (symmetric)
+    gpsa::gemm_mfma_kernel<double, false, false, double, float, float, false><<<grid, 256, 0, as_stream(stream)>>>(
+        M, M, M, 2.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
+  else
+    gpsa::gemm_mfma_kernel<double, false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
+        M, M, M, 1.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

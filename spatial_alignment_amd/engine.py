@@ -127,20 +127,23 @@ class KmatFn(torch.autograd.Function):
 
 
 class OmegaFn(torch.autograd.Function):
-    """Omega = A A^T + 1e-5 I in fp64 (vgpsa.py:206-210).  A [B,M,M] fp32 parameter rows."""
+    """Omega = A A^T + 1e-5 I in fp64 (vgpsa.py:206-210).  A [B,M,M] fp32 parameter rows.
+    ``symmetric_grad``: the caller promises that every gradient that reaches Omega is symmetric (true
+    for all consumers in this package: mirrored Gram sums and differences of inverses of symmetric
+    matrices, symmetric to rounding), so the adjoint (G + G^T) A is evaluated as 2 G A."""
 
     @staticmethod
-    def forward(ctx, A, out=None):
+    def forward(ctx, A, out=None, symmetric_grad=False):
         Ad = A.detach()
         Om = ops().omega_fwd(Ad, JITTER, out=out)  # ``out``: a slice of the step's factorisation batch
         ctx.save_for_backward(Ad)
-        ctx.adt = A.dtype
+        ctx.adt, ctx.sym = A.dtype, bool(symmetric_grad)
         return Om
 
     @staticmethod
     def backward(ctx, dOm):
         (Ad,) = ctx.saved_tensors
-        return ops().omega_bwd(dOm, Ad).to(ctx.adt), None
+        return ops().omega_bwd(dOm, Ad, symmetric=ctx.sym).to(ctx.adt), None, None
 
 
 def _project(o, fac, Kuf, T):

@@ -285,11 +285,11 @@ class VariationalGPSA(GPSA):
         KuuF = self._kmat("data", self.Gtilde, self.Gtilde, self.data_kernel_lengthscale,
                           self.data_kernel_variance, self.diagonal_offset, f64, True,
                           out=slot(1)[0] if slot else None)
-        cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list, slot(nG) if slot else None)
+        cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list, slot(nG) if slot else None, True)
         cache.Om_fwd = cache.Omega_G.split(D, 0)                      # rows v*D+j  (forward, quirk 2)
         cache.Om_kl = cache.Omega_G.view(D, V, M_X, M_X).unbind(1)    # rows j*V+v  (KL, quirk 2)
         for m, sh in zip(mods, sizes_F):
-            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m], slot(sh[0]) if slot else None)
+            cache.Omega_F[m] = E.OmegaFn.apply(self.Omega_sqt_F_dict[m], slot(sh[0]) if slot else None, True)
         mats = [Kuu_w[v].unsqueeze(0) for v in free] + [KuuF.unsqueeze(0), cache.Omega_G] + \
                [cache.Omega_F[m] for m in mods]
         cache.batch = None

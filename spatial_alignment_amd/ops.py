@@ -150,13 +150,13 @@ class HipOps:
         _lib.check(rc, "gpsa_omega_fwd")
         return out
 
-    def omega_bwd(self, G, A):
-        """dA = (G + G^T) A : G [B,M,M] fp64, A [B,M,M] fp32 -> fp32"""
+    def omega_bwd(self, G, A, symmetric=False):
+        """dA = (G + G^T) A : G [B,M,M] fp64, A [B,M,M] fp32 -> fp32; ``symmetric`` promises G = G^T"""
         G = self._c(G if G.dtype == torch.float64 else G.double())
         A = self._f32(A)
         Bn, M = A.shape[0], A.shape[-1]
         dA = torch.empty(Bn, M, M, dtype=torch.float32, device=A.device)
-        rc = self.lib.gpsa_omega_bwd(_p(G), _p(A), M, Bn, _p(dA), self._stream(A))
+        rc = self.lib.gpsa_omega_bwd(_p(G), _p(A), M, Bn, int(bool(symmetric)), _p(dA), self._stream(A))
         _lib.check(rc, "gpsa_omega_bwd")
         return dA
 

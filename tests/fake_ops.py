@@ -73,9 +73,9 @@ class FakeOps:
             return out
         return Om
 
-    def omega_bwd(self, G, A):
+    def omega_bwd(self, G, A, symmetric=False):
         G = G.double()
-        return ((G + G.transpose(-1, -2)) @ A.double()).float()
+        return ((2.0 * G if symmetric else G + G.transpose(-1, -2)) @ A.double()).float()
 
     def chol(self, A):
         L, info = torch.linalg.cholesky_ex(A)

@@ -140,6 +140,8 @@ def test_omega_fwd_bwd(hip, M, B):
     dA = hip.omega_bwd(G.to(DEV), A.to(DEV))
     assert dA.dtype == torch.float32
     close(dA, FK.omega_bwd(G, A), 2e-6)
+    Gs = G + G.transpose(1, 2)
+    close(hip.omega_bwd(Gs.to(DEV), A.to(DEV), symmetric=True), FK.omega_bwd(Gs, A), 2e-6)
 
 
 @pytest.mark.parametrize("M,B", [(1, 2), (5, 3), (50, 4), (200, 6), (233, 2)])
