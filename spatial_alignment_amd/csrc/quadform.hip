@@ -643,10 +643,13 @@ struct GramPlan {
 // acc[NS .. NS+GR_G-1] (never stored).
 constexpr int GR_G = 4;
 
-template <int MB, int NKB, int W, int NS>
+// NL outputs l per workgroup share every staged byte and every fragment read (their row fragments differ
+// only by the g row they are scaled with): the non-MFMA instructions of a chunk are amortised over NL x
+// the MFMAs.
+template <int MB, int NKB, int W, int NS, int NL>
 __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
                                                 const float* __restrict__ gvec, int kq,
-                                                f32x4 (&acc)[NS + GR_G]) {
+                                                f32x4 (&acc)[NL][NS + GR_G]) {
   constexpr GramPlan<MB> P{};
   constexpr int N = P.cnt[W];
   constexpr int NGRP = (((NS + GR_G - 1) / GR_G) + 1) & ~1;
@@ -657,11 +660,15 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
   auto tile_of = [](int s) { return s < N ? s : N - 1; };
   auto new_row = [&](int s) { return s < N && (s == 0 || P.rr[W][s] != P.rr[W][s - 1]); };
   // The raw row fragment is fetched with the group's column fragments, one group ahead; it is scaled by
-  // g when the group is CONSUMED (4 multiplies per row and K block, next to MFMAs that do not depend on
-  // them) - scaling at fetch time would wait out the LDS round trip of a read issued a moment ago.
+  // g when the group is CONSUMED (4 multiplies per row, output and K block, next to MFMAs that do not
+  // depend on them) - scaling at fetch time would wait out the LDS round trip of a read issued a moment ago.
   float4 araw[2][GR_G], fb[2][GR_G];
-  float4 gk = *reinterpret_cast<const float4*>(gvec + kq * 4), gn = gk;
-  float4 arow = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gk[NL], gn[NL], arow[NL];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    gn[q] = gk[q] = *reinterpret_cast<const float4*>(gvec + q * GR_KC + kq * 4);
+    arow[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #define GPSA_GR_FETCH(SLOT, KB, GP)                                                           \
   _Pragma("unroll") for (int u = 0; u < GR_G; ++u) {                                          \
     const int t__ = tile_of(GR_G * (GP) + u);                                                 \
@@ -671,41 +678,44 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
   GPSA_GR_FETCH(0, 0, 0)
 #pragma unroll 1
   for (int kb = 0; kb < NKB; ++kb) {
-    gk = gn;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) gk[q] = gn[q];
 #pragma unroll
     for (int gp = 0; gp < NGRP; ++gp) {
       const int cur = gp & 1, nxt = cur ^ 1;
       if (gp + 1 < NGRP) {
         GPSA_GR_FETCH(nxt, kb, gp + 1)
-      } else if (kb + 1 < NKB) {  // first group of the next K block (and its g)
-        gn = *reinterpret_cast<const float4*>(gvec + (kb + 1) * 16 + kq * 4);
+      } else if (kb + 1 < NKB) {  // first group of the next K block (and its g rows)
+#pragma unroll
+        for (int q = 0; q < NL; ++q)
+          gn[q] = *reinterpret_cast<const float4*>(gvec + q * GR_KC + (kb + 1) * 16 + kq * 4);
         GPSA_GR_FETCH(nxt, kb + 1, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
-      float4 a[GR_G];
+      float4 a[NL][GR_G];
       int sl[GR_G];
 #pragma unroll
       for (int u = 0; u < GR_G; ++u) {
         const int s_ = GR_G * gp + u;
         sl[u] = s_ < N ? s_ : NS + u;
-        if (new_row(s_)) {
-          const float4 r_ = araw[cur][u];
-          arow = make_float4(r_.x * gk.x, r_.y * gk.y, r_.z * gk.z, r_.w * gk.w);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+          if (new_row(s_)) {
+            const float4 r_ = araw[cur][u];
+            arow[q] = make_float4(r_.x * gk[q].x, r_.y * gk[q].y, r_.z * gk[q].z, r_.w * gk[q].w);
+          }
+          a[q][u] = arow[q];
         }
-        a[u] = arow;
       }
-#pragma unroll
-      for (int u = 0; u < GR_G; ++u)
-        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, fb[cur][u].x, acc[sl[u]], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < GR_G; ++u)
-        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, fb[cur][u].y, acc[sl[u]], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < GR_G; ++u)
-        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, fb[cur][u].z, acc[sl[u]], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < GR_G; ++u)
-        acc[sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, fb[cur][u].w, acc[sl[u]], 0, 0, 0);
+#define GPSA_GR_MMA(F)                                                                          \
+  _Pragma("unroll") for (int q = 0; q < NL; ++q)                                                \
+    _Pragma("unroll") for (int u = 0; u < GR_G; ++u)                                            \
+      acc[q][sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][u].F, fb[cur][u].F, acc[q][sl[u]], 0, 0, 0);
+      GPSA_GR_MMA(x)
+      GPSA_GR_MMA(y)
+      GPSA_GR_MMA(z)
+      GPSA_GR_MMA(w)
+#undef GPSA_GR_MMA
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -724,10 +734,10 @@ __device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS + GR_G], f
       P_[(long long)(P.rr[W][s] * 16 + kq * 4 + r) * MP + P.cc[W][s] * 16 + j] = acc[s][r];
 }
 
-template <int MB, bool ALIGNED>
-__global__ void __launch_bounds__(256, (MB >= 13) ? 1 : 2)
+template <int MB, bool ALIGNED, int NL>
+__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2)
 gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C,
-                 int nsplit, float* __restrict__ part) {
+                 int L, int nsplit, float* __restrict__ part) {
   constexpr int MP = MB * 16;
   constexpr GramPlan<MB> PLAN{};
   constexpr int NS = PLAN.max_cnt();
@@ -739,18 +749,20 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   // two slots: the chunk being multiplied and the next one in flight (a chunk is ~12k MFMA cycles per
   // wave, far longer than the DMA latency, so one stage ahead is enough and the chunks can be big)
   __shared__ __attribute__((aligned(16))) float sA[2][NPW * 4 * 256];
-  __shared__ __attribute__((aligned(16))) float sG[2][GR_KC];
+  __shared__ __attribute__((aligned(16))) float sG[2][NL * GR_KC];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int l = blockIdx.x, sp = blockIdx.y;
+  const int l0 = blockIdx.x * NL, sp = blockIdx.y;  // outputs l0 .. l0+NL-1 (clamped: a surplus one is not stored)
   const long long nch = (C + GR_KC - 1) / GR_KC;
   const long long ch0 = (long long)sp * nch / nsplit, ch1 = (long long)(sp + 1) * nch / nsplit;
 
-  f32x4 acc[NS + GR_G];
+  f32x4 acc[NL][NS + GR_G];
 #pragma unroll
-  for (int s = 0; s < NS + GR_G; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NL; ++q)
+#pragma unroll
+    for (int s = 0; s < NS + GR_G; ++s) acc[q][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // staging (LDS-DMA, ALIGNED): rows >= M are clamped to row M-1 and columns >= C to the last aligned
   // group; the clamped rows only feed output rows/cols >= M (never read back) and the clamped columns
@@ -774,9 +786,11 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
         glds16(alpha + (long long)row * C + col,                                             \
                __builtin_amdgcn_readfirstlane(lds_addr(&sA[BUF][slot * 256])));              \
       }                                                                                      \
-      if (lane < GR_KC / 4)                                                                  \
-        glds16(g + (long long)l * Cpad + cb__ + lane * 4,                                    \
+      if (lane < NL * (GR_KC / 4)) {                                                         \
+        const int lq__ = min(l0 + lane / (GR_KC / 4), L - 1);                                \
+        glds16(g + (long long)lq__ * Cpad + cb__ + (lane % (GR_KC / 4)) * 4,                 \
                __builtin_amdgcn_readfirstlane(lds_addr(&sG[BUF][0])));                       \
+      }                                                                                      \
     } else {                                                                                 \
       for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
         const int piece = e >> 8, ln = (e >> 2) & 63, r = e & 3;                             \
@@ -785,7 +799,8 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
         const long long col = cb__ + kb * 16 + (ln >> 4) * 4 + r;                            \
         sA[BUF][e] = (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;           \
       }                                                                                      \
-      if (tid < GR_KC) sG[BUF][tid] = g[(long long)l * Cpad + cb__ + tid];                   \
+      if (tid < NL * GR_KC)                                                                  \
+        sG[BUF][tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * Cpad + cb__ + tid % GR_KC]; \
     }                                                                                        \
   }
 
@@ -798,10 +813,10 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
     if (ch + 1 < ch1) GPSA_GR_STAGE(ch + 1, buf ^ 1)
     const float* img = &sA[buf][lane * 4];
     switch (w) {
-      case 0: gram_wave_chunk<MB, NKB, 0, NS>(img, sG[buf], kq, acc); break;
-      case 1: gram_wave_chunk<MB, NKB, 1, NS>(img, sG[buf], kq, acc); break;
-      case 2: gram_wave_chunk<MB, NKB, 2, NS>(img, sG[buf], kq, acc); break;
-      default: gram_wave_chunk<MB, NKB, 3, NS>(img, sG[buf], kq, acc); break;
+      case 0: gram_wave_chunk<MB, NKB, 0, NS, NL>(img, sG[buf], kq, acc); break;
+      case 1: gram_wave_chunk<MB, NKB, 1, NS, NL>(img, sG[buf], kq, acc); break;
+      case 2: gram_wave_chunk<MB, NKB, 2, NS, NL>(img, sG[buf], kq, acc); break;
+      default: gram_wave_chunk<MB, NKB, 3, NS, NL>(img, sG[buf], kq, acc); break;
     }
     GPSA_DMA_DRAIN();  // chunk ch+1 (issued a whole chunk of MFMAs ago) has landed
     __syncthreads();
@@ -809,12 +824,16 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   }
   GPSA_DMA_DRAIN();
 #undef GPSA_GR_STAGE
-  float* P = part + ((long long)l * nsplit + sp) * MP * MP;
-  switch (w) {
-    case 0: gram_wave_store<MB, 0, NS>(acc, P, j, kq); break;
-    case 1: gram_wave_store<MB, 1, NS>(acc, P, j, kq); break;
-    case 2: gram_wave_store<MB, 2, NS>(acc, P, j, kq); break;
-    default: gram_wave_store<MB, 3, NS>(acc, P, j, kq); break;
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    if (l0 + q >= L) break;
+    float* P = part + ((long long)(l0 + q) * nsplit + sp) * MP * MP;
+    switch (w) {
+      case 0: gram_wave_store<MB, 0, NS>(acc[q], P, j, kq); break;
+      case 1: gram_wave_store<MB, 1, NS>(acc[q], P, j, kq); break;
+      case 2: gram_wave_store<MB, 2, NS>(acc[q], P, j, kq); break;
+      default: gram_wave_store<MB, 3, NS>(acc[q], P, j, kq); break;
+    }
   }
 }
 
@@ -981,20 +1000,36 @@ __global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C,
 
 static inline long long gram_gpad_floats(long long C, int L) { return (long long)L * cdiv(C, GR_KC) * GR_KC; }
 
+// outputs per workgroup: two where the accumulators of both fit (MB <= 13), there are at least two, and
+// the column range is long enough for the saved staging to outweigh the doubled number of partial slabs
+// the reduce kernel adds (2.10 vs 2.28 ms at C = 100k, 0.33 vs 0.32 ms at C = 12.5k; L = 50)
+static inline int gram_nl(int MB, int L, long long C) {
+  static const int forced = [] { const char* e = getenv("GPSA_GRAM_NL"); return e ? atoi(e) : 0; }();
+  const bool can = L >= 2 && MB <= 13;
+  if (forced == 1 || forced == 2) return (forced == 2 && can) ? 2 : 1;
+  return (can && C >= 32768) ? 2 : 1;
+}
+
 static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
                             float* dOmega, float* ws, hipStream_t st) {
-  const int ns = gram_nsplit(C, L);
+  const int nl = gram_nl(MBsel, L, C);
+  const int ns = gram_nsplit(C, (L + nl - 1) / nl);
   const long long Cpad = cdiv(C, GR_KC) * GR_KC;
   float* gpad = ws;
   float* part = ws + ((gram_gpad_floats(C, L) + 63) / 64) * 64;
   pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, gpad);
   GPSA_LAUNCH_CHECK();
-  dim3 grid((unsigned)L, (unsigned)ns);
+  dim3 grid((unsigned)((L + nl - 1) / nl), (unsigned)ns);
   const bool al = (C % 4 == 0) && (C >= 8) && ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0);
-#define GPSA_GRAM_CASE(MBV)                                                                   \
-  case MBV:                                                                                   \
-    if (al) gram_mfma_kernel<MBV, true><<<grid, 256, 0, st>>>(alpha, gpad, M, C, ns, part);   \
-    else gram_mfma_kernel<MBV, false><<<grid, 256, 0, st>>>(alpha, gpad, M, C, ns, part);     \
+#define GPSA_GRAM_CASE(MBV)                                                                        \
+  case MBV:                                                                                        \
+    if (nl == 2 && MBV <= 13) {                                                                    \
+      if (al) gram_mfma_kernel<MBV, true, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part);  \
+      else gram_mfma_kernel<MBV, false, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part);    \
+    } else {                                                                                       \
+      if (al) gram_mfma_kernel<MBV, true, 1><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part); \
+      else gram_mfma_kernel<MBV, false, 1><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part);   \
+    }                                                                                              \
     break;
   switch (MBsel) {
     GPSA_GRAM_CASE(2)
@@ -1014,7 +1049,9 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
 }
 
 static inline long long gram_ws_bytes(int MB, long long C, int L) {
-  return (((gram_gpad_floats(C, L) + 63) / 64) * 64 + (long long)L * gram_nsplit(C, L) * MB * 16 * MB * 16) * 4;
+  const int nl = gram_nl(MB, L, C);
+  return (((gram_gpad_floats(C, L) + 63) / 64) * 64 +
+          (long long)L * gram_nsplit(C, (L + nl - 1) / nl) * MB * 16 * MB * 16) * 4;
 }
 
 // The M x M operands (Omega_l, L^-1) may arrive in either precision: the MFMA paths convert while
