@@ -170,8 +170,8 @@ def _solve_K(o, Linv, Kinv, abar):
 
 def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_ext=None):
     """shared backward of the sparse-GP layer: returns dKuu, dKuf, ddc, dOm (alpha's precision, dKuu
-    possibly fp64).  ``g_ext`` [L+1, C] = g rows followed by the qbar row in ONE buffer (the fused data
-    layer): qbar then rides through the Gram kernel as one more weight row, Q = sum_c qbar_c a_c a_c^T."""
+    possibly fp64).  ``g_ext`` [L+1, C] = g rows followed by the row qbar = -sum_l g in ONE buffer (the
+    fused data layer; its presence vouches for that identity, which the dK_uu shortcut below uses)."""
     M, Cn = alpha.shape
     L = Om.shape[0]
     T = alpha.dtype
@@ -189,15 +189,16 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
     if g_ext is not None and need_dOm and Cn >= 4 * L * M:
         # dK_uu = -(gamma + qbar a) a^T without a second C-long product:
         #   gamma a^T = K^-1 (abar a^T),   abar a^T = dc ddc^T + 2 sum_l Omega_l dOmega_l,   dOmega_l = sum_c g a a^T
+        #   (qbar a) a^T = sum_c qbar_c a_c a_c^T = - sum_l dOmega_l          (qbar = - sum_l g_l, exactly)
         # i.e. one product with K = L M (fp64, on what the Gram kernel already produced) instead of K = C
         f64 = torch.float64
-        dOm64 = o.quadform_bwd_omega(alpha, g_ext).to(f64)  # [L+1, M, M]; the caller wants fp64 anyway
-        P = o.gemm(Om.reshape(L * M, M), dOm64[:L].reshape(L * M, M), transA=True, alpha=2.0,
+        dOm64 = o.quadform_bwd_omega(alpha, g).to(f64)  # [L, M, M]; the caller wants fp64 anyway
+        P = o.gemm(Om.reshape(L * M, M), dOm64.reshape(L * M, M), transA=True, alpha=2.0,
                    splitk=o.pick_splitk(L * M, M, M))
         o.gemm(dcT.to(f64), ddc.to(f64), transB=True, beta=1.0, out=P)
-        dKuu = o.gemm(Kinv, P, alpha=-1.0, beta=-1.0, out=dOm64[L])  # -(K^-1 P) - Q, in Q's buffer
+        dKuu = o.gemm(Kinv, P, alpha=-1.0, beta=1.0, out=dOm64.sum(0))  # -(K^-1 P) + sum_l dOmega_l
         dKuf = o.col_axpy(gamma, alpha, qbar, 2.0, out=gamma)
-        return dKuu, dKuf, ddc, dOm64[:L]
+        return dKuu, dKuf, ddc, dOm64
     if need_dOm and T == torch.float64 and M <= 256 and Cn % 4 == 0 and Cn >= 4096:
         # fp64 layer (the warp GP): dOmega is a plain gradient (it takes no part in the sigma^2
         # cancellation that forces fp64 on dK_uu / dK_uf), so it runs on the fp32 MFMA Gram kernel on the

@@ -282,7 +282,7 @@ class HipOps:
 
     def data_sample_bwd(self, dF, eps, Sigma, var_u):
         """-> g_ext [L+1, C] (rows 0..L-1: g[l,c]; row L: qbar[c] = -sum_l g), dmeanT [L,C], dvar [1].
-        g and qbar share one buffer so that the Gram kernel can take qbar as one more weight row."""
+        (one buffer for both; qbar is exactly minus the column sums of g, which the layer backward uses)"""
         dF, eps = self._c(dF), self._c(eps)
         L, Cn = Sigma.shape
         g_ext = torch.empty(L + 1, Cn, dtype=torch.float32, device=Sigma.device)
