@@ -100,15 +100,17 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
 int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, long long C, int L,
                             void* dOmega, void* workspace, long long workspace_bytes, void* stream);
 
-/* alpha = Kinv Kuf on the fp64 matrix cores, with Kinv [M,M] = K_uu^-1 (fp64, from gpsa_chol_f64 /
- * gpsa_tri_inv_f64) and Kuf [M,C] fp64; alpha [M,C] is stored as alpha_dtype (GPSA_F32 / GPSA_F64);
- * q[c] = sum_m Kuf[m,c] alpha[m,c] (fp64, may be NULL).  These are the K_fu K_uu^-1 factors of the
- * conditional mean and covariance of both GP layers, gpsa/models/vgpsa.py:179-183 and 194-196.
- * M <= 256; GPSA_EUNSUPPORTED above (callers then chain gpsa_panel_mm).  workspace >=
+/* alpha = Kinv Kuf on the fp64 matrix cores, with Kinv [M,M] = K_uu^-1 (fp64, from gpsa_chol_inv_f64 +
+ * L^-T L^-1) and Kuf [M,C] stored as in_dtype (widened on the fly); alpha [M,C] is stored as alpha_dtype
+ * (GPSA_F32 / GPSA_F64); q[c] = sum_m Kuf[m,c] alpha[m,c] (fp64, may be NULL).  These are the
+ * K_fu K_uu^-1 factors of the conditional mean and covariance of both GP layers,
+ * gpsa/models/vgpsa.py:179-183 and 194-196, and - applied to a gradient panel - the K_uu^-1 solve of
+ * their backward.  M <= 256; GPSA_EUNSUPPORTED above (callers then chain gpsa_panel_mm).  workspace >=
  * gpsa_whiten_workspace(M) bytes. */
 long long gpsa_whiten_workspace(int M);
-int gpsa_whiten_f64(const double* Kinv, const double* Kuf, int M, long long C, int alpha_dtype,
-                    void* alpha, double* q, void* workspace, long long workspace_bytes, void* stream);
+int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, long long C,
+                    int alpha_dtype, void* alpha, double* q, void* workspace, long long workspace_bytes,
+                    void* stream);
 
 /* Y = op(P) X with P [M,M] (stored as p_dtype, op = transpose when transP), X [M,C] and Y in dtype
  * (+ optional colsq[c] = sum_m Y[m,c]^2, may be NULL).

@@ -32,7 +32,7 @@ SIGNATURES = {
     "gpsa_quadform_bwd_alpha": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_bwd_omega": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_whiten_workspace": (_ll, [_i]),
-    "gpsa_whiten_f64": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_whiten_f64": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_panel_mm": (_i, [_i, _i, _i, _vp, _vp, _i, _ll, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_col_axpy": (_i, [_i, _vp, _vp, _vp, _d, _i, _ll, _vp, _vp]),
     "gpsa_data_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp]),

@@ -44,9 +44,12 @@ __global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int M
   Apk[idx] = (row < M && k < M) ? Kinv[(long long)row * M + k] : 0.0;
 }
 
-template <int MB, typename TO>
+// TI: storage type of the right-hand side (fp64 covariance in the forward; the fp32 gradient panel in the
+// data layer's backward, widened on the fly: K^-1 in ONE fp64 pass there instead of two fp32
+// triangular passes), TO: storage type of the result.
+template <int MB, typename TI, typename TO>
 __global__ void __launch_bounds__(256, (MB >= 13) ? 1 : 2)
-whiten_mfma_kernel(const double* __restrict__ Apk, const double* __restrict__ X, int M, long long C,
+whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int M, long long C,
                    TO* __restrict__ alpha, double* __restrict__ q) {
   constexpr int CHUNK = 4 * MB * 64;          // doubles per K chunk (2*MB pieces of 1 KiB)
   constexpr int NPIECE = 2 * MB;
@@ -76,7 +79,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const double* __restrict__ X,
 #pragma unroll
   for (int s = 0; s < 4 * MB; ++s) {
     const int row = 4 * s + kq;
-    xb[s] = (okc && row < M) ? X[(long long)row * C + c] : 0.0;
+    xb[s] = (okc && row < M) ? (double)X[(long long)row * C + c] : 0.0;
   }
   f64x4 acc[MB];
 #pragma unroll
@@ -127,13 +130,13 @@ static inline int whiten_mb_for(int M) {
   return 0;
 }
 
-template <typename TO>
-static int whiten_launch(int MB, const double* Apk, const double* X, int M, long long C, TO* alpha,
+template <typename TI, typename TO>
+static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
                          double* q, hipStream_t st) {
   const unsigned grid = (unsigned)cdiv(C, 64);
 #define GPSA_WCASE(V)                                                                     \
   case V:                                                                                 \
-    whiten_mfma_kernel<V, TO><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);              \
+    whiten_mfma_kernel<V, TI, TO><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);          \
     break;
   switch (MB) {
     GPSA_WCASE(2)
@@ -158,11 +161,13 @@ long long gpsa_whiten_workspace(int M) {
   return MB ? (long long)MB * 16 * MB * 16 * 8 : 0;
 }
 
-int gpsa_whiten_f64(const double* Kinv, const double* Kuf, int M, long long C, int alpha_dtype,
-                    void* alpha, double* q, void* workspace, long long workspace_bytes, void* stream) {
+int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, long long C,
+                    int alpha_dtype, void* alpha, double* q, void* workspace, long long workspace_bytes,
+                    void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || Kinv == nullptr || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
   if (alpha_dtype != GPSA_F32 && alpha_dtype != GPSA_F64) return GPSA_EINVAL;
+  if (in_dtype != GPSA_F32 && in_dtype != GPSA_F64) return GPSA_EINVAL;
   const int MB = whiten_mb_for(M);
   if (MB == 0) return GPSA_EUNSUPPORTED;
   if (workspace_bytes < gpsa_whiten_workspace(M)) return GPSA_EWORKSPACE;
@@ -171,8 +176,14 @@ int gpsa_whiten_f64(const double* Kinv, const double* Kuf, int M, long long C, i
   const long long tot = (long long)MB * 4 * MB * 64;
   pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk);
   GPSA_LAUNCH_CHECK();
-  if (alpha_dtype == GPSA_F32) return whiten_launch<float>(MB, Apk, Kuf, M, C, (float*)alpha, q, st);
-  return whiten_launch<double>(MB, Apk, Kuf, M, C, (double*)alpha, q, st);
+  if (in_dtype == GPSA_F64) {
+    if (alpha_dtype == GPSA_F32)
+      return whiten_launch<double, float>(MB, Apk, (const double*)Kuf, M, C, (float*)alpha, q, st);
+    return whiten_launch<double, double>(MB, Apk, (const double*)Kuf, M, C, (double*)alpha, q, st);
+  }
+  if (alpha_dtype == GPSA_F32)
+    return whiten_launch<float, float>(MB, Apk, (const float*)Kuf, M, C, (float*)alpha, q, st);
+  return whiten_launch<float, double>(MB, Apk, (const float*)Kuf, M, C, (double*)alpha, q, st);
 }
 
 }  // extern "C"

@@ -159,11 +159,11 @@ def _project(o, fac, Kuf, T):
 
 
 def _solve_K(o, Linv, Kinv, abar):
-    """gamma = K_uu^-1 abar in abar's precision (same choice of path as _project)"""
-    if abar.dtype == torch.float64:
-        fused = o.whiten(Kinv, abar, torch.float64, want_q=False)
-        if fused is not None:
-            return fused[0]
+    """gamma = K_uu^-1 abar in abar's precision: ONE pass of the fp64-MFMA kernel with the explicit fp64
+    inverse (the panel is widened on the fly, fp32 or fp64), the two triangular passes beyond its size"""
+    fused = o.whiten(Kinv, abar, abar.dtype, want_q=False)
+    if fused is not None:
+        return fused[0]
     t, _ = o.panel_mm(Linv, abar)
     return o.panel_mm(Linv, t, transP=True)[0]
 

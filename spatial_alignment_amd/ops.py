@@ -244,10 +244,11 @@ class HipOps:
         return Y, q
 
     def whiten(self, Kinv, Kuf, out_dtype, want_q=True):
-        """alpha = Kinv @ Kuf (fp64 MFMA) stored as ``out_dtype``, q[c] = Kuf[:,c] . alpha[:,c] (fp64).
-        Returns None when M is beyond the register-resident kernel (callers chain panel_mm)."""
+        """alpha = Kinv @ Kuf (fp64 MFMA; Kuf fp32 or fp64, widened on the fly) stored as ``out_dtype``,
+        q[c] = Kuf[:,c] . alpha[:,c] (fp64).  Returns None when M is beyond the register-resident kernel
+        (callers chain panel_mm)."""
         Kinv, Kuf = self._c(Kinv), self._c(Kuf)
-        assert Kinv.dtype == torch.float64 and Kuf.dtype == torch.float64
+        assert Kinv.dtype == torch.float64
         M, Cn = Kuf.shape
         nbytes = self.lib.gpsa_whiten_workspace(M)
         if nbytes == 0:
@@ -255,8 +256,8 @@ class HipOps:
         alpha = torch.empty(M, Cn, dtype=out_dtype, device=Kuf.device)
         q = torch.empty(Cn, dtype=torch.float64, device=Kuf.device) if want_q else None
         ws = self._ws(nbytes, Kuf)
-        rc = self.lib.gpsa_whiten_f64(_p(Kinv), _p(Kuf), M, Cn, _dt(alpha), _p(alpha), _p(q), _p(ws),
-                                      nbytes, self._stream(Kuf))
+        rc = self.lib.gpsa_whiten_f64(_p(Kinv), _dt(Kuf), _p(Kuf), M, Cn, _dt(alpha), _p(alpha), _p(q),
+                                      _p(ws), nbytes, self._stream(Kuf))
         _lib.check(rc, "gpsa_whiten_f64")
         return alpha, q
 

@@ -104,8 +104,9 @@ class FakeOps:
         return Y, ((Y * Y).sum(0) if want_colsq else None)
 
     def whiten(self, Kinv, Kuf, out_dtype, want_q=True):
-        a = Kinv @ Kuf
-        return a.to(out_dtype), ((Kuf * a).sum(0) if want_q else None)
+        K64 = Kuf.double()
+        a = Kinv @ K64
+        return a.to(out_dtype), ((K64 * a).sum(0) if want_q else None)
 
     def col_axpy(self, Y, X, d, s=1.0, out=None):
         r = Y + s * d.unsqueeze(0) * X

@@ -287,6 +287,11 @@ def test_whiten_f64_mfma(hip, out_dtype, M, C):
     close(q, rq, 1e-13)
     a2, q2 = hip.whiten(Kinv.to(DEV), Kuf.to(DEV), out_dtype, want_q=False)
     assert q2 is None and torch.equal(a2, a)
+    # fp32 right-hand side, widened on the fly (the K^-1 solve of the data layer's backward)
+    a3, q3 = hip.whiten(Kinv.to(DEV), Kuf.float().to(DEV), out_dtype)
+    ra3, rq3 = FK.whiten(Kinv, Kuf.float(), f64)
+    close(a3, ra3, 1e-13 if out_dtype == f64 else 1e-6)
+    close(q3, rq3, 1e-13)
 
 
 def test_whiten_unsupported_size_is_reported(hip):

@@ -62,6 +62,15 @@ if "panel" in what:
         g = torch.randn(50, C, device=dev)
         print(f"panel_mm f32 (fp64 P) C={C}: {timeit(lambda: o.panel_mm(P, X), n=20):.1f} us", flush=True)
         print(f"quadform_bwd_alpha C={C}: {timeit(lambda: o.quadform_bwd_alpha(X, Om, g), n=10, warm=2):.1f} us", flush=True)
+if "solve" in what:  # gamma = K^-1 abar of the data-layer backward: one fp64-MFMA pass vs two fp32 triangular passes
+    for C in (12500, 100000):
+        Kinv = spd(1, 200)[0]
+        Linv = torch.linalg.inv(torch.linalg.cholesky(Kinv.cpu())).to(dev)
+        X = torch.randn(200, C, device=dev)
+        print(f"whiten fp32 in/out C={C}: {timeit(lambda: o.whiten(Kinv, X, torch.float32, want_q=False), n=20):.1f} us", flush=True)
+        print(f"2 x panel_mm C={C}: {timeit(lambda: o.panel_mm(Linv, o.panel_mm(Linv, X)[0], transP=True), n=20):.1f} us", flush=True)
+        X64 = X.double()
+        print(f"whiten fp64 in, fp32 out C={C}: {timeit(lambda: o.whiten(Kinv, X64, torch.float32), n=20):.1f} us", flush=True)
 if "gemm32" in what:  # the data layer's fp32 products (M = 200, L = 50, C columns)
     for C in (12500, 100000):
         al = torch.randn(200, C, device=dev)
