@@ -837,19 +837,23 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   }
 }
 
-// out[l][i][j] = sum_s part[l][s][max(i,j)][min(i,j)]
+// out[l][i][j] = out[l][j][i] = sum_s part[l][s][i][j] for i >= j: the partial slabs hold the lower
+// triangle only, so one thread per lower element (i, j <= i, rounded up to whole rows of the 32-wide
+// column blocks it touches) sums it once - coalesced along j - and writes both mirror positions; the
+// upper-triangle threads of the old one-thread-per-output scheme read the slabs a second time, strided.
 __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit,
                                    float* __restrict__ out) {
-  const long long idx = blockIdx.x * 256LL + threadIdx.x;
-  if (idx >= (long long)L * M * M) return;
-  const int l = (int)(idx / ((long long)M * M));
-  const int rem = (int)(idx % ((long long)M * M));
-  const int i = rem / M, jj = rem % M;
-  const int hi = i > jj ? i : jj, lo = i > jj ? jj : i;
-  const float* p = part + (long long)l * nsplit * MP * MP + (long long)hi * MP + lo;
+  // grid: (ceil(M / 32) column blocks, M rows, L); threads 32 x 8 (8 rows per block in y)
+  const int jj = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int i = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int l = blockIdx.z;
+  if (i >= M || jj > i) return;
+  const float* p = part + (long long)l * nsplit * MP * MP + (long long)i * MP + jj;
   float s = 0.f;
   for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * MP * MP];
-  out[idx] = s;
+  float* o = out + (long long)l * M * M;
+  o[(long long)i * M + jj] = s;
+  if (jj != i) o[(long long)jj * M + i] = s;
 }
 
 static inline int mfma_mb_for(int M) {
@@ -1042,8 +1046,8 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
   }
 #undef GPSA_GRAM_CASE
   GPSA_LAUNCH_CHECK();
-  const long long tot = (long long)L * M * M;
-  gram_reduce_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(part, M, MBsel * 16, L, ns, dOmega);
+  dim3 rgrid((unsigned)cdiv(M, 32), (unsigned)cdiv(M, 8), (unsigned)L);
+  gram_reduce_kernel<<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, dOmega);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
