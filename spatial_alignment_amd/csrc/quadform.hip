@@ -1006,12 +1006,12 @@ static inline long long gram_gpad_floats(long long C, int L) { return (long long
 
 // outputs per workgroup: two where the accumulators of both fit (MB <= 13), there are at least two, and
 // the column range is long enough for the saved staging to outweigh the doubled number of partial slabs
-// the reduce kernel adds (2.10 vs 2.28 ms at C = 100k, 0.33 vs 0.32 ms at C = 12.5k; L = 50)
+// the reduce kernel adds (2.05 vs 2.28 ms at C = 100k, 0.28 vs 0.30 ms at C = 12.5k; L = 50)
 static inline int gram_nl(int MB, int L, long long C) {
   static const int forced = [] { const char* e = getenv("GPSA_GRAM_NL"); return e ? atoi(e) : 0; }();
   const bool can = L >= 2 && MB <= 13;
   if (forced == 1 || forced == 2) return (forced == 2 && can) ? 2 : 1;
-  return (can && C >= 32768) ? 2 : 1;
+  return (can && C >= 8192) ? 2 : 1;
 }
 
 static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
