@@ -208,6 +208,14 @@ int gpsa_mvn_kl_grouped_bwd(const double* mats, const double* inv, const int* om
                             const double* KD, const double* g, int M, int T, int P, double* dOmega,
                             double* dD, double* S, void* stream);
 
+/* ---- ELBO scalar glue (vgpsa.py:540): loss = -(sum_i ll[i]) + kl_scale * sum_t kl[t] ---------------
+ * ll [n_ll], kl [n_kl] fp64 device arrays (the per-modality log-likelihoods and the per-term KLs),
+ * loss [1] fp32; gpsa_elbo_bwd is the adjoint: dll[i] = -gloss, dkl[t] = kl_scale * gloss. */
+int gpsa_elbo_fwd(const double* ll, int n_ll, const double* kl, int n_kl, double kl_scale, float* loss,
+                  void* stream);
+int gpsa_elbo_bwd(const float* gloss, int n_ll, int n_kl, double kl_scale, double* dll, double* dkl,
+                  void* stream);
+
 /* ---- inducing-point initialisation: Lloyd's k-means on the device ----------
  * replaces sklearn.cluster.KMeans at gpsa/models/vgpsa.py:74-76, 90-92.  X [N,D] fp32, centres [K,D].
  * gpsa_kmeans_assign: assign[n] = nearest centre (ties -> lowest index), d2[n] (may be NULL) its

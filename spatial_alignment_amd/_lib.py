@@ -51,6 +51,8 @@ SIGNATURES = {
     "gpsa_mvn_kl_grouped_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_mvn_kl_grouped_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp,
                                      _vp]),
+    "gpsa_elbo_fwd": (_i, [_vp, _i, _vp, _i, _d, _vp, _vp]),
+    "gpsa_elbo_bwd": (_i, [_vp, _i, _i, _d, _vp, _vp, _vp]),
     "gpsa_kmeans_workspace": (_ll, [_ll, _i, _i]),
     "gpsa_kmeans_assign": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _vp]),
     "gpsa_kmeans_update": (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _ll, _vp]),

@@ -368,6 +368,32 @@ static inline int loglik_blocks(long long tot) {
   return (int)b;
 }
 
+// ---- ELBO scalar glue ------------------------------------------------------------------------------
+// loss = -(sum_i ll[i]) + kl_scale * sum_t kl[t]   (vgpsa.py:540), fp64 sums in a fixed order, fp32 result;
+// one launch instead of the sum / neg / mul / add / cast chain, and one for its adjoint.
+__global__ void __launch_bounds__(256)
+elbo_fwd_kernel(const double* __restrict__ ll, int n_ll, const double* __restrict__ kl, int n_kl,
+                double kl_scale, float* __restrict__ loss) {
+  __shared__ double red[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n_kl; i += 256) a += kl[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n_ll; ++i) s += ll[i];
+    loss[0] = (float)(kl_scale * a - s);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+elbo_bwd_kernel(const float* __restrict__ gloss, int n_ll, int n_kl, double kl_scale,
+                double* __restrict__ dll, double* __restrict__ dkl) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double g = (double)gloss[0];
+  if (i < n_ll) dll[i] = -g;
+  if (i < n_kl) dkl[i] = kl_scale * g;
+}
+
 }  // namespace gpsa
 
 extern "C" {
@@ -467,6 +493,23 @@ int gpsa_loglik_bwd(const float* F, const float* Y, const float* noise_u, const 
   double* part = (double*)workspace;
   gpsa::loglik_bwd_kernel<<<nb, 256, 0, st>>>(F, Y, noise_u, gout, S, tot, NP, dF, part);
   gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(part, nb, noise_u, gout, S, dnoise_u);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_elbo_fwd(const double* ll, int n_ll, const double* kl, int n_kl, double kl_scale, float* loss,
+                  void* stream) {
+  if (n_ll < 1 || n_kl < 0) return GPSA_EINVAL;
+  gpsa::elbo_fwd_kernel<<<1, 256, 0, as_stream(stream)>>>(ll, n_ll, kl, n_kl, kl_scale, loss);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_elbo_bwd(const float* gloss, int n_ll, int n_kl, double kl_scale, double* dll, double* dkl,
+                  void* stream) {
+  if (n_ll < 1 || n_kl < 0) return GPSA_EINVAL;
+  const int n = n_ll > n_kl ? n_ll : n_kl;
+  gpsa::elbo_bwd_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(gloss, n_ll, n_kl, kl_scale, dll, dkl);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

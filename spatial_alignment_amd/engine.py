@@ -478,6 +478,31 @@ class LogLikFn(torch.autograd.Function):
         return dF, None, dn.to(ndt).reshape(nshape)
 
 
+class ElboFn(torch.autograd.Function):
+    """loss = -(sum of the modalities' log-likelihoods) + kl_scale * (sum of the KL terms), fp32 scalar
+    (vgpsa.py:540): one launch each way instead of the sum / neg / scale / add / cast chain."""
+
+    @staticmethod
+    def forward(ctx, ll, kl, kl_scale):
+        o = ops()
+        llv, klv = ll.detach().double().reshape(-1), kl.detach().double().reshape(-1)
+        ctx.shapes = (ll.shape, kl.shape, ll.dtype, kl.dtype)
+        ctx.kl_scale = float(kl_scale)
+        return o.elbo_fwd(llv, klv, kl_scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        o = ops()
+        lshape, kshape, ldt, kdt = ctx.shapes
+        n_ll, n_kl = 1, 1
+        for d in lshape:
+            n_ll *= d
+        for d in kshape:
+            n_kl *= d
+        dll, dkl = o.elbo_bwd(gloss.detach(), n_ll, n_kl, ctx.kl_scale)
+        return dll.reshape(lshape).to(ldt), dkl.reshape(kshape).to(kdt), None
+
+
 class KLPlan:
     """Static pairing of the KL terms of a model with the matrices of its factorisation batch
     (priors at batch positions 0..P-1, every variational covariance behind them, in forward's order).

@@ -524,7 +524,7 @@ class VariationalGPSA(GPSA):
             term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()
             kl = term if kl is None else kl + term
         KuuF, facF = cache.data
-        ll = None
+        lls = []
         for i, m in enumerate(self.modality_names):
             if not grouped:
                 term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF,
@@ -532,8 +532,7 @@ class VariationalGPSA(GPSA):
                 kl = term if kl is None else kl + term
             noise_u = self.noise_variance[-self.n_modalities + i]  # quirk 5 (used as a std)
             Y = data_dict[m]["outputs"]
-            t = E.LogLikFn.apply(F_samples[m], Y, noise_u)
-            ll = t if ll is None else ll + t
-        if self.kl_scale != 1.0:
-            kl = kl * self.kl_scale
-        return (-ll + kl).to(self.Xtilde.dtype)
+            lls.append(E.LogLikFn.apply(F_samples[m], Y, noise_u))
+        ll = lls[0] if len(lls) == 1 else torch.stack(lls)
+        # -LL + kl_scale * KL in one launch (kl: the per-term vector of the grouped path, or a scalar)
+        return E.ElboFn.apply(ll, kl, self.kl_scale).to(self.Xtilde.dtype)

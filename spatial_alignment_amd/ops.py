@@ -460,6 +460,25 @@ class HipOps:
         _lib.check(rc, "gpsa_mvn_kl_grouped_bwd")
         return dOm, dD, S
 
+    # ------------------------------------------------------------------ ELBO glue
+    def elbo_fwd(self, ll, kl, kl_scale):
+        """loss [1] fp32 = -sum(ll) + kl_scale * sum(kl);  ll, kl: fp64 vectors"""
+        ll, kl = self._c(ll), self._c(kl)
+        loss = torch.empty(1, dtype=torch.float32, device=ll.device)
+        rc = self.lib.gpsa_elbo_fwd(_p(ll), ll.numel(), _p(kl), kl.numel(), float(kl_scale), _p(loss),
+                                    self._stream(ll))
+        _lib.check(rc, "gpsa_elbo_fwd")
+        return loss
+
+    def elbo_bwd(self, gloss, n_ll, n_kl, kl_scale):
+        gloss = self._f32(gloss.reshape(1))
+        dll = torch.empty(n_ll, dtype=torch.float64, device=gloss.device)
+        dkl = torch.empty(max(n_kl, 1), dtype=torch.float64, device=gloss.device)[:n_kl]
+        rc = self.lib.gpsa_elbo_bwd(_p(gloss), n_ll, n_kl, float(kl_scale), _p(dll), _p(dkl),
+                                    self._stream(gloss))
+        _lib.check(rc, "gpsa_elbo_bwd")
+        return dll, dkl
+
     # ------------------------------------------------------------------ k-means (initialisation)
     def kmeans_assign(self, X, centres, want_d2=False):
         X, centres = self._c(X), self._c(centres)

@@ -167,6 +167,13 @@ class FakeOps:
         ds = ((r * r) / s**3 - 1.0 / s).sum() / S
         return dF.float(), (gout[0] * ds * e).float().reshape(1)
 
+    def elbo_fwd(self, ll, kl, kl_scale):
+        return (kl_scale * kl.double().sum() - ll.double().sum()).float().reshape(1)
+
+    def elbo_bwd(self, gloss, n_ll, n_kl, kl_scale):
+        g = gloss.double().reshape(())
+        return (-g).expand(n_ll).clone(), (kl_scale * g).expand(n_kl).clone()
+
     def mvn_kl_grouped_fwd(self, mats, inv, logdet, plan, D):
         T, M = D.shape
         kl = torch.zeros(T, dtype=torch.float64)
