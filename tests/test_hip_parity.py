@@ -210,6 +210,41 @@ def test_graphed_step_equals_eager_step():
         assert (a - b).norm() <= 1e-5 * max(a.norm().item(), 1e-6), k
 
 
+@pytest.mark.parametrize("name", ["c2_three_free_views", "c5_two_modalities"])
+def test_adam_trajectory_matches_cpu_host_logic(name):
+    """six Adam steps with the same injected noise: the HIP path and the CPU restatement of the ops
+    contract (tests/fake_ops.py, fp64 arithmetic under the same host logic) must walk the same path"""
+    from fake_ops import FakeOps
+    from spatial_alignment_amd import ops as ops_mod
+    from spatial_alignment_amd.train import train_step
+
+    g = Golden(name)
+    traces, finals = [], []
+    for dev in (DEV, "cpu"):
+        if dev == "cpu":
+            ops_mod.set_ops(FakeOps())
+        try:
+            model, dd = build_model(g, device=dev)
+            view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            eps_G = [e.to(dev) for e in g.eps_G]
+            eps_F = {m: e.to(dev) for m, e in g.eps_F.items()}
+            tr = []
+            for _ in range(6):
+                model.inject_noise(eps_G, eps_F)
+                tr.append(float(train_step(model, opt, dd, view_idx, Ns, S=g.S).detach()))
+            traces.append(tr)
+            finals.append({k: v.detach().cpu().double() for k, v in model.state_dict().items()})
+        finally:
+            ops_mod.set_ops(None)
+    for a, b in zip(*traces):
+        assert abs(a - b) <= 2e-5 * abs(b), traces
+    assert traces[0][-1] < traces[0][0]
+    for k in finals[0]:
+        a, b = finals[0][k], finals[1][k]
+        assert (a - b).norm() <= 2e-3 * max(b.norm().item(), 1e-6), k
+
+
 def _custom_m32(x1, x2, lengthscale_unconstrained, output_variance_unconstrained, diag=False):
     import spatial_alignment_amd as gp
 
