@@ -97,4 +97,16 @@ __global__ void reduce_rows_kernel(const TI* __restrict__ part, long long rows, 
   if (grp == 0 && j < n) out[j] = (TO)(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale);
 }
 
+// compute units of the current device (256 on MI355X); cached after the first call
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 }  // namespace gpsa

@@ -875,17 +875,6 @@ static inline bool force_generic() {
   return v == 1;
 }
 
-static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return n;
-}
-
 // Adds, in workgroup order, the partial-tile slabs that panel_mfma_kernel<ACCUM> wrote: tile t is
 // shared by the workgroups whose item ranges [b*T/G, (b+1)*T/G) cut into [t*L, (t+1)*L).
 __global__ void __launch_bounds__(256)

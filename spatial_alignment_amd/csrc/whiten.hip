@@ -47,8 +47,13 @@ __global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int M
 // TI: storage type of the right-hand side (fp64 covariance in the forward; the fp32 gradient panel in the
 // data layer's backward, widened on the fly: K^-1 in ONE fp64 pass there instead of two fp32
 // triangular passes), TO: storage type of the result.
-template <int MB, typename TI, typename TO>
-__global__ void __launch_bounds__(256, (MB >= 13) ? 1 : 2)
+//
+// STREAM: the right-hand side streams through registers one K chunk (16 rows) ahead of the MFMAs that
+// consume it, so the accumulators are the only resident state and two workgroups share a CU (q then
+// closes against a second, cache-warm read of the column); otherwise the whole 16-column slab stays in
+// registers, one workgroup per CU -- the shorter dependency chain when the grid does not fill the chip.
+template <int MB, typename TI, typename TO, bool STREAM>
+__global__ void __launch_bounds__(256, (MB >= (STREAM ? 14 : 13)) ? 1 : 2)
 whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int M, long long C,
                    TO* __restrict__ alpha, double* __restrict__ q) {
   constexpr int CHUNK = 4 * MB * 64;          // doubles per K chunk (2*MB pieces of 1 KiB)
@@ -62,6 +67,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
   const int j = lane & 15, kq = lane >> 4;
   const long long c = blockIdx.x * 64LL + w * 16 + j;
   const bool okc = c < C;
+  const TI* xcol = X + (okc ? c : 0);
 
 #define GPSA_WSTAGE(Q, BUF)                                                                    \
   {                                                                                            \
@@ -73,13 +79,18 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
                      (unsigned)(unsigned long long)(lds_ptr64_t)(&lds[BUF][piece * 128])));    \
     }                                                                                          \
   }
+#define GPSA_WLOADB(DST, KC)                                                                   \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                           \
+    const int row = 16 * (KC) + 4 * ks + kq;                                                   \
+    DST[ks] = (okc && row < M) ? (double)xcol[(long long)row * C] : 0.0;                       \
+  }
   GPSA_WSTAGE(0, 0)
 
-  double xb[4 * MB];
+  double xb[STREAM ? 2 : MB][4];
+  GPSA_WLOADB(xb[0], 0)
+  if constexpr (!STREAM) {
 #pragma unroll
-  for (int s = 0; s < 4 * MB; ++s) {
-    const int row = 4 * s + kq;
-    xb[s] = (okc && row < M) ? (double)X[(long long)row * C + c] : 0.0;
+    for (int kc = 1; kc < MB; ++kc) GPSA_WLOADB(xb[kc], kc)
   }
   f64x4 acc[MB];
 #pragma unroll
@@ -91,11 +102,14 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
     // done with chunk kc-1, whose slot the next stage overwrites
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kc + 1 < MB) GPSA_WSTAGE(kc + 1, (kc + 1) & 1)
+    if (kc + 1 < MB) {
+      GPSA_WSTAGE(kc + 1, (kc + 1) & 1)
+      if constexpr (STREAM) GPSA_WLOADB(xb[(kc + 1) & 1], kc + 1)
+    }
     const double* base = &lds[kc & 1][lane];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const double b = xb[4 * kc + ks];
+      const double b = xb[STREAM ? (kc & 1) : kc][ks];
 #pragma unroll
       for (int rt = 0; rt < MB; ++rt)
         acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[(ks * MB + rt) * 64], b, acc[rt], 0, 0, 0);
@@ -103,16 +117,27 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
   }
 #undef GPSA_WSTAGE
 
+  // the accumulator row of register r is the row the lane held as B operand (4 r + kq within the
+  // tile), so q = k^T alpha closes lane-locally
   double s = 0.0;
 #pragma unroll
-  for (int rt = 0; rt < MB; ++rt)
+  for (int rt = 0; rt < MB; ++rt) {
+    double kb[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (STREAM) {
+      if (q != nullptr) GPSA_WLOADB(kb, rt)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kb[r] = xb[rt][r];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rt * 16 + 4 * r + kq;
       const double y = acc[rt][r];
-      s += y * xb[4 * rt + r];
+      s += y * kb[r];
       if (okc && row < M) alpha[(long long)row * C + c] = (TO)y;
     }
+  }
+#undef GPSA_WLOADB
   if (q != nullptr) {
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
@@ -134,9 +159,13 @@ template <typename TI, typename TO>
 static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
                          double* q, hipStream_t st) {
   const unsigned grid = (unsigned)cdiv(C, 64);
+  const bool stream = q == nullptr || (long long)grid > num_cus();
 #define GPSA_WCASE(V)                                                                     \
   case V:                                                                                 \
-    whiten_mfma_kernel<V, TI, TO><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);          \
+    if (stream)                                                                           \
+      whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);  \
+    else                                                                                  \
+      whiten_mfma_kernel<V, TI, TO, false><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q); \
     break;
   switch (MB) {
     GPSA_WCASE(2)

@@ -274,7 +274,7 @@ def test_quadform_fp64_omega_fp32_alpha(hip, M, C, L):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129)])
+@pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129), (200, 20001), (100, 17000)])
 def test_whiten_f64_mfma(hip, out_dtype, M, C):
     """alpha = Kinv Kuf and q = diag(Kuf^T alpha) on the fp64 matrix cores vs a CPU fp64 product."""
     f64 = torch.float64

@@ -10,6 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
+if os.environ.get("GPSA_AB_LIB"):  # A/B a second build of the library inside one GPU call
+    from spatial_alignment_amd import _lib as _lib_mod  # noqa: E402
+
+    _lib_mod.LIB_PATH = os.path.abspath(os.environ["GPSA_AB_LIB"])
 ge.build()
 from spatial_alignment_amd import ops as ops_mod  # noqa: E402
 
@@ -71,6 +75,8 @@ if "solve" in what:  # gamma = K^-1 abar of the data-layer backward: one fp64-MF
         print(f"2 x panel_mm C={C}: {timeit(lambda: o.panel_mm(Linv, o.panel_mm(Linv, X)[0], transP=True), n=20):.1f} us", flush=True)
         X64 = X.double()
         print(f"whiten fp64 in, fp32 out C={C}: {timeit(lambda: o.whiten(Kinv, X64, torch.float32), n=20):.1f} us", flush=True)
+        Xw = X64[:, : C // 10].contiguous()  # one view's warp-layer panel
+        print(f"whiten fp64 in/out C={C // 10}: {timeit(lambda: o.whiten(Kinv, Xw, torch.float64), n=20):.1f} us", flush=True)
 if "gemm32" in what:  # the data layer's fp32 products (M = 200, L = 50, C columns)
     for C in (12500, 100000):
         al = torch.randn(200, C, device=dev)
