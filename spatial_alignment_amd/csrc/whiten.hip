@@ -79,18 +79,20 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
                      (unsigned)(unsigned long long)(lds_ptr64_t)(&lds[BUF][piece * 128])));    \
     }                                                                                          \
   }
-#define GPSA_WLOADB(DST, KC)                                                                   \
+#define GPSA_WLOADB(DST, KC, T)                                                                \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                           \
     const int row = 16 * (KC) + 4 * ks + kq;                                                   \
-    DST[ks] = (okc && row < M) ? (double)xcol[(long long)row * C] : 0.0;                       \
+    DST[ks] = (okc && row < M) ? (T)xcol[(long long)row * C] : (T)0;                           \
   }
   GPSA_WSTAGE(0, 0)
 
-  double xb[STREAM ? 2 : MB][4];
-  GPSA_WLOADB(xb[0], 0)
-  if constexpr (!STREAM) {
+  double xb[STREAM ? 1 : MB][4];  // resident slab (!STREAM)
+  TI xr[2][4];                    // STREAM: raw values of this chunk and the next
+  if constexpr (STREAM) {
+    GPSA_WLOADB(xr[0], 0, TI)
+  } else {
 #pragma unroll
-    for (int kc = 1; kc < MB; ++kc) GPSA_WLOADB(xb[kc], kc)
+    for (int kc = 0; kc < MB; ++kc) GPSA_WLOADB(xb[kc], kc, double)
   }
   f64x4 acc[MB];
 #pragma unroll
@@ -100,16 +102,25 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
   for (int kc = 0; kc < MB; ++kc) {
     // chunk kc has landed (this wave's share; the barrier publishes everyone's) and every wave is
     // done with chunk kc-1, whose slot the next stage overwrites
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STREAM) {
+      // the wait also hands this chunk's right-hand-side registers to the compiler as ready, so it
+      // neither waits again behind the loads issued below nor widens fp32 values before they land
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(xr[kc & 1][0]), "+v"(xr[kc & 1][1]), "+v"(xr[kc & 1][2]), "+v"(xr[kc & 1][3])
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     if (kc + 1 < MB) {
       GPSA_WSTAGE(kc + 1, (kc + 1) & 1)
-      if constexpr (STREAM) GPSA_WLOADB(xb[(kc + 1) & 1], kc + 1)
+      if constexpr (STREAM) GPSA_WLOADB(xr[(kc + 1) & 1], kc + 1, TI)
     }
     const double* base = &lds[kc & 1][lane];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const double b = xb[STREAM ? (kc & 1) : kc][ks];
+      const double b = STREAM ? (double)xr[kc & 1][ks] : xb[STREAM ? 0 : kc][ks];
 #pragma unroll
       for (int rt = 0; rt < MB; ++rt)
         acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[(ks * MB + rt) * 64], b, acc[rt], 0, 0, 0);
@@ -124,10 +135,10 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
   for (int rt = 0; rt < MB; ++rt) {
     double kb[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (STREAM) {
-      if (q != nullptr) GPSA_WLOADB(kb, rt)
+      if (q != nullptr) GPSA_WLOADB(kb, rt, double)
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) kb[r] = xb[rt][r];
+      for (int r = 0; r < 4; ++r) kb[r] = xb[STREAM ? 0 : rt][r];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -159,7 +170,8 @@ template <typename TI, typename TO>
 static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
                          double* q, hipStream_t st) {
   const unsigned grid = (unsigned)cdiv(C, 64);
-  const bool stream = q == nullptr || (long long)grid > num_cus();
+  bool stream = q == nullptr || (long long)grid > num_cus();
+  if (const char* e = getenv("GPSA_WHITEN_STREAM")) stream = atoi(e) != 0;
 #define GPSA_WCASE(V)                                                                     \
   case V:                                                                                 \
     if (stream)                                                                           \
