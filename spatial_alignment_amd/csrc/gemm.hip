@@ -277,20 +277,39 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
       }
 }
 
+// 64 outputs per block, four waves each summing every fourth partial with four independent accumulators
+// (the partials of one output are L*m*n apart: a single running sum is one load latency per partial)
 template <typename T>
-__global__ void splitk_reduce_kernel(const T* __restrict__ part, int batch, int splitk, int m, int n,
-                                     T alpha, T beta, T* __restrict__ C, long long ldc,
-                                     long long sC) {
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const T* __restrict__ part, int batch, int splitk, int m, int n, T alpha, T beta,
+                     T* __restrict__ C, long long ldc, long long sC) {
+  __shared__ T red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const long long mn = (long long)m * n;
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (idx >= mn * batch) return;
-  const int b = (int)(idx / mn);
-  const long long e = idx % mn;
-  const int r = (int)(e / n), c = (int)(e % n);
-  T s = T(0);
-  for (int sp = 0; sp < splitk; ++sp) s += part[((long long)b * splitk + sp) * mn + e];
-  T* p = C + (long long)b * sC + (long long)r * ldc + c;
-  *p = (beta == T(0)) ? alpha * s : alpha * s + beta * (*p);
+  const long long idx = blockIdx.x * 64LL + lane;
+  const bool ok = idx < mn * batch;
+  const int b = ok ? (int)(idx / mn) : 0;
+  const long long e = ok ? idx % mn : 0;
+  T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+  if (ok) {
+    const T* p = part + (long long)b * splitk * mn + e;
+    int sp = grp;
+    for (; sp + 12 < splitk; sp += 16) {
+      a0 += p[sp * mn];
+      a1 += p[(sp + 4) * mn];
+      a2 += p[(sp + 8) * mn];
+      a3 += p[(sp + 12) * mn];
+    }
+    for (; sp < splitk; sp += 4) a0 += p[sp * mn];
+  }
+  red[grp][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && ok) {
+    const T s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int r = (int)(e / n), c = (int)(e % n);
+    T* q = C + (long long)b * sC + (long long)r * ldc + c;
+    *q = (beta == T(0)) ? alpha * s : alpha * s + beta * (*q);
+  }
 }
 
 static inline bool gemm_force_vector() {
@@ -333,7 +352,7 @@ int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha,
   GPSA_LAUNCH_CHECK();
   if (splitk > 1) {
     const long long tot = (long long)m * n * batch;
-    splitk_reduce_kernel<T><<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(part, batch, splitk, m, n,
+    splitk_reduce_kernel<T><<<(unsigned)cdiv(tot, 64), 256, 0, st>>>(part, batch, splitk, m, n,
                                                                      (T)alpha, (T)beta, C, ldc, sC);
     GPSA_LAUNCH_CHECK();
   }
