@@ -162,13 +162,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
 
 // src [L][M][M] (row-major) -> dst fp32, zero padded, in MFMA-fragment order:
-//   dst[l][kc][rt][kq][j][r] = P_l[16 rt + j][16 kc + 4 kq + r]
+//   dst[l][kc][rt][kq][j][r] = P_l[16 rt + j][16 kc + 4 kq + r]      (PACK_KSTEP: ... + 4 r + kq)
 // so that K chunk kc of matrix l is one contiguous MP*64-byte block made of MB 1-KiB pieces, and
 // piece rt, copied lane-linearly into LDS (global_load_lds, lane = j + 16 kq), is read back as the
 // A fragment of row tile rt by one conflict-free ds_read_b128 at lane*16 bytes.
+// PACK_KSTEP orders the 16 K values of a chunk so that MFMA step r contracts k = 4 r .. 4 r + 3 (instead
+// of r, r+4, r+8, r+12): with M % 16 != 0 the trailing steps of the last chunk are then all padding and
+// the ACCUM / STORE kernels skip them.  (QUAD keeps the interleaved order: there the B slab doubles as
+// the C-layout operand that closes the form in registers.)
+// PACK_SYM_UPPER: the symmetric quadratic form's operand (tiles kc >= rt only, off-diagonal ones doubled);
+// PACK_KSTEP_LAST: K-step order for the last chunk only.
+enum { PACK_SYM_UPPER = 1, PACK_KSTEP = 2, PACK_KSTEP_LAST = 4 };
+
 template <typename TS>
 __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, int L, int transpose,
-                                   float* __restrict__ dst, int sym_lower) {
+                                   float* __restrict__ dst, int layout) {
   const int MP = MB * 16;
   const long long per = (long long)MP * MP;
   const long long idx = blockIdx.x * 256LL + threadIdx.x;
@@ -178,14 +186,16 @@ __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, in
   const int kc = e / (MP * 16);
   const int rem = e % (MP * 16);
   const int rt = rem / 256, lane = (rem % 256) / 4, r = rem % 4;
-  const int i = rt * 16 + (lane & 15), k = kc * 16 + (lane >> 4) * 4 + r;
+  const int i = rt * 16 + (lane & 15);
+  const bool kstep = (layout & PACK_KSTEP) || ((layout & PACK_KSTEP_LAST) && kc == MB - 1);
+  const int k = kc * 16 + (kstep ? r * 4 + (lane >> 4) : (lane >> 4) * 4 + r);
   float v = 0.f;
   if (i < M && k < M) {
     const TS* sp = src + (long long)l * M * M;
     v = (float)(transpose ? sp[(long long)k * M + i] : sp[(long long)i * M + k]);
   }
-  // symmetric quadratic form: only tiles rt >= kc are used; off-diagonal ones count twice
-  if (sym_lower) v = (rt > kc) ? 2.f * v : (rt == kc ? v : 0.f);
+  // symmetric quadratic form: only tiles kc >= rt are used; off-diagonal ones count twice
+  if (layout & PACK_SYM_UPPER) v = (kc > rt) ? 2.f * v : (rt == kc ? v : 0.f);
   dst[idx] = v;
 }
 
@@ -256,7 +266,9 @@ struct TileOrder {
 // X is (re)loaded only when the column tile changes (at most ~T/G/L + 2 times).  In ACCUM mode a column
 // tile whose l-range is split between two workgroups is combined with float atomics into a
 // pre-zeroed output (at most two contributors per element => order-independent result).
-template <int MB, int NCT, int MODE>
+// RL: MFMA steps of the last K chunk that are issued (4, or 2 when M % 16 <= 8 leaves the rest padding;
+// ACCUM / STORE only, see PACK_KSTEP).
+template <int MB, int NCT, int MODE, int RL>
 __global__ void __launch_bounds__(256, (MB * NCT >= 24) ? 1 : 2)
 panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
                   const float* __restrict__ X,    // [M][C]
@@ -363,8 +375,8 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
 #pragma unroll
       for (int t = 0; t < MB; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = t * 16 + kq * 4 + r;
+        for (int r = 0; r < 4; ++r) {  // B operand of MFMA step r (the packed operand's K order)
+          const int row = t * 16 + ((MODE == MODE_QUAD) ? kq * 4 + r : r * 4 + kq);
           xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
     }
@@ -402,10 +414,12 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
           __builtin_amdgcn_sched_barrier(0);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r) {
+            if (kc == MB - 1 && r >= RL) continue;  // all-padding K steps (compile time)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
               acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         GPSA_DMA_WAIT(NPW);
@@ -443,16 +457,19 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
 }
 
 // ------------------------------------------------------------------------------------------------
-// Symmetric quadratic form:  v[l,c] = alpha_c^T Omega_l alpha_c  using only the lower-triangle tiles
-//   v = sum_rt alpha_rt . ( Omega[rt,rt] alpha_rt + 2 sum_{kc<rt} Omega[rt,kc] alpha_kc )
-// (the factor 2 and the zero upper tiles are baked into the packed operand, pack_panels sym_lower).
-// 91 instead of 169 tile products at M = 200.  K chunks are processed in pairs (kc, MB-1-kc) so that
-// every step between two barriers has the same MB+1 row-tile products.  Same register-resident alpha
+// Symmetric quadratic form:  v[l,c] = alpha_c^T Omega_l alpha_c  using only the upper-triangle tiles
+//   v = sum_rt alpha_rt . ( Omega[rt,rt] alpha_rt + 2 sum_{kc>rt} Omega[rt,kc] alpha_kc )
+// (the factor 2 and the zero lower tiles are baked into the packed operand, PACK_SYM_UPPER).
+// 91 instead of 169 tile products at M = 200.  K chunks are processed in pairs (MB-1-p, p) so that
+// every step between two barriers has the same MB+1 row-tile products.  The upper triangle puts the
+// padding of M % 16 != 0 into the K direction of the last chunk's MB products, where whole MFMA steps
+// are skipped (RL of 4 issued, as in panel_mfma_kernel; that chunk is packed in K-step order and
+// contracts against the small slab xk), instead of into the rows of a tile row that cannot be.  Same register-resident alpha
 // slab, LDS-DMA staging, persistent balanced items and in-register closing as panel_mfma_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NCT>
+template <int MB, int NCT, int RL>
 __global__ void __launch_bounds__(256, (MB * NCT >= 24) ? 1 : 2)
-quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_lower-packed
+quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] PACK_SYM_UPPER-packed
                      const float* __restrict__ X, int M, long long C, int L,
                      float* __restrict__ out) {
   constexpr int WGCOLS = 64 * NCT;
@@ -472,9 +489,10 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
   if (it0 >= it1) return;
 
   float xb[NCT][MB][4];
+  float xk[NCT][RL < 4 ? RL : 1];
   f32x4 acc[MB][NCT];
-  // step P of matrix LL: pieces (rt, kc=P) for rt = P..MB-1 go to LDS slots 0..MB-1-P, then pieces
-  // (rt, kc=MB-1-P) for rt = MB-1-P..MB-1 to slots MB-P..MB   (second group absent when 2P == MB-1).
+  // step P of matrix LL: pieces (rt, kc=MB-1-P) for rt = 0..MB-1-P go to LDS slots 0..MB-1-P, then
+  // pieces (rt, kc=P) for rt = 0..P to slots MB-P..MB   (second group absent when 2P == MB-1).
   // Every wave issues exactly NPW operations (surplus slots re-load the step's first piece).
 #define GPSA_QS_STAGE(LL, P, BUF)                                                              \
   {                                                                                            \
@@ -484,8 +502,8 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
     _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
       const int sl = pc * 4 + w;                                                               \
       const int se = sl < n1__ + n2__ ? sl : 0;                                                \
-      const int kc__ = se < n1__ ? p__ : q__;                                                  \
-      const int rt__ = se < n1__ ? p__ + se : q__ + (se - n1__);                               \
+      const int kc__ = se < n1__ ? q__ : p__;                                                  \
+      const int rt__ = se < n1__ ? se : se - n1__;                                             \
       glds16(m__ + (kc__ * MB + rt__) * 256,                                                   \
              __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][sl * 256])));                   \
     }                                                                                          \
@@ -529,6 +547,13 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
           const int row = t * 16 + kq * 4 + r;
           xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
+      if (RL < 4) {
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {  // last chunk, K-step order: MFMA step r contracts rows 4 r .. 4 r + 3
+          const int row = (MB - 1) * 16 + r * 4 + kq;
+          xk[ct][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < MB; ++rt)
@@ -546,17 +571,21 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] sym_low
 #pragma unroll
         for (int sl = 0; sl < MB + 1; ++sl) {
           if (sl < n1 + n2) {
-            const int kc = sl < n1 ? p : q;
-            const int rt = sl < n1 ? p + sl : q + (sl - n1);
+            const int kc = sl < n1 ? q : p;
+            const int rt = sl < n1 ? sl : sl - n1;
             const float4 a4 = a_nxt;
             if (sl + 1 < n1 + n2) a_nxt = *reinterpret_cast<const float4*>(base + (sl + 1) * 256);
             __builtin_amdgcn_sched_barrier(0);
             const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+              if (kc == MB - 1 && r >= RL) continue;  // all-padding K steps (compile time)
 #pragma unroll
-              for (int ct = 0; ct < NCT; ++ct)
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xb[ct][kc][r], acc[rt][ct], 0, 0, 0);
+              for (int ct = 0; ct < NCT; ++ct) {
+                const float b = (RL < 4 && kc == MB - 1) ? xk[ct][r < RL ? r : 0] : xb[ct][kc][r];
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b, acc[rt][ct], 0, 0, 0);
+              }
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -915,8 +944,13 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
     long long grid = (long long)num_cus() * wgs_per_cu;                                         \
     if (MODE == MODE_STORE) grid = T;              /* L == 1: one item per tile */              \
     if (grid > T) grid = T;                                                                     \
-    panel_mfma_kernel<MBV, NCTV, MODE><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, g, M, C, L, out, \
-                                                                       colsq, scale, slab);     \
+    constexpr int RLV = (MODE == MODE_QUAD) ? 4 : 2;                                            \
+    if (RLV == 2 && M - 16 * (MBV - 1) <= 8)                                                    \
+      panel_mfma_kernel<MBV, NCTV, MODE, RLV><<<(unsigned)grid, 256, 0, st>>>(                  \
+          Ppk, X, g, M, C, L, out, colsq, scale, slab);                                         \
+    else                                                                                        \
+      panel_mfma_kernel<MBV, NCTV, MODE, 4><<<(unsigned)grid, 256, 0, st>>>(                    \
+          Ppk, X, g, M, C, L, out, colsq, scale, slab);                                         \
     if (MODE == MODE_ACCUM) {                                                                   \
       dim3 rg((unsigned)ntiles, 8);                                                             \
       panel_slab_reduce_kernel<<<rg, 256, 0, st>>>(slab, M, MBV * 16, 64 * NCTV, C, L, ntiles,  \
@@ -951,7 +985,10 @@ static int quad_sym_launch(int MBsel, const float* Ppk, const float* X, int M, l
     const long long T = cdiv(C, 64 * NCTV) * L;                                                  \
     long long grid = (long long)num_cus() * ((MBV * NCTV >= 24) ? 1 : 2);                        \
     if (grid > T) grid = T;                                                                      \
-    quad_sym_mfma_kernel<MBV, NCTV><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, M, C, L, out);       \
+    if (M - 16 * (MBV - 1) <= 8)                                                                 \
+      quad_sym_mfma_kernel<MBV, NCTV, 2><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, M, C, L, out);  \
+    else                                                                                         \
+      quad_sym_mfma_kernel<MBV, NCTV, 4><<<(unsigned)grid, 256, 0, st>>>(Ppk, X, M, C, L, out);  \
   } break;
   switch (MBsel) {
     GPSA_QS_CASE(2, 4)
@@ -1050,13 +1087,13 @@ static inline long long gram_ws_bytes(int MB, long long C, int L) {
 // The M x M operands (Omega_l, L^-1) may arrive in either precision: the MFMA paths convert while
 // packing, the generic paths take a converted copy from the head of the workspace.
 static int pack_any(int p_dtype, const void* src, int M, int MB, int L, int transpose, float* dst,
-                    hipStream_t st, int sym_lower = 0) {
+                    hipStream_t st, int layout = 0) {
   const long long tot = (long long)L * MB * 16 * MB * 16;
   const unsigned grid = (unsigned)cdiv(tot, 256);
   if (p_dtype == GPSA_F32)
-    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, sym_lower);
+    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, layout);
   else if (p_dtype == GPSA_F64)
-    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, sym_lower);
+    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, layout);
   else
     return GPSA_EINVAL;
   GPSA_LAUNCH_CHECK();
@@ -1126,7 +1163,9 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
       if (workspace_bytes < (long long)L * MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
       static const bool full = [] { const char* e = getenv("GPSA_QUAD_FULL"); return e && e[0] == '1'; }();
-      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, full ? 0 : 1);
+      // (the last chunk goes in K-step order exactly when quad_sym_launch picks the step-skipping kernel)
+      const int sym = PACK_SYM_UPPER | ((M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0);
+      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, full ? 0 : sym);
       if (rc) return rc;
       if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
@@ -1160,7 +1199,7 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
       const long long pk = (long long)L * MB * 16 * MB * 16;
       if (workspace_bytes < (pk + accum_slab_floats(MB)) * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st);
+      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, PACK_KSTEP);
       if (rc) return rc;
       return panel_mfma_launch<MODE_ACCUM>(MB, Ppk, (const float*)alpha, (const float*)g, M, C, L,
                                            (float*)dalpha, nullptr, 2.f, Ppk + pk, st);
@@ -1231,7 +1270,7 @@ int gpsa_panel_mm(int dtype, int p_dtype, int transP, const void* P, const void*
     if (MB && !force_generic()) {
       if (workspace_bytes < (long long)MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      int rc = pack_any(p_dtype, P, M, MB, 1, tp, Ppk, st);
+      int rc = pack_any(p_dtype, P, M, MB, 1, tp, Ppk, st, PACK_KSTEP);
       if (rc) return rc;
       return panel_mfma_launch<MODE_STORE>(MB, Ppk, (const float*)X, nullptr, M, C, 1, (float*)Y,
                                            (float*)colsq, 1.f, nullptr, st);

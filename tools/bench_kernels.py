@@ -66,6 +66,8 @@ if "panel" in what:
         g = torch.randn(50, C, device=dev)
         print(f"panel_mm f32 (fp64 P) C={C}: {timeit(lambda: o.panel_mm(P, X), n=20):.1f} us", flush=True)
         print(f"quadform_bwd_alpha C={C}: {timeit(lambda: o.quadform_bwd_alpha(X, Om, g), n=10, warm=2):.1f} us", flush=True)
+        Os = Om + Om.transpose(1, 2)
+        print(f"quadform_fwd C={C}: {timeit(lambda: o.quadform_fwd(X, Os), n=10, warm=2):.1f} us", flush=True)
 if "solve" in what:  # gamma = K^-1 abar of the data-layer backward: one fp64-MFMA pass vs two fp32 triangular passes
     for C in (12500, 100000):
         Kinv = spd(1, 200)[0]
