@@ -233,11 +233,11 @@ def main():
             except Exception:
                 pmc = None
         kernel_of = {
-            "quadform_fwd": "quad_sym_mfma_kernel (gpsa_quadform_fwd; lower-triangle tiles: executes 0.54x "
-                            "of the nominal 2*C*L*M^2 flops)",
+            "quadform_fwd": "quad_sym_mfma_kernel (gpsa_quadform_fwd; upper-triangle tiles, all-padding K steps "
+                            "skipped: executes 0.54x of the nominal 2*C*L*M^2 flops)",
             "quadform_bwd_alpha": "panel_mfma_kernel<MODE_ACCUM> (gpsa_quadform_bwd_alpha)",
             "quadform_bwd_omega": "gram_mfma_kernel (gpsa_quadform_bwd_omega; lower-triangle tiles: executes "
-                                  "0.54x of the nominal flops)",
+                                  "0.58x of the nominal flops)",
         }
         roof = None
         if ks:
