@@ -96,6 +96,14 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
 int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const void* Omega,
                             const void* g, int M, long long C, int L, void* dalpha, void* workspace,
                             long long workspace_bytes, void* stream);
+/* The same form for a layer with few outputs (the warp GP: L = D <= 3), keeping the products
+ * W[l] = Omega[l] alpha ([L,M,C], dtype) it is made of, so that its backward is one streaming pass
+ *   dalpha[:,c] = 2 * sum_l g[l,c] * W[l][:,c]
+ * instead of L more M x M x C products.  Omega in dtype.  (vgpsa.py:192-196 and its autograd.) */
+int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
+                           void* v, void* W, void* stream);
+int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
+                                 void* dalpha, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]) */
 int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, long long C, int L,
                             void* dOmega, void* workspace, long long workspace_bytes, void* stream);

@@ -68,6 +68,39 @@ coldot_kernel(const T* __restrict__ X, const T* __restrict__ Tm, int M, long lon
   if (qr == 0 && c < C) v[(long long)blockIdx.y * vstride + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+// out[m,c] = 2 sum_l g[l,c] W[l][m,c]
+template <typename T>
+__global__ void col_wsum_kernel(const T* __restrict__ W, const T* __restrict__ g, int M, long long C,
+                                int L, T* __restrict__ out) {
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= C) return;
+  for (int m = blockIdx.y; m < M; m += gridDim.y) {
+    T s = T(0);
+    for (int l = 0; l < L; ++l) s += g[(long long)l * C + c] * W[((long long)l * M + m) * C + c];
+    out[(long long)m * C + c] = T(2) * s;
+  }
+}
+
+template <typename T>
+int quadform_fwd_keep(const T* alpha, const T* Omega, int M, long long C, int L, T* v, T* W,
+                      hipStream_t st) {
+  int rc = gemm_launch<T>(0, 0, M, (int)C, M, 1.0, Omega, M, (long long)M * M, alpha, C, 0, 0.0, W, C,
+                          (long long)M * C, L, 1, nullptr, 0, st);
+  if (rc) return rc;
+  dim3 grid((unsigned)cdiv(C, 64), (unsigned)L);
+  coldot_kernel<T><<<grid, 256, 0, st>>>(alpha, W, M, C, v, C);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int quadform_bwd_alpha_kept(const T* W, const T* g, int M, long long C, int L, T* dalpha, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64));
+  col_wsum_kernel<T><<<grid, 256, 0, st>>>(W, g, M, C, L, dalpha);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 int generic_quadform_fwd(const T* alpha, const T* Omega, int M, long long C, int L, T* v, void* ws,
                          long long ws_bytes, hipStream_t st) {
@@ -1217,6 +1250,32 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
     return generic_quadform_bwd_alpha<double>((const double*)alpha, Om, (const double*)g, M, C, L,
                                               (double*)dalpha, workspace, workspace_bytes, st);
   }
+  return GPSA_EINVAL;
+}
+
+int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
+                           void* v, void* W, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || L < 1 || C > 0x7fffffffLL) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (dtype == GPSA_F32)
+    return quadform_fwd_keep<float>((const float*)alpha, (const float*)Omega, M, C, L, (float*)v,
+                                    (float*)W, st);
+  if (dtype == GPSA_F64)
+    return quadform_fwd_keep<double>((const double*)alpha, (const double*)Omega, M, C, L, (double*)v,
+                                     (double*)W, st);
+  return GPSA_EINVAL;
+}
+
+int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
+                                 void* dalpha, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || L < 1) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (dtype == GPSA_F32)
+    return quadform_bwd_alpha_kept<float>((const float*)W, (const float*)g, M, C, L, (float*)dalpha, st);
+  if (dtype == GPSA_F64)
+    return quadform_bwd_alpha_kept<double>((const double*)W, (const double*)g, M, C, L, (double*)dalpha, st);
   return GPSA_EINVAL;
 }
 

@@ -168,7 +168,7 @@ def _solve_K(o, Linv, Kinv, abar):
     return o.panel_mm(Linv, t, transP=True)[0]
 
 
-def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_ext=None):
+def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_ext=None, W=None):
     """shared backward of the sparse-GP layer: returns dKuu, dKuf, ddc, dOm (alpha's precision, dKuu
     possibly fp64).  ``g_ext`` [L+1, C] = g rows followed by the row qbar = -sum_l g in ONE buffer (the
     fused data layer; its presence vouches for that identity, which the dK_uu shortcut below uses)."""
@@ -182,7 +182,8 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
     else:
         g = zeros(L, Cn) if g is None else g.to(T).contiguous()
         qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
-    abar = o.quadform_bwd_alpha(alpha, Om, g)
+    # W: the products Omega_l alpha kept by the forward (few-output layers): one streaming pass
+    abar = o.quadform_bwd_alpha(alpha, Om, g) if W is None else o.quadform_bwd_alpha_kept(W, g)
     o.gemm(dcT, dmeanT, beta=1.0, out=abar)
     ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
     gamma = _solve_K(o, Linv, Kinv, abar)
@@ -321,10 +322,12 @@ class SGPWarpLayerFn(torch.autograd.Function):
         dcT = dc.detach().to(f64).contiguous()
         Om = Omega.detach()
         meanT = o.gemm(dcT, alpha, transA=True)
-        v = o.quadform_fwd(alpha, Om)
+        # D <= 3 outputs: keep W_j = Omega_j alpha (D x M x n fp64) for the backward instead of
+        # recomputing D products there
+        v, W = o.quadform_fwd_keep(alpha, Om)
         sl, ic = slopes.detach(), intercept.detach()
         Gmean, Gs, bad = o.warp_sample_fwd(meanT, v, q, vars_, Xs, sl, ic, eps)
-        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_, eps)
+        ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_, eps, W)
         ctx.kind = kind
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
                     dc.dtype, Omega.dtype, slopes.dtype, intercept.dtype)
@@ -334,13 +337,13 @@ class SGPWarpLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dGmean, dGs, _dbad):
         o = ops()
-        alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, varb, eps = ctx.saved_tensors
+        alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, varb, eps, W = ctx.saved_tensors
         zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt, sdt, idt = ctx.meta
         if dGs is None:
             dGs = torch.zeros(eps.shape, dtype=torch.float32, device=eps.device)
         dmeanT, g, qbar, dvar_s, dslopes, dint = o.warp_sample_bwd(dGmean, dGs.float(), eps, varb, Xb)
         dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar,
-                                               ctx.needs_input_grad[7])
+                                               ctx.needs_input_grad[7], W=W)
         need_x = ctx.needs_input_grad[2]
         dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, varb, dKuf, need_dX=need_x)
         dvar = dpar[1:2] + dvar_s.to(dpar.dtype)  # variance enters the covariance and the sampler

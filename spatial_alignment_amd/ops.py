@@ -220,6 +220,26 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_bwd_alpha")
         return out
 
+    def quadform_fwd_keep(self, alpha, Omega):
+        """(v, W): the form and the products W[l] = Omega[l] alpha it is made of (few-output layers)"""
+        alpha, Omega = self._c(alpha), self._c(Omega.to(alpha.dtype))
+        M, Cn = alpha.shape
+        L = Omega.shape[0]
+        v = torch.empty(L, Cn, dtype=alpha.dtype, device=alpha.device)
+        W = torch.empty(L, M, Cn, dtype=alpha.dtype, device=alpha.device)
+        rc = self.lib.gpsa_quadform_fwd_keep(_dt(alpha), _p(alpha), _p(Omega), M, Cn, L, _p(v), _p(W),
+                                             self._stream(alpha))
+        _lib.check(rc, "gpsa_quadform_fwd_keep")
+        return v, W
+
+    def quadform_bwd_alpha_kept(self, W, g):
+        W, g = self._c(W), self._c(g)
+        L, M, Cn = W.shape
+        out = torch.empty(M, Cn, dtype=W.dtype, device=W.device)
+        rc = self.lib.gpsa_quadform_bwd_alpha_kept(_dt(W), _p(W), _p(g), M, Cn, L, _p(out), self._stream(W))
+        _lib.check(rc, "gpsa_quadform_bwd_alpha_kept")
+        return out
+
     def quadform_bwd_omega(self, alpha, g):
         alpha, g = self._c(alpha), self._c(g)
         M, Cn = alpha.shape

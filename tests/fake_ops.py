@@ -96,6 +96,13 @@ class FakeOps:
     def quadform_bwd_alpha(self, alpha, Omega, g):
         return 2.0 * torch.einsum("lc,lmk,kc->mc", g, Omega.to(alpha.dtype), alpha)
 
+    def quadform_fwd_keep(self, alpha, Omega):
+        W = torch.einsum("lmk,kc->lmc", Omega.to(alpha.dtype), alpha)
+        return torch.einsum("mc,lmc->lc", alpha, W), W
+
+    def quadform_bwd_alpha_kept(self, W, g):
+        return 2.0 * torch.einsum("lc,lmc->mc", g, W)
+
     def quadform_bwd_omega(self, alpha, g):
         return torch.einsum("lc,mc,kc->lmk", g, alpha, alpha)
 

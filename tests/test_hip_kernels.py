@@ -221,6 +221,23 @@ def test_quadform(hip, dtype, M, C, L):
     close(hip.quadform_bwd_omega(al.to(DEV), g.to(DEV)), FK.quadform_bwd_omega(al.double(), g.double()), t)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("M,C,L", [(12, 50, 1), (200, 1250, 2), (65, 777, 3)])
+def test_quadform_kept_products(hip, dtype, M, C, L):
+    """few-output form that keeps W_l = Omega_l alpha, and the backward made of the kept products"""
+    al = rnd(M, C, dtype=dtype)
+    A = rnd(L, M, M, dtype=torch.float64, seed=1, scale=0.3)
+    Om = (A @ A.transpose(1, 2)).to(dtype)
+    g = rnd(L, C, dtype=dtype, seed=2)
+    t = 3e-5 if dtype == torch.float32 else 1e-11
+    v, W = hip.quadform_fwd_keep(al.to(DEV), Om.to(DEV))
+    rv, rW = FK.quadform_fwd_keep(al.double(), Om.double())
+    assert W.shape == (L, M, C) and W.dtype == dtype
+    close(v, rv, t)
+    close(W, rW, t)
+    close(hip.quadform_bwd_alpha_kept(W, g.to(DEV)), FK.quadform_bwd_alpha(al.double(), Om.double(), g.double()), t)
+
+
 def test_quadform_mfma_matches_generic_large(hip):
     """MFMA path vs the generic tiled path (same inputs, both on the GPU) at a headline-like shape."""
     M, C, L = 200, 20000, 6
