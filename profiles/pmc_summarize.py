@@ -9,6 +9,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -34,9 +35,10 @@ def main():
         wb = 1024.0 * sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
         out["kernels"][k[:120]] = {"launches": len(fetch[k]), "fetch_bytes": fb, "write_bytes": wb}
         bl = out.setdefault("hbm_bytes_per_launch", {})
-        if "quad_sym_mfma_kernel" in k or ("panel_mfma_kernel" in k and ", 0>" in k):
+        pm = re.search(r"panel_mfma_kernel<\d+, \d+, (\d+)", k)  # third argument: 0 QUAD, 1 ACCUM, 2 STORE
+        if "quad_sym_mfma_kernel" in k or (pm and pm.group(1) == "0"):
             bl["quadform_fwd"] = fb + wb
-        elif "panel_mfma_kernel" in k and ", 1>" in k:
+        elif pm and pm.group(1) == "1":
             bl["quadform_bwd_alpha"] = fb + wb
         elif "gram_mfma_kernel" in k:
             bl["quadform_bwd_omega"] = fb + wb

@@ -950,18 +950,29 @@ panel_slab_reduce_kernel(const float* __restrict__ slab, int M, int MP, int wgco
   long long b1 = b0;
   while (b1 + 1 < G && ((b1 + 1) * T / G) < hi) ++b1;
   if (b0 == b1) return;  // a single workgroup owned the whole tile: it stored straight to `out`
+  // slab offsets of the contributors, worked out once per block (not per element: 64-bit divisions)
+  __shared__ long long soff[512];
+  __shared__ int scount;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (long long b = b0; b <= b1 && n < 512; ++b) {
+      const long long i0 = b * T / G, i1 = (b + 1) * T / G;
+      if (i1 <= i0) continue;
+      const int which = ((i0 / L) == t) ? 0 : 1;  // the tile is this workgroup's first tile, else its last
+      soff[n++] = (b * 2 + which) * (long long)MP * wgcols;
+    }
+    scount = n;
+  }
+  __syncthreads();
+  const int n = scount;
   const long long cbase = t * wgcols;
   for (int e = threadIdx.x + blockIdx.y * 256; e < M * wgcols; e += 256 * gridDim.y) {
     const int row = e / wgcols, cl = e % wgcols;
     const long long c = cbase + cl;
     if (c >= C) continue;
+    const float* p = slab + (long long)row * wgcols + cl;
     float s = 0.f;
-    for (long long b = b0; b <= b1; ++b) {
-      const long long i0 = b * T / G, i1 = (b + 1) * T / G;
-      if (i1 <= i0) continue;
-      const int which = ((i0 / L) == t) ? 0 : 1;  // the tile is this workgroup's first tile, else its last
-      s += slab[((b * 2 + which) * MP + row) * (long long)wgcols + cl];
-    }
+    for (int k = 0; k < n; ++k) s += p[soff[k]];  // workgroup order: bitwise reproducible
     out[(long long)row * C + c] = s;
   }
 }
