@@ -125,6 +125,7 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
   const int i = (int)(e / M), j = (int)(e % M);
   const double kin = inv[(long long)p * mm + e];
   double s = 0.0, gs = 0.0;
+#pragma unroll 4
   for (int q = t0; q < t1; ++q) {
     const int t = order[q], o = om_idx[t];
     const double gt = g[t];

@@ -61,8 +61,18 @@ coldot_kernel(const T* __restrict__ X, const T* __restrict__ Tm, int M, long lon
   const long long c = blockIdx.x * 64LL + lane;
   const T* t = Tm + (long long)blockIdx.y * M * C;
   T s = T(0);
-  if (c < C)
-    for (int m = qr; m < M; m += 4) s += X[(long long)m * C + c] * t[(long long)m * C + c];
+  if (c < C) {  // four independent partial sums: the loads of one row do not wait for the previous row
+    T s1 = T(0), s2 = T(0), s3 = T(0);
+    int m = qr;
+    for (; m + 12 < M; m += 16) {
+      s += X[(long long)m * C + c] * t[(long long)m * C + c];
+      s1 += X[(long long)(m + 4) * C + c] * t[(long long)(m + 4) * C + c];
+      s2 += X[(long long)(m + 8) * C + c] * t[(long long)(m + 8) * C + c];
+      s3 += X[(long long)(m + 12) * C + c] * t[(long long)(m + 12) * C + c];
+    }
+    for (; m < M; m += 4) s += X[(long long)m * C + c] * t[(long long)m * C + c];
+    s = (s + s1) + (s2 + s3);
+  }
   red[qr][lane] = s;
   __syncthreads();
   if (qr == 0 && c < C) v[(long long)blockIdx.y * vstride + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
