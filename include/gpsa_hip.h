@@ -104,9 +104,11 @@ int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int 
                            void* v, void* W, void* stream);
 int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
                                  void* dalpha, void* stream);
-/* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]) */
-int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, long long C, int L,
-                            void* dOmega, void* workspace, long long workspace_bytes, void* stream);
+/* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
+ * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
+ * GPSA_EUNSUPPORTED otherwise, and the caller converts) */
+int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const void* g, int M, long long C,
+                            int L, void* dOmega, void* workspace, long long workspace_bytes, void* stream);
 
 /* alpha = Kinv Kuf on the fp64 matrix cores, with Kinv [M,M] = K_uu^-1 (fp64, from gpsa_chol_inv_f64 +
  * L^-T L^-1) and Kuf [M,C] stored as in_dtype (widened on the fly); alpha [M,C] is stored as alpha_dtype

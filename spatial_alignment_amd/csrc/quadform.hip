@@ -913,17 +913,18 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
 // triangle only, so one thread per lower element (i, j <= i, rounded up to whole rows of the 32-wide
 // column blocks it touches) sums it once - coalesced along j - and writes both mirror positions; the
 // upper-triangle threads of the old one-thread-per-output scheme read the slabs a second time, strided.
+template <typename TO>
 __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit,
-                                   float* __restrict__ out) {
+                                   TO* __restrict__ out) {
   // grid: (ceil(M / 32) column blocks, M rows, L); threads 32 x 8 (8 rows per block in y)
   const int jj = blockIdx.x * 32 + (threadIdx.x & 31);
   const int i = blockIdx.y * 8 + (threadIdx.x >> 5);
   const int l = blockIdx.z;
   if (i >= M || jj > i) return;
   const float* p = part + (long long)l * nsplit * MP * MP + (long long)i * MP + jj;
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * MP * MP];
-  float* o = out + (long long)l * M * M;
+  TO s = TO(0);  // fp64 output: the partials are widened before they are added
+  for (int sp = 0; sp < nsplit; ++sp) s += (TO)p[(long long)sp * MP * MP];
+  TO* o = out + (long long)l * M * M;
   o[(long long)i * M + jj] = s;
   if (jj != i) o[(long long)jj * M + i] = s;
 }
@@ -1095,7 +1096,7 @@ static inline int gram_nl(int MB, int L, long long C) {
 }
 
 static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
-                            float* dOmega, float* ws, hipStream_t st) {
+                            void* dOmega, int out_dtype, float* ws, hipStream_t st) {
   const int nl = gram_nl(MBsel, L, C);
   const int ns = gram_nsplit(C, (L + nl - 1) / nl);
   const long long Cpad = cdiv(C, GR_KC) * GR_KC;
@@ -1127,7 +1128,10 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
 #undef GPSA_GRAM_CASE
   GPSA_LAUNCH_CHECK();
   dim3 rgrid((unsigned)cdiv(M, 32), (unsigned)cdiv(M, 8), (unsigned)L);
-  gram_reduce_kernel<<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, dOmega);
+  if (out_dtype == GPSA_F64)
+    gram_reduce_kernel<double><<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, (double*)dOmega);
+  else
+    gram_reduce_kernel<float><<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, (float*)dOmega);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -1300,24 +1304,28 @@ int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M,
   return GPSA_EINVAL;
 }
 
-int gpsa_quadform_bwd_omega(int dtype, const void* alpha, const void* g, int M, long long C, int L,
-                            void* dOmega, void* workspace, long long workspace_bytes, void* stream) {
+int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const void* g, int M, long long C,
+                            int L, void* dOmega, void* workspace, long long workspace_bytes, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1) return GPSA_EINVAL;
+  if (out_dtype != GPSA_F32 && out_dtype != GPSA_F64) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
     if (MB && !force_generic()) {
       if (workspace_bytes < gram_ws_bytes(MB, C, L)) return GPSA_EWORKSPACE;
-      return gram_mfma_launch(MB, (const float*)alpha, (const float*)g, M, C, L, (float*)dOmega,
+      return gram_mfma_launch(MB, (const float*)alpha, (const float*)g, M, C, L, dOmega, out_dtype,
                               (float*)workspace, st);
     }
+    if (out_dtype != dtype) return GPSA_EUNSUPPORTED;
     return generic_quadform_bwd_omega<float>((const float*)alpha, (const float*)g, M, C, L,
                                              (float*)dOmega, workspace, workspace_bytes, st);
   }
-  if (dtype == GPSA_F64)
+  if (dtype == GPSA_F64) {
+    if (out_dtype != dtype) return GPSA_EUNSUPPORTED;
     return generic_quadform_bwd_omega<double>((const double*)alpha, (const double*)g, M, C, L,
                                               (double*)dOmega, workspace, workspace_bytes, st);
+  }
   return GPSA_EINVAL;
 }
 

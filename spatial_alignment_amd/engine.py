@@ -193,7 +193,7 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
         #   (qbar a) a^T = sum_c qbar_c a_c a_c^T = - sum_l dOmega_l          (qbar = - sum_l g_l, exactly)
         # i.e. one product with K = L M (fp64, on what the Gram kernel already produced) instead of K = C
         f64 = torch.float64
-        dOm64 = o.quadform_bwd_omega(alpha, g).to(f64)  # [L, M, M]; the caller wants fp64 anyway
+        dOm64 = o.quadform_bwd_omega(alpha, g, out_dtype=f64)  # [L, M, M]; the caller wants fp64 anyway
         P = o.gemm(Om.reshape(L * M, M), dOm64.reshape(L * M, M), transA=True, alpha=2.0,
                    splitk=o.pick_splitk(L * M, M, M))
         o.gemm(dcT.to(f64), ddc.to(f64), transB=True, beta=1.0, out=P)
@@ -205,7 +205,7 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
         # cancellation that forces fp64 on dK_uu / dK_uf), so it runs on the fp32 MFMA Gram kernel on the
         # rounded alpha: 3 launches instead of L x (scale + C-long fp64 product + split-K reduce).  Only
         # where it pays: the LDS-DMA staging needs 16-byte aligned rows, and a small C is latency either way
-        dOm = o.quadform_bwd_omega(alpha.float(), g.float()).to(T)
+        dOm = o.quadform_bwd_omega(alpha.float(), g.float(), out_dtype=T)
     else:
         dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
     W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
@@ -332,6 +332,7 @@ class SGPWarpLayerFn(torch.autograd.Function):
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
                     dc.dtype, Omega.dtype, slopes.dtype, intercept.dtype)
         ctx.mark_non_differentiable(bad)
+        ctx.set_materialize_grads(False)  # G_mean usually takes no part in the loss: no zero-fill launches
         return Gmean, Gs, bad
 
     @staticmethod
@@ -377,6 +378,7 @@ class MeanResidFn(torch.autograd.Function):
         ctx.scale = scale
         ctx.meta = (Z.dtype, slopes.dtype, intercept.dtype, delta.dtype)
         ctx.mark_non_differentiable(mu)
+        ctx.set_materialize_grads(False)
         return mu, resid
 
     @staticmethod
@@ -384,6 +386,8 @@ class MeanResidFn(torch.autograd.Function):
         o = ops()
         Z, slopes = ctx.saved_tensors
         zdt, sdt, idt, ddt = ctx.meta
+        if dresid is None:
+            return None, None, None, None, None
         ddelta, dZ, dslopes, dint = o.mean_resid_bwd(dresid, Z, slopes, ctx.scale)
         return dZ.to(zdt), dslopes.to(sdt), dint.to(idt), ddelta.to(ddt), None
 
@@ -402,6 +406,7 @@ class WarpSampleFn(torch.autograd.Function):
         ctx.save_for_backward(eps, var_d, Xd)
         ctx.vmeta = (var_u.dtype, var_u.shape, slopes.dtype, intercept.dtype)
         ctx.mark_non_differentiable(bad)
+        ctx.set_materialize_grads(False)
         return Gmean, Gs, bad
 
     @staticmethod

@@ -240,14 +240,19 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_bwd_alpha_kept")
         return out
 
-    def quadform_bwd_omega(self, alpha, g):
+    def quadform_bwd_omega(self, alpha, g, out_dtype=None):
+        """``out_dtype``: storage type of the result (fp64 from fp32 inputs: the MFMA path widens its
+        partial sums while adding them; elsewhere a converted copy)"""
         alpha, g = self._c(alpha), self._c(g)
         M, Cn = alpha.shape
         L = g.shape[0]
-        out = torch.empty(L, M, M, dtype=alpha.dtype, device=alpha.device)
+        odt = alpha.dtype if out_dtype is None else out_dtype
+        out = torch.empty(L, M, M, dtype=odt, device=alpha.device)
         ws = self._qf_ws(alpha, L)
-        rc = self.lib.gpsa_quadform_bwd_omega(_dt(alpha), _p(alpha), _p(g), M, Cn, L, _p(out), _p(ws),
-                                              ws.numel(), self._stream(alpha))
+        rc = self.lib.gpsa_quadform_bwd_omega(_dt(alpha), _dt(out), _p(alpha), _p(g), M, Cn, L, _p(out),
+                                              _p(ws), ws.numel(), self._stream(alpha))
+        if rc == _lib.GPSA_EUNSUPPORTED and odt != alpha.dtype:
+            return self.quadform_bwd_omega(alpha, g).to(odt)
         _lib.check(rc, "gpsa_quadform_bwd_omega")
         return out
 

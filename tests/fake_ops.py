@@ -103,8 +103,9 @@ class FakeOps:
     def quadform_bwd_alpha_kept(self, W, g):
         return 2.0 * torch.einsum("lc,lmc->mc", g, W)
 
-    def quadform_bwd_omega(self, alpha, g):
-        return torch.einsum("lc,mc,kc->lmk", g, alpha, alpha)
+    def quadform_bwd_omega(self, alpha, g, out_dtype=None):
+        r = torch.einsum("lc,mc,kc->lmk", g, alpha, alpha)
+        return r if out_dtype is None else r.to(out_dtype)
 
     def panel_mm(self, P, X, want_colsq=False, transP=False):
         Y = (P.t() if transP else P).to(X.dtype) @ X

@@ -219,6 +219,10 @@ def test_quadform(hip, dtype, M, C, L):
     close(hip.quadform_bwd_alpha(al.to(DEV), Om.to(DEV), g.to(DEV)),
           FK.quadform_bwd_alpha(al.double(), Om.double(), g.double()), t)
     close(hip.quadform_bwd_omega(al.to(DEV), g.to(DEV)), FK.quadform_bwd_omega(al.double(), g.double()), t)
+    if dtype == torch.float32:  # fp64 result from fp32 inputs (partials widened while added, or a converted copy)
+        wide = hip.quadform_bwd_omega(al.to(DEV), g.to(DEV), out_dtype=torch.float64)
+        assert wide.dtype == torch.float64
+        close(wide, FK.quadform_bwd_omega(al.double(), g.double()), t)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])

@@ -1,0 +1,58 @@
+"""Step time of the other BASELINE.json configurations (or the largest single-GPU cut of them) on one MI355X.
+Diagnostic: these are parity-test configurations, not bench lines.
+usage: python tools/run_config.py c2|c3|c4 [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+ge.build()
+import spatial_alignment_amd as gp  # noqa: E402
+from spatial_alignment_amd.synthetic import make_grid_problem, make_model  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+CFG = {
+    # 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2 warp / RBF data
+    "c2": dict(side=100, views=4, outputs=500, M=200, latent=10, fixed=None, warp=gp.matern12_kernel, S=5),
+    # Visium-scale: 8 views x 5k spots (71 x 71), 2000 genes through 20 latent GPs, M = 500, view 0 fixed
+    "c3": dict(side=71, views=8, outputs=2000, M=500, latent=20, fixed=0, warp=gp.rbf_kernel, S=5),
+    # Slide-seq-scale cut that fits one GPU step: 2 views x 100k spots (316 x 316), 1000 genes / 10 latent, M = 1000
+    "c4": dict(side=316, views=2, outputs=1000, M=1000, latent=10, fixed=None, warp=gp.rbf_kernel, S=1),
+}[which]
+dd_cpu = make_grid_problem(side=CFG["side"], n_views=CFG["views"], n_outputs=CFG["outputs"], device="cpu")
+model = make_model(dd_cpu, m=CFG["M"], n_latent_gps={"expression": CFG["latent"]}, fixed_view_idx=CFG["fixed"],
+                   device=dev, kernel_func_warp=CFG["warp"], kernel_func_data=gp.rbf_kernel)
+dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
+          "n_samples_list": d["n_samples_list"]} for m, d in dd_cpu.items()}
+view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+Xs = {m: d["spatial_coords"] for m, d in dd.items()}
+opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+
+
+def step():
+    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=CFG["S"])
+    loss = model.loss_fn(dd, out[3])
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    l0 = step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print(f"{which}: {CFG['views']} views x {CFG['side'] ** 2} spots, {CFG['outputs']} outputs via {CFG['latent']} latent GPs, "
+      f"M={CFG['M']}, S={CFG['S']}: {dt * 1e3:.2f} ms/step, loss {float(l0):.4g} -> {float(loss):.4g}, "
+      f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)

@@ -1,17 +1,19 @@
-"""Which torch-native ops (and from where) run inside one training step of the default bench workload.
-Diagnostic tool.  usage: python tools/torch_ops_profile.py [shard_factor]"""
+"""Which torch-native (non-view) ops run inside one training step of the default bench workload, and the
+host line that issued each (autograd-engine = a built-in backward node).  Diagnostic tool.
+usage: python tools/torch_ops_profile.py [shard_factor]"""
 import os
 import sys
+import traceback
+from collections import Counter
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 ge.build()
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
-
 from spatial_alignment_amd.parallel import shard_data_dict  # noqa: E402
 from spatial_alignment_amd.synthetic import make_grid_problem, make_model  # noqa: E402
 
@@ -38,11 +40,27 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+VIEWS = {"view", "select", "slice", "unsqueeze", "squeeze", "expand", "transpose", "t", "detach", "alias",
+         "_unsafe_view", "reshape", "unbind", "split", "split_with_sizes", "as_strided", "permute", "empty",
+         "empty_like", "empty_strided", "set_", "lift_fresh", "is_same_size", "sym_size", "sym_stride",
+         "_local_scalar_dense", "item", "new_empty_strided", "record_stream", "is_pinned", "resize_"}
+cn = Counter()
+
+
+class Mode(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split(".")[0]
+        if name not in VIEWS:
+            fr = [f for f in traceback.extract_stack() if "spatial_alignment_amd" in f.filename]
+            where = f"{fr[-1].filename.split('/')[-1]}:{fr[-1].lineno} {(fr[-1].line or '')[:80]}" if fr else "autograd-engine / optimizer"
+            shapes = [tuple(a.shape) for a in args if isinstance(a, torch.Tensor)][:2]
+            cn[(where, name, str(shapes))] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Mode():
     step()
-    torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and e.self_device_time_total > 0]
-rows.sort(key=lambda e: -e.self_device_time_total)
-for e in rows[:80]:
-    where = [s for s in e.stack if "spatial_alignment_amd" in s or "bench" in s or "tools/" in s][:2]
-    print(f"{e.count:3d} x {e.key:32s} dev {e.self_device_time_total:8.1f} us  cpu {e.self_cpu_time_total:8.1f} us  {' <- '.join(w.strip()[-70:] for w in where)}")
+torch.cuda.synchronize()
+for (where, name, shapes), v in sorted(cn.items()):
+    print(f"{v:3d} {name:22s} {shapes:40s} | {where}")
+print("total", sum(cn.values()))
