@@ -92,6 +92,11 @@ class VariationalGPSA(GPSA):
         self.fixed_view_idx = fixed_view_idx
         self.check_numerics = True  # one host sync per forward; raises like the reference would
         self.kl_scale = 1.0  # data-parallel ranks add 1/world of the KL each (parallel.py)
+        # output-sharded ranks (parallel.shard_outputs) own their outputs' KL terms in full and share the
+        # warp GPs': weight of the warp-GP KL terms inside the KL sum, and separate generators for the
+        # draws every rank must agree on (warp) and the ones it must not share (its own outputs)
+        self.kl_weight_G = 1.0
+        self.noise_generators = None  # {"G": torch.Generator, "F": torch.Generator} or None
         # warp GPs of different views on side HIP streams: pays under hipGraph replay (-0.2 ms at the
         # headline config), costs CPU time per launch in eager mode, so train.GraphedTrainStep turns it on
         self.overlap_views = False
@@ -225,8 +230,9 @@ class VariationalGPSA(GPSA):
             pool.append(torch.cuda.Stream(device=device))
         return pool[:n]
 
-    def _draw(self, shape, device):
-        return torch.empty(shape, dtype=torch.float32, device=device).normal_()
+    def _draw(self, shape, device, which="G"):
+        gen = None if self.noise_generators is None else self.noise_generators.get(which)
+        return torch.empty(shape, dtype=torch.float32, device=device).normal_(generator=gen)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, X_spatial, view_idx, Ns, S=1, prediction_mode=False, G_test=None):
@@ -412,7 +418,7 @@ class VariationalGPSA(GPSA):
             if noise is not None and noise[eps_key] is not None:
                 eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
             else:
-                eps = torch.randn([S_, N_, L], device=dev).reshape(S_ * N_, L)
+                eps = self._draw([S_, N_, L], dev, "F").reshape(S_ * N_, L)
             kind = builtin_kind(self.kernel_func_data)
             if kind is not None:  # covariance, projection, contractions and the draw as one node
                 Fl = E.SGPDataLayerFn.apply(kind, self.Gtilde, Gf, ls_u, var_u, KuuF, self.delta_F_dict[m],
@@ -499,6 +505,8 @@ class VariationalGPSA(GPSA):
         priors = [cache.warp[v][0] for v in free] + [cache.data[0]]
         kl = E.MvnKLGroupedFn.apply(plan, cache.batch, Dall, *priors, cache.Omega_G,
                                     *[cache.Omega_F[m] for m in mods])
+        if self.kl_weight_G != 1.0:  # output-sharded rank: its share of the warp GPs' terms
+            return kl[: V * D].sum() * self.kl_weight_G + kl[V * D:].sum()
         return kl.sum()
 
     # ------------------------------------------------------------------------------------------
@@ -522,6 +530,8 @@ class VariationalGPSA(GPSA):
             Om = cache.Om_kl[v]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
             ofac = (cache.Omega_G_fac[0][v::V], cache.Omega_G_fac[1][v::V])
             term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()
+            if self.kl_weight_G != 1.0:
+                term = term * self.kl_weight_G
             kl = term if kl is None else kl + term
         KuuF, facF = cache.data
         lls = []

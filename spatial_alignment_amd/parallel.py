@@ -4,6 +4,12 @@ Everything N-scaled is independent per spot given the (replicated) M x M factors
 a contiguous slice of EVERY view's rows: it runs the warp + data layers and the likelihood for its
 rows, adds 1/world of the KL terms, and one all-reduce (RCCL over xGMI; backend "nccl" on ROCm) of
 the flattened gradient makes every rank's gradient the full-ELBO gradient.  No other collective.
+
+For many outputs (L = P in the thousands: BASELINE.json configs 4/5) the L axis shards instead
+(``shard_outputs`` / ``setup_output_sharding``): a rank owns a slice of the output columns with their
+``Omega_sqt_F`` rows and ``delta_F`` columns - the 2 GB of gradient those hold never leave the GPU -,
+every rank runs the (cheap, identical) warp GPs, and only the gradients of the shared parameters
+(a few MB) are all-reduced.
 """
 import torch
 import torch.distributed as dist
@@ -34,6 +40,59 @@ def shard_data_dict(data_dict, rank, world):
             "n_samples_list": new_ns,
         }
     return out
+
+
+def shard_outputs(data_dict, rank, world):
+    """per-rank data_dict: every row, this rank's contiguous slice of each modality's output columns"""
+    out = {}
+    for mod, d in data_dict.items():
+        lo, hi = shard_rows(d["outputs"].shape[1], rank, world)
+        out[mod] = {
+            "spatial_coords": d["spatial_coords"],
+            "outputs": d["outputs"][:, lo:hi].contiguous(),
+            "n_samples_list": list(d["n_samples_list"]),
+        }
+    return out
+
+
+OUTPUT_LOCAL_PREFIXES = ("Omega_sqt_F_dict.", "delta_F_dict.")
+
+
+def shared_parameters(model):
+    """the parameters every output-sharded rank holds a copy of (everything but the per-output
+    variational parameters of the data GP)"""
+    return [p for n, p in model.named_parameters() if not n.startswith(OUTPUT_LOCAL_PREFIXES)]
+
+
+def setup_output_sharding(model, rank, world, seed=0):
+    """Turn a model built on ``shard_outputs(data_dict, rank, world)`` into rank ``rank`` of an
+    output-sharded job (no latent mixing: n_latent_gps None, so outputs are independent given G):
+
+    * loss = -LL(own outputs) + KL(own outputs) + KL(warp GPs) / world: summed over ranks this is the
+      full negative ELBO, and so is the sum of the shared parameters' gradients;
+    * the warp draws come from a generator seeded alike on every rank (all ranks must see the same
+      aligned coordinates), the output draws from one seeded per rank;
+    * shared parameters are broadcast from rank 0 (construction may have consumed the RNG differently).
+
+    Returns the GradAllReducer over the shared parameters: call it between backward() and step()."""
+    for m in model.modality_names:
+        if model.n_latent_gps[m] is not None:
+            raise ValueError("output sharding needs independent outputs (n_latent_gps[mod] = None)")
+    model.kl_scale = 1.0
+    model.kl_weight_G = 1.0 / world
+    dev = model.Xtilde.device
+    g_common, g_local = torch.Generator(device=dev), torch.Generator(device=dev)
+    g_common.manual_seed(int(seed))
+    g_local.manual_seed(int(seed) * 1000003 + 7919 * (rank + 1))
+    model.noise_generators = {"G": g_common, "F": g_local}
+    shared = shared_parameters(model)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        with torch.no_grad():
+            for p in shared:
+                dist.broadcast(p, src=0)
+            for name, b in model.named_buffers():
+                dist.broadcast(b, src=0)
+    return GradAllReducer(shared)
 
 
 class GradAllReducer:

@@ -94,3 +94,115 @@ def test_sharded_step_equals_full_step():
             assert np.linalg.norm(a - b) <= 2e-3 * max(np.linalg.norm(a), 1e-6), k
     finally:
         ops_mod.set_ops(None)
+
+
+# ---- output (L-axis) sharding: SURVEY.md §8e "alternative for large L" ---------------------------------
+def _problem_outputs():
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+    dd = make_grid_problem(side=8, n_views=2, n_outputs=4)
+    return dd, make_model(dd, m=9)
+
+
+def _rank_model(full, dd, rank, world):
+    """rank's model on its output slice, carrying the full model's parameters (shared: copies; per-output:
+    the rank's rows / columns)"""
+    from spatial_alignment_amd.parallel import shard_outputs, shard_rows
+    from spatial_alignment_amd.synthetic import make_model
+
+    sdd = shard_outputs(dd, rank, world)
+    model = make_model(sdd, m=9, seed=100 + rank)  # deliberately different construction RNG per rank
+    lo, hi = shard_rows(4, rank, world)
+    with torch.no_grad():
+        for (n, p), (_, pf) in zip(model.named_parameters(), full.named_parameters()):
+            if n.startswith("Omega_sqt_F_dict."):
+                p.copy_(pf[lo:hi])
+            elif n.startswith("delta_F_dict."):
+                p.copy_(pf[:, lo:hi])
+            elif rank == 0:  # the other ranks get the shared parameters by broadcast
+                p.copy_(pf)
+    return sdd, model, (lo, hi)
+
+
+def _worker_outputs(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    from fake_ops import FakeOps
+    from spatial_alignment_amd import ops as ops_mod
+    from spatial_alignment_amd.parallel import setup_output_sharding
+
+    ops_mod.set_ops(FakeOps())
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dd, full = _problem_outputs()
+    sdd, model, (lo, hi) = _rank_model(full, dd, rank, world)
+    reducer = setup_output_sharding(model, rank, world, seed=5)
+    assert model.kl_weight_G == 0.5 and model.kl_scale == 1.0
+    gen = torch.Generator().manual_seed(3)
+    eG = [torch.randn(2, 64, 2, generator=gen) for _ in range(2)]
+    eF = torch.randn(2, 128, 4, generator=gen)
+    loss = _grads(model, sdd, eG, {"expression": eF[:, :, lo:hi]}, 1.0)
+    reducer()
+    dist.all_reduce(loss)
+    grads = {k: p.grad.clone().numpy() for k, p in model.named_parameters()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, grads)
+    if rank == 0:
+        q.put((float(loss), gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_output_sharded_step_equals_full_step():
+    from fake_ops import FakeOps
+    from spatial_alignment_amd import ops as ops_mod
+    from spatial_alignment_amd.parallel import shard_rows
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_outputs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    loss2, per_rank = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ops_mod.set_ops(FakeOps())
+    try:
+        dd, model = _problem_outputs()
+        gen = torch.Generator().manual_seed(3)
+        eG = [torch.randn(2, 64, 2, generator=gen) for _ in range(2)]
+        eF = torch.randn(2, 128, 4, generator=gen)
+        loss1 = _grads(model, dd, eG, {"expression": eF})
+        assert abs(float(loss1) - loss2) <= 1e-4 * abs(float(loss1))
+        for k, p in model.named_parameters():
+            a = p.grad.numpy()
+            if k.startswith("Omega_sqt_F_dict."):  # per-output parameters: each rank holds its rows
+                b = np.concatenate([per_rank[r][k] for r in range(2)], 0)
+            elif k.startswith("delta_F_dict."):
+                b = np.concatenate([per_rank[r][k] for r in range(2)], 1)
+            else:  # shared: all-reduced, identical on both ranks
+                b = per_rank[0][k]
+                assert np.array_equal(per_rank[0][k], per_rank[1][k]), k
+            assert np.linalg.norm(a - b) <= 2e-3 * max(np.linalg.norm(a), 1e-6), k
+        assert shard_rows(4, 1, 2) == (2, 4)
+    finally:
+        ops_mod.set_ops(None)
+
+
+def test_output_sharding_rejects_latent_mixing_and_separates_generators():
+    from spatial_alignment_amd.parallel import setup_output_sharding, shared_parameters
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+    dd = make_grid_problem(side=6, n_views=2, n_outputs=4)
+    with pytest.raises(ValueError):
+        setup_output_sharding(make_model(dd, m=4, n_latent_gps={"expression": 2}), 0, 2)
+    a, b = make_model(dd, m=4), make_model(dd, m=4)
+    setup_output_sharding(a, 0, 2, seed=9)
+    setup_output_sharding(b, 1, 2, seed=9)
+    assert torch.equal(a._draw([3, 2], "cpu", "G"), b._draw([3, 2], "cpu", "G"))       # common warp draws
+    assert not torch.equal(a._draw([3, 2], "cpu", "F"), b._draw([3, 2], "cpu", "F"))   # own output draws
+    names = {n for n, _ in a.named_parameters()}
+    shared = {id(p) for p in shared_parameters(a)}
+    local = {n for n, p in a.named_parameters() if id(p) not in shared}
+    assert local == {n for n in names if n.startswith(("Omega_sqt_F_dict.", "delta_F_dict."))} and local
