@@ -80,6 +80,12 @@ int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream);
  *   Same reference lines as the pair it fuses. */
 int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
                       void* stream);
+/* gpsa_chol_inv_blocked_f64: the same result for any M: right-looking over diagonal blocks of <= 256
+ *   columns (register-resident kernel per block, fp64-MFMA products for the panel, the trailing update and
+ *   the rows of the inverse).  workspace >= gpsa_chol_inv_blocked_workspace(M, batch) bytes. */
+long long gpsa_chol_inv_blocked_workspace(int M, int batch);
+int gpsa_chol_inv_blocked_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
+                              void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- the dominant contraction: variational variance term --------------------------------------
  * v[l,c] = alpha[:,c]^T Omega[l] alpha[:,c]            (vgpsa.py:192-196 a_t_Omega_tril, square, sum;

@@ -27,6 +27,8 @@ SIGNATURES = {
     "gpsa_chol_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "gpsa_chol_inv_blocked_workspace": (_ll, [_i, _i]),
+    "gpsa_chol_inv_blocked_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_workspace": (_ll, [_i, _i, _ll, _i]),
     "gpsa_quadform_fwd": (_i, [_i, _i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_bwd_alpha": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),

@@ -195,22 +195,26 @@ tri_inv_global_kernel(const double* __restrict__ L, double* __restrict__ Linv, i
 template <int NT, int TS>
 __global__ void __launch_bounds__(TS * TS)
 chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Linv,
-                    double* __restrict__ logdet, int* __restrict__ info) {
+                    double* __restrict__ logdet, int* __restrict__ info, int lda, long long sA, int ldo,
+                    long long sO, int col0, int accumulate) {
+  // lda / sA, ldo / sO: row and batch strides of the input and output (a diagonal block of a larger
+  // matrix in the blocked factorisation); col0: column offset reported in info; accumulate: add to
+  // logdet and keep an earlier block's info
   constexpr int NTH = TS * TS;
   __shared__ double col[2][NT * TS];
   __shared__ double xrow[2][NT * TS];
   __shared__ double sdiag[NT * TS];
   __shared__ double red[16];
   const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
-  const double* G = A + (long long)blockIdx.x * M * M;
-  double* O = Linv + (long long)blockIdx.x * M * M;
+  const double* G = A + (long long)blockIdx.x * sA;
+  double* O = Linv + (long long)blockIdx.x * sO;
   double t[NT][NT];
 #pragma unroll
   for (int qa = 0; qa < NT; ++qa)
 #pragma unroll
     for (int qb = 0; qb < NT; ++qb) {
       const int i = TS * qa + ty, k = TS * qb + tx;
-      t[qa][qb] = (qb <= qa && i < M && k < M) ? G[(long long)i * M + k] : 0.0;
+      t[qa][qb] = (qb <= qa && i < M && k < M) ? G[(long long)i * lda + k] : 0.0;
     }
   int bad = 0;
 #pragma unroll
@@ -287,15 +291,21 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
     for (int j = tid; j < M; j += NTH) lg -= log(sdiag[j]);  // sdiag = 1 / L(j,j)
   lg = block_sum(lg, red);
   if (tid == 0) {
-    logdet[blockIdx.x] = bad ? __builtin_nan("") : 2.0 * lg;
-    info[blockIdx.x] = bad;
+    const double ld = bad ? __builtin_nan("") : 2.0 * lg;
+    if (accumulate) {
+      logdet[blockIdx.x] += ld;
+      if (info[blockIdx.x] == 0 && bad) info[blockIdx.x] = col0 + bad;
+    } else {
+      logdet[blockIdx.x] = ld;
+      info[blockIdx.x] = bad ? col0 + bad : 0;
+    }
   }
 #pragma unroll
   for (int qa = 0; qa < NT; ++qa)
 #pragma unroll
     for (int qb = 0; qb < NT; ++qb) {
       const int i = TS * qa + ty, k = TS * qb + tx;
-      if (i < M && k < M) O[(long long)i * M + k] = (qb <= qa && k <= i) ? t[qa][qb] : 0.0;
+      if (i < M && k < M) O[(long long)i * ldo + k] = (qb <= qa && k <= i) ? t[qa][qb] : 0.0;
     }
 }
 
@@ -328,6 +338,96 @@ __global__ void add_diag_kernel(T* __restrict__ A, int M, int batch, T s) {
   if (idx >= (long long)M * batch) return;
   const long long b = idx / M, i = idx % M;
   A[b * M * M + i * M + i] += s;
+}
+
+// one launch of the register-resident kernel on (a diagonal block of) a batch of matrices
+static int chol_inv_reg_launch(const double* A, int M, double* Linv, double* logdet, int* info, int lda,
+                               long long sA, int ldo, long long sO, int col0, int accumulate, int batch,
+                               hipStream_t st) {
+#define GPSA_CI_CASE(V, TSV)                                                                        \
+  chol_inv_reg_kernel<V, TSV><<<batch, TSV * TSV, 0, st>>>(A, M, Linv, logdet, info, lda, sA, ldo, sO, \
+                                                            col0, accumulate)
+  // 16 x 16 threads (one wave per SIMD) while a thread's share fits comfortably in registers: 166 vs
+  // 185 us at M = 200; 32 x 32 above (252 vs 287 us at M = 256)
+  static const int forced = [] { const char* e = getenv("GPSA_CHOL_TS"); return e ? atoi(e) : 0; }();
+  const int ts = forced ? forced : (M <= 208 ? 16 : 32);
+  if (ts == 32) {
+    const int nt = (M + 31) / 32;
+    if (nt <= 1) GPSA_CI_CASE(1, 32);
+    else if (nt <= 2) GPSA_CI_CASE(2, 32);
+    else if (nt <= 4) GPSA_CI_CASE(4, 32);
+    else if (nt <= 7) GPSA_CI_CASE(7, 32);
+    else if (nt <= 8) GPSA_CI_CASE(8, 32);
+    else return GPSA_EUNSUPPORTED;
+  } else {
+    const int nt = (M + 15) / 16;
+    if (nt <= 2) GPSA_CI_CASE(2, 16);
+    else if (nt <= 4) GPSA_CI_CASE(4, 16);
+    else if (nt <= 7) GPSA_CI_CASE(7, 16);
+    else if (nt <= 13) GPSA_CI_CASE(13, 16);
+    else if (nt <= 16) GPSA_CI_CASE(16, 16);
+    else return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_CI_CASE
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                long long lda, long long sA, const T* B, long long ldb, long long sB, double beta, T* C,
+                long long ldc, long long sC, int batch, int splitk, void* part, long long part_bytes,
+                hipStream_t st);  // gemm.hip
+
+static inline int chol_block_size(int M) {
+  const int nb = (M + 255) / 256;
+  int bs = (((M + nb - 1) / nb + 15) / 16) * 16;
+  return bs > 256 ? 256 : bs;
+}
+
+// Blocked factorisation for M beyond the register-resident kernel: right-looking over diagonal blocks of
+// <= 256 columns.  Block k:  L_kk^-1 by the register kernel on the (updated) diagonal block;  panel
+// L[r,k] = W[r,k] L_kk^-T and trailing update W[r,r] -= L[r,k] L[r,k]^T as two fp64-MFMA products;  row k
+// of the inverse X[k,<k] = -L_kk^-1 (L[k,<k] X[<k,<k]) as two more.  ~5 launches per block instead of one
+// latency-bound global-memory sweep over all M columns (M = 1000, 17 matrices: 120 + 54 ms before).
+static int chol_inv_blocked(const double* A, double* Linv, int M, int batch, double* logdet, int* info,
+                            double* ws, hipStream_t st) {
+  const long long mm = (long long)M * M;
+  const int bs = chol_block_size(M), nb = (M + bs - 1) / bs;
+  double* W = ws;                    // working copy of A (lower part is read)
+  double* Lf = W + (long long)batch * mm;   // the factor's off-diagonal blocks
+  double* T = Lf + (long long)batch * mm;   // [batch][bs][M] scratch
+  const long long sT = (long long)bs * M;
+  hipError_t e = hipMemcpyAsync(W, A, (size_t)batch * mm * 8, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(Linv, 0, (size_t)batch * mm * 8, st);
+  if (e != hipSuccess) return (int)e;
+  for (int k = 0; k < nb; ++k) {
+    const long long o = (long long)k * bs;
+    const int b = (int)((M - o < bs) ? M - o : bs);
+    const long long r = o + b;
+    const int mr = (int)(M - r);
+    double* Dinv = Linv + o * M + o;
+    int rc = chol_inv_reg_launch(W + o * M + o, b, Dinv, logdet, info, M, mm, M, mm, (int)o, k > 0, batch, st);
+    if (rc) return rc;
+    if (mr > 0) {
+      rc = gemm_launch<double>(0, 1, mr, b, b, 1.0, W + r * M + o, M, mm, Dinv, M, mm, 0.0, Lf + r * M + o, M,
+                               mm, batch, 1, nullptr, 0, st);
+      if (rc) return rc;
+      rc = gemm_launch<double>(0, 1, mr, mr, b, -1.0, Lf + r * M + o, M, mm, Lf + r * M + o, M, mm, 1.0,
+                               W + r * M + r, M, mm, batch, 1, nullptr, 0, st);
+      if (rc) return rc;
+    }
+    if (k > 0) {
+      rc = gemm_launch<double>(0, 0, b, (int)o, o, 1.0, Lf + o * M, M, mm, Linv, M, mm, 0.0, T, M, sT, batch,
+                               1, nullptr, 0, st);
+      if (rc) return rc;
+      rc = gemm_launch<double>(0, 0, b, (int)o, b, -1.0, Dinv, M, mm, T, M, sT, 0.0, Linv + o * M, M, mm,
+                               batch, 1, nullptr, 0, st);
+      if (rc) return rc;
+    }
+  }
+  return 0;
 }
 
 }  // namespace gpsa
@@ -382,34 +482,23 @@ int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet,
                       void* stream) {
   using namespace gpsa;
   if (M < 1 || batch < 1) return GPSA_EINVAL;
-  hipStream_t st = as_stream(stream);
-#define GPSA_CI_CASE(V, TSV)                                                                      \
-  chol_inv_reg_kernel<V, TSV><<<batch, TSV * TSV, 0, st>>>((const double*)A, M, (double*)Linv,       \
-                                                            (double*)logdet, info)
-  // 16 x 16 threads (one wave per SIMD) while a thread's share fits comfortably in registers: 166 vs
-  // 185 us at M = 200; 32 x 32 above (252 vs 287 us at M = 256)
-  static const int forced = [] { const char* e = getenv("GPSA_CHOL_TS"); return e ? atoi(e) : 0; }();
-  const int ts = forced ? forced : (M <= 208 ? 16 : 32);
-  if (ts == 32) {
-    const int nt = (M + 31) / 32;
-    if (nt <= 1) GPSA_CI_CASE(1, 32);
-    else if (nt <= 2) GPSA_CI_CASE(2, 32);
-    else if (nt <= 4) GPSA_CI_CASE(4, 32);
-    else if (nt <= 7) GPSA_CI_CASE(7, 32);
-    else if (nt <= 8) GPSA_CI_CASE(8, 32);
-    else return GPSA_EUNSUPPORTED;
-  } else {
-    const int nt = (M + 15) / 16;
-    if (nt <= 2) GPSA_CI_CASE(2, 16);
-    else if (nt <= 4) GPSA_CI_CASE(4, 16);
-    else if (nt <= 7) GPSA_CI_CASE(7, 16);
-    else if (nt <= 13) GPSA_CI_CASE(13, 16);
-    else if (nt <= 16) GPSA_CI_CASE(16, 16);
-    else return GPSA_EUNSUPPORTED;
-  }
-#undef GPSA_CI_CASE
-  GPSA_LAUNCH_CHECK();
-  return 0;
+  return chol_inv_reg_launch((const double*)A, M, (double*)Linv, (double*)logdet, info, M,
+                             (long long)M * M, M, (long long)M * M, 0, 0, batch, as_stream(stream));
+}
+
+long long gpsa_chol_inv_blocked_workspace(int M, int batch) {
+  if (M < 1 || batch < 1) return 0;
+  const int bs = gpsa::chol_block_size(M);
+  return ((long long)2 * M * M + (long long)bs * M) * batch * 8;
+}
+
+int gpsa_chol_inv_blocked_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
+                              void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  if (workspace_bytes < gpsa_chol_inv_blocked_workspace(M, batch)) return GPSA_EWORKSPACE;
+  return chol_inv_blocked((const double*)A, (double*)Linv, M, batch, (double*)logdet, info,
+                          (double*)workspace, as_stream(stream));
 }
 
 int gpsa_bdot(int dtype, const void* A, long long strideA, const void* B, long long strideB,

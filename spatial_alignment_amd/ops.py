@@ -179,16 +179,20 @@ class HipOps:
         return out
 
     def chol_inv(self, A):
-        """A [B,M,M] fp64 (not modified) -> L^-1 [B,M,M], logdet [B], info [B]; one fused sweep for
-        M <= 256, the chol + tri_inv pair above that."""
+        """A [B,M,M] fp64 (not modified) -> L^-1 [B,M,M], logdet [B], info [B]; one fused register-resident
+        sweep for M <= 256, the blocked factorisation (that sweep per diagonal block + fp64-MFMA
+        products) above that."""
         A = self._c(A)
         Bn, M = A.shape[0], A.shape[-1]
-        if M > 256:
-            L, logdet, info = self.chol(A)
-            return self.tri_inv(L), logdet, info
         Linv = torch.empty_like(A)
         logdet = torch.empty(Bn, dtype=torch.float64, device=A.device)
         info = torch.empty(Bn, dtype=torch.int32, device=A.device)
+        if M > 256:
+            ws = self._ws(self.lib.gpsa_chol_inv_blocked_workspace(M, Bn), A)
+            rc = self.lib.gpsa_chol_inv_blocked_f64(_p(A), _p(Linv), M, Bn, _p(logdet), _p(info), _p(ws),
+                                                    ws.numel(), self._stream(A))
+            _lib.check(rc, "gpsa_chol_inv_blocked_f64")
+            return Linv, logdet, info
         rc = self.lib.gpsa_chol_inv_f64(_p(A), _p(Linv), M, Bn, _p(logdet), _p(info), self._stream(A))
         _lib.check(rc, "gpsa_chol_inv_f64")
         return Linv, logdet, info

@@ -1,6 +1,7 @@
 """GPU: every C-ABI kernel against its contract (tests/fake_ops.py evaluated on the CPU in fp64)."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -157,7 +158,8 @@ def test_chol_and_tri_inv(hip, M, B):
 
 
 @pytest.mark.parametrize("M,B", [(1, 2), (5, 3), (31, 2), (32, 2), (33, 2), (50, 4), (64, 1), (100, 3), (128, 2),
-                                 (200, 57), (224, 2), (225, 2), (256, 3), (300, 2)])
+                                 (200, 57), (224, 2), (225, 2), (256, 3), (257, 2), (300, 2), (500, 3),
+                                 (513, 1), (1000, 2)])
 def test_chol_inv_fused(hip, M, B):
     """register-resident Cholesky + inverse of the factor vs LAPACK (and the unfused pair's results)."""
     A = rnd(B, M, M, dtype=torch.float64, seed=M)
@@ -194,6 +196,19 @@ def test_chol_inv_flags_indefinite(hip):
     _, logdet, info = hip.chol_inv(K.to(DEV))
     assert info.cpu().tolist() == [0, 8, 40]
     assert bool(torch.isnan(logdet[1])) and bool(torch.isnan(logdet[2])) and float(logdet[0]) == 0.0
+
+
+def test_chol_inv_blocked_flags_indefinite(hip):
+    """M > 256 (blocked): the first non-positive pivot is reported with its global column, whichever block"""
+    K = torch.eye(600, dtype=torch.float64).repeat(4, 1, 1) * 2.0
+    K[1, 7, 7] = -1.0       # first block
+    K[2, 450, 450] = 0.0    # second block (blocks of 304 columns)
+    K[3, 599, 599] = -3.0   # last column of the last block
+    Linv, logdet, info = hip.chol_inv(K.to(DEV))
+    assert info.cpu().tolist() == [0, 8, 451, 600]
+    assert all(bool(torch.isnan(logdet[i])) for i in (1, 2, 3))
+    close(logdet[:1], torch.tensor([600 * np.log(2.0)]), 1e-12)
+    close(Linv[0], torch.eye(600, dtype=torch.float64) / np.sqrt(2.0), 1e-12)
 
 
 def test_chol_flags_indefinite(hip):
