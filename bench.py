@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="disable the per-forward numerics sync")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay timing")
+    ap.add_argument("--no-s1", action="store_true", help="skip the secondary S = 1 timing")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--static-grads", action="store_true", help="diagnostic: zero_grad(set_to_none=False)")
     ap.add_argument("--overlap", action="store_true", help="diagnostic: per-view side streams in eager mode too")
@@ -205,6 +206,34 @@ def main():
     dt = float(t.item())
     final_loss = float(loss.item())
 
+    # secondary: the same step at S = 1, the reference's forward default; same protocol
+    s1 = None
+    if args.S != 1 and not args.no_s1:
+        def step1():
+            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=1)
+            l1 = model.loss_fn(dd, out[3])
+            opt.zero_grad(set_to_none=not args.static_grads)
+            l1.backward()
+            reducer()
+            opt.step()
+
+        for _ in range(args.warmup):
+            step1()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step1()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        s1 = dict(S=1, value=args.steps / float(tt.item()), unit="steps/s",
+                  ms_per_step=1e3 * float(tt.item()) / args.steps)
+
     graph_info = None
     if world == 1 and not args.no_graph and not args.graph_only:
         # extra: the SAME step captured into a hipGraph and replayed (train.GraphedTrainStep); run in a
@@ -277,6 +306,7 @@ def main():
                 "final_loss": final_loss,
             },
             "roofline": roof,
+            "secondary_S1": s1,
             "graph_replay": graph_info,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-graph"
+B="$R/bench.py --no-cpu-baseline --no-graph --no-s1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $B --steps 10 --warmup 2 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $B --steps 3 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $B --steps 3 --warmup 1 > $O/write.log 2>&1
