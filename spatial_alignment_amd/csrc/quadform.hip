@@ -929,6 +929,12 @@ __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP
   if (jj != i) o[(long long)jj * M + i] = s;
 }
 
+// row tiles of the panel / quadratic-form kernels' instantiations (0: no MFMA variant, generic path).
+// 24 and 32 (M <= 512) run one column tile per wave: the accumulators + the B slab of a wave are then
+// 2 x 4 MB registers, the whole 512-register budget at MB = 32 (it spills there).  Measured against the
+// generic tiled path at C = 50k, L = 8: accumulate 1.5x (M = 380) and 1.33x (M = 500) faster, quadratic
+// form 2.7x faster at 380 but 2.4x SLOWER at 500, store (L = 1) slower at both: hence the caps below.
+constexpr int MB_MAX_ACCUM = 32, MB_MAX_QUAD = 24, MB_MAX_STORE = 16;
 static inline int mfma_mb_for(int M) {
   const int mb = (M + 15) / 16;
   if (mb <= 2) return 2;
@@ -936,8 +942,18 @@ static inline int mfma_mb_for(int M) {
   if (mb <= 7) return 7;
   if (mb <= 13) return 13;
   if (mb <= 16) return 16;
+  if (mb <= 24) return 24;
+  if (mb <= 32) return 32;
   return 0;
 }
+
+// the Gram kernel keeps ALL lower tiles of an output in one workgroup's accumulators: M <= 256 only
+static inline int gram_mb_for(int M) {
+  const int mb = mfma_mb_for(M);
+  return mb <= 16 ? mb : 0;
+}
+
+static inline int panel_nct_for(int MB) { return MB >= 24 ? 1 : (MB == 16 ? 2 : (MB == 13 ? 3 : 4)); }
 
 static inline bool force_generic() {
   static int v = -1;
@@ -993,7 +1009,8 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
                       long long C, int L, float* out, float* colsq, float scale, float* slab,
                       hipStream_t st) {
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
-  case MBV: {                                                                                   \
+  case MBV:                                                                                     \
+    if constexpr (MBV <= 16 || MODE == MODE_ACCUM) {  /* 24 / 32 row tiles: accumulate only */  \
     const long long ntiles = cdiv(C, 64 * NCTV), T = ntiles * L;                                \
     const int wgs_per_cu = (MBV * NCTV >= 24) ? 1 : 2;                                          \
     long long grid = (long long)num_cus() * wgs_per_cu;                                         \
@@ -1011,13 +1028,18 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
       panel_slab_reduce_kernel<<<rg, 256, 0, st>>>(slab, M, MBV * 16, 64 * NCTV, C, L, ntiles,  \
                                                    (int)grid, out);                             \
     }                                                                                           \
-  } break;
+    } else {                                                                                    \
+      return GPSA_EUNSUPPORTED;                                                                 \
+    }                                                                                           \
+    break;
   switch (MBsel) {
     GPSA_PANEL_CASE(2, 4)
     GPSA_PANEL_CASE(4, 4)
     GPSA_PANEL_CASE(7, 4)
     GPSA_PANEL_CASE(13, 3)
     GPSA_PANEL_CASE(16, 2)
+    GPSA_PANEL_CASE(24, 1)
+    GPSA_PANEL_CASE(32, 1)
     default:
       return GPSA_EUNSUPPORTED;
   }
@@ -1028,7 +1050,7 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
 
 // floats of slab space behind the packed operand: 2 partial tiles per workgroup of the persistent grid
 static inline long long accum_slab_floats(int MB) {
-  const int nct = (MB == 16) ? 2 : (MB == 13 ? 3 : 4);
+  const int nct = panel_nct_for(MB);
   const long long G = (long long)num_cus() * ((MB * nct >= 24) ? 1 : 2);
   return G * 2 * (long long)MB * 16 * 64 * nct;
 }
@@ -1051,6 +1073,7 @@ static int quad_sym_launch(int MBsel, const float* Ppk, const float* X, int M, l
     GPSA_QS_CASE(7, 4)
     GPSA_QS_CASE(13, 3)
     GPSA_QS_CASE(16, 2)
+    GPSA_QS_CASE(24, 1)
     default:
       return GPSA_EUNSUPPORTED;
   }
@@ -1198,7 +1221,7 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   long long mfma = 0;
   if (dtype == GPSA_F32 && MB) {
     mfma = ((long long)L * MB * 16 * MB * 16 + gpsa::accum_slab_floats(MB)) * 4;
-    const long long gw = gpsa::gram_ws_bytes(MB, C, L);
+    const long long gw = gpsa::gram_mb_for(M) ? gpsa::gram_ws_bytes(MB, C, L) : 0;
     if (gw > mfma) mfma = gw;
   }
   int lc = L < 4 ? L : 4;
@@ -1217,7 +1240,7 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
-    if (MB && !force_generic()) {
+    if (MB && MB <= MB_MAX_QUAD && !force_generic()) {
       if (workspace_bytes < (long long)L * MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
       static const bool full = [] { const char* e = getenv("GPSA_QUAD_FULL"); return e && e[0] == '1'; }();
@@ -1253,7 +1276,7 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
-    if (MB && !force_generic()) {
+    if (MB && MB <= MB_MAX_ACCUM && !force_generic()) {
       const long long pk = (long long)L * MB * 16 * MB * 16;
       if (workspace_bytes < (pk + accum_slab_floats(MB)) * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
@@ -1311,7 +1334,7 @@ int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const v
   if (out_dtype != GPSA_F32 && out_dtype != GPSA_F64) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32) {
-    const int MB = mfma_mb_for(M);
+    const int MB = gram_mb_for(M);
     if (MB && !force_generic()) {
       if (workspace_bytes < gram_ws_bytes(MB, C, L)) return GPSA_EWORKSPACE;
       return gram_mfma_launch(MB, (const float*)alpha, (const float*)g, M, C, L, dOmega, out_dtype,
@@ -1355,7 +1378,7 @@ int gpsa_panel_mm(int dtype, int p_dtype, int transP, const void* P, const void*
   const int tp = transP ? 1 : 0;
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
-    if (MB && !force_generic()) {
+    if (MB && MB <= MB_MAX_STORE && !force_generic()) {
       if (workspace_bytes < (long long)MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
       int rc = pack_any(p_dtype, P, M, MB, 1, tp, Ppk, st, PACK_KSTEP);

@@ -163,7 +163,8 @@ static inline int whiten_mb_for(int M) {
   if (mb <= 7) return 7;
   if (mb <= 13) return 13;
   if (mb <= 16) return 16;
-  return 0;
+  if (mb <= 24) return 24;  // M <= 384: streamed right-hand side only (the accumulators alone are 8 MB registers;
+  return 0;                 // 32 row tiles do not fit the register file next to the operands)
 }
 
 template <typename TI, typename TO>
@@ -172,6 +173,7 @@ static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long lon
   const unsigned grid = (unsigned)cdiv(C, 64);
   bool stream = q == nullptr || (long long)grid > num_cus();
   if (const char* e = getenv("GPSA_WHITEN_STREAM")) stream = atoi(e) != 0;
+  if (MB > 16) stream = true;
 #define GPSA_WCASE(V)                                                                     \
   case V:                                                                                 \
     if (stream)                                                                           \
@@ -179,16 +181,22 @@ static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long lon
     else                                                                                  \
       whiten_mfma_kernel<V, TI, TO, false><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q); \
     break;
+#define GPSA_WCASE_STREAM(V)                                                              \
+  case V:                                                                                 \
+    whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);    \
+    break;
   switch (MB) {
     GPSA_WCASE(2)
     GPSA_WCASE(4)
     GPSA_WCASE(7)
     GPSA_WCASE(13)
     GPSA_WCASE(16)
+    GPSA_WCASE_STREAM(24)
     default:
       return GPSA_EUNSUPPORTED;
   }
 #undef GPSA_WCASE
+#undef GPSA_WCASE_STREAM
   GPSA_LAUNCH_CHECK();
   return 0;
 }

@@ -219,7 +219,7 @@ def test_chol_flags_indefinite(hip):
 
 
 QF = [(10, 100, 3), (25, 1000, 5), (50, 333, 2), (100, 500, 4), (200, 2100, 7), (256, 300, 2), (16, 64, 1),
-      (300, 130, 2), (200, 50001, 3), (13, 7, 1)]
+      (300, 130, 2), (200, 50001, 3), (13, 7, 1), (380, 1000, 3), (392, 200, 2), (500, 700, 3), (513, 100, 2)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
@@ -310,7 +310,8 @@ def test_quadform_fp64_omega_fp32_alpha(hip, M, C, L):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129), (200, 20001), (100, 17000)])
+@pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129), (200, 20001), (100, 17000),
+                                 (300, 500), (384, 129), (380, 17000)])
 def test_whiten_f64_mfma(hip, out_dtype, M, C):
     """alpha = Kinv Kuf and q = diag(Kuf^T alpha) on the fp64 matrix cores vs a CPU fp64 product."""
     f64 = torch.float64
@@ -332,7 +333,7 @@ def test_whiten_f64_mfma(hip, out_dtype, M, C):
 
 def test_whiten_unsupported_size_is_reported(hip):
     f64 = torch.float64
-    assert hip.whiten(torch.eye(300, dtype=f64, device=DEV), torch.ones(300, 8, dtype=f64, device=DEV), f64) is None
+    assert hip.whiten(torch.eye(400, dtype=f64, device=DEV), torch.ones(400, 8, dtype=f64, device=DEV), f64) is None
 
 
 @pytest.mark.parametrize("C,L", [(100, 5), (4097, 50), (33, 33)])

@@ -112,3 +112,18 @@ if "gemm64" in what:
         A = torch.randn(B, 200, 200, device=dev, dtype=torch.float64)
         print(f"gemm f64 NT batch={B} 200^3: {timeit(lambda: o.gemm(A, A, transB=True)):.1f} us", flush=True)
         print(f"gemm f64 TN batch={B} 200^3: {timeit(lambda: o.gemm(A, A, transA=True)):.1f} us", flush=True)
+if "bigm" in what:  # M beyond 256: MFMA panel variants (24 / 32 row tiles) vs the generic tiled path (GPSA_FORCE_GENERIC=1)
+    for M in (380, 500):
+        C, L = 50000, 8
+        X = torch.randn(M, C, device=dev)
+        A = torch.randn(L, M, M, device=dev, dtype=torch.float64) / M ** 0.5
+        Om = A @ A.transpose(1, 2)
+        g = torch.randn(L, C, device=dev)
+        print(f"M={M} quadform_fwd: {timeit(lambda: o.quadform_fwd(X, Om), n=5, warm=2):.0f} us", flush=True)
+        print(f"M={M} quadform_bwd_alpha: {timeit(lambda: o.quadform_bwd_alpha(X, Om, g), n=5, warm=2):.0f} us", flush=True)
+        P = torch.randn(M, M, device=dev, dtype=torch.float64).tril()
+        print(f"M={M} panel_mm: {timeit(lambda: o.panel_mm(P, X), n=5, warm=2):.0f} us", flush=True)
+        Kinv = spd(1, M)[0]
+        X64 = X[:, :20000].double().contiguous()
+        r = o.whiten(Kinv, X64, torch.float64)
+        print(f"M={M} whiten f64 C=20000: " + ("unsupported" if r is None else f"{timeit(lambda: o.whiten(Kinv, X64, torch.float64), n=5, warm=2):.0f} us"), flush=True)
