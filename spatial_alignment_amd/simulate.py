@@ -60,7 +60,10 @@ def gp_draws(x, n_draws, variance=1.0, lengthscale=1.0, mean=None, jitter=1e-3, 
         x64 = x.to(f64)
         K = rbf_covariance(x64, x64, variance, lengthscale)
         K.diagonal().add_(jitter)
-        L = torch.linalg.cholesky(K)
+        L, info = torch.linalg.cholesky_ex(K)
+        if int(info) != 0:  # smooth kernel, no jitter: numerically semi-definite -> symmetric square root
+            lam, V = torch.linalg.eigh(K)  # (scipy's multivariate_normal.rvs factors through the SVD as well)
+            L = V * lam.clamp_min(0.0).sqrt()
         z = torch.randn(n, n_draws, dtype=f64, device=dev, generator=generator)
         f = L @ z
     elif method == "rff":

@@ -104,6 +104,15 @@ def test_gp_warp_scatters_around_the_mean_function():
     assert not torch.allclose(X[vidx[0]], X[vidx[1]])
 
 
+def test_semidefinite_covariance_is_sampled_through_its_square_root():
+    """lengthscale 5 on a 20 x 20 lattice with no jitter: Cholesky fails in fp64, the draw must not"""
+    Xs = sim.lattice_2d(20, dtype=torch.float64)
+    f = sim.gp_draws(Xs, 3, variance=0.1, lengthscale=5.0, jitter=0.0, method="exact",
+                     generator=torch.Generator().manual_seed(0))
+    assert f.shape == (400, 3) and torch.isfinite(f).all()
+    assert 0.05 < float(f.std()) < 0.8
+
+
 def test_large_lattice_uses_features_and_is_fast():
     X, Y, nsl, _ = sim.generate_twod_data(2, 8, 80, seed=0, n_features=256)  # 6400 points per view > 4096
     assert X.shape == (12800, 2) and Y.shape == (12800, 8) and torch.isfinite(Y).all()
