@@ -37,6 +37,17 @@ __global__ void colscale_kernel(const T* __restrict__ X, const T* __restrict__ g
   for (int m = blockIdx.y; m < M; m += gridDim.y) out[(long long)m * C + c] = X[(long long)m * C + c] * gv;
 }
 
+// out[b][m,c] = X[m,c] * g[b][c]   (grid.z = b)
+template <typename T>
+__global__ void colscale_batched_kernel(const T* __restrict__ X, const T* __restrict__ g, int M, long long C,
+                                        T* __restrict__ out) {
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= C) return;
+  const T gv = g[(long long)blockIdx.z * C + c];
+  T* o = out + (long long)blockIdx.z * M * C;
+  for (int m = blockIdx.y; m < M; m += gridDim.y) o[(long long)m * C + c] = X[(long long)m * C + c] * gv;
+}
+
 // out[m,c] = Y[m,c] + s * d[c] * X[m,c]
 template <typename T>
 __global__ void col_axpy_kernel(const T* __restrict__ Y, const T* __restrict__ X,
@@ -162,18 +173,23 @@ static inline int gram_splitk(long long C, int M) {
 template <typename T>
 int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, int L, T* dOmega,
                                void* ws, long long ws_bytes, hipStream_t st) {
+  // up to 4 outputs per pass: one scaling launch and one batched split-K product for the group
   const int sk = gram_splitk(C, M);
   const long long tmp_b = (long long)M * C * (long long)sizeof(T);
   const long long part_b = (sk > 1) ? (long long)sk * M * M * (long long)sizeof(T) : 0;
-  if (ws_bytes < tmp_b + part_b) return GPSA_EWORKSPACE;
-  T* tmp = reinterpret_cast<T*>(ws);
-  void* part = reinterpret_cast<char*>(ws) + tmp_b;
-  for (int l = 0; l < L; ++l) {
-    dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64));
-    colscale_kernel<T><<<grid, 256, 0, st>>>(alpha, g + (long long)l * C, M, C, tmp);
+  long long nbmax = ws_bytes / (tmp_b + part_b);
+  if (nbmax < 1) return GPSA_EWORKSPACE;
+  if (nbmax > 4) nbmax = 4;
+  for (int l0 = 0; l0 < L; l0 += (int)nbmax) {
+    const int nb = (int)((L - l0 < nbmax) ? L - l0 : nbmax);
+    T* tmp = reinterpret_cast<T*>(ws);
+    void* part = reinterpret_cast<char*>(ws) + (long long)nb * tmp_b;
+    dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64), (unsigned)nb);
+    colscale_batched_kernel<T><<<grid, 256, 0, st>>>(alpha, g + (long long)l0 * C, M, C, tmp);
     GPSA_LAUNCH_CHECK();
-    int rc = gemm_launch<T>(0, 1, M, M, C, 1.0, tmp, C, 0, alpha, C, 0, 0.0,
-                            dOmega + (long long)l * M * M, M, 0, 1, sk, part, part_b, st);
+    int rc = gemm_launch<T>(0, 1, M, M, C, 1.0, tmp, C, (long long)M * C, alpha, C, 0, 0.0,
+                            dOmega + (long long)l0 * M * M, M, (long long)M * M, nb, sk, part,
+                            (long long)nb * part_b, st);
     if (rc) return rc;
   }
   return 0;
@@ -922,8 +938,19 @@ __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP
   const int l = blockIdx.z;
   if (i >= M || jj > i) return;
   const float* p = part + (long long)l * nsplit * MP * MP + (long long)i * MP + jj;
-  TO s = TO(0);  // fp64 output: the partials are widened before they are added
-  for (int sp = 0; sp < nsplit; ++sp) s += (TO)p[(long long)sp * MP * MP];
+  // fp64 output: the partials are widened before they are added; four independent running sums (the
+  // partials of an element are MP*MP apart: one chain is one load latency per partial)
+  const long long mm = (long long)MP * MP;
+  TO s = TO(0), s1 = TO(0), s2 = TO(0), s3 = TO(0);
+  int sp = 0;
+  for (; sp + 3 < nsplit; sp += 4) {
+    s += (TO)p[sp * mm];
+    s1 += (TO)p[(sp + 1) * mm];
+    s2 += (TO)p[(sp + 2) * mm];
+    s3 += (TO)p[(sp + 3) * mm];
+  }
+  for (; sp < nsplit; ++sp) s += (TO)p[sp * mm];
+  s = (s + s1) + (s2 + s3);
   TO* o = out + (long long)l * M * M;
   o[(long long)i * M + jj] = s;
   if (jj != i) o[(long long)jj * M + i] = s;
@@ -1226,7 +1253,7 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   }
   int lc = L < 4 ? L : 4;
   long long generic = (long long)M * C * sz * lc;                         // fwd: lc slabs of T
-  long long bo = (long long)M * C * sz + (long long)gpsa::gram_splitk(C, M) * M * M * sz;  // bwd_omega
+  long long bo = ((long long)M * C * sz + (long long)gpsa::gram_splitk(C, M) * M * M * sz) * lc;  // bwd_omega
   long long r = generic > bo ? generic : bo;
   r += (long long)L * M * M * sz + 256;  // converted copy of Omega (generic paths, other precision)
   return (r > mfma ? r : mfma) + 256;
