@@ -1,0 +1,82 @@
+"""GPU: the row-sharded step through the REAL HIP path (two processes sharing cuda:0, gradients all-reduced
+over gloo - RCCL refuses two ranks on one device) equals the single-process step on the full problem."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(dev):
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+    dd = make_grid_problem(side=20, n_views=2, n_outputs=6)
+    model = make_model(dd, m=25, device=dev)
+    dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
+              "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
+    return dd, model
+
+
+def _noise():
+    gen = torch.Generator().manual_seed(11)
+    return [torch.randn(3, 400, 2, generator=gen) for _ in range(2)], torch.randn(3, 800, 6, generator=gen)
+
+
+def _grads(model, dd, eG, eF, kl_scale):
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    model.kl_scale = kl_scale
+    model.inject_noise(eG, {"expression": eF})
+    model.zero_grad()
+    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=3)
+    loss = model.loss_fn(dd, out[3])
+    loss.backward()
+    return loss.detach()
+
+
+def _worker(rank, world, port, q):
+    import __graft_entry__ as ge
+    from spatial_alignment_amd.parallel import GradAllReducer, shard_data_dict, shard_rows
+
+    ge.build()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    dd, model = _problem(dev)
+    eG, eF = _noise()
+    sdd = shard_data_dict(dd, rank, world)
+    lo, hi = shard_rows(400, rank, world)
+    rows = torch.cat([torch.arange(lo, hi), 400 + torch.arange(lo, hi)])
+    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0 / world)
+    GradAllReducer(model.parameters())()
+    dist.all_reduce(loss)
+    if rank == 0:
+        q.put((float(loss), {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_hip_step_equals_full_hip_step():
+    import __graft_entry__ as ge
+
+    ge.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    loss2, g2 = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    dd, model = _problem(torch.device("cuda:0"))
+    eG, eF = _noise()
+    loss1 = _grads(model, dd, eG, eF, 1.0)
+    assert abs(float(loss1) - loss2) <= 1e-5 * abs(float(loss1))
+    for k, p in model.named_parameters():
+        a, b = p.grad.detach().cpu().numpy(), g2[k]
+        assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
