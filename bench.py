@@ -122,9 +122,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # diagnostics for a 1-GPU box: GPSA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and the collectives
+    # on gloo (RCCL refuses two ranks per device), which exercises this file's N > 1 path end to end
+    one_dev = os.environ.get("GPSA_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     assert world == args.gpus or world == 1, (world, args.gpus)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
