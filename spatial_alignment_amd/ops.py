@@ -35,6 +35,7 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._scratch = {}
+        self._wsq_cache = {}
         if not torch.cuda.is_available():
             raise _lib.GpsaHipError("no HIP device visible: the GPSA hot path has no CPU fallback")
 
@@ -45,6 +46,15 @@ class HipOps:
     def _stream(t):
         """raw hipStream_t of the current stream of t's device"""
         return _raw_stream(t.get_device())
+
+    def _wsq(self, name, *args):
+        """memoised *_workspace(...) query: the sizes depend on the arguments only, and a step asks the same
+        two dozen questions every time (an FFI call each otherwise)"""
+        key = (name,) + args
+        v = self._wsq_cache.get(key)
+        if v is None:
+            v = self._wsq_cache[key] = int(getattr(self.lib, name)(*args))
+        return v
 
     def _ws(self, nbytes, like):
         """scratch of >= nbytes for ONE launch sequence on the current stream.  One buffer per
@@ -93,7 +103,7 @@ class HipOps:
         dZ = torch.empty_like(Z)
         dX = torch.empty_like(X) if (need_dX and not same) else None
         dpar = torch.empty(2, dtype=Z.dtype, device=Z.device)
-        wsb = self.lib.gpsa_kmat_bwd_workspace(_dt(Kbar), M, Cn, D)
+        wsb = self._wsq("gpsa_kmat_bwd_workspace", _dt(Kbar), M, Cn, D)
         ws = self._ws(wsb, Z)
         rc = self.lib.gpsa_kmat_bwd(_dt(Kbar), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u),
                                     _p(var_u), _p(Kbar), int(bool(same)), _p(dZ), _p(dX), _p(dpar), _p(ws),
@@ -122,7 +132,7 @@ class HipOps:
         sA = A.stride(0) if A.dim() == 3 else 0
         sB = B.stride(0) if B.dim() == 3 else 0
         sC = out.stride(0) if out.dim() == 3 else 0
-        wsb = self.lib.gpsa_gemm_workspace(_dt(A), m, n, nb, splitk)
+        wsb = self._wsq("gpsa_gemm_workspace", _dt(A), m, n, nb, splitk) if splitk > 1 else 0
         ws = self._ws(wsb, A) if splitk > 1 else None
         rc = self.lib.gpsa_gemm(_dt(A), int(transA), int(transB), m, n, k, float(alpha), _p(A),
                                 A.stride(-2), sA, _p(B), B.stride(-2), sB, float(beta), _p(out),
@@ -188,7 +198,7 @@ class HipOps:
         logdet = torch.empty(Bn, dtype=torch.float64, device=A.device)
         info = torch.empty(Bn, dtype=torch.int32, device=A.device)
         if M > 256:
-            ws = self._ws(self.lib.gpsa_chol_inv_blocked_workspace(M, Bn), A)
+            ws = self._ws(self._wsq("gpsa_chol_inv_blocked_workspace", M, Bn), A)
             rc = self.lib.gpsa_chol_inv_blocked_f64(_p(A), _p(Linv), M, Bn, _p(logdet), _p(info), _p(ws),
                                                     ws.numel(), self._stream(A))
             _lib.check(rc, "gpsa_chol_inv_blocked_f64")
@@ -200,7 +210,7 @@ class HipOps:
     # ------------------------------------------------------------------ quadratic forms
     def _qf_ws(self, alpha, L):
         M, Cn = alpha.shape
-        return self._ws(self.lib.gpsa_quadform_workspace(_dt(alpha), M, Cn, L), alpha)
+        return self._ws(self._wsq("gpsa_quadform_workspace", _dt(alpha), M, Cn, L), alpha)
 
     def quadform_fwd(self, alpha, Omega):
         alpha, Omega = self._c(alpha), self._c(Omega)
@@ -279,7 +289,7 @@ class HipOps:
         Kinv, Kuf = self._c(Kinv), self._c(Kuf)
         assert Kinv.dtype == torch.float64
         M, Cn = Kuf.shape
-        nbytes = self.lib.gpsa_whiten_workspace(M)
+        nbytes = self._wsq("gpsa_whiten_workspace", M)
         if nbytes == 0:
             return None
         alpha = torch.empty(M, Cn, dtype=out_dtype, device=Kuf.device)
