@@ -127,3 +127,18 @@ if "bigm" in what:  # M beyond 256: MFMA panel variants (24 / 32 row tiles) vs t
         X64 = X[:, :20000].double().contiguous()
         r = o.whiten(Kinv, X64, torch.float64)
         print(f"M={M} whiten f64 C=20000: " + ("unsupported" if r is None else f"{timeit(lambda: o.whiten(Kinv, X64, torch.float64), n=5, warm=2):.0f} us"), flush=True)
+if "lib64" in what:  # the library's batched fp64 GEMM (rocBLAS / hipBLASLt through torch) on the M x M x M shapes
+    for B in (4, 50, 57):
+        A = torch.randn(B, 200, 200, device=dev, dtype=torch.float64)
+        print(f"ours  f64 NT batch={B} 200^3: {timeit(lambda: o.gemm(A, A, transB=True)):.1f} us", flush=True)
+        print(f"torch f64 NT batch={B} 200^3: {timeit(lambda: torch.bmm(A, A.transpose(1, 2))):.1f} us", flush=True)
+        print(f"ours  f64 TN batch={B} 200^3: {timeit(lambda: o.gemm(A, A, transA=True)):.1f} us", flush=True)
+        print(f"torch f64 TN batch={B} 200^3: {timeit(lambda: torch.bmm(A.transpose(1, 2), A)):.1f} us", flush=True)
+    for C in (1250, 10000):
+        X = torch.randn(200, C, device=dev, dtype=torch.float64)
+        K = torch.randn(200, 200, device=dev, dtype=torch.float64)
+        sk = o.pick_splitk(C, 200, 200)
+        print(f"ours  f64 NT 200x{C}x200 splitk={sk}: {timeit(lambda: o.gemm(X, X, transB=True, splitk=sk)):.1f} us", flush=True)
+        print(f"torch f64 NT 200x{C}x200: {timeit(lambda: X @ X.t()):.1f} us", flush=True)
+        print(f"ours  f64 NN 200x200x{C}: {timeit(lambda: o.gemm(K, X)):.1f} us", flush=True)
+        print(f"torch f64 NN 200x200x{C}: {timeit(lambda: K @ X):.1f} us", flush=True)
