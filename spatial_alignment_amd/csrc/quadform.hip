@@ -1117,9 +1117,14 @@ static inline int gram_nsplit(long long C, int L) {
   const int cus = num_cus();
   static const int forced = [] { const char* e = getenv("GPSA_GRAM_NSPLIT"); return e ? atoi(e) : 0; }();
   if (forced > 0) return (int)(forced < nch ? forced : nch);
-  long long ns = cus / (L > 0 ? L : 1);
-  if (ns > nch / 4) ns = nch / 4;  // at least 4 K chunks per workgroup
-  if (ns > 64) ns = 64;
+  // W workgroups per output group fill the chip once; each takes c = ceil(nch / W) chunks.  (Few outputs -
+  // the warp GPs' L = 2 - used to be held to >= 4 chunks per workgroup, i.e. 39 workgroups on 256 CUs at
+  // C = 10k: 75 us; one chunk each, 157 workgroups: 44 us including the larger reduce.)
+  long long W = cus / (L > 0 ? L : 1);
+  if (W < 1) W = 1;
+  const long long c = cdiv(nch, W);
+  long long ns = cdiv(nch, c);
+  if (ns > 256) ns = 256;
   if (ns < 1) ns = 1;
   return (int)ns;
 }

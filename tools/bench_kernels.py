@@ -142,3 +142,8 @@ if "lib64" in what:  # the library's batched fp64 GEMM (rocBLAS / hipBLASLt thro
         print(f"torch f64 NT 200x{C}x200: {timeit(lambda: X @ X.t()):.1f} us", flush=True)
         print(f"ours  f64 NN 200x200x{C}: {timeit(lambda: o.gemm(K, X)):.1f} us", flush=True)
         print(f"torch f64 NN 200x200x{C}: {timeit(lambda: K @ X):.1f} us", flush=True)
+if "gramw" in what:  # the warp layer's Gram shape: L = D = 2 outputs, one view's columns
+    for C in (10000, 20000, 4096):
+        a = torch.randn(200, C, device=dev)
+        g = torch.randn(2, C, device=dev)
+        print(f"quadform_bwd_omega L=2 C={C}: {timeit(lambda: o.quadform_bwd_omega(a, g, out_dtype=torch.float64), n=20, warm=3):.1f} us", flush=True)
