@@ -105,9 +105,11 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
 /* The same form for a layer with few outputs (the warp GP: L = D <= 3), keeping the products
  * W[l] = Omega[l] alpha ([L,M,C], dtype) it is made of, so that its backward is one streaming pass
  *   dalpha[:,c] = 2 * sum_l g[l,c] * W[l][:,c]
- * instead of L more M x M x C products.  Omega in dtype.  (vgpsa.py:192-196 and its autograd.) */
+ * instead of L more M x M x C products.  Omega in dtype.  (vgpsa.py:192-196 and its autograd.)
+ * dcT [M,L] / meanT [L,C] (both or neither NULL): the layer's mean term meanT[l,c] = sum_m dcT[m,l] alpha[m,c]
+ * (vgpsa.py:182-184) in the same pass over alpha that closes the form. */
 int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
-                           void* v, void* W, void* stream);
+                           void* v, void* W, const void* dcT, void* meanT, void* stream);
 int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
                                  void* dalpha, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype

@@ -102,14 +102,51 @@ __global__ void col_wsum_kernel(const T* __restrict__ W, const T* __restrict__ g
   }
 }
 
+// coldot for output b plus, in the same pass over X, mean[b,c] = sum_m A[m,b] X[m,c]   (A [M,L])
+template <typename T>
+__global__ void __launch_bounds__(256)
+coldot_mean_kernel(const T* __restrict__ X, const T* __restrict__ Tm, const T* __restrict__ A, int M,
+                   long long C, int L, T* __restrict__ v, T* __restrict__ mean) {
+  __shared__ T red[2][4][64];
+  const int lane = threadIdx.x & 63, qr = threadIdx.x >> 6, b = blockIdx.y;
+  const long long c = blockIdx.x * 64LL + lane;
+  const T* t = Tm + (long long)b * M * C;
+  T s0 = T(0), s1 = T(0), m0 = T(0), m1 = T(0);
+  if (c < C) {
+    int m = qr;
+    for (; m + 4 < M; m += 8) {
+      const T x0 = X[(long long)m * C + c], x1 = X[(long long)(m + 4) * C + c];
+      s0 += x0 * t[(long long)m * C + c];
+      s1 += x1 * t[(long long)(m + 4) * C + c];
+      m0 += x0 * A[(long long)m * L + b];
+      m1 += x1 * A[(long long)(m + 4) * L + b];
+    }
+    for (; m < M; m += 4) {
+      const T x0 = X[(long long)m * C + c];
+      s0 += x0 * t[(long long)m * C + c];
+      m0 += x0 * A[(long long)m * L + b];
+    }
+  }
+  red[0][qr][lane] = s0 + s1;
+  red[1][qr][lane] = m0 + m1;
+  __syncthreads();
+  if (qr == 0 && c < C) {
+    v[(long long)b * C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    mean[(long long)b * C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  }
+}
+
 template <typename T>
 int quadform_fwd_keep(const T* alpha, const T* Omega, int M, long long C, int L, T* v, T* W,
-                      hipStream_t st) {
+                      const T* dcT, T* meanT, hipStream_t st) {
   int rc = gemm_launch<T>(0, 0, M, (int)C, M, 1.0, Omega, M, (long long)M * M, alpha, C, 0, 0.0, W, C,
                           (long long)M * C, L, 1, nullptr, 0, st);
   if (rc) return rc;
   dim3 grid((unsigned)cdiv(C, 64), (unsigned)L);
-  coldot_kernel<T><<<grid, 256, 0, st>>>(alpha, W, M, C, v, C);
+  if (dcT != nullptr)
+    coldot_mean_kernel<T><<<grid, 256, 0, st>>>(alpha, W, dcT, M, C, L, v, meanT);
+  else
+    coldot_kernel<T><<<grid, 256, 0, st>>>(alpha, W, M, C, v, C);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -1334,16 +1371,17 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
 }
 
 int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
-                           void* v, void* W, void* stream) {
+                           void* v, void* W, const void* dcT, void* meanT, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1 || C > 0x7fffffffLL) return GPSA_EINVAL;
+  if ((dcT == nullptr) != (meanT == nullptr)) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32)
     return quadform_fwd_keep<float>((const float*)alpha, (const float*)Omega, M, C, L, (float*)v,
-                                    (float*)W, st);
+                                    (float*)W, (const float*)dcT, (float*)meanT, st);
   if (dtype == GPSA_F64)
     return quadform_fwd_keep<double>((const double*)alpha, (const double*)Omega, M, C, L, (double*)v,
-                                     (double*)W, st);
+                                     (double*)W, (const double*)dcT, (double*)meanT, st);
   return GPSA_EINVAL;
 }
 

@@ -321,10 +321,9 @@ class SGPWarpLayerFn(torch.autograd.Function):
         del Kuf
         dcT = dc.detach().to(f64).contiguous()
         Om = Omega.detach()
-        meanT = o.gemm(dcT, alpha, transA=True)
         # D <= 3 outputs: keep W_j = Omega_j alpha (D x M x n fp64) for the backward instead of
-        # recomputing D products there
-        v, W = o.quadform_fwd_keep(alpha, Om)
+        # recomputing D products there; the mean term rides on the pass over alpha that closes the form
+        v, W, meanT = o.quadform_fwd_keep(alpha, Om, dcT)
         sl, ic = slopes.detach(), intercept.detach()
         Gmean, Gs, bad = o.warp_sample_fwd(meanT, v, q, vars_, Xs, sl, ic, eps)
         ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_, eps, W)

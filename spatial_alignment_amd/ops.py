@@ -234,17 +234,23 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_bwd_alpha")
         return out
 
-    def quadform_fwd_keep(self, alpha, Omega):
-        """(v, W): the form and the products W[l] = Omega[l] alpha it is made of (few-output layers)"""
+    def quadform_fwd_keep(self, alpha, Omega, dcT=None):
+        """(v, W[, meanT]): the form, the products W[l] = Omega[l] alpha it is made of (few-output layers)
+        and, with ``dcT`` [M,L], the mean term meanT = dcT^T alpha from the same pass over alpha"""
         alpha, Omega = self._c(alpha), self._c(Omega.to(alpha.dtype))
         M, Cn = alpha.shape
         L = Omega.shape[0]
         v = torch.empty(L, Cn, dtype=alpha.dtype, device=alpha.device)
         W = torch.empty(L, M, Cn, dtype=alpha.dtype, device=alpha.device)
+        meanT = None
+        if dcT is not None:
+            dcT = self._c(dcT.to(alpha.dtype))
+            assert dcT.shape == (M, L)
+            meanT = torch.empty(L, Cn, dtype=alpha.dtype, device=alpha.device)
         rc = self.lib.gpsa_quadform_fwd_keep(_dt(alpha), _p(alpha), _p(Omega), M, Cn, L, _p(v), _p(W),
-                                             self._stream(alpha))
+                                             _p(dcT), _p(meanT), self._stream(alpha))
         _lib.check(rc, "gpsa_quadform_fwd_keep")
-        return v, W
+        return (v, W) if dcT is None else (v, W, meanT)
 
     def quadform_bwd_alpha_kept(self, W, g):
         W, g = self._c(W), self._c(g)

@@ -96,9 +96,10 @@ class FakeOps:
     def quadform_bwd_alpha(self, alpha, Omega, g):
         return 2.0 * torch.einsum("lc,lmk,kc->mc", g, Omega.to(alpha.dtype), alpha)
 
-    def quadform_fwd_keep(self, alpha, Omega):
+    def quadform_fwd_keep(self, alpha, Omega, dcT=None):
         W = torch.einsum("lmk,kc->lmc", Omega.to(alpha.dtype), alpha)
-        return torch.einsum("mc,lmc->lc", alpha, W), W
+        v = torch.einsum("mc,lmc->lc", alpha, W)
+        return (v, W) if dcT is None else (v, W, dcT.to(alpha.dtype).t() @ alpha)
 
     def quadform_bwd_alpha_kept(self, W, g):
         return 2.0 * torch.einsum("lc,lmc->mc", g, W)

@@ -103,7 +103,7 @@ if "splitk" in what:
     for dt in (torch.float64, torch.float32):
         for K in (10000, 100000, 1250):
             X = torch.randn(200, K, device=dev, dtype=dt)
-            for sk in (4, 8, 16, 32, 64):
+            for sk in (4, 8, 16, 32, 64, 128, 256):
                 if K // sk < 64:
                     continue
                 print(f"{dt} NT 200x{K}x200 splitk={sk}: {timeit(lambda: o.gemm(X, X, transB=True, splitk=sk), n=20):.1f} us", flush=True)
