@@ -110,8 +110,9 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
  * (vgpsa.py:182-184) in the same pass over alpha that closes the form. */
 int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int M, long long C, int L,
                            void* v, void* W, const void* dcT, void* meanT, void* stream);
+/* dcT [M,L] / dmeanT [L,C] (both or neither NULL): adds the mean term's share dcT dmeanT to dalpha. */
 int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
-                                 void* dalpha, void* stream);
+                                 const void* dcT, const void* dmeanT, void* dalpha, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
  * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */

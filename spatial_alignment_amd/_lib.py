@@ -33,7 +33,7 @@ SIGNATURES = {
     "gpsa_quadform_fwd": (_i, [_i, _i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_bwd_alpha": (_i, [_i, _i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_fwd_keep": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp]),
-    "gpsa_quadform_bwd_alpha_kept": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp]),
+    "gpsa_quadform_bwd_alpha_kept": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     "gpsa_quadform_bwd_omega": (_i, [_i, _i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
     "gpsa_whiten_workspace": (_ll, [_i]),
     "gpsa_whiten_f64": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),

@@ -89,16 +89,20 @@ coldot_kernel(const T* __restrict__ X, const T* __restrict__ Tm, int M, long lon
   if (qr == 0 && c < C) v[(long long)blockIdx.y * vstride + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
-// out[m,c] = 2 sum_l g[l,c] W[l][m,c]
+// out[m,c] = 2 sum_l g[l,c] W[l][m,c]  (+ sum_l A[m,l] dm[l,c] when A is given: the mean term's share)
 template <typename T>
 __global__ void col_wsum_kernel(const T* __restrict__ W, const T* __restrict__ g, int M, long long C,
-                                int L, T* __restrict__ out) {
+                                int L, const T* __restrict__ A, const T* __restrict__ dm,
+                                T* __restrict__ out) {
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   if (c >= C) return;
   for (int m = blockIdx.y; m < M; m += gridDim.y) {
-    T s = T(0);
-    for (int l = 0; l < L; ++l) s += g[(long long)l * C + c] * W[((long long)l * M + m) * C + c];
-    out[(long long)m * C + c] = T(2) * s;
+    T s = T(0), t = T(0);
+    for (int l = 0; l < L; ++l) {
+      s += g[(long long)l * C + c] * W[((long long)l * M + m) * C + c];
+      if (A != nullptr) t += A[(long long)m * L + l] * dm[(long long)l * C + c];
+    }
+    out[(long long)m * C + c] = T(2) * s + t;
   }
 }
 
@@ -152,9 +156,10 @@ int quadform_fwd_keep(const T* alpha, const T* Omega, int M, long long C, int L,
 }
 
 template <typename T>
-int quadform_bwd_alpha_kept(const T* W, const T* g, int M, long long C, int L, T* dalpha, hipStream_t st) {
+int quadform_bwd_alpha_kept(const T* W, const T* g, int M, long long C, int L, const T* dcT, const T* dmeanT,
+                            T* dalpha, hipStream_t st) {
   dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64));
-  col_wsum_kernel<T><<<grid, 256, 0, st>>>(W, g, M, C, L, dalpha);
+  col_wsum_kernel<T><<<grid, 256, 0, st>>>(W, g, M, C, L, dcT, dmeanT, dalpha);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -1386,14 +1391,17 @@ int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int 
 }
 
 int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
-                                 void* dalpha, void* stream) {
+                                 const void* dcT, const void* dmeanT, void* dalpha, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1) return GPSA_EINVAL;
+  if ((dcT == nullptr) != (dmeanT == nullptr)) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32)
-    return quadform_bwd_alpha_kept<float>((const float*)W, (const float*)g, M, C, L, (float*)dalpha, st);
+    return quadform_bwd_alpha_kept<float>((const float*)W, (const float*)g, M, C, L, (const float*)dcT,
+                                          (const float*)dmeanT, (float*)dalpha, st);
   if (dtype == GPSA_F64)
-    return quadform_bwd_alpha_kept<double>((const double*)W, (const double*)g, M, C, L, (double*)dalpha, st);
+    return quadform_bwd_alpha_kept<double>((const double*)W, (const double*)g, M, C, L, (const double*)dcT,
+                                           (const double*)dmeanT, (double*)dalpha, st);
   return GPSA_EINVAL;
 }
 

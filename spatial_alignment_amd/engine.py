@@ -182,9 +182,11 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
     else:
         g = zeros(L, Cn) if g is None else g.to(T).contiguous()
         qbar = zeros(Cn) if qbar is None else qbar.to(T).contiguous()
-    # W: the products Omega_l alpha kept by the forward (few-output layers): one streaming pass
-    abar = o.quadform_bwd_alpha(alpha, Om, g) if W is None else o.quadform_bwd_alpha_kept(W, g)
-    o.gemm(dcT, dmeanT, beta=1.0, out=abar)
+    if W is None:
+        abar = o.quadform_bwd_alpha(alpha, Om, g)
+        o.gemm(dcT, dmeanT, beta=1.0, out=abar)
+    else:  # the products Omega_l alpha kept by the forward (few-output layers): one streaming pass, the mean
+        abar = o.quadform_bwd_alpha_kept(W, g, dcT, dmeanT)  # term's share dcT dmeanT included
     ddc = o.gemm(alpha, dmeanT, transB=True, splitk=o.pick_splitk(Cn, M, L))
     gamma = _solve_K(o, Linv, Kinv, abar)
     if g_ext is not None and need_dOm and Cn >= 4 * L * M:

@@ -252,11 +252,16 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_fwd_keep")
         return (v, W) if dcT is None else (v, W, meanT)
 
-    def quadform_bwd_alpha_kept(self, W, g):
+    def quadform_bwd_alpha_kept(self, W, g, dcT=None, dmeanT=None):
+        """2 sum_l g_l o W_l  (+ dcT dmeanT, the mean term's share of the alpha-gradient, in the same pass)"""
         W, g = self._c(W), self._c(g)
         L, M, Cn = W.shape
+        if dcT is not None:
+            dcT, dmeanT = self._c(dcT.to(W.dtype)), self._c(dmeanT.to(W.dtype))
+            assert dcT.shape == (M, L) and dmeanT.shape == (L, Cn)
         out = torch.empty(M, Cn, dtype=W.dtype, device=W.device)
-        rc = self.lib.gpsa_quadform_bwd_alpha_kept(_dt(W), _p(W), _p(g), M, Cn, L, _p(out), self._stream(W))
+        rc = self.lib.gpsa_quadform_bwd_alpha_kept(_dt(W), _p(W), _p(g), M, Cn, L, _p(dcT), _p(dmeanT), _p(out),
+                                                   self._stream(W))
         _lib.check(rc, "gpsa_quadform_bwd_alpha_kept")
         return out
 

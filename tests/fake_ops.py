@@ -101,8 +101,9 @@ class FakeOps:
         v = torch.einsum("mc,lmc->lc", alpha, W)
         return (v, W) if dcT is None else (v, W, dcT.to(alpha.dtype).t() @ alpha)
 
-    def quadform_bwd_alpha_kept(self, W, g):
-        return 2.0 * torch.einsum("lc,lmc->mc", g, W)
+    def quadform_bwd_alpha_kept(self, W, g, dcT=None, dmeanT=None):
+        r = 2.0 * torch.einsum("lc,lmc->mc", g, W)
+        return r if dcT is None else r + dcT.to(W.dtype) @ dmeanT.to(W.dtype)
 
     def quadform_bwd_omega(self, alpha, g, out_dtype=None):
         r = torch.einsum("lc,mc,kc->lmk", g, alpha, alpha)

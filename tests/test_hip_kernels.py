@@ -255,7 +255,10 @@ def test_quadform_kept_products(hip, dtype, M, C, L):
     close(v, rv, t)
     close(W, rW, t)
     close(hip.quadform_bwd_alpha_kept(W, g.to(DEV)), FK.quadform_bwd_alpha(al.double(), Om.double(), g.double()), t)
-    dcT = rnd(M, L, dtype=dtype, seed=5)  # with the layer's mean term from the same pass
+    dcT, dm = rnd(M, L, dtype=dtype, seed=5), rnd(L, C, dtype=dtype, seed=6)
+    close(hip.quadform_bwd_alpha_kept(W, g.to(DEV), dcT.to(DEV), dm.to(DEV)),
+          FK.quadform_bwd_alpha(al.double(), Om.double(), g.double()) + dcT.double() @ dm.double(), t)
+    # the forward with the layer's mean term from the same pass
     v2, W2, mean = hip.quadform_fwd_keep(al.to(DEV), Om.to(DEV), dcT.to(DEV))
     assert torch.equal(W2, W)
     close(v2, rv, t)
