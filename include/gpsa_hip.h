@@ -21,7 +21,14 @@
 extern "C" {
 #endif
 
-enum { GPSA_F32 = 0, GPSA_F64 = 1 };
+enum {
+  GPSA_F32 = 0,
+  GPSA_F64 = 1,
+  GPSA_F32_X64 = 2,   /* gpsa_kmat in_dtype only: fp32 Z / hyper-parameters, fp64 X */
+  GPSA_F32_OUT64 = 3, /* gpsa_kmat_bwd in_dtype only: fp32 inputs, fp64 gradients (with dtype = GPSA_F64) */
+  GPSA_F32_ACC64 = 4  /* gpsa_kmat_bwd in_dtype only: fp32 inputs AND an fp32 Kbar, fp64 arithmetic / partial
+                         sums / gradients (with dtype = GPSA_F64) */
+};
 enum { GPSA_K_RBF = 0, GPSA_K_MATERN12 = 1, GPSA_K_MATERN32 = 2 };
 enum { GPSA_EINVAL = -1, GPSA_EWORKSPACE = -2, GPSA_EUNSUPPORTED = -3 };
 
@@ -35,7 +42,9 @@ const char* gpsa_build_arch(void);    /* "gfx950" */
  * as called from gpsa/models/vgpsa.py:314-318, 390-392, 409.
  * Z [M,D], X [C,D], K [M,C]; ls_u / var_u: device scalars (log lengthscale, log variance). D <= 4.
  * dtype = type K is computed and stored in; in_dtype = storage type of Z, X, ls_u, var_u (the fp32
- * parameters are read as they are).  Supported (dtype, in_dtype): (F32,F32), (F64,F64), (F64,F32). */
+ * parameters are read as they are).  Supported (dtype, in_dtype): (F32,F32), (F64,F64), (F64,F32) and
+ * (F64, F32_X64): fp32 Z / hyper-parameters with an fp64 X - the data GP's k(Gtilde, G_samples) on the warp
+ * GP's unrounded draws. */
 int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
               int D, const void* ls_u, const void* var_u, double jitter, void* K, void* stream);
 
@@ -43,7 +52,10 @@ int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const voi
  *   dZ [M,D], dX [C,D] (may be NULL), dparams[2] = {dLoss/d ls_u, dLoss/d var_u}.
  * same != 0: Z and X are the same points (K_uu, C == M): the X-side sums are added into dZ and dX is
  * not written.  (autograd of util.py:8-66 in the reference).  Deterministic: per-workgroup partial sums
- * (in dtype) in the workspace, then ONE second launch that adds them in a fixed order. */
+ * (in dtype) in the workspace, then ONE second launch that adds them in a fixed order.
+ * in_dtype = GPSA_F32_OUT64 (dtype GPSA_F64): fp32 inputs, dZ / dX / dparams stored as fp64 - the data GP's
+ * backward, whose sigma^2 and coordinate gradients are differences of large terms; GPSA_F32_ACC64: the
+ * same with Kbar itself stored as fp32 (the data GP's gradient panel). */
 long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D);
 int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const void* X, long long C,
                   int D, const void* ls_u, const void* var_u, const void* Kbar, int same, void* dZ,
@@ -157,15 +169,19 @@ int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, 
  *   var = exp(var_u) - q[c] + v[j,c] + 2e-5 ; Gmean[c,j] = (X[c,:] slopes)[j] + intercept[j] + meanT[j,c] ;
  *   Gs[s,c,j] = Gmean[c,j] + var * eps[s,c,j].
  * X [n,D], slopes [D,D], intercept [D], var_u: fp32 as stored.  bad[ceil(n/256)]: per-block flags, 1 if
- * any var <= 0 or NaN (the reference's Normal(...) argument validation raises ValueError there). */
+ * any var <= 0 or NaN (the reference's Normal(...) argument validation raises ValueError there).
+ * Gs64 [S,n,D] (may be NULL): the same draws before they are rounded to the fp32 API tensor; the data GP's
+ * covariance k(Gtilde, G) (vgpsa.py:409) is evaluated on these, as the reference's fp64 run does. */
 int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const float* var_u,
                          const float* X, const float* slopes, const float* intercept,
                          const float* eps, long long n, int D, int S, float* Gmean, float* Gs,
-                         int* bad, void* stream);
-/* given dGmean [n,D] (may be NULL), dGs [S,n,D]:  dmeanT[j,c], g[j,c] = sum_s dGs*eps, qbar[c],
+                         double* Gs64, int* bad, void* stream);
+/* given dGmean [n,D] (may be NULL) and dGs [S,n,D] as the sum of an fp32 part dGs and an fp64 part dGs64
+ * (either may be NULL: the gradient wrt the fp32 API tensor and wrt its unrounded copy Gs64):
+ *   dmeanT[j,c], g[j,c] = sum_s dGs*eps, qbar[c],
  *   dvar_u, dslopes [D,D], dintercept [D] (overwritten).  workspace >= 8*21*ceil(n/256) bytes */
-int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps, const float* var_u,
-                         const float* X, long long n, int D, int S, double* dmeanT, double* g,
+int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const double* dGs64, const float* eps,
+                         const float* var_u, const float* X, long long n, int D, int S, double* dmeanT, double* g,
                          double* qbar, float* dvar_u, float* dslopes, float* dintercept,
                          void* workspace, long long workspace_bytes, void* stream);
 

@@ -41,8 +41,8 @@ SIGNATURES = {
     "gpsa_col_axpy": (_i, [_i, _vp, _vp, _vp, _d, _i, _ll, _vp, _vp]),
     "gpsa_data_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     "gpsa_data_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
-    "gpsa_warp_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
-    "gpsa_warp_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "gpsa_warp_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gpsa_warp_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _ll, _vp]),
     "gpsa_mean_resid_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
     "gpsa_mean_resid_bwd": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),

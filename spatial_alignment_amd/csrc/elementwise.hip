@@ -130,7 +130,7 @@ warp_sample_fwd_kernel(const double* __restrict__ meanT, const double* __restric
                        const float* __restrict__ X, const float* __restrict__ slopes,
                        const float* __restrict__ intercept, const float* __restrict__ eps,
                        long long n, int D, int S, float* __restrict__ Gmean, float* __restrict__ Gs,
-                       int* __restrict__ bad) {
+                       double* __restrict__ Gs64, int* __restrict__ bad) {
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   int flag = 0;
   if (c < n) {
@@ -149,7 +149,9 @@ warp_sample_fwd_kernel(const double* __restrict__ meanT, const double* __restric
       Gmean[c * D + j] = (float)mu;
       for (int s = 0; s < S; ++s) {
         const long long e = ((long long)s * n + c) * D + j;
-        Gs[e] = (float)(mu + var * (double)eps[e]);  // variance used as the std
+        const double gv = mu + var * (double)eps[e];  // variance used as the std
+        Gs[e] = (float)gv;
+        if (Gs64 != nullptr) Gs64[e] = gv;  // unrounded copy: what the data GP's covariance is built from
       }
     }
   }
@@ -162,7 +164,8 @@ constexpr int WS_NPART = 1 + MAXD * MAXD + MAXD;
 
 __global__ void __launch_bounds__(256)
 warp_sample_bwd_kernel(const float* __restrict__ dGmean, const float* __restrict__ dGs,
-                       const float* __restrict__ eps, const float* __restrict__ X, long long n,
+                       const double* __restrict__ dGs64, const float* __restrict__ eps,
+                       const float* __restrict__ X, long long n,
                        int D, int S, double* __restrict__ dmeanT, double* __restrict__ g,
                        double* __restrict__ qbar, double* __restrict__ part) {
   __shared__ double red[4];
@@ -180,7 +183,8 @@ warp_sample_bwd_kernel(const float* __restrict__ dGmean, const float* __restrict
         double dm = dGmean ? (double)dGmean[c * D + j] : 0.0, gj = 0.0;
         for (int s = 0; s < S; ++s) {
           const long long e = ((long long)s * n + c) * D + j;
-          const double d = (double)dGs[e];
+          // the data GP's gradient arrives along the fp64 copy of the draws, a caller's own along the fp32 one
+          const double d = (dGs ? (double)dGs[e] : 0.0) + (dGs64 ? dGs64[e] : 0.0);
           dm += d;
           gj += d * (double)eps[e];
         }
@@ -424,16 +428,16 @@ int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, 
 int gpsa_warp_sample_fwd(const double* meanT, const double* v, const double* q, const float* var_u,
                          const float* X, const float* slopes, const float* intercept,
                          const float* eps, long long n, int D, int S, float* Gmean, float* Gs,
-                         int* bad, void* stream) {
+                         double* Gs64, int* bad, void* stream) {
   if (n < 1 || D < 1 || D > gpsa::MAXD || S < 0) return GPSA_EINVAL;
   gpsa::warp_sample_fwd_kernel<<<(unsigned)cdiv(n, 256), 256, 0, as_stream(stream)>>>(
-      meanT, v, q, var_u, X, slopes, intercept, eps, n, D, S, Gmean, Gs, bad);
+      meanT, v, q, var_u, X, slopes, intercept, eps, n, D, S, Gmean, Gs, Gs64, bad);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
 
-int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps, const float* var_u,
-                         const float* X, long long n, int D, int S, double* dmeanT, double* g,
+int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const double* dGs64, const float* eps,
+                         const float* var_u, const float* X, long long n, int D, int S, double* dmeanT, double* g,
                          double* qbar, float* dvar_u, float* dslopes, float* dintercept,
                          void* workspace, long long workspace_bytes, void* stream) {
   if (n < 1 || D < 1 || D > gpsa::MAXD || S < 0) return GPSA_EINVAL;
@@ -441,8 +445,8 @@ int gpsa_warp_sample_bwd(const float* dGmean, const float* dGs, const float* eps
   if (workspace_bytes < nb * gpsa::WS_NPART * 8) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* part = (double*)workspace;
-  gpsa::warp_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dGmean, dGs, eps, X, n, D, S, dmeanT, g,
-                                                             qbar, part);
+  gpsa::warp_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dGmean, dGs, dGs64, eps, X, n, D, S, dmeanT,
+                                                             g, qbar, part);
   gpsa::warp_sample_bwd_finish_kernel<<<1, 64, 0, st>>>(part, nb, D, var_u, dvar_u, dslopes, dintercept);
   GPSA_LAUNCH_CHECK();
   return 0;

@@ -48,9 +48,10 @@ constexpr int KM_ROWS = 16;
 
 // TI: storage type of the coordinates and hyper-parameters (the fp32 parameters are read as they are,
 // no cast launches); T: type the covariance is computed and stored in.
-template <typename TI, typename T, int KIND>
+// TX: storage type of X alone (the data GP reads the warp GP's unrounded fp64 draws next to fp32 parameters).
+template <typename TI, typename TX, typename T, int KIND>
 __global__ void __launch_bounds__(256)
-kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long long C, int D,
+kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long long C, int D,
                 const TI* __restrict__ ls_u, const TI* __restrict__ var_u, T jitter,
                 T* __restrict__ K) {
   __shared__ T Zs[KM_ROWS][MAXD];
@@ -89,11 +90,12 @@ constexpr int KB_MAXBX = 1024;  // column-block workgroups per row chunk (beyond
 //   zpart[bx][m*D+d]      dZ contribution of column block bx (rows of chunk by only)
 //   xpart[by][c*D+d]      dX contribution of row chunk by
 //   spart[bx*ny+by][0..1] d ls_u, d var_u
-template <typename TI, typename T, int KIND, int MCH>
+// TK: storage type of Kbar (an fp32 gradient panel can be contracted in fp64: T = double)
+template <typename TI, typename T, int KIND, int MCH, typename TK = T>
 __global__ void __launch_bounds__(256)
 kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long long C, int D,
                 const TI* __restrict__ ls_u, const TI* __restrict__ var_u,
-                const T* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
+                const TK* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
                 T* __restrict__ spart) {
   __shared__ T Zs[MCH][MAXD];
   __shared__ T acc[4][MCH][MAXD];
@@ -124,7 +126,7 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
     for (int r = 0; r < mc; ++r) {
       T k, cd, pl;
       cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
-      T kb = live ? Kbar[(long long)(m0 + r) * C + c] : T(0);
+      T kb = live ? (T)Kbar[(long long)(m0 + r) * C + c] : T(0);
       s_ls += kb * pl;
       s_var += kb * k;
       T wgt = kb * cd;
@@ -210,19 +212,19 @@ kmat_bwd_finish_kernel(const T* __restrict__ zpart, long long nbx, long long nz,
   }
 }
 
-template <typename TI, typename T>
-int kmat_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
+template <typename TI, typename TX, typename T>
+int kmat_launch(int kind, const TI* Z, int M, const TX* X, long long C, int D, const TI* ls_u,
                 const TI* var_u, double jitter, T* K, hipStream_t st) {
   dim3 grid((unsigned)cdiv(C, 256), (unsigned)cdiv(M, KM_ROWS));
   switch (kind) {
     case GPSA_K_RBF:
-      kmat_fwd_kernel<TI, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, TX, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
       break;
     case GPSA_K_MATERN12:
-      kmat_fwd_kernel<TI, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, TX, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
       break;
     case GPSA_K_MATERN32:
-      kmat_fwd_kernel<TI, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, TX, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
       break;
     default:
       return GPSA_EINVAL;
@@ -231,9 +233,10 @@ int kmat_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, c
   return 0;
 }
 
-template <typename TI, typename T>
+// TO: storage type of the gradients (the fp64 backward of the data GP keeps them fp64 from fp32 inputs)
+template <typename TI, typename T, typename TO = TI, typename TK = T>
 int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
-                    const TI* var_u, const T* Kbar, TI* dZ, TI* dX, TI* dparams, int same, void* ws,
+                    const TI* var_u, const TK* Kbar, TO* dZ, TO* dX, TO* dparams, int same, void* ws,
                     long long ws_bytes, hipStream_t st) {
   const int mch = kb_rows(M, C);
   const long long ncb = cdiv(C, 256), nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX, nby = cdiv(M, mch);
@@ -247,11 +250,12 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
   T* xp = (dX || same) ? xpart : nullptr;  // K_uu: the X-side partials are folded into dZ
 #define GPSA_KB_CASE(KIND)                                                                          \
   if (mch == KB_MCHUNK)                                                                             \
-    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, Kbar,  \
-                                                                  zpart, xp, spart);                \
+    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK, TK><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u,    \
+                                                                      Kbar, zpart, xp, spart);      \
   else                                                                                              \
-    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK_SMALL><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u,  \
-                                                                        Kbar, zpart, xp, spart);
+    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK_SMALL, TK><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u,     \
+                                                                            var_u, Kbar, zpart, xp, \
+                                                                            spart);
   switch (kind) {
     case GPSA_K_RBF: GPSA_KB_CASE(GPSA_K_RBF) break;
     case GPSA_K_MATERN12: GPSA_KB_CASE(GPSA_K_MATERN12) break;
@@ -263,7 +267,7 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
   GPSA_LAUNCH_CHECK();
   const bool fold = same != 0;
   if (fold && (nx != nz)) return GPSA_EINVAL;
-  kmat_bwd_finish_kernel<T, TI><<<(unsigned)(cdiv(nz, 16) + cdiv(nx, 64) + 1), 256, 0, st>>>(
+  kmat_bwd_finish_kernel<T, TO><<<(unsigned)(cdiv(nz, 16) + cdiv(nx, 64) + 1), 256, 0, st>>>(
       zpart, nbx, nz, xp, nby, nx, spart, nbx * nby, fold ? 1 : 0, dZ, dX, dparams);
   GPSA_LAUNCH_CHECK();
   return 0;
@@ -278,14 +282,17 @@ int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const voi
   if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32 && in_dtype == GPSA_F32)
-    return gpsa::kmat_launch<float, float>(kind, (const float*)Z, M, (const float*)X, C, D,
+    return gpsa::kmat_launch<float, float, float>(kind, (const float*)Z, M, (const float*)X, C, D,
                                            (const float*)ls_u, (const float*)var_u, jitter, (float*)K, st);
   if (dtype == GPSA_F64 && in_dtype == GPSA_F64)
-    return gpsa::kmat_launch<double, double>(kind, (const double*)Z, M, (const double*)X, C, D,
+    return gpsa::kmat_launch<double, double, double>(kind, (const double*)Z, M, (const double*)X, C, D,
                                              (const double*)ls_u, (const double*)var_u, jitter, (double*)K, st);
   if (dtype == GPSA_F64 && in_dtype == GPSA_F32)
-    return gpsa::kmat_launch<float, double>(kind, (const float*)Z, M, (const float*)X, C, D,
-                                            (const float*)ls_u, (const float*)var_u, jitter, (double*)K, st);
+    return gpsa::kmat_launch<float, float, double>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                                   (const float*)ls_u, (const float*)var_u, jitter, (double*)K, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F32_X64)
+    return gpsa::kmat_launch<float, double, double>(kind, (const float*)Z, M, (const double*)X, C, D,
+                                                    (const float*)ls_u, (const float*)var_u, jitter, (double*)K, st);
   return GPSA_EINVAL;
 }
 
@@ -314,6 +321,15 @@ int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const
                                                 (const float*)ls_u, (const float*)var_u,
                                                 (const double*)Kbar, (float*)dZ, (float*)dX,
                                                 (float*)dparams, same, workspace, workspace_bytes, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F32_OUT64)
+    return gpsa::kmat_bwd_launch<float, double, double>(kind, (const float*)Z, M, (const float*)X, C, D,
+                                                        (const float*)ls_u, (const float*)var_u,
+                                                        (const double*)Kbar, (double*)dZ, (double*)dX,
+                                                        (double*)dparams, same, workspace, workspace_bytes, st);
+  if (dtype == GPSA_F64 && in_dtype == GPSA_F32_ACC64)
+    return gpsa::kmat_bwd_launch<float, double, double, float>(
+        kind, (const float*)Z, M, (const float*)X, C, D, (const float*)ls_u, (const float*)var_u,
+        (const float*)Kbar, (double*)dZ, (double*)dX, (double*)dparams, same, workspace, workspace_bytes, st);
   return GPSA_EINVAL;
 }
 

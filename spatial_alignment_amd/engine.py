@@ -211,7 +211,13 @@ def _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar, need_dOm, g_
     else:
         dOm = o.quadform_bwd_omega(alpha, g) if need_dOm else None
     W = o.col_axpy(gamma, alpha, qbar, 1.0, out=gamma)
-    dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
+    if T == torch.float32:
+        # fp32 layer, few columns (the shortcut above does not pay): the C-long product still has to be
+        # ADDED in fp64 - dK_uu meets dK_uf in the covariance parameters' gradients, where the two cancel to
+        # ~1e-4 of their size (measured at M = 1000: data_kernel_variance 4.9e-2 -> 1.1e-5 off the oracle)
+        dKuu = o.gemm(W.double(), alpha.double(), transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
+    else:
+        dKuu = o.gemm(W, alpha, transB=True, alpha=-1.0, splitk=o.pick_splitk(Cn, M, M))
     dKuf = o.col_axpy(W, alpha, qbar, 1.0, out=W)
     return dKuu, dKuf, ddc, dOm
 
@@ -262,11 +268,13 @@ class SGPDataLayerFn(torch.autograd.Function):
     fp64 covariance + projection, fp32 MFMA contractions, fp32 backward.  Returns F [C, L] fp32."""
 
     @staticmethod
-    def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, eps):
+    def forward(ctx, kind, Z, X, ls_u, var_u, Kuu, dc, Omega, fac, eps, X64=None):
         o = ops()
         f64, T = torch.float64, torch.float32
         Zs, Xs, lss, vars_ = _cov_inputs(Z, X, ls_u, var_u, f64)
-        Kuf = o.kmat(kind, Zs, Xs, lss, vars_, 0.0, dtype=f64)
+        # X64: the warp GP's draws before their rounding to the fp32 API tensor X (same values otherwise):
+        # the covariance is built from those, as in the reference's fp64 run; the backward keeps fp32 X
+        Kuf = o.kmat(kind, Zs, Xs if X64 is None else X64.detach(), lss, vars_, 0.0, dtype=f64)
         alpha, q = _project(o, fac, Kuf, T)
         del Kuf
         dcT = dc.detach().to(T).contiguous()
@@ -281,6 +289,7 @@ class SGPDataLayerFn(torch.autograd.Function):
         ctx.kind = kind
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
                     dc.dtype, Omega.dtype)
+        ctx.via_x64 = X64 is not None and X64.requires_grad
         return F
 
     @staticmethod
@@ -291,19 +300,27 @@ class SGPDataLayerFn(torch.autograd.Function):
         g_ext, dmeanT, dvar_s = o.data_sample_bwd(dF.contiguous(), eps, Sigma, var32)
         dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, None, None,
                                                ctx.needs_input_grad[7], g_ext=g_ext)
-        need_x = ctx.needs_input_grad[2]
-        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, var32, dKuf, need_dX=need_x)
-        dvar = dpar[1:2] + dvar_s  # sigma^2 enters through the covariance and through var = sigma^2 - q + v
+        # the coordinates' gradient goes back to the warp GP along the fp64 tensor when there is one: its
+        # backward amplifies the rounding noise of an fp32 gradient by cond(K_uu) (measured: 1e-4 -> 1e-7 on
+        # the warp GP's parameter gradients at M = 1000)
+        need_x = ctx.needs_input_grad[2] or ctx.via_x64
+        # covariance backward: fp32 panel and inputs as stored, fp64 arithmetic, partial sums and results (the
+        # hyper-parameter and coordinate gradients are sums over M x C terms that cancel against dK_uu's)
+        dZ, dX, dpar = o.kmat_bwd(ctx.kind, Zb, Xb, lsb, var32, dKuf, need_dX=need_x, out_dtype=torch.float64)
+        dvar = dpar[1:2] + dvar_s.double()  # sigma^2 enters the covariance and var = sigma^2 - q + v
+        dX64 = None
+        if ctx.via_x64 and dX is not None:
+            dX64, dX = dX, None
         return (
             None,
             dZ.to(zdt) if ctx.needs_input_grad[1] else None,
-            dX.to(xdt) if (need_x and dX is not None) else None,
+            dX.to(xdt) if (ctx.needs_input_grad[2] and dX is not None) else None,
             dpar[0].to(ldt).reshape(lshape) if ctx.needs_input_grad[3] else None,
             dvar.to(vdt).reshape(vshape) if ctx.needs_input_grad[4] else None,
             dKuu.to(kdt),
             ddc.to(ddt),
             dOm.to(odt) if dOm is not None else None,
-            None, None,
+            None, None, dX64,
         )
 
 
@@ -327,23 +344,23 @@ class SGPWarpLayerFn(torch.autograd.Function):
         # recomputing D products there; the mean term rides on the pass over alpha that closes the form
         v, W, meanT = o.quadform_fwd_keep(alpha, Om, dcT)
         sl, ic = slopes.detach(), intercept.detach()
-        Gmean, Gs, bad = o.warp_sample_fwd(meanT, v, q, vars_, Xs, sl, ic, eps)
+        Gmean, Gs, bad, Gs64 = o.warp_sample_fwd(meanT, v, q, vars_, Xs, sl, ic, eps)
         ctx.save_for_backward(alpha, dcT, Om, fac.Linv, fac.Kinv, Zs, Xs, lss, vars_, eps, W)
         ctx.kind = kind
         ctx.meta = (Z.dtype, X.dtype, ls_u.dtype, ls_u.shape, var_u.dtype, var_u.shape, Kuu.dtype,
                     dc.dtype, Omega.dtype, slopes.dtype, intercept.dtype)
         ctx.mark_non_differentiable(bad)
         ctx.set_materialize_grads(False)  # G_mean usually takes no part in the loss: no zero-fill launches
-        return Gmean, Gs, bad
+        return Gmean, Gs, bad, Gs64
 
     @staticmethod
-    def backward(ctx, dGmean, dGs, _dbad):
+    def backward(ctx, dGmean, dGs, _dbad, dGs64):
         o = ops()
         alpha, dcT, Om, Linv, Kinv, Zb, Xb, lsb, varb, eps, W = ctx.saved_tensors
         zdt, xdt, ldt, lshape, vdt, vshape, kdt, ddt, odt, sdt, idt = ctx.meta
-        if dGs is None:
-            dGs = torch.zeros(eps.shape, dtype=torch.float32, device=eps.device)
-        dmeanT, g, qbar, dvar_s, dslopes, dint = o.warp_sample_bwd(dGmean, dGs.float(), eps, varb, Xb)
+        # the draws feed the data GP through their fp64 copy (gradient dGs64) and a caller's own losses
+        # through the fp32 API tensor (dGs): the sampler's backward adds the two
+        dmeanT, g, qbar, dvar_s, dslopes, dint = o.warp_sample_bwd(dGmean, dGs, eps, varb, Xb, dGs64)
         dKuu, dKuf, ddc, dOm = _layer_backward(o, alpha, dcT, Om, Linv, Kinv, dmeanT, g, qbar,
                                                ctx.needs_input_grad[7], W=W)
         need_x = ctx.needs_input_grad[2]
@@ -402,21 +419,19 @@ class WarpSampleFn(torch.autograd.Function):
     def forward(ctx, meanT, v, q, var_u, X, slopes, intercept, eps):
         o = ops()
         Xd, var_d = X.detach(), var_u.detach().reshape(1)
-        Gmean, Gs, bad = o.warp_sample_fwd(meanT.detach(), v.detach(), q.detach(), var_d, Xd,
-                                           slopes.detach(), intercept.detach(), eps)
+        Gmean, Gs, bad, Gs64 = o.warp_sample_fwd(meanT.detach(), v.detach(), q.detach(), var_d, Xd,
+                                                 slopes.detach(), intercept.detach(), eps)
         ctx.save_for_backward(eps, var_d, Xd)
         ctx.vmeta = (var_u.dtype, var_u.shape, slopes.dtype, intercept.dtype)
         ctx.mark_non_differentiable(bad)
         ctx.set_materialize_grads(False)
-        return Gmean, Gs, bad
+        return Gmean, Gs, bad, Gs64
 
     @staticmethod
-    def backward(ctx, dGmean, dGs, _dbad):
+    def backward(ctx, dGmean, dGs, _dbad, dGs64):
         o = ops()
         eps, var_d, Xd = ctx.saved_tensors
-        if dGs is None:
-            dGs = torch.zeros(eps.shape, dtype=torch.float32, device=eps.device)
-        dmeanT, g, qbar, dvar, dslopes, dint = o.warp_sample_bwd(dGmean, dGs.float(), eps, var_d, Xd)
+        dmeanT, g, qbar, dvar, dslopes, dint = o.warp_sample_bwd(dGmean, dGs, eps, var_d, Xd, dGs64)
         vdt, vshape, sdt, idt = ctx.vmeta
         return (dmeanT, g, qbar, dvar.to(vdt).reshape(vshape), None, dslopes.to(sdt), dint.to(idt), None)
 

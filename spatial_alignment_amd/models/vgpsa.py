@@ -185,10 +185,36 @@ class VariationalGPSA(GPSA):
         self._noise = dict(G=eps_G, F=eps_F, F_test=eps_F_test)
 
     def compute_mean_and_var(self, Kff_diag, Kuf, Kuu_chol, mu_x, mu_z, delta, Omega_tril):
-        raise NotImplementedError(
-            "the sparse-GP conditional is fused into the HIP layer kernels (engine.SGPCoreFn); "
-            "there is no eager path"
-        )
+        """The sparse-GP conditional of vgpsa.py:174-204 as a stand-alone call with the reference's arguments
+        and return shapes (2-D ``Kuf`` [M,n]: mean [V,n,D], var [V*D,n]; 3-D ``Kuf`` [S,M,N]: mean [S,N,L],
+        var [S,L,N]; the jitter is added twice, quirk 3).  ``forward`` does not go through here - it runs the
+        fused layer nodes - but the numbers are the same HIP kernels (engine.SGPCoreFn): fp64 projection,
+        fp64 forms for the 2-D (warp) branch, fp32 matrix-core forms for the 3-D (data) branch.
+        Differentiable wrt Kuf, delta - mu_z and the two factors."""
+        f64 = torch.float64
+        Lk, Lo = Kuu_chol.to(f64), Omega_tril.to(f64)
+        Kuu = Lk @ Lk.transpose(-1, -2)
+        Om = Lo @ Lo.transpose(-1, -2)  # Omega_tril Omega_tril^T == Omega: the kernels take Omega itself
+        fac = E.Factor(Kuu)
+        jit2 = 2.0 * self.diagonal_offset
+        dcm = delta - mu_z
+        if Kuf.dim() == 2:
+            M, n = Kuf.shape
+            dc3 = dcm.reshape(-1, M, dcm.shape[-1])                      # [V, M, D]
+            V, D = dc3.shape[0], dc3.shape[2]
+            dc2 = dc3.permute(1, 0, 2).reshape(M, V * D)                 # column v*D + j
+            meanT, v, q = E.SGPCoreFn.apply(Kuu, Kuf.to(f64), dc2.to(f64), Om, fac, f64)
+            mean = mu_x.unsqueeze(0) + meanT.reshape(V, D, n).transpose(1, 2)
+            var = Kff_diag - q.unsqueeze(0) + v + jit2
+        else:
+            S, M, N = Kuf.shape
+            K2 = Kuf.permute(1, 0, 2).reshape(M, S * N)
+            meanT, v, q = E.SGPCoreFn.apply(Kuu, K2.to(f64), dcm, Om, fac, torch.float32)
+            L = v.shape[0]
+            mean = mu_x.unsqueeze(0) + meanT.reshape(L, S, N).permute(1, 2, 0)
+            kff = Kff_diag.unsqueeze(1) if torch.is_tensor(Kff_diag) and Kff_diag.dim() >= 1 else Kff_diag
+            var = kff - q.reshape(S, 1, N) + v.reshape(L, S, N).permute(1, 0, 2) + jit2
+        return mean.to(Kuf.dtype), var.to(Kuf.dtype)
 
     def get_Omega_from_Omega_sqt(self, Omega_sqt):
         """Omega = A A^T + 1e-5 I (vgpsa.py:206-210); fp64 result."""
@@ -247,10 +273,18 @@ class VariationalGPSA(GPSA):
 
         # per-view slices of the parameters, unbound once (one autograd node per parameter instead of
         # a zero-fill + copy + add per slice in the backward)
-        Xt_v = self.Xtilde.unbind(0)
+        # The inducing locations and the covariance hyper-parameters enter through fp64 copies: each of them
+        # collects gradients along several paths (K_uu, K_uf, the mean function; the prior's KL term) that
+        # cancel to ~1e-4 of their size when the inducing points are dense - summed in fp64 and rounded to
+        # the parameter's fp32 ONCE, by the cast's backward (rounding each path's share to fp32 first costs
+        # 1e-3 on grad/Xtilde at M = 200 and 3e-3 at M = 1000; measured against the reference's fp64 run)
+        wide = lambda t: t.double() if t.dtype == torch.float32 else t
+        Xt_v = wide(self.Xtilde).unbind(0)
         dG_v = self.delta_G_list.unbind(0)
-        wls_v = self.warp_kernel_lengthscales.unbind(0)
-        wvar_v = self.warp_kernel_variances.unbind(0)
+        wls_v = wide(self.warp_kernel_lengthscales).unbind(0)
+        wvar_v = wide(self.warp_kernel_variances).unbind(0)
+        Gt64 = wide(self.Gtilde)
+        dls64, dvar64 = wide(self.data_kernel_lengthscale), wide(self.data_kernel_variance)
         slopes_v = self.mean_slopes.unbind(0)
         icpt_v = self.mean_intercepts.unbind(0)
         mu_z, resid = [], []
@@ -264,15 +298,18 @@ class VariationalGPSA(GPSA):
         # ---- everything M x M first: all prior covariances and variational covariances of the step
         #      are factorised by ONE batched Cholesky / triangular-inverse launch per matrix size
         rows_of = {v: {m: _as_index(view_idx[m][v], dev) for m in mods} for v in range(V)}
-        free = [v for v in range(V)
-                if not self._is_fixed(v) and sum(rows_of[v][m][1] for m in mods) > 0]
+        # every non-fixed view keeps its prior factorisation and its KL terms, with or without rows in THIS
+        # call: a data-parallel rank whose slice of a view is empty still owes its 1/world share of that
+        # view's KL (the reference leaves NaN factors for an empty view and fails in kl_divergence)
+        free = [v for v in range(V) if not self._is_fixed(v)]
+        nonempty = [v for v in free if sum(rows_of[v][m][1] for m in mods) > 0]
         M_X, nG = self.Omega_sqt_G_list.shape[-1], self.Omega_sqt_G_list.shape[0]
         sizes_F = [self.Omega_sqt_F_dict[m].shape for m in mods]
         builtin = builtin_kind(self.kernel_func_warp) is not None and builtin_kind(self.kernel_func_data) is not None
         # when every matrix of the step has the same size and comes from a built-in covariance, the
         # kernels write straight into ONE [T, M, M] batch (no concatenation before the factorisation)
         stack, slot = None, None
-        if builtin and all(sh[-1] == M_X for sh in sizes_F) and self.Gtilde.shape[0] == M_X \
+        if builtin and all(sh[-1] == M_X for sh in sizes_F) and Gt64.shape[0] == M_X \
                 and all(Xt_v[v].shape[0] == M_X for v in free):
             total = len(free) + 1 + nG + sum(sh[0] for sh in sizes_F)
             stack = torch.empty(total, M_X, M_X, dtype=f64, device=dev)
@@ -288,8 +325,7 @@ class VariationalGPSA(GPSA):
             Z = Xt_v[v]
             Kuu_w[v] = self._kmat("warp", Z, Z, wls_v[v], wvar_v[v], self.diagonal_offset, f64, True,
                                   out=slot(1)[0] if slot else None)
-        KuuF = self._kmat("data", self.Gtilde, self.Gtilde, self.data_kernel_lengthscale,
-                          self.data_kernel_variance, self.diagonal_offset, f64, True,
+        KuuF = self._kmat("data", Gt64, Gt64, dls64, dvar64, self.diagonal_offset, f64, True,
                           out=slot(1)[0] if slot else None)
         cache.Omega_G = E.OmegaFn.apply(self.Omega_sqt_G_list, slot(nG) if slot else None, True)
         cache.Om_fwd = cache.Omega_G.split(D, 0)                      # rows v*D+j  (forward, quirk 2)
@@ -318,10 +354,10 @@ class VariationalGPSA(GPSA):
         # the views' warp GPs are independent and each fills only part of the chip (one view of 10k
         # spots = 157 workgroups on 256 CUs): run them on side streams so that they overlap; autograd
         # replays each node's backward on the stream of its forward, so the backward overlaps too
-        side = self._side_streams(len(free), dev) if (self.overlap_views and dev.type == "cuda"
-                                                      and len(free) > 1) else None
+        side = self._side_streams(len(nonempty), dev) if (self.overlap_views and dev.type == "cuda"
+                                                          and len(nonempty) > 1) else None
         main = torch.cuda.current_stream(dev) if side is not None else None
-        for draw, v in enumerate(free):
+        for draw, v in enumerate(nonempty):
             if side is not None:
                 side[draw].wait_stream(main)
             with (torch.cuda.stream(side[draw]) if side is not None else contextlib.nullcontext()):
@@ -343,23 +379,26 @@ class VariationalGPSA(GPSA):
                         torch.empty(0, n, D, device=dev)
                 kind = builtin_kind(self.kernel_func_warp)
                 if kind is not None:  # covariance, projection, contractions and the draws as one fp64 node
-                    Gm, Gs, bad = E.SGPWarpLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac,
-                                                         slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
+                    Gm, Gs, bad, Gs64 = E.SGPWarpLayerFn.apply(kind, Z, Xv, ls_u, var_u, Kuu, dc, Om, fac,
+                                                               slopes_v[v], icpt_v[v], eps)  # quirk 1 inside
                 else:
                     Kuf = self._kmat("warp", Z, Xv, ls_u, var_u, 0.0, f64, False)
                     meanT, vq, q = E.SGPCoreFn.apply(Kuu, Kuf, dc, Om, fac, f64)
-                    Gm, Gs, bad = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)
+                    Gm, Gs, bad, Gs64 = E.WarpSampleFn.apply(meanT, vq, q, var_u, Xv, slopes_v[v], icpt_v[v], eps)
                 if side is not None:  # consumed on the main stream from here on
-                    for t in (Gm, Gs, bad):
+                    for t in (Gm, Gs, bad, Gs64):
                         t.record_stream(main)
             cache.flags.append(bad)
-            warp_out[v] = (Gm, Gs)
+            warp_out[v] = (Gm, Gs, Gs64)
         if side is not None:
-            for draw in range(len(free)):
+            for draw in range(len(nonempty)):
                 main.wait_stream(side[draw])
 
         # ---- assemble G_means [N,D] / G_samples [S,N,D] per modality --------------------------------
-        G_means, G_samples = {}, {}
+        # G64[m]: G_samples[m] before its rounding to the fp32 API tensor (fp64 draws of the warp GPs, the raw
+        # coordinates of fixed views).  The data GP's covariance is evaluated on it: handing the rounded
+        # tensor over costs 1e-4 on F at short lengthscales (measured on the 1-D golden case)
+        G_means, G_samples, G64 = {}, {}, {}
         for mi, m in enumerate(mods):
             # fast path: the views are consecutive row blocks covering 0..N (what create_view_idx_dict
             # produces): concatenate (its backward is a set of views, no zero-fill / copy / add)
@@ -370,7 +409,7 @@ class VariationalGPSA(GPSA):
                 edges += cnt
             ok = ok and edges == int(Ns[m])
             if ok:
-                pm, ps = [], []
+                pm, ps, p64 = [], [], []
                 for v in range(V):
                     r, cnt = rows_of[v][m]
                     if cnt == 0:
@@ -379,13 +418,17 @@ class VariationalGPSA(GPSA):
                         xv = X_spatial[m][r]
                         pm.append(xv)
                         ps.append(xv.unsqueeze(0).expand(S, -1, -1))
+                        p64.append(ps[-1])
                     else:
                         a = sum(rows_of[v][mm][1] for mm in mods[:mi])
-                        Gm, Gs = warp_out[v]
+                        Gm, Gs, Gs64 = warp_out[v]
                         pm.append(Gm[a : a + cnt])
                         ps.append(Gs[:, a : a + cnt])
+                        p64.append(Gs64[:, a : a + cnt])
                 G_means[m] = torch.cat(pm, 0) if len(pm) > 1 else pm[0].clone()
                 G_samples[m] = torch.cat(ps, 1) if len(ps) > 1 else ps[0].clone()
+                if S > 0 and X_spatial[m].dtype == torch.float32:  # differentiable: the gradient returns in fp64
+                    G64[m] = torch.cat([t.to(f64) for t in p64], 1) if len(p64) > 1 else p64[0].to(f64)
                 continue
             nan = float("nan")  # general index sets / empty views: NaN-filled scatter like the reference
             G_means[m] = torch.full([int(Ns[m]), D], nan, device=dev)
@@ -397,7 +440,7 @@ class VariationalGPSA(GPSA):
                     G_samples[m][:, r, :] = X_spatial[m][r]
                 elif v in warp_out:
                     a = sum(rows_of[v][mm][1] for mm in mods[:mi])
-                    Gm, Gs = warp_out[v]
+                    Gm, Gs, _ = warp_out[v]
                     G_means[m][r] = Gm[a : a + cnt]
                     G_samples[m][:, r, :] = Gs[:, a : a + cnt]
 
@@ -407,13 +450,14 @@ class VariationalGPSA(GPSA):
         pending = self._post_flags(cache) if self.check_numerics else None
 
         # ---- data GP (vgpsa.py:353-477) ----------------------------------------------------------
-        ls_u, var_u = self.data_kernel_lengthscale, self.data_kernel_variance
+        ls_u, var_u = dls64, dvar64
         KuuF, facF = cache.data
 
-        def data_layer(G, eps_key, m):
+        def data_layer(G, eps_key, m, G64m=None):
             S_, N_ = G.shape[0], G.shape[1]
             L = self.n_latent_outputs[m]
             Gf = G.reshape(S_ * N_, D)
+            Gf64 = None if G64m is None else G64m.reshape(S_ * N_, D)
             # covariance + whitening in fp64 (gradient-only fp32 backward); mean / variance form in fp32
             if noise is not None and noise[eps_key] is not None:
                 eps = noise[eps_key][m].to(device=dev, dtype=torch.float32).reshape(S_ * N_, L)
@@ -421,10 +465,10 @@ class VariationalGPSA(GPSA):
                 eps = self._draw([S_, N_, L], dev, "F").reshape(S_ * N_, L)
             kind = builtin_kind(self.kernel_func_data)
             if kind is not None:  # covariance, projection, contractions and the draw as one node
-                Fl = E.SGPDataLayerFn.apply(kind, self.Gtilde, Gf, ls_u, var_u, KuuF, self.delta_F_dict[m],
-                                            cache.Omega_F[m], facF, eps).reshape(S_, N_, L)
+                Fl = E.SGPDataLayerFn.apply(kind, Gt64, Gf, ls_u, var_u, KuuF, self.delta_F_dict[m],
+                                            cache.Omega_F[m], facF, eps, Gf64).reshape(S_, N_, L)
             else:
-                Kuf = self._kmat("data", self.Gtilde, Gf, ls_u, var_u, 0.0, f64, False, torch.float32)
+                Kuf = self._kmat("data", Gt64, Gf, ls_u, var_u, 0.0, f64, False, torch.float32)
                 meanT, vq, q = E.SGPCoreFn.apply(
                     KuuF, Kuf, self.delta_F_dict[m], cache.Omega_F[m], facF, torch.float32
                 )
@@ -437,7 +481,7 @@ class VariationalGPSA(GPSA):
         if G_test is not None:
             self.F_latent_samples_test, self.F_observed_samples_test = {}, {}
         for m in mods:
-            self.F_latent_samples[m], self.F_observed_samples[m] = data_layer(G_samples[m], "F", m)
+            self.F_latent_samples[m], self.F_observed_samples[m] = data_layer(G_samples[m], "F", m, G64.get(m))
             if G_test is not None:
                 Gt = G_test[m].to(device=dev, dtype=torch.float32)
                 lt, ot = data_layer(Gt, "F_test", m)

@@ -82,30 +82,40 @@ class HipOps:
 
     def kmat(self, kind, Z, X, ls_u, var_u, jitter=0.0, dtype=None, out=None):
         """K = k(Z, X) computed and stored in ``dtype`` (default: Z's) from inputs of Z's dtype"""
-        Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
+        in_dt = None
+        if X.dtype == torch.float64 and Z.dtype == torch.float32 and dtype == torch.float64:
+            # fp32 parameters next to the warp GP's unrounded fp64 draws: read both as stored
+            Z, X, in_dt = self._c(Z), self._c(X), 2  # GPSA_F32_X64
+        else:
+            Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
         dtype = dtype or Z.dtype
         M, D = Z.shape
         Cn = X.shape[0]
         K = torch.empty(M, Cn, dtype=dtype, device=Z.device) if out is None else out
         assert K.shape == (M, Cn) and K.dtype == dtype and K.is_contiguous()
-        rc = self.lib.gpsa_kmat(_dt(K), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u), _p(var_u),
-                                float(jitter), _p(K), self._stream(Z))
+        rc = self.lib.gpsa_kmat(_dt(K), _dt(Z) if in_dt is None else in_dt, KINDS[kind], _p(Z), M, _p(X), Cn, D,
+                                _p(ls_u), _p(var_u), float(jitter), _p(K), self._stream(Z))
         _lib.check(rc, "gpsa_kmat")
         return K
 
-    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True, same=False):
-        """gradients in Z's dtype; the arithmetic and partial sums run in Kbar's dtype.  ``same``: Z and
-        X are the same points (K_uu): returns dZ + dX as dZ, and None for dX."""
+    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True, same=False, out_dtype=None):
+        """gradients in Z's dtype (``out_dtype`` = fp64 with fp32 inputs and an fp64 Kbar: stored as fp64);
+        the arithmetic and partial sums run in Kbar's dtype.  ``same``: Z and X are the same points (K_uu):
+        returns dZ + dX as dZ, and None for dX."""
         Z, X, ls_u, var_u = self._cov_args(Z, X, ls_u, var_u)
         Kbar = self._c(Kbar)
         M, D = Z.shape
         Cn = X.shape[0]
-        dZ = torch.empty_like(Z)
-        dX = torch.empty_like(X) if (need_dX and not same) else None
-        dpar = torch.empty(2, dtype=Z.dtype, device=Z.device)
-        wsb = self._wsq("gpsa_kmat_bwd_workspace", _dt(Kbar), M, Cn, D)
+        odt, in_dt, kdt = Z.dtype, _dt(Z), _dt(Kbar)
+        if out_dtype == torch.float64 and Z.dtype == torch.float32:
+            # fp64 arithmetic and gradients from fp32 inputs; Kbar in either precision
+            odt, in_dt, kdt = torch.float64, (3 if Kbar.dtype == torch.float64 else 4), F64
+        dZ = torch.empty(Z.shape, dtype=odt, device=Z.device)
+        dX = torch.empty(X.shape, dtype=odt, device=Z.device) if (need_dX and not same) else None
+        dpar = torch.empty(2, dtype=odt, device=Z.device)
+        wsb = self._wsq("gpsa_kmat_bwd_workspace", kdt, M, Cn, D)
         ws = self._ws(wsb, Z)
-        rc = self.lib.gpsa_kmat_bwd(_dt(Kbar), _dt(Z), KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u),
+        rc = self.lib.gpsa_kmat_bwd(kdt, in_dt, KINDS[kind], _p(Z), M, _p(X), Cn, D, _p(ls_u),
                                     _p(var_u), _p(Kbar), int(bool(same)), _p(dZ), _p(dX), _p(dpar), _p(ws),
                                     ws.numel(), self._stream(Z))
         _lib.check(rc, "gpsa_kmat_bwd")
@@ -352,27 +362,31 @@ class HipOps:
         return t if t.is_contiguous() else t.contiguous()
 
     def warp_sample_fwd(self, meanT, v, q, var_u, X, slopes, intercept, eps):
-        """-> Gmean [n,D], Gs [S,n,D] (fp32), bad [blocks] (int32 flags)"""
+        """-> Gmean [n,D], Gs [S,n,D] (fp32), bad [blocks] (int32 flags), Gs64 [S,n,D] (the draws unrounded)"""
         meanT, v, q, eps = self._c(meanT), self._c(v), self._c(q), self._c(eps)
         var_u, X, slopes, intercept = (self._f32(t) for t in (var_u, X, slopes, intercept))
         D, n = meanT.shape
         S = eps.shape[0]
         Gmean = torch.empty(n, D, dtype=torch.float32, device=meanT.device)
         Gs = torch.empty(S, n, D, dtype=torch.float32, device=meanT.device)
+        Gs64 = torch.empty(S, n, D, dtype=torch.float64, device=meanT.device)
         bad = torch.empty((n + 255) // 256, dtype=torch.int32, device=meanT.device)
         rc = self.lib.gpsa_warp_sample_fwd(_p(meanT), _p(v), _p(q), _p(var_u), _p(X), _p(slopes),
-                                           _p(intercept), _p(eps), n, D, S, _p(Gmean), _p(Gs), _p(bad),
-                                           self._stream(meanT))
+                                           _p(intercept), _p(eps), n, D, S, _p(Gmean), _p(Gs), _p(Gs64),
+                                           _p(bad), self._stream(meanT))
         _lib.check(rc, "gpsa_warp_sample_fwd")
-        return Gmean, Gs, bad
+        return Gmean, Gs, bad, Gs64
 
-    def warp_sample_bwd(self, dGmean, dGs, eps, var_u, X):
-        """-> dmeanT, g [D,n], qbar [n] (fp64); dvar_u [1], dslopes [D,D], dintercept [D] (fp32)"""
-        dGs, eps = self._c(dGs), self._c(eps)
+    def warp_sample_bwd(self, dGmean, dGs, eps, var_u, X, dGs64=None):
+        """-> dmeanT, g [D,n], qbar [n] (fp64); dvar_u [1], dslopes [D,D], dintercept [D] (fp32).
+        The draws' gradient is dGs (fp32, may be None) + dGs64 (fp64, may be None)."""
+        eps = self._c(eps)
+        dGs = None if dGs is None else self._f32(dGs)
+        dGs64 = None if dGs64 is None else self._c(dGs64)
         dGmean = None if dGmean is None else self._c(dGmean)
         var_u, X = self._f32(var_u), self._f32(X)
-        S, n, D = dGs.shape
-        dev = dGs.device
+        S, n, D = eps.shape
+        dev = eps.device
         f64, f32 = torch.float64, torch.float32
         dmeanT = torch.empty(D, n, dtype=f64, device=dev)
         g = torch.empty(D, n, dtype=f64, device=dev)
@@ -380,10 +394,10 @@ class HipOps:
         dvar = torch.empty(1, dtype=f32, device=dev)
         dslopes = torch.empty(D, D, dtype=f32, device=dev)
         dint = torch.empty(D, dtype=f32, device=dev)
-        ws = self._ws(8 * 21 * ((n + 255) // 256) + 64, dGs)
-        rc = self.lib.gpsa_warp_sample_bwd(_p(dGmean), _p(dGs), _p(eps), _p(var_u), _p(X), n, D, S,
+        ws = self._ws(8 * 21 * ((n + 255) // 256) + 64, eps)
+        rc = self.lib.gpsa_warp_sample_bwd(_p(dGmean), _p(dGs), _p(dGs64), _p(eps), _p(var_u), _p(X), n, D, S,
                                            _p(dmeanT), _p(g), _p(qbar), _p(dvar), _p(dslopes), _p(dint),
-                                           _p(ws), ws.numel(), self._stream(dGs))
+                                           _p(ws), ws.numel(), self._stream(eps))
         _lib.check(rc, "gpsa_warp_sample_bwd")
         return dmeanT, g, qbar, dvar, dslopes, dint
 

@@ -115,6 +115,7 @@ class GradAllReducer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         # pack (one batched launch), reduce, unpack (one batched launch): not one copy per parameter
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        # view(-1), not reshape(-1): a non-contiguous .grad must raise here, not be reduced into a temporary
+        torch.cat([p.grad.view(-1) for p in self.params], out=self.flat)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        torch._foreach_copy_([p.grad.reshape(-1) for p in self.params], self.views)
+        torch._foreach_copy_([p.grad.view(-1) for p in self.params], self.views)

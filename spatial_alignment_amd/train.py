@@ -65,8 +65,9 @@ class GraphedTrainStep:
 
     * every kernel of the step (HIP kernels of this package, Adam, RNG) is inside the graph; replaying
       does all the work of an eager step on the same static buffers;
-    * the per-forward numerics check cannot sync inside a capture: the flags are kept on the device
-      and ``check()`` raises afterwards (call it every N steps);
+    * the per-forward numerics check cannot sync inside a capture: every replay folds its flags (a
+      non-positive pivot, a non-positive warp variance, a non-finite loss) into a STICKY device word, and
+      ``check()`` raises if any step since the last check tripped it (call it every N steps);
     * the optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``);
     * single-GPU only (an all-reduce inside the graph is not attempted here).
     """
@@ -75,9 +76,10 @@ class GraphedTrainStep:
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a HIP device")
         self.model, self.optimizer = model, optimizer
-        self._saved_check = model.check_numerics
+        saved = (model.check_numerics, model.overlap_views)
         model.check_numerics = False
         model.overlap_views = True  # independent views become parallel branches of the graph
+        self.sticky = torch.zeros((), dtype=torch.int32, device=next(model.parameters()).device)
         # drop every reference to an earlier autograd graph (capture needs fresh AccumulateGrad nodes
         # on the capture stream)
         model._cache = None
@@ -94,14 +96,22 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = train_step(model, optimizer, data_dict, view_idx, Ns, S, static_grads=True)
-            flags = model._cache.flags
-            self.flags = torch.cat([f.reshape(-1).to(torch.int32) for f in flags]).abs().max()
+            flags = [f.reshape(-1).to(torch.int32) for f in model._cache.flags]
+            flags.append((~torch.isfinite(self.loss.detach())).reshape(-1).to(torch.int32))
+            self.sticky.copy_(torch.maximum(self.sticky, torch.cat(flags).abs().max()))
+        # eager forwards after this keep their own numerics check and stream behaviour
+        model.check_numerics, model.overlap_views = saved
 
     def step(self):
         self.graph.replay()
         return self.loss
 
     def check(self):
-        """host sync: raise if any step since the last check hit a non-PD covariance / bad variance"""
-        if int(self.flags.item()) != 0:
-            raise torch.linalg.LinAlgError("GPSA graphed step: non-positive-definite covariance")
+        """host sync: raise if ANY replay since the last check hit a non-PD covariance, a non-positive warp
+        variance or a non-finite loss (the flag is sticky across replays and reset here)"""
+        bad = int(self.sticky.item())
+        if bad != 0:
+            self.sticky.zero_()
+            raise torch.linalg.LinAlgError(
+                "GPSA graphed step: non-positive-definite covariance, non-positive warp variance or "
+                "non-finite loss in a step since the last check")

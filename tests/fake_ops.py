@@ -40,14 +40,15 @@ class FakeOps:
             return out
         return K
 
-    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True, same=False):
-        dt = Kbar.dtype
+    def kmat_bwd(self, kind, Z, X, ls_u, var_u, Kbar, need_dX=True, same=False, out_dtype=None):
+        dt = out_dtype or Kbar.dtype
+        Kbar = Kbar.to(dt)
         with torch.enable_grad():
             Zr, Xr = Z.to(dt).clone().requires_grad_(True), X.to(dt).clone().requires_grad_(True)
             lr, vr = ls_u.to(dt).clone().requires_grad_(True), var_u.to(dt).clone().requires_grad_(True)
             K = _cov(kind, Zr, Xr, lr, vr)
             gz, gx, gl, gv = torch.autograd.grad(K, [Zr, Xr, lr, vr], Kbar)
-        o = Z.dtype
+        o = out_dtype or Z.dtype
         if same:
             return (gz + gx).to(o), None, torch.cat([gl.reshape(1), gv.reshape(1)]).to(o)
         return gz.to(o), (gx.to(o) if need_dX else None), torch.cat([gl.reshape(1), gv.reshape(1)]).to(o)
@@ -141,10 +142,12 @@ class FakeOps:
         mu = X.double() @ slopes.double() + intercept.double() + meanT.t()
         Gs = mu.unsqueeze(0) + Sigma.t().unsqueeze(0) * eps.double()
         bad = (~(Sigma > 0)).any().to(torch.int32).reshape(1)
-        return mu.float(), Gs.float(), bad
+        return mu.float(), Gs.float(), bad, Gs
 
-    def warp_sample_bwd(self, dGmean, dGs, eps, var_u, X):
-        d = dGs.double()
+    def warp_sample_bwd(self, dGmean, dGs, eps, var_u, X, dGs64=None):
+        d = torch.zeros(eps.shape, dtype=torch.float64) if dGs is None else dGs.double()
+        if dGs64 is not None:
+            d = d + dGs64
         dm = d.sum(0)
         if dGmean is not None:
             dm = dm + dGmean.double()

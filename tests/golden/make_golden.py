@@ -302,6 +302,14 @@ def main():
         fixed_view_idx=1, fixed_warp_kernel_variances=[0.5, 0.7],
         fixed_warp_kernel_lengthscales=[4.0, 6.0], fixed_data_kernel_lengthscales=[1.5],
     )
+    # BASELINE config 4 in miniature: 8 views, view 0 fixed (the 8-view loop of vgpsa.py:259-273)
+    X, Y, ns = recipes.grid_views(side=6, n_views=8, n_out=5, seed=19)
+    cases["c9_eight_views_fixed0"] = dict(
+        mods=["expression"], X={"expression": X}, Y={"expression": Y},
+        n_samples={"expression": ns}, m_X=14, m_G=16, S=2, seed=9,
+        n_latent_gps={"expression": None}, kernel_warp="rbf", kernel_data="rbf",
+        fixed_view_idx=0,
+    )
     # conditioning study: M=200 (warp-GP K_uu cond ~ 2e7), parameters from a seeded recipe
     rc = dict(side=50, n_views=2, n_out=4, seed=18, m=200, state_seed=180)
     X, Y, ns = recipes.grid_views(side=rc["side"], n_views=2, n_out=rc["n_out"], seed=rc["seed"])

@@ -59,13 +59,13 @@ def run_step(model, dd, g, device="cpu"):
     return res
 
 
-def compare(res, g, tol_out, tol_grad, tag="ref64", ref32_bar=True):
+def compare(res, g, tol_out, tol_grad, tag="ref64", ref32_bar=False):
     """norm-wise relative errors vs the reference; returns ({key: (err, tol)} violations, all errs).
 
-    Criterion: ||build - ref_fp64|| / ||ref_fp64|| <= tol.  With ``ref32_bar`` the
-    tolerance of a key is widened to the fp32 REFERENCE's own distance from its fp64 run when that is
-    larger: the API hands fp32 tensors from the warp to the data GP, so the build cannot be asked to
-    be closer to fp64 than an fp32 interface allows (it is, by 10-1000x, on most keys).
+    Criterion (BASELINE.json north_star): ||build - ref_fp64|| / ||ref_fp64|| <= tol_out
+    (1e-4) on every output, HARD - no widening.  ``ref32_bar`` (off by default) widens a key's tolerance
+    to the fp32 REFERENCE's own distance from its fp64 run; it is kept for the CPU test of the fp32
+    oracle only (an fp32 restatement cannot be closer to fp64 than the fp32 reference is).
     """
     from golden_io import compare_summary, rel
 

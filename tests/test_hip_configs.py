@@ -1,0 +1,159 @@
+"""End-to-end parity of the HIP path at the SHAPES of BASELINE.json configs 3, 4 and 5.
+
+Configs 4 (8 views, view 0 fixed, M = 500) and 5 (2 views, M = 1000) run the whole step - forward,
+ELBO, backward, every parameter gradient - against the fp64 CPU oracle with the spot and gene counts
+cut down so that the oracle's materialised [S,L,N,M] tensor fits in seconds; M, the view structure,
+the fixed view and the independent-output layout are the configs'.  Reference path exercised:
+gpsa/models/vgpsa.py:259-273 (fixed view inside the 8-view loop), :390-421 (data GP at M = 500 / 1000:
+blocked factorisation, the MFMA / generic Gram and panel paths beyond one LDS tile).
+Config 3 runs at FULL size (4 x 10k spots, 500 genes through 10 latent GPs, Matern-1/2 warp) through
+size-independent properties, like test_hip_parity.test_full_size_properties does for config 2.
+"""
+import numpy as np
+import pytest
+import torch
+
+import spatial_alignment_amd as gp
+from golden_io import rel
+from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MOD = "expression"
+
+
+def _perturb(model, seed):
+    """move the parameters off the initial state (delta_G == Xtilde, unit hyper-parameters), seeded"""
+    gen = torch.Generator().manual_seed(seed)
+    r = lambda t, s: s * torch.randn(t.shape, generator=gen)
+    with torch.no_grad():
+        model.delta_G_list.add_(r(model.delta_G_list, 0.15))
+        model.Xtilde.add_(r(model.Xtilde, 0.03))
+        model.Gtilde.add_(r(model.Gtilde, 0.03))
+        model.warp_kernel_variances.add_(r(model.warp_kernel_variances, 0.3))
+        model.warp_kernel_lengthscales.add_(r(model.warp_kernel_lengthscales, 0.2))
+        model.data_kernel_lengthscale.add_(r(model.data_kernel_lengthscale, 0.2))
+        model.data_kernel_variance.add_(r(model.data_kernel_variance, 0.2))
+        model.noise_variance.add_(r(model.noise_variance, 0.3))
+
+
+def _step_vs_oracle(side, views, outputs, M, S, fixed, seed, kernel_warp=gp.rbf_kernel):
+    from oracle import gpsa_oracle as orc
+
+    dd = make_grid_problem(side=side, n_views=views, n_outputs=outputs, device="cpu")
+    model = make_model(dd, m=M, n_latent_gps={MOD: None}, fixed_view_idx=fixed, device="cpu", seed=seed,
+                       kernel_func_warp=kernel_warp, kernel_func_data=gp.rbf_kernel)
+    _perturb(model, seed + 1)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for name in ("mean_slopes", "mean_intercepts"):
+        state.setdefault(name, getattr(model, name).detach().clone())
+    model = model.to(DEV)
+    n, N, L = side * side, side * side * views, outputs
+    gen = torch.Generator().manual_seed(seed + 2)
+    fixed_set = set() if fixed is None else ({fixed} if isinstance(fixed, int) else set(fixed))
+    eps_G = [torch.randn(S, n, 2, generator=gen) for v in range(views) if v not in fixed_set]
+    eps_F = {MOD: torch.randn(S, N, L, generator=gen)}
+    ddd = {MOD: {"spatial_coords": dd[MOD]["spatial_coords"].to(DEV), "outputs": dd[MOD]["outputs"].to(DEV),
+                 "n_samples_list": dd[MOD]["n_samples_list"]}}
+    view_idx, Ns, _, _ = model.create_view_idx_dict(ddd)
+    model.inject_noise(eps_G, eps_F, None)
+    out = model.forward({MOD: ddd[MOD]["spatial_coords"]}, view_idx=view_idx, Ns=Ns, S=S)
+    loss = model.loss_fn(ddd, out[3])
+    loss.backward()
+    cfg = dict(modality_names=[MOD], n_views=views, n_spatial_dims=2,
+               kernel_warp={gp.rbf_kernel: "rbf", gp.matern12_kernel: "matern12"}[kernel_warp],
+               kernel_data="rbf", n_latent_gps={MOD: None}, fixed_view_idx=fixed)
+    ref = orc.evaluate(state, cfg, {MOD: dd[MOD]["spatial_coords"]}, {MOD: dd[MOD]["outputs"]},
+                       {MOD: dd[MOD]["n_samples_list"]}, S, eps_G, eps_F, dtype=torch.float64)
+    errs = {
+        "G_means": rel(out[0][MOD].detach().cpu().numpy(), ref["G_means"][MOD].numpy()),
+        "G_samples": rel(out[1][MOD].detach().cpu().numpy(), ref["G_samples"][MOD].numpy()),
+        "F_samples": rel(out[3][MOD].detach().cpu().numpy(), ref["F_obs"][MOD].numpy()),
+        "loss": rel(loss.detach().cpu().numpy(), ref["loss"].numpy()),
+    }
+    gerr = {}
+    for k, p in model.named_parameters():
+        gr = ref["grads"].get(k)
+        if gr is None:
+            continue
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy()
+        if float(gr.norm()) == 0.0:
+            assert np.abs(got).max() == 0.0, k  # fixed view / unused parameter: exactly zero
+            continue
+        gerr[k] = rel(got, gr.numpy())
+    return errs, gerr, out, ddd
+
+
+def test_config4_shape_eight_views_fixed0_m500_matches_oracle():
+    """BASELINE config 4's structure: 8 views, fixed_view_idx=0, M_X = M_G = 500, independent outputs."""
+    errs, gerr, out, ddd = _step_vs_oracle(side=14, views=8, outputs=6, M=500, S=2, fixed=0, seed=40)
+    print("config-4 shape:", {k: f"{v:.1e}" for k, v in errs.items()},
+          {k: f"{v:.1e}" for k, v in gerr.items()})
+    n = 14 * 14
+    X = ddd[MOD]["spatial_coords"]
+    assert torch.equal(out[0][MOD][:n], X[:n]) and torch.equal(out[1][MOD][:, :n], X[:n].expand(2, -1, -1))
+    assert errs["G_means"] < 1e-4 and errs["G_samples"] < 1e-4 and errs["F_samples"] < 1e-4
+    assert errs["loss"] < 1e-4
+    for k, e in gerr.items():
+        assert e < 5e-3, (k, e, gerr)
+
+
+def test_config5_shape_two_views_m1000_matches_oracle():
+    """BASELINE config 5's structure: 2 views, M_X = M_G = 1000 (blocked factorisation, generic Gram and
+    panel paths end to end), independent outputs."""
+    errs, gerr, _, _ = _step_vs_oracle(side=24, views=2, outputs=4, M=1000, S=1, fixed=None, seed=50)
+    print("config-5 shape:", {k: f"{v:.1e}" for k, v in errs.items()},
+          {k: f"{v:.1e}" for k, v in gerr.items()})
+    assert errs["G_means"] < 1e-4 and errs["G_samples"] < 1e-4 and errs["F_samples"] < 1e-4
+    assert errs["loss"] < 1e-4
+    for k, e in gerr.items():
+        assert e < 5e-3, (k, e, gerr)
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 at full size: 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2
+    warp / RBF data, M = 200, S = 5.  Finite outputs of the right shapes, the LMC mixing is exactly
+    F_latent @ W, the step is bitwise repeatable, and the ELBO gradient matches directional finite
+    differences wrt the LMC weights and the variational means."""
+    dd = make_grid_problem(side=100, n_views=4, n_outputs=500, device=DEV)
+    model = make_model(dd, m=200, n_latent_gps={MOD: 10}, fixed_view_idx=None, device=DEV,
+                       kernel_func_warp=gp.matern12_kernel, kernel_func_data=gp.rbf_kernel)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {MOD: dd[MOD]["spatial_coords"]}
+    gen = torch.Generator().manual_seed(31)
+    S, n, N, L, P = 5, 10000, 40000, 10, 500
+    eps_G = [torch.randn(S, n, 2, generator=gen).to(DEV) for _ in range(4)]
+    eps_F = {MOD: torch.randn(S, N, L, generator=gen).to(DEV)}
+
+    def loss_at():
+        model.inject_noise(eps_G, eps_F)
+        out = model.forward(Xs, view_idx, Ns, S=S)
+        return model.loss_fn(dd, out[3]), out
+
+    model.zero_grad()
+    loss, out = loss_at()
+    loss.backward()
+    assert out[2][MOD].shape == (S, N, L) and out[3][MOD].shape == (S, N, P)
+    assert torch.isfinite(loss) and all(torch.isfinite(o[MOD]).all() for o in out)
+    mix = out[2][MOD].detach().double() @ model.W_dict[MOD].detach().double()
+    assert (mix - out[3][MOD].detach().double()).norm() <= 1e-5 * mix.norm()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    model.zero_grad()
+    loss2, _ = loss_at()
+    loss2.backward()
+    assert float(loss2) == float(loss)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, grads[k]), k  # deterministic reductions: bitwise repeatable
+    for p, h in ((model.W_dict[MOD], 2e-2), (model.delta_F_dict[MOD], 2e-2)):
+        d = torch.randn(p.shape, generator=gen).to(DEV)
+        gdir = float((p.grad * d).sum())
+        with torch.no_grad():
+            p.add_(h * d)
+            lp, _ = loss_at()
+            p.sub_(2 * h * d)
+            lm, _ = loss_at()
+            p.add_(h * d)
+        fd = float(lp - lm) / (2 * h)
+        assert abs(fd - gdir) <= 3e-2 * max(abs(gdir), 1.0), (fd, gdir)

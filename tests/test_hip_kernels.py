@@ -369,17 +369,23 @@ def test_warp_sample(hip, n, D, S):
     A, b = torch.eye(D) + 0.1 * rnd(D, D, seed=7), rnd(D, seed=8)
     eps, var_u = rnd(S, n, D, seed=4), torch.tensor([0.2])
     dev = lambda *ts: [t.to(DEV) for t in ts]
-    Gm, Gs, bad = hip.warp_sample_fwd(*dev(meanT, v, q, var_u, X, A, b, eps))
-    rGm, rGs, rbad = FK.warp_sample_fwd(meanT, v, q, var_u, X, A, b, eps)
+    Gm, Gs, bad, Gs64 = hip.warp_sample_fwd(*dev(meanT, v, q, var_u, X, A, b, eps))
+    rGm, rGs, rbad, rGs64 = FK.warp_sample_fwd(meanT, v, q, var_u, X, A, b, eps)
     close(Gm, rGm, 1e-6)
     close(Gs, rGs, 1e-6)
+    close(Gs64, rGs64, 1e-13)  # the draws before their rounding to the fp32 API tensor
+    assert torch.equal(Gs64.float(), Gs)
     assert bad.numel() == (n + 255) // 256 and int(bad.abs().max()) == 0
     dGm, dGs = rnd(n, D, seed=5), rnd(S, n, D, seed=6)
-    got = hip.warp_sample_bwd(*dev(dGm, dGs, eps, var_u, X))
-    want = FK.warp_sample_bwd(dGm, dGs, eps, var_u, X)
-    for a, w in zip(got, want):
-        close(a, w, 1e-11 if a.dtype == f64 else 2e-6)
-    _, _, bad = hip.warp_sample_fwd(*dev(meanT, v - 100, q, var_u, X, A, b, eps))
+    dGs64 = rnd(S, n, D, seed=9, dtype=f64)
+    # the draws' gradient arrives as an fp32 part, an fp64 part, or both
+    for a32, a64 in ((dGs, None), (None, dGs64), (dGs, dGs64)):
+        got = hip.warp_sample_bwd(dGm.to(DEV), None if a32 is None else a32.to(DEV), *dev(eps, var_u, X),
+                                  None if a64 is None else a64.to(DEV))
+        want = FK.warp_sample_bwd(dGm, a32, eps, var_u, X, a64)
+        for a, w in zip(got, want):
+            close(a, w, 1e-11 if a.dtype == f64 else 2e-6)
+    _, _, bad, _ = hip.warp_sample_fwd(*dev(meanT, v - 100, q, var_u, X, A, b, eps))
     assert int(bad.max()) == 1
 
 

@@ -70,4 +70,4 @@ def test_random_configuration_matches_oracle(seed):
     assert rel(loss.detach().cpu().numpy(), ref["loss"].numpy()) < 1e-5, c
     for k, p in model.named_parameters():
         if k in ref["grads"] and p.grad is not None and float(ref["grads"][k].norm()) > 0:
-            assert rel(p.grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-2, (k, c)
+            assert rel(p.grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-3, (k, c)

@@ -19,9 +19,13 @@ def test_step_matches_reference_fp64(name):
     model, dd = build_model(g, device=DEV)
     res = run_step(model, dd, g, device=DEV)
     big = bool(g.cfg.get("summary_only"))
-    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=5e-3 if not big else 2e-2)
-    print(name, {k: f"{v:.1e}" for k, v in errs.items() if not k.startswith("grad/")})
+    # outputs: the 1e-4 contract, HARD on every key (measured 2e-8 .. 2e-7: profiles/r02_parity_table.md);
+    # gradients: 1e-4 on the small cases (measured <= 1e-5), 3e-3 at M = 200 where the warp GP's K_uu has
+    # condition number 2e7 (measured 7e-4 on grad/Gtilde, <= 2e-5 on every other parameter)
+    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4 if not big else 3e-3)
+    print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert not bad, bad
+    assert max(v for k, v in errs.items() if not k.startswith("grad/")) < 2e-6, errs  # regression bar
 
 
 def test_inside_reference_fp32_error_bar_m200():
@@ -57,7 +61,7 @@ def test_hip_matches_oracle_fresh_noise():
     assert rel(res["loss"], ref["loss"].numpy()) < 1e-5
     for k, gr in ref["grads"].items():
         if gr.norm() > 0:
-            assert rel(res[f"grad/{k}"], gr.numpy()) < 5e-3, k
+            assert rel(res[f"grad/{k}"], gr.numpy()) < 1e-4, k
 
 
 @pytest.mark.parametrize("M,mG", [(288, 288), (300, 96)])
@@ -99,7 +103,7 @@ def test_large_and_mixed_inducing_counts_match_oracle(M, mG):
     assert rel(loss.detach().cpu().numpy(), ref["loss"].numpy()) < 1e-5
     grads = dict(model.named_parameters())
     for k in ("Xtilde", "delta_G_list", f"Omega_sqt_F_dict.{m}", "data_kernel_lengthscale"):
-        assert rel(grads[k].grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-2, k
+        assert rel(grads[k].grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-3, k
 
 
 def test_training_reduces_loss_and_is_deterministic():
@@ -257,7 +261,7 @@ def test_custom_callable_plugin_on_gpu():
     model, dd = build_model(g, device=DEV)
     model.kernel_func_data = _custom_m32
     res = run_step(model, dd, g, device=DEV)
-    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=5e-3)
+    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-3)  # plug-in path: per-node fp32 gradient sums
     assert not bad, bad
 
 

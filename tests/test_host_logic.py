@@ -137,3 +137,63 @@ def test_fit_loop_matches_manual_steps_and_stops_on_checker():
     chk = LossNotDecreasingChecker(max_epochs=40, atol=1e9, window_size=3)  # any decrease is "too small"
     tr = fit(model, dd, n_epochs=40, S=1, sync_every=2, checker=chk)
     assert 3 <= len(tr) < 40
+
+
+@pytest.mark.parametrize("branch", ["warp2d", "data3d"])
+def test_compute_mean_and_var_matches_reference_formula(branch):
+    """the public method of vgpsa.py:174-204 (reference arguments and return shapes) against the oracle's
+    restatement of it, both branches"""
+    from golden_io import rel
+    from oracle import gpsa_oracle as orc
+
+    g = Golden("c2_three_free_views")
+    model, _ = build_model(g)
+    gen = torch.Generator().manual_seed(3)
+    f64 = torch.float64
+    M, V, D, L, n, S = 12, 3, 2, 5, 40, 2
+    Z = 3.0 * torch.randn(M, D, generator=gen, dtype=f64)
+    K = orc.rbf_kernel(Z, Z, torch.tensor(1.0, dtype=f64), torch.tensor(0.3, dtype=f64)) + 1e-5 * torch.eye(M, dtype=f64)
+    Lk = torch.linalg.cholesky(K)
+    kff = torch.exp(torch.tensor(0.3, dtype=f64))
+    if branch == "warp2d":
+        X = 3.0 * torch.randn(n, D, generator=gen, dtype=f64)
+        Kuf = orc.rbf_kernel(Z, X, torch.tensor(1.0, dtype=f64), torch.tensor(0.3, dtype=f64))
+        A = 0.3 * torch.randn(V * D, M, M, generator=gen, dtype=f64)
+        Lo = torch.linalg.cholesky(A @ A.transpose(-1, -2) + 1e-5 * torch.eye(M, dtype=f64))
+        delta, mu_z = torch.randn(V, M, D, generator=gen, dtype=f64), torch.randn(V, M, D, generator=gen, dtype=f64)
+        args = (kff, Kuf, Lk, X, mu_z, delta, Lo)
+    else:
+        X = 3.0 * torch.randn(S, n, D, generator=gen, dtype=f64)
+        Kuf = orc.rbf_kernel(Z, X, torch.tensor(1.0, dtype=f64), torch.tensor(0.3, dtype=f64))
+        A = 0.3 * torch.randn(L, M, M, generator=gen, dtype=f64)
+        Lo = torch.linalg.cholesky(A @ A.transpose(-1, -2) + 1e-5 * torch.eye(M, dtype=f64))
+        delta, mu_z = torch.randn(M, L, generator=gen, dtype=f64), torch.zeros(M, L, dtype=f64)
+        args = (kff * torch.ones(S, n, dtype=f64), Kuf, Lk, torch.zeros(n, L, dtype=f64), mu_z, delta, Lo)
+    want_mean, want_var = orc.conditional(*args)
+    got_mean, got_var = model.compute_mean_and_var(*args)
+    assert got_mean.shape == want_mean.shape and got_var.shape == want_var.shape
+    assert rel(got_mean.numpy(), want_mean.numpy()) < 1e-6 and rel(got_var.numpy(), want_var.numpy()) < 1e-6
+
+
+def test_empty_free_view_keeps_its_kl_terms():
+    """a non-fixed view without rows in this call (a data-parallel rank's empty slice) is skipped by the
+    warp GP but keeps its prior factorisation and KL terms: its parameters still receive the KL gradient"""
+    import spatial_alignment_amd as gp
+
+    gen = torch.Generator().manual_seed(0)
+    X = 10 * torch.rand(30, 2, generator=gen)
+    Y = torch.randn(30, 3, generator=gen)
+    full = {"expression": {"spatial_coords": X, "outputs": Y, "n_samples_list": [15, 15]}}
+    torch.manual_seed(1)
+    model = gp.VariationalGPSA(full, m_X_per_view=6, m_G=6, data_init=False, n_latent_gps={"expression": None})
+    with torch.no_grad():  # off the initial state delta_G == Xtilde, where the KL's mean term has no gradient
+        model.delta_G_list.add_(0.1 * torch.randn(model.delta_G_list.shape, generator=gen))
+    part = {"expression": {"spatial_coords": X[:15], "outputs": Y[:15], "n_samples_list": [15, 0]}}
+    view_idx, Ns, _, _ = model.create_view_idx_dict(part)
+    out = model.forward({"expression": X[:15]}, view_idx, Ns, S=2)
+    assert out[1]["expression"].shape == (2, 15, 2)
+    loss = model.loss_fn(part, out[3])
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert model.Xtilde.grad[1].abs().max() > 0 and model.delta_G_list.grad[1].abs().max() > 0
+    assert model.Omega_sqt_G_list.grad.abs().sum((-1, -2)).min() > 0
