@@ -48,39 +48,35 @@ def parse():
 
 
 class KernelTimer:
-    """HIP-event timing of the contraction kernels on the stream they are launched on."""
+    """HIP-event timing of the three contraction launches, recorded by the step engine itself on the stream it
+    launches them on (gpsa_step_timing: events around gpsa_quadform_fwd / _bwd_alpha / _bwd_omega of the data
+    GP), for every step of the timed region."""
 
-    def __init__(self, ops):
-        self.ops, self.rec, self.on = ops, {}, False
-        for name in ("quadform_fwd", "quadform_bwd_alpha", "quadform_bwd_omega"):
-            self._wrap(name)
+    NAMES = ("quadform_fwd", "quadform_bwd_alpha", "quadform_bwd_omega")
 
-    def _wrap(self, name):
-        inner = getattr(self.ops, name)
+    def __init__(self, model, steps):
+        self.model, self.steps, self.plans = model, steps, []
 
-        def timed(*a, **k):
-            if not self.on or a[0].dtype != torch.float32:
-                return inner(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = inner(*a, **k)
-            e1.record()
-            M, C = a[0].shape
-            L = a[1].shape[0] if name != "quadform_bwd_omega" else a[1].shape[0]
-            self.rec.setdefault(name, []).append((e0, e1, 2.0 * M * M * C * L))
-            return r
+    def start(self):
+        for plan in self.model.__dict__.get("_step_plans", {}).values():
+            if plan.S == self.S and plan.lib.gpsa_step_timing(plan.handle, self.steps) == 0:
+                self.plans.append(plan)
 
-        setattr(self.ops, name, timed)
+    def summary(self, M, C, L):
+        import ctypes
 
-    def summary(self):
         out = {}
-        for name, evs in self.rec.items():
-            big = max(f for _, _, f in evs)  # the data-layer launches (the warp layer reuses the Gram kernel on 1/250 of the flops)
-            evs = [e for e in evs if e[2] == big]
-            ms = [a.elapsed_time(b) for a, b, _ in evs]
-            fl = [f for _, _, f in evs]
-            out[name] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), flops=fl[0],
-                             tflops=sum(fl) / (sum(ms) * 1e-3) / 1e12)
+        for plan in self.plans:
+            buf = (ctypes.c_float * (3 * self.steps))()
+            n = plan.lib.gpsa_step_timing_read(plan.handle, buf, self.steps)
+            plan.lib.gpsa_step_timing(plan.handle, 0)
+            if n <= 0:
+                continue
+            flops = 2.0 * M * M * C * L
+            for k, name in enumerate(self.NAMES):
+                ms = [buf[i * 3 + k] for i in range(n)]
+                out[name] = dict(launches=n, avg_ms=sum(ms) / n, flops=flops,
+                                 tflops=flops * n / (sum(ms) * 1e-3) / 1e12)
         return out
 
 
@@ -193,7 +189,9 @@ def main():
     if args.graph_only:
         from spatial_alignment_amd.train import GraphedTrainStep
 
-        gopt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        from spatial_alignment_amd.optim import FusedAdam
+
+        gopt = FusedAdam(model.parameters(), lr=1e-2)  # device-side step counter: capturable
         gs = GraphedTrainStep(model, gopt, dd, view_idx, Ns, S=args.S, warmup=3)
         for _ in range(2):
             gs.step()
@@ -209,9 +207,12 @@ def main():
                               note="same step (forward+ELBO+backward+Adam) as ONE hipGraph replay")),
               flush=True)
         return
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)  # same update, one fused launch
+    from spatial_alignment_amd.optim import FusedAdam
+
+    opt = FusedAdam(model.parameters(), lr=1e-2)  # torch.optim.Adam's update as one HIP launch
     reducer = GradAllReducer(model.parameters())
-    timer = KernelTimer(ops_mod.get_ops())
+    timer = KernelTimer(model, args.steps)
+    timer.S = args.S
 
     def step():
         out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=args.S)
@@ -227,7 +228,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = True
+    timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -235,7 +236,6 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    timer.on = False
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,8 +287,8 @@ def main():
             graph_info = dict(error=f"{type(e).__name__}: {e}"[:300])
 
     if rank == 0:
-        ks = timer.summary()
         N = int(sum(dd_full["expression"]["n_samples_list"]))
+        ks = timer.summary(args.M, args.S * int(sum(dd["expression"]["n_samples_list"])), args.outputs)
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_cfg = (args.S, args.side, args.views, args.outputs, args.M, world) == (5, 100, 2, 50, 200, 1)

@@ -262,6 +262,192 @@ int gpsa_kmeans_assign(const float* X, long long N, int D, const float* centres,
 int gpsa_kmeans_update(const float* X, const int* assign, long long N, int D, int K, float* centres,
                        int* counts, void* workspace, long long workspace_bytes, void* stream);
 
+
+/* ---- batched forms: the warp GPs of several views in one launch each way -------------------------------
+ * View-blocked layout: the per-view panels of a batch are [M, C] blocks back to back (C = the batch's
+ * column stride, >= every view's spot count); problem b has n_live[b] live columns, the rest are zero
+ * padding written by the forward (everything computed from a zero column is zero).  fp32 inputs as stored
+ * (inducing points, hyper-parameters, coordinates), fp64 arithmetic and results.
+ * gpsa_kmat_batched: K[b] = k(Z + b strideZ, X + b strideX) (+ jitter on the diagonal), ls_u / var_u + b
+ *   stride_par; n_live (HOST array of batch entries) may be NULL (all C columns live).  batch <= 16.
+ * gpsa_kmat_bwd_batched: its adjoint: dZ + b stride_dZ [M,D] and dparams + 2 b (fp64); same != 0: X are the
+ *   inducing points themselves (K_uu), the X-side sums are folded into dZ.
+ * References as gpsa_kmat / gpsa_kmat_bwd (util.py:8-66 called from vgpsa.py:314-318 for every view). */
+int gpsa_kmat_batched(int kind, const float* Z, long long strideZ, int M, const float* X, long long strideX,
+                      long long C, int D, const float* ls_u, const float* var_u, int stride_par,
+                      const long long* n_live, int batch, double jitter, double* K, long long strideK,
+                      void* stream);
+long long gpsa_kmat_bwd_batched_workspace(int M, long long C, int D, int batch);
+int gpsa_kmat_bwd_batched(int kind, const float* Z, long long strideZ, int M, const float* X, long long strideX,
+                          long long C, int D, const float* ls_u, const float* var_u, int stride_par,
+                          const long long* n_live, int batch, const double* Kbar, long long strideK, int same,
+                          double* dZ, long long stride_dZ, double* dparams, void* workspace,
+                          long long workspace_bytes, void* stream);
+/* The data GP's covariance backward (autograd of vgpsa.py:409): fp32 Z / hyper-parameters, X = the warp
+ * GP's unrounded fp64 draws, an fp32 gradient panel Kbar [M,C]; fp64 arithmetic, partial sums and results
+ * (dZ [M,D], dX [C,D] or NULL, dparams[2]).  workspace >= gpsa_kmat_bwd_workspace(GPSA_F64, M, C, D). */
+int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                      const float* var_u, const float* Kbar, double* dZ, double* dX, double* dparams,
+                      void* workspace, long long workspace_bytes, void* stream);
+/* gpsa_whiten_f64 for a batch of fp64 panels with one inverse each: problem b reads Kinv + b strideKinv and
+ * Kuf + b strideX, writes alpha + b strideX and q + b C (q may be NULL).
+ * workspace >= batch * gpsa_whiten_workspace(M). */
+int gpsa_whiten_batched_f64(const double* Kinv, long long strideKinv, const double* Kuf, int M, long long C,
+                            long long strideX, double* alpha, double* q, int batch, void* workspace,
+                            long long workspace_bytes, void* stream);
+/* gpsa_quadform_fwd_keep / _bwd_alpha_kept / gpsa_col_axpy (fp64) for ``batch`` layers with contiguous
+ * operands: alpha [batch][M,C], Omega [batch][L,M,M], W [batch][L,M,C], v / meanT / g / dmeanT [batch][L,C],
+ * dcT [batch][M,L], d [batch][C]. */
+int gpsa_quadform_fwd_keep_batched_f64(const double* alpha, const double* Omega, int M, long long C, int L,
+                                       double* v, double* W, const double* dcT, double* meanT, int batch,
+                                       void* stream);
+int gpsa_quadform_bwd_alpha_kept_batched_f64(const double* W, const double* g, int M, long long C, int L,
+                                             const double* dcT, const double* dmeanT, double* dalpha,
+                                             int batch, void* stream);
+int gpsa_col_axpy_batched_f64(const double* Y, const double* X, const double* d, double s, int M, long long C,
+                              double* out, int batch, void* stream);
+/* dOmega[b][l] = sum_c g[b][l,c] alpha[b][:,c] alpha[b][:,c]^T (fp64, ``batch`` layers with contiguous
+ * operands; gpsa_quadform_bwd_omega for the views' warp GPs in one launch sequence). */
+long long gpsa_gram_batched_workspace(int M, long long C, int L, int batch);
+int gpsa_gram_batched_f64(const double* alpha, const double* g, int M, long long C, int L, double* dOmega,
+                          int batch, void* workspace, long long workspace_bytes, void* stream);
+/* gpsa_mvn_kl_grouped_bwd with accumulate != 0: dOmega += ... (it already holds the layers' share). */
+int gpsa_mvn_kl_grouped_bwd_acc(const double* mats, const double* inv, const int* om_idx,
+                                const int* pr_list, const int* grp_off, const int* order, const double* D,
+                                const double* KD, const double* g, int M, int T, int P, double* dOmega,
+                                double* dD, double* S, int accumulate, void* stream);
+
+/* ==== the step engine: forward(S) and its backward as ONE host call each =================================
+ * Replaces the body of VariationalGPSA.forward (gpsa/models/vgpsa.py:212-489) plus the KL terms of loss_fn
+ * (vgpsa.py:498-530), and what autograd derives from them, for the built-in covariance functions: the host
+ * enqueues the whole launch sequence of a step from C++ (no per-launch Python / ctypes round trip), the
+ * warp GPs of all free views run batched in the same launches, every parameter gradient is accumulated in
+ * fp64 along all of its paths and rounded to the fp32 parameter once.
+ *
+ * A plan (gpsa_step_create) fixes the problem's shape; it owns only host tables and a few hundred bytes of
+ * device index tables (allocated at creation - the ONLY allocation of the library; the hot entry points
+ * below allocate nothing, never synchronise, and are safe to capture into a hipGraph).  The caller passes
+ * two arenas per call: ``saved`` (gpsa_step_saved_bytes: what the backward needs from the forward; one per
+ * live forward) and ``scratch`` (gpsa_step_scratch_bytes: transient, reusable by the next call on the same
+ * stream).
+ *
+ * Views are consecutive row blocks of each modality (what GPSA.create_view_idx_dict produces,
+ * gpsa/models/gpsa.py:155-183); spots of all modalities of a view share that view's warp GP
+ * (vgpsa.py:284-294).  All parameters are the fp32 tensors of the reference's state_dict. */
+#define GPSA_MAX_MODS 4
+
+typedef struct gpsa_step_desc {
+  int n_views, n_dims, n_mods, n_samples;   /* V, D (<= 4), modalities (<= GPSA_MAX_MODS), S */
+  int m_x, m_g;                             /* inducing points per view / of the data GP */
+  int kind_warp, kind_data;                 /* GPSA_K_* */
+  int n_latent[GPSA_MAX_MODS];              /* L_m: latent outputs of the data GP (= P_m without LMC) */
+  int n_out[GPSA_MAX_MODS];                 /* P_m */
+  int has_lmc[GPSA_MAX_MODS];               /* F_obs = F_latent W (vgpsa.py:428-432) */
+  long long n_rows[GPSA_MAX_MODS];          /* N_m */
+  int s_test;                               /* leading dim of G_test, 0: no test pass (vgpsa.py:437-477) */
+  long long n_test[GPSA_MAX_MODS];          /* rows of G_test[m] */
+  int want_kl;                              /* factorise the variational covariances and evaluate the KL terms */
+  const int* view_fixed;                    /* HOST [V]: 1 = fixed view (vgpsa.py:262-273) */
+  const long long* view_rows;               /* HOST [n_mods * V]: rows of view v in modality m, [m * V + v] */
+} gpsa_step_desc;
+
+typedef struct gpsa_step_params {           /* device pointers, fp32, the reference's parameter layout */
+  const float* Xtilde;                      /* [V, m_x, D] */
+  const float* delta_G;                     /* [V, m_x, D] */
+  const float* Omega_sqt_G;                 /* [V*D, m_x, m_x], row j*V+v (vgpsa.py:131-143) */
+  const float* warp_ls;                     /* [V] log lengthscales */
+  const float* warp_var;                    /* [V] log variances */
+  const float* slopes;                      /* [V, D, D] */
+  const float* intercepts;                  /* [V, D] */
+  const float* Gtilde;                      /* [m_g, D] */
+  const float* data_ls;                     /* [1] */
+  const float* data_var;                    /* [1] */
+  const float* Omega_sqt_F[GPSA_MAX_MODS];  /* [L_m, m_g, m_g] */
+  const float* delta_F[GPSA_MAX_MODS];      /* [m_g, L_m] */
+  const float* W[GPSA_MAX_MODS];            /* [L_m, P_m] or NULL */
+} gpsa_step_params;
+
+typedef struct gpsa_step_param_grads {      /* fp32 outputs, overwritten; NULL = not wanted */
+  float *Xtilde, *delta_G, *Omega_sqt_G, *warp_ls, *warp_var, *Gtilde, *data_ls, *data_var;
+  float* Omega_sqt_F[GPSA_MAX_MODS];
+  float* delta_F[GPSA_MAX_MODS];
+  float* W[GPSA_MAX_MODS];
+} gpsa_step_param_grads;
+
+typedef struct gpsa_step_io {
+  const float* X[GPSA_MAX_MODS];            /* in  [N_m, D] spatial coordinates */
+  const float* eps_G;                       /* in  standard-normal draws of the free, non-empty views back to
+                                                   back, each [S, n_v, D] (order of vgpsa.py:346-348) */
+  const float* eps_F[GPSA_MAX_MODS];        /* in  [S, N_m, L_m] (vgpsa.py:423) */
+  const float* G_test[GPSA_MAX_MODS];       /* in  [s_test, n_test_m, D] or NULL */
+  const float* eps_F_test[GPSA_MAX_MODS];   /* in  [s_test, n_test_m, L_m] */
+  float* G_means[GPSA_MAX_MODS];            /* out [N_m, D] */
+  float* G_samples[GPSA_MAX_MODS];          /* out [S, N_m, D] */
+  float* F_latent[GPSA_MAX_MODS];           /* out [S, N_m, L_m] */
+  float* F_obs[GPSA_MAX_MODS];              /* out [S, N_m, P_m] with LMC, else NULL (F_obs is F_latent) */
+  float* F_latent_test[GPSA_MAX_MODS];      /* out [s_test, n_test_m, L_m] */
+  float* F_obs_test[GPSA_MAX_MODS];
+  float* mu_z;                              /* out [V, m_x, D]: prior means at the inducing points (mu_z_G) */
+  double* kl;                               /* out [gpsa_step_n_kl] per-term KL (order: Omega_G rows r = j*V+v,
+                                                   then every modality's outputs), NULL with want_kl = 0 */
+  int* flag;                                /* out [1]: nonzero = a covariance was not positive definite or a
+                                                   warp variance not positive (the reference raises there) */
+} gpsa_step_io;
+
+typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */
+  const float* dG_means[GPSA_MAX_MODS];     /* each may be NULL (= zero) */
+  const float* dG_samples[GPSA_MAX_MODS];
+  const float* dF_latent[GPSA_MAX_MODS];
+  const float* dF_obs[GPSA_MAX_MODS];
+  const float* dF_latent_test[GPSA_MAX_MODS];
+  const float* dF_obs_test[GPSA_MAX_MODS];
+  const double* dkl;                        /* [n_kl] or NULL */
+} gpsa_step_out_grads;
+
+void* gpsa_step_create(const gpsa_step_desc* desc);   /* NULL: invalid / unsupported description */
+void gpsa_step_destroy(void* plan);
+long long gpsa_step_saved_bytes(const void* plan);
+long long gpsa_step_scratch_bytes(const void* plan);
+int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
+long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
+/* stages: bit 0 = the M x M factorisations, the KL terms and the warp GPs (everything ``flag`` depends on),
+ * bit 1 = the data GPs.  3 = the whole forward; a caller that wants to look at ``flag`` while the data GPs
+ * run enqueues the two stages with two calls and its flag copy in between. */
+int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_step_io* io, void* saved,
+                      void* scratch, int stages, void* stream);
+/* diagnostic (bench.py's roofline figures): HIP events around the three contraction launches (the variance
+ * form, its alpha-gradient, its Omega-gradient) of the first data-GP pass, on the stream they are launched on,
+ * for a ring of ``slots`` steps; gpsa_step_timing_read returns the recorded steps' durations [n][3] in ms
+ * (after the caller synchronised).  slots = 0 switches the events off. */
+int gpsa_step_timing(void* plan, int slots);
+int gpsa_step_timing_read(void* plan, float* ms, int max_steps);
+/* backward of the forward that filled ``saved`` (same params / io pointers and contents) */
+int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_step_io* io,
+                       const gpsa_step_out_grads* og, void* saved, void* scratch,
+                       const gpsa_step_param_grads* grads, void* stream);
+
+/* ---- Gaussian likelihood + ELBO in one call each way (vgpsa.py:532-540) ------------------------------------
+ * loss[0] = -(sum_i LL_i) + kl_scale * sum_t kl[t],  LL_i = sum log N(Y_i; F_i, exp(noise_u[i]) + 1e-5) / S_i
+ * (n_ll likelihood terms: one per modality; F_i [S, N_i, P_i], Y_i [N_i, P_i]; kl [n_kl] fp64 or NULL).
+ * backward: dF_i (overwritten), dnoise[i] (overwritten), dkl[t] = kl_scale * gloss.
+ * workspace >= 8 * 4100 * n_ll bytes. */
+int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                       const int* S, const long long* N, const int* P, const double* kl, int n_kl,
+                       double kl_scale, float* loss, double* ll_out, void* workspace,
+                       long long workspace_bytes, void* stream);
+int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                       const int* S, const long long* N, const int* P, const float* gloss, int n_kl,
+                       double kl_scale, float* const* dF, float* const* dnoise, double* dkl, void* workspace,
+                       long long workspace_bytes, void* stream);
+
+/* ---- fused Adam over a list of tensors (torch.optim.Adam, no weight decay / amsgrad; the optimiser step of
+ * the reference loop, examples/grid_example.py:59-78), ONE launch: for every element
+ *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * with t = ++step[0] kept on the device (capturable).  ptrs: HOST arrays of n device pointers. */
+int gpsa_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const long long* numel, double lr, double beta1, double beta2,
+                   double eps, float* step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,88 @@ SIGNATURES = {
     "gpsa_kmeans_update": (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _ll, _vp]),
 }
 
+MAX_MODS = 4  # GPSA_MAX_MODS
+
+
+class StepDesc(C.Structure):
+    """gpsa_step_desc (include/gpsa_hip.h)"""
+    _fields_ = [
+        ("n_views", _i), ("n_dims", _i), ("n_mods", _i), ("n_samples", _i),
+        ("m_x", _i), ("m_g", _i), ("kind_warp", _i), ("kind_data", _i),
+        ("n_latent", _i * MAX_MODS), ("n_out", _i * MAX_MODS), ("has_lmc", _i * MAX_MODS),
+        ("n_rows", _ll * MAX_MODS), ("s_test", _i), ("n_test", _ll * MAX_MODS), ("want_kl", _i),
+        ("view_fixed", C.POINTER(_i)), ("view_rows", C.POINTER(_ll)),
+    ]
+
+
+class StepParams(C.Structure):
+    """gpsa_step_params / gpsa_step_param_grads: the same field order, device pointers"""
+    _fields_ = [
+        ("Xtilde", _vp), ("delta_G", _vp), ("Omega_sqt_G", _vp), ("warp_ls", _vp), ("warp_var", _vp),
+        ("slopes", _vp), ("intercepts", _vp), ("Gtilde", _vp), ("data_ls", _vp), ("data_var", _vp),
+        ("Omega_sqt_F", _vp * MAX_MODS), ("delta_F", _vp * MAX_MODS), ("W", _vp * MAX_MODS),
+    ]
+
+
+class StepParamGrads(C.Structure):
+    _fields_ = [
+        ("Xtilde", _vp), ("delta_G", _vp), ("Omega_sqt_G", _vp), ("warp_ls", _vp), ("warp_var", _vp),
+        ("Gtilde", _vp), ("data_ls", _vp), ("data_var", _vp),
+        ("Omega_sqt_F", _vp * MAX_MODS), ("delta_F", _vp * MAX_MODS), ("W", _vp * MAX_MODS),
+    ]
+
+
+class StepIO(C.Structure):
+    _fields_ = [
+        ("X", _vp * MAX_MODS), ("eps_G", _vp), ("eps_F", _vp * MAX_MODS), ("G_test", _vp * MAX_MODS),
+        ("eps_F_test", _vp * MAX_MODS), ("G_means", _vp * MAX_MODS), ("G_samples", _vp * MAX_MODS),
+        ("F_latent", _vp * MAX_MODS), ("F_obs", _vp * MAX_MODS), ("F_latent_test", _vp * MAX_MODS),
+        ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp),
+    ]
+
+
+class StepOutGrads(C.Structure):
+    _fields_ = [
+        ("dG_means", _vp * MAX_MODS), ("dG_samples", _vp * MAX_MODS), ("dF_latent", _vp * MAX_MODS),
+        ("dF_obs", _vp * MAX_MODS), ("dF_latent_test", _vp * MAX_MODS), ("dF_obs_test", _vp * MAX_MODS),
+        ("dkl", _vp),
+    ]
+
+
+_pp = C.POINTER(_vp)  # host array of device pointers
+
+SIGNATURES.update({
+    "gpsa_kmat_batched": (_i, [_i, _vp, _ll, _i, _vp, _ll, _ll, _i, _vp, _vp, _i, C.POINTER(_ll), _i, _d, _vp, _ll, _vp]),
+    "gpsa_kmat_bwd_batched_workspace": (_ll, [_i, _ll, _i, _i]),
+    "gpsa_kmat_bwd_batched": (_i, [_i, _vp, _ll, _i, _vp, _ll, _ll, _i, _vp, _vp, _i, C.POINTER(_ll), _i, _vp, _ll, _i,
+                                   _vp, _ll, _vp, _vp, _ll, _vp]),
+    "gpsa_kmat_bwd_x64": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_whiten_batched_f64": (_i, [_vp, _ll, _vp, _i, _ll, _ll, _vp, _vp, _i, _vp, _ll, _vp]),
+    "gpsa_quadform_fwd_keep_batched_f64": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gpsa_quadform_bwd_alpha_kept_batched_f64": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _i, _vp]),
+    "gpsa_col_axpy_batched_f64": (_i, [_vp, _vp, _vp, _d, _i, _ll, _vp, _i, _vp]),
+    "gpsa_gram_batched_workspace": (_ll, [_i, _ll, _i, _i]),
+    "gpsa_gram_batched_f64": (_i, [_vp, _vp, _i, _ll, _i, _vp, _i, _vp, _ll, _vp]),
+    "gpsa_mvn_kl_grouped_bwd_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i,
+                                         _vp]),
+    "gpsa_step_create": (_vp, [C.POINTER(StepDesc)]),
+    "gpsa_step_destroy": (None, [_vp]),
+    "gpsa_step_saved_bytes": (_ll, [_vp]),
+    "gpsa_step_scratch_bytes": (_ll, [_vp]),
+    "gpsa_step_n_kl": (_i, [_vp]),
+    "gpsa_step_eps_g_numel": (_ll, [_vp]),
+    "gpsa_step_timing": (_i, [_vp, _i]),
+    "gpsa_step_timing_read": (_i, [_vp, _vp, _i]),
+    "gpsa_step_forward": (_i, [_vp, C.POINTER(StepParams), C.POINTER(StepIO), _vp, _vp, _i, _vp]),
+    "gpsa_step_backward": (_i, [_vp, C.POINTER(StepParams), C.POINTER(StepIO), C.POINTER(StepOutGrads), _vp, _vp,
+                                C.POINTER(StepParamGrads), _vp]),
+    "gpsa_elbo_loss_fwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _vp, _i, _d, _vp,
+                                _vp, _vp, _ll, _vp]),
+    "gpsa_elbo_loss_bwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _vp, _i, _d, _pp, _pp,
+                                _vp, _vp, _ll, _vp]),
+    "gpsa_adam_step": (_i, [_i, _pp, _pp, _pp, _pp, C.POINTER(_ll), _d, _d, _d, _d, _vp, _vp]),
+})
+
 _lib = None
 
 

@@ -359,6 +359,81 @@ int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha,
   return 0;
 }
 
+// Products accumulated in fp64 on the matrix cores from operands stored in either precision, result
+// stored in either precision (split-K partials in fp64).  The step engine's few mixed products: K^-1 times
+// an fp32 gradient panel, the C-long product of two fp32 panels that must be ADDED in fp64.
+template <typename TO>
+__global__ void __launch_bounds__(256)
+splitk_reduce64_kernel(const double* __restrict__ part, int batch, int splitk, int m, int n, double alpha,
+                       double beta, TO* __restrict__ C, long long ldc, long long sC) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long mn = (long long)m * n;
+  const long long idx = blockIdx.x * 64LL + lane;
+  const bool ok = idx < mn * batch;
+  const int b = ok ? (int)(idx / mn) : 0;
+  const long long e = ok ? idx % mn : 0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (ok) {
+    const double* p = part + (long long)b * splitk * mn + e;
+    int sp = grp;
+    for (; sp + 12 < splitk; sp += 16) {
+      a0 += p[sp * mn];
+      a1 += p[(sp + 4) * mn];
+      a2 += p[(sp + 8) * mn];
+      a3 += p[(sp + 12) * mn];
+    }
+    for (; sp < splitk; sp += 4) a0 += p[sp * mn];
+  }
+  red[grp][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && ok) {
+    const double s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int r = (int)(e / n), c = (int)(e % n);
+    TO* q = C + (long long)b * sC + (long long)r * ldc + c;
+    *q = (TO)((beta == 0.0) ? alpha * s : alpha * s + beta * (double)(*q));
+  }
+}
+
+template <typename TIA, typename TIB, typename TO>
+int gemm64_launch(int transA, int transB, int m, int n, long long k, double alpha, const TIA* A,
+                  long long lda, long long sA, const TIB* B, long long ldb, long long sB, double beta,
+                  TO* C, long long ldc, long long sC, int batch, int splitk, void* ws, long long ws_bytes,
+                  hipStream_t st) {
+  if (m < 1 || n < 1 || k < 1 || batch < 1 || splitk < 1) return GPSA_EINVAL;
+  if ((long long)batch * splitk > 65535) return GPSA_EINVAL;
+  double* part = nullptr;
+  if (splitk > 1) {
+    if (ws_bytes < (long long)batch * splitk * m * n * 8) return GPSA_EWORKSPACE;
+    part = reinterpret_cast<double*>(ws);
+  }
+  dim3 grid((unsigned)cdiv(n, GB_N), (unsigned)cdiv(m, GB_M), (unsigned)(batch * splitk));
+#define GPSA_G64X(TA, TB)                                                                              \
+  gemm_mfma_kernel<double, TA, TB, TIA, TIB, TO, false><<<grid, 256, 0, st>>>(                          \
+      m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, splitk, part, 0.0)
+  if (!transA && !transB) GPSA_G64X(false, false);
+  else if (transA && !transB) GPSA_G64X(true, false);
+  else if (!transA && transB) GPSA_G64X(false, true);
+  else GPSA_G64X(true, true);
+#undef GPSA_G64X
+  GPSA_LAUNCH_CHECK();
+  if (splitk > 1) {
+    const long long tot = (long long)m * n * batch;
+    splitk_reduce64_kernel<TO><<<(unsigned)cdiv(tot, 64), 256, 0, st>>>(part, batch, splitk, m, n, alpha, beta,
+                                                                        C, ldc, sC);
+    GPSA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+#define GPSA_G64_INST(TIA, TIB, TO)                                                                          \
+  template int gemm64_launch<TIA, TIB, TO>(int, int, int, int, long long, double, const TIA*, long long,      \
+                                           long long, const TIB*, long long, long long, double, TO*, long long, \
+                                           long long, int, int, void*, long long, hipStream_t);
+GPSA_G64_INST(double, float, float)   // gamma = K^-1 abar beyond the projection kernel's size
+GPSA_G64_INST(float, float, double)   // dK_uu = -W alpha^T on few columns; dc ddc^T
+GPSA_G64_INST(double, double, float)  // alpha = K^-1 K_uf stored fp32 beyond the projection kernel's size
+#undef GPSA_G64_INST
+
 // explicit instantiations used from other translation units
 template int gemm_launch<float>(int, int, int, int, long long, double, const float*, long long,
                                 long long, const float*, long long, long long, double, float*,

@@ -1,0 +1,19 @@
+// Launchers shared between the translation units of libgpsa_hip (defined where their kernels live).
+#pragma once
+#include "common.hpp"
+
+namespace gpsa {
+
+// gemm.hip: C[b] = alpha op(A[b]) op(B[b]) + beta C[b], row-major, strided batch, deterministic split-K
+template <typename T>
+int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A, long long lda,
+                long long sA, const T* B, long long ldb, long long sB, double beta, T* C, long long ldc,
+                long long sC, int batch, int splitk, void* ws, long long ws_bytes, hipStream_t st);
+// the same accumulated in fp64 from operands / into results of either precision (instantiated for
+// (double,float,float), (float,float,double), (double,double,float))
+template <typename TIA, typename TIB, typename TO>
+int gemm64_launch(int transA, int transB, int m, int n, long long k, double alpha, const TIA* A, long long lda,
+                  long long sA, const TIB* B, long long ldb, long long sB, double beta, TO* C, long long ldc,
+                  long long sC, int batch, int splitk, void* ws, long long ws_bytes, hipStream_t st);
+
+}  // namespace gpsa

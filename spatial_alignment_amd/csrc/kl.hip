@@ -102,14 +102,14 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
                           const int* __restrict__ grp_off, const int* __restrict__ order,
                           const double* __restrict__ D, const double* __restrict__ KD,
                           const double* __restrict__ g, int M, int P, double* __restrict__ dOmega,
-                          double* __restrict__ dD, double* __restrict__ S) {
+                          double* __restrict__ dD, double* __restrict__ S, int accumulate) {
   const int pg = blockIdx.y;
   const long long mm = (long long)M * M, e = blockIdx.x * 256LL + threadIdx.x;
   const int t0 = grp_off[pg], t1 = grp_off[pg + 1];
   if (pg == P) {  // pseudo-group of the absent terms
     for (int q = t0; q < t1; ++q) {
       const int t = order[q];
-      if (e < mm) dOmega[(long long)t * mm + e] = 0.0;
+      if (e < mm && !accumulate) dOmega[(long long)t * mm + e] = 0.0;
       if (blockIdx.x == 0)
         for (int m = threadIdx.x; m < M; m += 256) dD[(long long)t * M + m] = 0.0;
     }
@@ -130,7 +130,9 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
     const int t = order[q], o = om_idx[t];
     const double gt = g[t];
     gs += gt;
-    dOmega[(long long)t * mm + e] = 0.5 * gt * (kin - inv[(long long)o * mm + e]);
+    const double dom = 0.5 * gt * (kin - inv[(long long)o * mm + e]);
+    // accumulate: dOmega already holds the layers' share of the gradient (the step engine's buffer)
+    dOmega[(long long)t * mm + e] = accumulate ? dOmega[(long long)t * mm + e] + dom : dom;
     s += gt * (mats[(long long)o * mm + e] + D[(long long)t * M + i] * D[(long long)t * M + j]);
   }
   S[(long long)pg * mm + e] = gs * mats[(long long)p * mm + e] - s;
@@ -150,16 +152,24 @@ int gpsa_mvn_kl_grouped_fwd(const double* mats, const double* inv, const double*
   return 0;
 }
 
+int gpsa_mvn_kl_grouped_bwd_acc(const double* mats, const double* inv, const int* om_idx,
+                                const int* pr_list, const int* grp_off, const int* order, const double* D,
+                                const double* KD, const double* g, int M, int T, int P, double* dOmega,
+                                double* dD, double* S, int accumulate, void* stream) {
+  if (M < 1 || T < 1 || P < 1) return GPSA_EINVAL;
+  dim3 grid((unsigned)cdiv((long long)M * M, 256), (unsigned)(P + 1));
+  gpsa::mvn_kl_grouped_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+      mats, inv, om_idx, pr_list, grp_off, order, D, KD, g, M, P, dOmega, dD, S, accumulate);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
 int gpsa_mvn_kl_grouped_bwd(const double* mats, const double* inv, const int* om_idx,
                             const int* pr_list, const int* grp_off, const int* order, const double* D,
                             const double* KD, const double* g, int M, int T, int P, double* dOmega,
                             double* dD, double* S, void* stream) {
-  if (M < 1 || T < 1 || P < 1) return GPSA_EINVAL;
-  dim3 grid((unsigned)cdiv((long long)M * M, 256), (unsigned)(P + 1));
-  gpsa::mvn_kl_grouped_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(mats, inv, om_idx, pr_list, grp_off,
-                                                                       order, D, KD, g, M, P, dOmega, dD, S);
-  GPSA_LAUNCH_CHECK();
-  return 0;
+  return gpsa_mvn_kl_grouped_bwd_acc(mats, inv, om_idx, pr_list, grp_off, order, D, KD, g, M, T, P, dOmega,
+                                     dD, S, 0, stream);
 }
 
 int gpsa_mvn_kl_fwd(const double* Kinv, const double* logdetK, const double* Omega,

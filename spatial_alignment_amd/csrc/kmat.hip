@@ -46,6 +46,25 @@ __device__ __forceinline__ void cov_eval(const T* z, const T* x, int D, T ell, T
 
 constexpr int KM_ROWS = 16;
 
+// A batch of covariance problems in ONE launch (blockIdx.z = problem b): the views' warp GPs of a step.
+// Every problem has the same M, D and column stride C; its operands sit at fixed strides from the first
+// problem's (elements): Z + b sZ, X + b sX, K / Kbar + b sK, the two hyper-parameters + b sP.  n[b] <= C is
+// the number of LIVE columns of problem b: the forward writes zeros beyond it (the padding of the
+// view-blocked layout: everything computed from a zero column is zero), the backward skips them.
+constexpr int KM_MAXB = 16;
+struct KmatBatch {
+  long long sZ, sX, sK;
+  int sP, ragged;  // ragged: use n[]; otherwise every problem has C live columns
+  long long n[KM_MAXB];
+};
+static inline KmatBatch kmat_single() {
+  KmatBatch kb;
+  kb.sZ = kb.sX = kb.sK = 0;
+  kb.sP = kb.ragged = 0;
+  for (int i = 0; i < KM_MAXB; ++i) kb.n[i] = 0;
+  return kb;
+}
+
 // TI: storage type of the coordinates and hyper-parameters (the fp32 parameters are read as they are,
 // no cast launches); T: type the covariance is computed and stored in.
 // TX: storage type of X alone (the data GP reads the warp GP's unrounded fp64 draws next to fp32 parameters).
@@ -53,8 +72,15 @@ template <typename TI, typename TX, typename T, int KIND>
 __global__ void __launch_bounds__(256)
 kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long long C, int D,
                 const TI* __restrict__ ls_u, const TI* __restrict__ var_u, T jitter,
-                T* __restrict__ K) {
+                T* __restrict__ K, KmatBatch kb) {
   __shared__ T Zs[KM_ROWS][MAXD];
+  const int b = blockIdx.z;
+  Z += b * kb.sZ;
+  X += b * kb.sX;
+  K += b * kb.sK;
+  ls_u += b * kb.sP;
+  var_u += b * kb.sP;
+  const long long live = kb.ragged ? kb.n[b] : C;
   const int m0 = blockIdx.y * KM_ROWS;
   if (threadIdx.x < KM_ROWS * MAXD) {
     int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
@@ -63,11 +89,15 @@ kmat_fwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long 
   __syncthreads();
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   if (c >= C) return;
+  const int mend = min(KM_ROWS, M - m0);
+  if (c >= live) {  // padding column of a view block
+    for (int r = 0; r < mend; ++r) K[(long long)(m0 + r) * C + c] = T(0);
+    return;
+  }
   const T ell = t_exp<T>((T)ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>((T)var_u[0]);
   T x[MAXD];
 #pragma unroll
   for (int d = 0; d < MAXD; ++d) x[d] = (d < D) ? (T)X[c * D + d] : T(0);
-  const int mend = min(KM_ROWS, M - m0);
   for (int r = 0; r < mend; ++r) {
     T k, cd, pl;
     cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
@@ -91,12 +121,24 @@ constexpr int KB_MAXBX = 1024;  // column-block workgroups per row chunk (beyond
 //   xpart[by][c*D+d]      dX contribution of row chunk by
 //   spart[bx*ny+by][0..1] d ls_u, d var_u
 // TK: storage type of Kbar (an fp32 gradient panel can be contracted in fp64: T = double)
-template <typename TI, typename T, int KIND, int MCH, typename TK = T>
+template <typename TI, typename T, int KIND, int MCH, typename TK = T, typename TX = TI>
 __global__ void __launch_bounds__(256)
-kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long long C, int D,
+kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long long C, int D,
                 const TI* __restrict__ ls_u, const TI* __restrict__ var_u,
                 const TK* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
-                T* __restrict__ spart) {
+                T* __restrict__ spart, KmatBatch bt) {
+  {  // problem b of the batch: operands at fixed strides, partial sums in its own workspace region
+    const long long b = blockIdx.z;
+    Z += b * bt.sZ;
+    X += b * bt.sX;
+    Kbar += b * bt.sK;
+    ls_u += b * bt.sP;
+    var_u += b * bt.sP;
+    zpart += b * (long long)gridDim.x * M * D;
+    if (xpart != nullptr) xpart += b * (long long)gridDim.y * C * D;
+    spart += b * (long long)gridDim.x * gridDim.y * 2;
+  }
+  const long long nlive = bt.ragged ? bt.n[blockIdx.z] : C;
   __shared__ T Zs[MCH][MAXD];
   __shared__ T acc[4][MCH][MAXD];
   __shared__ T red[4];
@@ -116,7 +158,7 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
   const long long ncb = (C + 255) / 256;
   for (long long cb = blockIdx.x; cb < ncb; cb += gridDim.x) {
     const long long c = cb * 256 + threadIdx.x;
-    const bool live = c < C;
+    const bool live = c < nlive;
     T x[MAXD], dx[MAXD];
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
@@ -139,7 +181,7 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TI* __restrict__ X, long 
           if (lane == 0) acc[w][r][d] += tz;
         }
     }
-    if (xpart != nullptr && live) {
+    if (xpart != nullptr && c < C) {
       T* xr = xpart + (long long)blockIdx.y * C * D;
       for (int d = 0; d < D; ++d) xr[c * D + d] = dx[d];
     }
@@ -168,7 +210,16 @@ __global__ void __launch_bounds__(256)
 kmat_bwd_finish_kernel(const T* __restrict__ zpart, long long nbx, long long nz,
                        const T* __restrict__ xpart, long long nby, long long nx,
                        const T* __restrict__ spart, long long ns, int same, TO* __restrict__ dZ,
-                       TO* __restrict__ dX, TO* __restrict__ dparams) {
+                       TO* __restrict__ dX, TO* __restrict__ dparams, long long sdZ, long long sdX) {
+  {  // problem blockIdx.y of a batch (strides of the results in elements; partials are back to back)
+    const long long b = blockIdx.y;
+    zpart += b * nbx * nz;
+    if (xpart != nullptr) xpart += b * nby * nx;
+    spart += b * ns * 2;
+    dZ += b * sdZ;
+    if (dX != nullptr) dX += b * sdX;
+    dparams += b * 2;
+  }
   __shared__ double red[256];
   const long long zb = (nz + 15) / 16, xb = (nx + 63) / 64;
   const T* part;
@@ -214,17 +265,19 @@ kmat_bwd_finish_kernel(const T* __restrict__ zpart, long long nbx, long long nz,
 
 template <typename TI, typename TX, typename T>
 int kmat_launch(int kind, const TI* Z, int M, const TX* X, long long C, int D, const TI* ls_u,
-                const TI* var_u, double jitter, T* K, hipStream_t st) {
-  dim3 grid((unsigned)cdiv(C, 256), (unsigned)cdiv(M, KM_ROWS));
+                const TI* var_u, double jitter, T* K, hipStream_t st, int batch = 1,
+                KmatBatch kb = kmat_single()) {
+  if (batch < 1 || batch > KM_MAXB) return GPSA_EINVAL;
+  dim3 grid((unsigned)cdiv(C, 256), (unsigned)cdiv(M, KM_ROWS), (unsigned)batch);
   switch (kind) {
     case GPSA_K_RBF:
-      kmat_fwd_kernel<TI, TX, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, TX, T, GPSA_K_RBF><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K, kb);
       break;
     case GPSA_K_MATERN12:
-      kmat_fwd_kernel<TI, TX, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, TX, T, GPSA_K_MATERN12><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K, kb);
       break;
     case GPSA_K_MATERN32:
-      kmat_fwd_kernel<TI, TX, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K);
+      kmat_fwd_kernel<TI, TX, T, GPSA_K_MATERN32><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, (T)jitter, K, kb);
       break;
     default:
       return GPSA_EINVAL;
@@ -234,28 +287,30 @@ int kmat_launch(int kind, const TI* Z, int M, const TX* X, long long C, int D, c
 }
 
 // TO: storage type of the gradients (the fp64 backward of the data GP keeps them fp64 from fp32 inputs)
-template <typename TI, typename T, typename TO = TI, typename TK = T>
-int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int D, const TI* ls_u,
+template <typename TI, typename T, typename TO = TI, typename TK = T, typename TX = TI>
+int kmat_bwd_launch(int kind, const TI* Z, int M, const TX* X, long long C, int D, const TI* ls_u,
                     const TI* var_u, const TK* Kbar, TO* dZ, TO* dX, TO* dparams, int same, void* ws,
-                    long long ws_bytes, hipStream_t st) {
-  const int mch = kb_rows(M, C);
+                    long long ws_bytes, hipStream_t st, int batch = 1, KmatBatch kb = kmat_single(),
+                    long long sdZ = 0, long long sdX = 0) {
+  if (batch < 1 || batch > KM_MAXB) return GPSA_EINVAL;
+  const int mch = kb_rows(M, C * batch);
   const long long ncb = cdiv(C, 256), nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX, nby = cdiv(M, mch);
   const long long nz = (long long)M * D, nx = C * D;
-  const long long need = (nbx * nz + nby * nx + nbx * nby * 2) * (long long)sizeof(T);
+  const long long need = (nbx * nz + nby * nx + nbx * nby * 2) * (long long)sizeof(T) * batch;
   if (ws_bytes < need) return GPSA_EWORKSPACE;
   T* zpart = reinterpret_cast<T*>(ws);
-  T* xpart = zpart + nbx * nz;
-  T* spart = xpart + nby * nx;
-  dim3 grid((unsigned)nbx, (unsigned)nby);
+  T* xpart = zpart + nbx * nz * batch;
+  T* spart = xpart + nby * nx * batch;
+  dim3 grid((unsigned)nbx, (unsigned)nby, (unsigned)batch);
   T* xp = (dX || same) ? xpart : nullptr;  // K_uu: the X-side partials are folded into dZ
 #define GPSA_KB_CASE(KIND)                                                                          \
   if (mch == KB_MCHUNK)                                                                             \
-    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK, TK><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u,    \
-                                                                      Kbar, zpart, xp, spart);      \
+    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK, TK, TX><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, \
+                                                                      Kbar, zpart, xp, spart, kb);  \
   else                                                                                              \
-    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK_SMALL, TK><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u,     \
+    kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK_SMALL, TK, TX><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, \
                                                                             var_u, Kbar, zpart, xp, \
-                                                                            spart);
+                                                                            spart, kb);
   switch (kind) {
     case GPSA_K_RBF: GPSA_KB_CASE(GPSA_K_RBF) break;
     case GPSA_K_MATERN12: GPSA_KB_CASE(GPSA_K_MATERN12) break;
@@ -267,8 +322,9 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TI* X, long long C, int 
   GPSA_LAUNCH_CHECK();
   const bool fold = same != 0;
   if (fold && (nx != nz)) return GPSA_EINVAL;
-  kmat_bwd_finish_kernel<T, TO><<<(unsigned)(cdiv(nz, 16) + cdiv(nx, 64) + 1), 256, 0, st>>>(
-      zpart, nbx, nz, xp, nby, nx, spart, nbx * nby, fold ? 1 : 0, dZ, dX, dparams);
+  dim3 fgrid((unsigned)(cdiv(nz, 16) + cdiv(nx, 64) + 1), (unsigned)batch);
+  kmat_bwd_finish_kernel<T, TO><<<fgrid, 256, 0, st>>>(zpart, nbx, nz, xp, nby, nx, spart, nbx * nby,
+                                                       fold ? 1 : 0, dZ, dX, dparams, sdZ, sdX);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -331,6 +387,56 @@ int gpsa_kmat_bwd(int dtype, int in_dtype, int kind, const void* Z, int M, const
         kind, (const float*)Z, M, (const float*)X, C, D, (const float*)ls_u, (const float*)var_u,
         (const float*)Kbar, (double*)dZ, (double*)dX, (double*)dparams, same, workspace, workspace_bytes, st);
   return GPSA_EINVAL;
+}
+
+/* ---- batched forms (the views' warp GPs of a step in ONE launch each way; see KmatBatch) -------------- */
+static gpsa::KmatBatch make_batch(long long sZ, long long sX, long long sK, int sP, const long long* n_live,
+                                  int batch) {
+  gpsa::KmatBatch kb = gpsa::kmat_single();
+  kb.sZ = sZ;
+  kb.sX = sX;
+  kb.sK = sK;
+  kb.sP = sP;
+  kb.ragged = n_live != nullptr;
+  for (int i = 0; i < batch && i < gpsa::KM_MAXB; ++i) kb.n[i] = n_live ? n_live[i] : 0;
+  return kb;
+}
+
+int gpsa_kmat_batched(int kind, const float* Z, long long strideZ, int M, const float* X, long long strideX,
+                      long long C, int D, const float* ls_u, const float* var_u, int stride_par,
+                      const long long* n_live, int batch, double jitter, double* K, long long strideK,
+                      void* stream) {
+  if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1 || batch < 1 || batch > gpsa::KM_MAXB) return GPSA_EINVAL;
+  return gpsa::kmat_launch<float, float, double>(kind, Z, M, X, C, D, ls_u, var_u, jitter, K, as_stream(stream),
+                                                 batch, make_batch(strideZ, strideX, strideK, stride_par, n_live, batch));
+}
+
+long long gpsa_kmat_bwd_batched_workspace(int M, long long C, int D, int batch) {
+  const int mch = gpsa::kb_rows(M, C * batch);
+  const long long ncb = cdiv(C, 256), nbx = ncb < gpsa::KB_MAXBX ? ncb : gpsa::KB_MAXBX, nby = cdiv(M, mch);
+  return (nbx * M * D + nby * C * D + nbx * nby * 2) * 8LL * batch;
+}
+
+int gpsa_kmat_bwd_batched(int kind, const float* Z, long long strideZ, int M, const float* X, long long strideX,
+                          long long C, int D, const float* ls_u, const float* var_u, int stride_par,
+                          const long long* n_live, int batch, const double* Kbar, long long strideK, int same,
+                          double* dZ, long long stride_dZ, double* dparams, void* workspace,
+                          long long workspace_bytes, void* stream) {
+  if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1 || batch < 1 || batch > gpsa::KM_MAXB) return GPSA_EINVAL;
+  return gpsa::kmat_bwd_launch<float, double, double, double, float>(
+      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, (double*)nullptr, dparams, same, workspace, workspace_bytes,
+      as_stream(stream), batch, make_batch(strideZ, strideX, strideK, stride_par, n_live, batch), stride_dZ, 0);
+}
+
+/* The data GP's covariance backward: fp32 Z / hyper-parameters, X = the warp GP's unrounded fp64 draws, an
+ * fp32 gradient panel Kbar; fp64 arithmetic, partial sums and results (dZ [M,D], dX [C,D] or NULL,
+ * dparams[2]).  workspace >= gpsa_kmat_bwd_workspace(GPSA_F64, M, C, D). */
+int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                      const float* var_u, const float* Kbar, double* dZ, double* dX, double* dparams,
+                      void* workspace, long long workspace_bytes, void* stream) {
+  if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
+  return gpsa::kmat_bwd_launch<float, double, double, float, double>(
+      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, dX, dparams, 0, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -37,27 +37,30 @@ __global__ void colscale_kernel(const T* __restrict__ X, const T* __restrict__ g
   for (int m = blockIdx.y; m < M; m += gridDim.y) out[(long long)m * C + c] = X[(long long)m * C + c] * gv;
 }
 
-// out[b][m,c] = X[m,c] * g[b][c]   (grid.z = b)
+// out[b][m,c] = X[b / per][m,c] * g[b][c]   (grid.z = b; per = outputs that share one X panel: all of them
+// for a single layer, L per view for a batch of views' layers)
 template <typename T>
 __global__ void colscale_batched_kernel(const T* __restrict__ X, const T* __restrict__ g, int M, long long C,
-                                        T* __restrict__ out) {
+                                        T* __restrict__ out, int per = 0x7fffffff) {
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   if (c >= C) return;
   const T gv = g[(long long)blockIdx.z * C + c];
   T* o = out + (long long)blockIdx.z * M * C;
-  for (int m = blockIdx.y; m < M; m += gridDim.y) o[(long long)m * C + c] = X[(long long)m * C + c] * gv;
+  const T* x = X + (long long)(blockIdx.z / per) * M * C;
+  for (int m = blockIdx.y; m < M; m += gridDim.y) o[(long long)m * C + c] = x[(long long)m * C + c] * gv;
 }
 
-// out[m,c] = Y[m,c] + s * d[c] * X[m,c]
+// out[m,c] = Y[m,c] + s * d[c] * X[m,c]      (blockIdx.z = problem of a batch of contiguous [M,C] panels)
 template <typename T>
 __global__ void col_axpy_kernel(const T* __restrict__ Y, const T* __restrict__ X,
                                 const T* __restrict__ d, T s, int M, long long C,
                                 T* __restrict__ out) {
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   if (c >= C) return;
-  const T dv = s * d[c];
+  const long long pb = (long long)blockIdx.z * M * C;
+  const T dv = s * d[(long long)blockIdx.z * C + c];
   for (int m = blockIdx.y; m < M; m += gridDim.y) {
-    const long long o = (long long)m * C + c;
+    const long long o = pb + (long long)m * C + c;
     out[o] = Y[o] + dv * X[o];
   }
 }
@@ -90,12 +93,23 @@ coldot_kernel(const T* __restrict__ X, const T* __restrict__ Tm, int M, long lon
 }
 
 // out[m,c] = 2 sum_l g[l,c] W[l][m,c]  (+ sum_l A[m,l] dm[l,c] when A is given: the mean term's share)
+// blockIdx.z = problem of a batch of contiguous operands
 template <typename T>
 __global__ void col_wsum_kernel(const T* __restrict__ W, const T* __restrict__ g, int M, long long C,
                                 int L, const T* __restrict__ A, const T* __restrict__ dm,
                                 T* __restrict__ out) {
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   if (c >= C) return;
+  {
+    const long long b = blockIdx.z;
+    W += b * L * M * C;
+    g += b * L * C;
+    if (A != nullptr) {
+      A += b * M * L;
+      dm += b * L * C;
+    }
+    out += b * M * C;
+  }
   for (int m = blockIdx.y; m < M; m += gridDim.y) {
     T s = T(0), t = T(0);
     for (int l = 0; l < L; ++l) {
@@ -114,6 +128,14 @@ coldot_mean_kernel(const T* __restrict__ X, const T* __restrict__ Tm, const T* _
   __shared__ T red[2][4][64];
   const int lane = threadIdx.x & 63, qr = threadIdx.x >> 6, b = blockIdx.y;
   const long long c = blockIdx.x * 64LL + lane;
+  {  // blockIdx.z = problem of a batch of contiguous operands
+    const long long pz = blockIdx.z;
+    X += pz * M * C;
+    Tm += pz * L * M * C;
+    A += pz * M * L;
+    v += pz * L * C;
+    mean += pz * L * C;
+  }
   const T* t = Tm + (long long)b * M * C;
   T s0 = T(0), s1 = T(0), m0 = T(0), m1 = T(0);
   if (c < C) {
@@ -140,25 +162,35 @@ coldot_mean_kernel(const T* __restrict__ X, const T* __restrict__ Tm, const T* _
   }
 }
 
+// batch > 1: ``batch`` layers with contiguous operands (alpha [batch][M,C], Omega [batch][L,M,M], W
+// [batch][L,M,C], v / meanT [batch][L,C], dcT [batch][M,L]): the views' warp GPs in ONE launch sequence.
+// The product W_b = Omega_b alpha_b is ONE strided-batched product with the L outputs stacked as rows.
 template <typename T>
 int quadform_fwd_keep(const T* alpha, const T* Omega, int M, long long C, int L, T* v, T* W,
-                      const T* dcT, T* meanT, hipStream_t st) {
-  int rc = gemm_launch<T>(0, 0, M, (int)C, M, 1.0, Omega, M, (long long)M * M, alpha, C, 0, 0.0, W, C,
-                          (long long)M * C, L, 1, nullptr, 0, st);
+                      const T* dcT, T* meanT, hipStream_t st, int batch = 1) {
+  int rc;
+  if (batch == 1)
+    rc = gemm_launch<T>(0, 0, M, (int)C, M, 1.0, Omega, M, (long long)M * M, alpha, C, 0, 0.0, W, C,
+                        (long long)M * C, L, 1, nullptr, 0, st);
+  else
+    rc = gemm_launch<T>(0, 0, L * M, (int)C, M, 1.0, Omega, M, (long long)L * M * M, alpha, C,
+                        (long long)M * C, 0.0, W, C, (long long)L * M * C, batch, 1, nullptr, 0, st);
   if (rc) return rc;
-  dim3 grid((unsigned)cdiv(C, 64), (unsigned)L);
+  dim3 grid((unsigned)cdiv(C, 64), (unsigned)L, (unsigned)batch);
   if (dcT != nullptr)
     coldot_mean_kernel<T><<<grid, 256, 0, st>>>(alpha, W, dcT, M, C, L, v, meanT);
-  else
+  else if (batch == 1)
     coldot_kernel<T><<<grid, 256, 0, st>>>(alpha, W, M, C, v, C);
+  else
+    return GPSA_EINVAL;
   GPSA_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T>
 int quadform_bwd_alpha_kept(const T* W, const T* g, int M, long long C, int L, const T* dcT, const T* dmeanT,
-                            T* dalpha, hipStream_t st) {
-  dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64));
+                            T* dalpha, hipStream_t st, int batch = 1) {
+  dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64), (unsigned)batch);
   col_wsum_kernel<T><<<grid, 256, 0, st>>>(W, g, M, C, L, dcT, dmeanT, dalpha);
   GPSA_LAUNCH_CHECK();
   return 0;
@@ -1428,6 +1460,59 @@ int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const v
                                               (double*)dOmega, workspace, workspace_bytes, st);
   }
   return GPSA_EINVAL;
+}
+
+/* batched fp64 forms of the two calls above and of gpsa_col_axpy: ``batch`` layers with contiguous operands
+ * (see quadform_fwd_keep) - the warp GPs of several views in one launch sequence. */
+int gpsa_quadform_fwd_keep_batched_f64(const double* alpha, const double* Omega, int M, long long C, int L,
+                                       double* v, double* W, const double* dcT, double* meanT, int batch,
+                                       void* stream) {
+  if (M < 1 || C < 1 || L < 1 || batch < 1 || C > 0x7fffffffLL || dcT == nullptr || meanT == nullptr)
+    return GPSA_EINVAL;
+  return gpsa::quadform_fwd_keep<double>(alpha, Omega, M, C, L, v, W, dcT, meanT, as_stream(stream), batch);
+}
+
+int gpsa_quadform_bwd_alpha_kept_batched_f64(const double* W, const double* g, int M, long long C, int L,
+                                             const double* dcT, const double* dmeanT, double* dalpha,
+                                             int batch, void* stream) {
+  if (M < 1 || C < 1 || L < 1 || batch < 1) return GPSA_EINVAL;
+  if ((dcT == nullptr) != (dmeanT == nullptr)) return GPSA_EINVAL;
+  return gpsa::quadform_bwd_alpha_kept<double>(W, g, M, C, L, dcT, dmeanT, dalpha, as_stream(stream), batch);
+}
+
+int gpsa_col_axpy_batched_f64(const double* Y, const double* X, const double* d, double s, int M, long long C,
+                              double* out, int batch, void* stream) {
+  if (M < 1 || C < 1 || batch < 1) return GPSA_EINVAL;
+  dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64), (unsigned)batch);
+  gpsa::col_axpy_kernel<double><<<grid, 256, 0, as_stream(stream)>>>(Y, X, d, s, M, C, out);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+/* dOmega[b][l] = sum_c g[b][l,c] alpha[b][:,c] alpha[b][:,c]^T for ``batch`` fp64 layers with contiguous
+ * operands (alpha [batch][M,C], g [batch][L,C], dOmega [batch][L,M,M]): one scaling launch and ONE
+ * strided-batched split-K product with the L outputs of a layer stacked as rows.
+ * workspace >= gpsa_gram_batched_workspace(M, C, L, batch). */
+long long gpsa_gram_batched_workspace(int M, long long C, int L, int batch) {
+  const int sk = gpsa::gram_splitk(C, M);
+  return ((long long)L * M * C + (sk > 1 ? (long long)sk * L * M * M : 0)) * 8LL * batch + 256;
+}
+
+int gpsa_gram_batched_f64(const double* alpha, const double* g, int M, long long C, int L, double* dOmega,
+                          int batch, void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || L < 1 || batch < 1) return GPSA_EINVAL;
+  if (workspace_bytes < gpsa_gram_batched_workspace(M, C, L, batch)) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int sk = gram_splitk(C, M);
+  double* tmp = (double*)workspace;
+  double* part = tmp + (long long)batch * L * M * C;
+  dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64), (unsigned)(batch * L));
+  colscale_batched_kernel<double><<<grid, 256, 0, st>>>(alpha, g, M, C, tmp, L);
+  GPSA_LAUNCH_CHECK();
+  return gemm_launch<double>(0, 1, L * M, M, C, 1.0, tmp, C, (long long)L * M * C, alpha, C, (long long)M * C,
+                             0.0, dOmega, M, (long long)L * M * M, batch, sk, part,
+                             (long long)batch * sk * L * M * M * 8, st);
 }
 
 int gpsa_col_axpy(int dtype, const void* Y, const void* X, const void* d, double s, int M,

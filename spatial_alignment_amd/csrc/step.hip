@@ -1,0 +1,1604 @@
+// The step engine: VariationalGPSA.forward (gpsa/models/vgpsa.py:212-489) with the KL terms of loss_fn
+// (vgpsa.py:498-530), and their backward, each as ONE host call that enqueues the whole launch sequence.
+//
+// What it changes against one autograd node per layer driven from Python:
+//   * no per-launch host round trip (a step was ~160 launches x ~11 us of Python / ctypes each);
+//   * the warp GPs of all free views share their launches (view-blocked layout: every per-view panel is an
+//     [M, Cs] block with a common column stride Cs, zero padded, problem index = blockIdx.z / .y);
+//   * every parameter gradient is accumulated in fp64 along all of its paths (K_uu, K_uf, mean function,
+//     KL) and rounded to the fp32 parameter once, by step_finalize_kernel;
+//   * nothing is allocated here: the caller passes a ``saved`` arena (forward -> backward) and a ``scratch``
+//     arena; both sizes come from a dry run of the very code that uses them (Arena::dry).
+//
+// Math and precision plan: as spatial_alignment_amd/engine.py documents (fp64 factorisations, fp64 warp GP,
+// fp64 projection + fp32 matrix-core contractions in the data GP, fp64 gradient sums).
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace gpsa {
+
+constexpr int MAXMODS = GPSA_MAX_MODS;
+constexpr int KM_MAXB_STEP = 16;  // views per batched launch (kmat.hip: KM_MAXB)
+
+// ---------------------------------------------------------------------------------------------------------
+// arenas
+// ---------------------------------------------------------------------------------------------------------
+struct Arena {
+  char* base = nullptr;
+  long long off = 0, high = 0;
+  bool dry = false;
+  template <typename T>
+  T* get(long long n) {
+    off = (off + 255) & ~255LL;
+    T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += n * (long long)sizeof(T);
+    if (off > high) high = off;
+    return p;
+  }
+  long long mark() const { return off; }
+  void release(long long m) { off = m; }
+};
+
+#define GPSA_CK(x)               \
+  do {                           \
+    int rc__ = (x);              \
+    if (rc__ != 0) return rc__;  \
+  } while (0)
+// launches are skipped in a dry run (which only measures the arenas)
+#define GPSA_RUN(x)      \
+  do {                   \
+    if (!dry) GPSA_CK(x); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// device tables of a plan (uploaded once at creation)
+// ---------------------------------------------------------------------------------------------------------
+struct ViewTab {            // device copy: how the rows of the modalities map onto the view blocks
+  int V, D, S, nm, nf;
+  long long Cs;             // column stride of a view block
+  const long long* vstart;  // [nm][V+1] first row of view v in modality m
+  const long long* colbase; // [nm][V]   offset of modality m's rows inside view v's block
+  const long long* nview;   // [V]       live columns of view v (spots of all modalities)
+  const long long* epsoff;  // [V]       offset of view v's draws in eps_G (floats)
+  const int* bidx;          // [V]       index among the free views, -1: fixed
+};
+
+struct ModPtrs {            // per-modality pointers passed by value
+  const float* X[MAXMODS];
+  float* Gm[MAXMODS];
+  float* Gs[MAXMODS];
+  double* G64[MAXMODS];
+  const float* dGm[MAXMODS];
+  const float* dGs[MAXMODS];
+  const double* dG64[MAXMODS];
+  long long N[MAXMODS];
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels of the engine itself
+// ---------------------------------------------------------------------------------------------------------
+
+// blocks [0, V): view v: mu_z = scale (Z slopes + intercept) (fp32, the reference's mu_z_G; scale = 100 on a
+// fixed view: quirk 7, inert), resid = delta - mu_z (fp64), and the rows r = j*V + v of the KL terms'
+// mean-difference matrix (quirk 2: the KL pairs row r with view r % V, coordinate r / V).
+// blocks >= V: the data GP's rows: Dd[t][i] = delta_F[m][i][l] (mu = 0), one block per 256 elements.
+struct PrepArgs {
+  const float *Xtilde, *delta_G, *slopes, *intercepts;
+  const float* delta_F[MAXMODS];
+  int L[MAXMODS], Loff[MAXMODS];
+  int V, D, Mx, Mg, nm;
+  const int* bidx;
+  float* mu_z;
+  double* resid;   // [V, Mx, D]
+  double* Dw;      // [V*D, Mx]
+  double* Dd;      // [sum L, Mg]
+};
+
+__global__ void __launch_bounds__(256) step_prep_kernel(PrepArgs a) {
+  const int D = a.D;
+  if ((int)blockIdx.x < a.V) {
+    const int v = blockIdx.x;
+    const double scale = a.bidx[v] < 0 ? 100.0 : 1.0;
+    const float* Z = a.Xtilde + (long long)v * a.Mx * D;
+    const float* dl = a.delta_G + (long long)v * a.Mx * D;
+    const float* A = a.slopes + (long long)v * D * D;
+    const float* b = a.intercepts + (long long)v * D;
+    for (int i = threadIdx.x; i < a.Mx * D; i += 256) {
+      const int m = i / D, j = i - m * D;
+      double mu = (double)b[j];
+      for (int d = 0; d < D; ++d) mu += (double)Z[m * D + d] * (double)A[d * D + j];
+      mu *= scale;
+      if (a.mu_z != nullptr) a.mu_z[(long long)v * a.Mx * D + i] = (float)mu;
+      const double r = (double)dl[i] - mu;
+      a.resid[(long long)v * a.Mx * D + i] = r;
+      if (a.Dw != nullptr) a.Dw[((long long)j * a.V + v) * a.Mx + m] = r;
+    }
+    return;
+  }
+  if (a.Dd == nullptr) return;
+  long long e = ((long long)blockIdx.x - a.V) * 256 + threadIdx.x;
+  for (int m = 0; m < a.nm; ++m) {
+    const long long cnt = (long long)a.L[m] * a.Mg;
+    if (e < cnt) {
+      const int l = (int)(e / a.Mg), i = (int)(e - (long long)l * a.Mg);
+      a.Dd[((long long)a.Loff[m] + l) * a.Mg + i] = (double)a.delta_F[m][(long long)i * a.L[m] + l];
+      return;
+    }
+    e -= cnt;
+  }
+}
+
+// (view block b, column c) -> modality and row: the spots of view v are the concatenation over the
+// modalities of their rows of v (vgpsa.py:284-294)
+__device__ __forceinline__ bool block_col_to_row(const ViewTab& t, int v, long long c, int& m, long long& r) {
+  for (int mm = 0; mm < t.nm; ++mm) {
+    const long long lo = t.colbase[(long long)mm * t.V + v];
+    const long long cnt = t.vstart[(long long)mm * (t.V + 1) + v + 1] - t.vstart[(long long)mm * (t.V + 1) + v];
+    if (c >= lo && c < lo + cnt) {
+      m = mm;
+      r = t.vstart[(long long)mm * (t.V + 1) + v] + (c - lo);
+      return true;
+    }
+  }
+  return false;
+}
+
+// Xv[b][c][d] = coordinates of column c of free view b (zero in the padding); grid (Cs/256, nf)
+__global__ void __launch_bounds__(256)
+warp_gather_kernel(ViewTab t, const int* __restrict__ free_views, ModPtrs p, float* __restrict__ Xv) {
+  const int b = blockIdx.y, v = free_views[b];
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= t.Cs) return;
+  int m = 0;
+  long long r = 0;
+  const bool live = block_col_to_row(t, v, c, m, r);
+  float* dst = Xv + ((long long)b * t.Cs + c) * t.D;
+  for (int d = 0; d < t.D; ++d) dst[d] = live ? p.X[m][r * t.D + d] : 0.f;
+}
+
+constexpr double TWO_JITTER_STEP = 2e-5;  // the jitter enters the variance twice (vgpsa.py:191/201 and :204)
+
+// Output-driven sampler of ALL views of one modality (vgpsa.py:186-191, 262-273, 334-351): thread = row r.
+//   fixed view:  G_means = G_samples[s] = X (exactly)
+//   free view:   var = exp(var_u[v]) - q + v_j + 2e-5;  mu = X slopes_v + intercept_v + mean_j;
+//                G_samples[s] = mu + var * eps (variance used as the std: quirk 1)
+// also writes the fp64 copy of the draws (what the data GP's covariance is built from) and one flag per
+// block: a non-positive variance.
+__global__ void __launch_bounds__(256)
+warp_sample_views_fwd_kernel(ViewTab t, int m, const float* __restrict__ X, const double* __restrict__ meanT,
+                             const double* __restrict__ vq, const double* __restrict__ q,
+                             const float* __restrict__ var_u, const float* __restrict__ slopes,
+                             const float* __restrict__ intercepts, const float* __restrict__ eps, long long N,
+                             float* __restrict__ Gm, float* __restrict__ Gs, double* __restrict__ G64,
+                             int* __restrict__ bad) {
+  const long long r = blockIdx.x * 256LL + threadIdx.x;
+  const int D = t.D, S = t.S;
+  int flag = 0;
+  if (r < N) {
+    const long long* vs = t.vstart + (long long)m * (t.V + 1);
+    int lo = 0, hi = t.V;  // view of row r: vs[v] <= r < vs[v+1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (vs[mid] <= r) lo = mid; else hi = mid;
+    }
+    int v = lo;
+    while (v + 1 < t.V && vs[v + 1] <= r) ++v;  // skip empty views at the boundary
+    const int b = t.bidx[v];
+    double x[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) x[d] = d < D ? (double)X[r * D + d] : 0.0;
+    if (b < 0) {
+      for (int j = 0; j < D; ++j) {
+        const float xf = X[r * D + j];
+        Gm[r * D + j] = xf;
+        for (int s = 0; s < S; ++s) {
+          const long long e = ((long long)s * N + r) * D + j;
+          Gs[e] = xf;
+          G64[e] = (double)xf;
+        }
+      }
+    } else {
+      const long long cv = t.colbase[(long long)m * t.V + v] + (r - vs[v]);  // column in the view block
+      const long long nv = t.nview[v];
+      const double var0 = exp((double)var_u[v]), qc = q[(long long)b * t.Cs + cv];
+      const float* A = slopes + (long long)v * D * D;
+      const float* e0 = eps + t.epsoff[v];
+      for (int j = 0; j < D; ++j) {
+        const long long o = ((long long)b * D + j) * t.Cs + cv;
+        const double var = var0 - qc + vq[o] + TWO_JITTER_STEP;
+        double mu = (double)intercepts[(long long)v * D + j] + meanT[o];
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+          if (d < D) mu += x[d] * (double)A[d * D + j];
+        if (!(var > 0.0)) flag = 1;
+        Gm[r * D + j] = (float)mu;
+        for (int s = 0; s < S; ++s) {
+          const double gv = mu + var * (double)e0[((long long)s * nv + cv) * D + j];
+          const long long e = ((long long)s * N + r) * D + j;
+          Gs[e] = (float)gv;
+          G64[e] = gv;
+        }
+      }
+    }
+  }
+  flag = __syncthreads_or(flag);
+  if (threadIdx.x == 0) bad[blockIdx.x] = flag;
+}
+
+// Column-driven backward of the sampler: thread = (free view b, column c of its block).
+//   dmu = dG_means + sum_s dG_s ;  g_j = sum_s dG_s eps ;  qbar = -sum_j g_j ;  part[b][block] = sum g
+// with dG_s = (fp32 gradient of the API tensor, may be absent) + (fp64 gradient from the data GP, may be
+// absent).  Zeros in the padding columns.  grid (Cs/256, nf).
+__global__ void __launch_bounds__(256)
+warp_sample_views_bwd_kernel(ViewTab t, const int* __restrict__ free_views, ModPtrs p,
+                             const float* __restrict__ eps, double* __restrict__ dmeanT,
+                             double* __restrict__ g, double* __restrict__ qbar, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, v = free_views[b], D = t.D, S = t.S;
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  double gtot = 0.0;
+  if (c < t.Cs) {
+    int m = 0;
+    long long r = 0;
+    const bool live = block_col_to_row(t, v, c, m, r);
+    const long long nv = t.nview[v], N = live ? p.N[m] : 0;
+    const float* e0 = eps + t.epsoff[v];
+    for (int j = 0; j < D; ++j) {
+      double dm = 0.0, gj = 0.0;
+      if (live) {
+        if (p.dGm[m] != nullptr) dm = (double)p.dGm[m][r * D + j];
+        for (int s = 0; s < S; ++s) {
+          const long long e = ((long long)s * N + r) * D + j;
+          double d = 0.0;
+          if (p.dGs[m] != nullptr) d += (double)p.dGs[m][e];
+          if (p.dG64[m] != nullptr) d += p.dG64[m][e];
+          dm += d;
+          gj += d * (double)e0[((long long)s * nv + c) * D + j];
+        }
+      }
+      const long long o = ((long long)b * D + j) * t.Cs + c;
+      dmeanT[o] = dm;
+      g[o] = gj;
+      gtot += gj;
+    }
+    qbar[(long long)b * t.Cs + c] = -gtot;
+  }
+  const double tot = block_sum(gtot, red);
+  if (threadIdx.x == 0) part[(long long)b * gridDim.x + blockIdx.x] = tot;
+}
+
+// dvar_s[b] = exp(var_u[v]) * sum_blocks part[b][.]   (the variance enters var = sigma^2 - q + v directly)
+__global__ void __launch_bounds__(64)
+warp_sample_views_bwd_finish_kernel(const double* __restrict__ part, long long nblk,
+                                    const int* __restrict__ free_views, const float* __restrict__ var_u,
+                                    double* __restrict__ dvar_s) {
+  const int b = blockIdx.x;
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < nblk; i += 64) s += part[(long long)b * nblk + i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dvar_s[b] = s * exp((double)var_u[free_views[b]]);
+}
+
+// flag[0] = max over the Cholesky infos and the samplers' block flags (all >= 0)
+__global__ void __launch_bounds__(256)
+flag_reduce_kernel(const int* __restrict__ a, long long na, const int* __restrict__ b, long long nb,
+                   int* __restrict__ out) {
+  __shared__ int red[256];
+  int w = 0;
+  for (long long i = threadIdx.x; i < na; i += 256) w = max(w, abs(a[i]));
+  for (long long i = threadIdx.x; i < nb; i += 256) w = max(w, abs(b[i]));
+  red[threadIdx.x] = w;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// out[i] += in[i]
+__global__ void __launch_bounds__(256) add_inplace_kernel(double* __restrict__ out, const double* __restrict__ in,
+                                                          long long n) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i < n) out[i] += in[i];
+}
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) convert_kernel_step(const TS* __restrict__ src, long long n,
+                                                           TD* __restrict__ dst) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i < n) dst[i] = (TD)src[i];
+}
+
+// q[c] = sum_m A[m,c] B[m,c]   ([M,C] panels; blockIdx.y = problem of a batch at stride M*C, q at stride C)
+__global__ void __launch_bounds__(256)
+coldot2_kernel(const double* __restrict__ A, const double* __restrict__ B, int M, long long C,
+               double* __restrict__ q) {
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= C) return;
+  const long long pb = (long long)blockIdx.y * M * C;
+  double s0 = 0.0, s1 = 0.0;
+  int m = 0;
+  for (; m + 1 < M; m += 2) {
+    s0 += A[pb + (long long)m * C + c] * B[pb + (long long)m * C + c];
+    s1 += A[pb + (long long)(m + 1) * C + c] * B[pb + (long long)(m + 1) * C + c];
+  }
+  if (m < M) s0 += A[pb + (long long)m * C + c] * B[pb + (long long)m * C + c];
+  q[(long long)blockIdx.y * C + c] = s0 + s1;
+}
+
+// Every small parameter gradient of the step from its fp64 pieces, rounded to fp32 ONCE:
+//   Xtilde[v]   = dZ(K_uf) + dZ(K_uu) - scale * dresid slopes_v^T          (free views; zero for fixed)
+//   delta_G[v]  = dresid                                                   (dresid = layer's share + KL's)
+//   warp_ls[v]  = dls(K_uf) + dls(K_uu);  warp_var[v] = dvar(K_uf) + dvar(K_uu) + dvar(sampler)
+//   Gtilde      = sum_passes dZ(K_uf) + dZ(K_uu);  data_ls / data_var likewise (+ the samplers' share)
+//   delta_F[m]  = ddc (layer, fp32 [Mg, L]) + KL's dD rows ([L, Mg], transposed)
+struct FinalArgs {
+  int V, D, Mx, Mg, nm, nf, npass;
+  const int* bidx;
+  const float* slopes;
+  const double *dZ_wf, *dZ_wu, *dpar_wf, *dpar_wu, *dvar_ws;  // per free view b: [Mx,D], [Mx,D], [2], [2], [1]
+  const double* dresid;                                        // [V, Mx, D] layer's share (free views)
+  const double* dD_w;                                          // [V*D, Mx] KL's share, row j*V+v (or NULL)
+  const double *dZ_df, *dpar_df;                               // per pass: [Mg, D], [2]
+  const float* dvar_ds;                                        // per pass: [1] (fp32 scalar of the sampler)
+  const double *dZ_du, *dpar_du;                               // K_uu of the data GP
+  const float* ddc_F[MAXMODS];                                 // [Mg, L] or NULL (no gradient reached F)
+  const double* dD_d;                                          // [sum L, Mg] or NULL
+  int L[MAXMODS], Loff[MAXMODS];
+  gpsa_step_param_grads out;
+};
+
+__global__ void __launch_bounds__(256) step_finalize_kernel(FinalArgs a) {
+  const int D = a.D;
+  const long long nX = (long long)a.V * a.Mx * D;
+  long long e = blockIdx.x * 256LL + threadIdx.x;
+  // --- Xtilde / delta_G
+  if (e < nX) {
+    const int v = (int)(e / ((long long)a.Mx * D));
+    const int i = (int)(e - (long long)v * a.Mx * D), m = i / D, j = i - m * D;
+    const int b = a.bidx[v];
+    double gx = 0.0, gd = 0.0;
+    if (b >= 0) {
+      const double* dr = a.dresid + (long long)v * a.Mx * D;
+      gd = dr[i];
+      if (a.dD_w != nullptr) gd += a.dD_w[((long long)j * a.V + v) * a.Mx + m];
+      // mean function at the inducing points: resid = delta - (Z A + b)  =>  dZ = - dresid_total A^T
+      double mr = 0.0;
+      for (int jj = 0; jj < D; ++jj) {
+        double t = dr[m * D + jj];
+        if (a.dD_w != nullptr) t += a.dD_w[((long long)jj * a.V + v) * a.Mx + m];
+        mr += t * (double)a.slopes[(long long)v * D * D + j * D + jj];
+      }
+      gx = -mr;
+      if (a.dZ_wf != nullptr) gx += a.dZ_wf[(long long)b * a.Mx * D + i];
+      gx += a.dZ_wu[(long long)b * a.Mx * D + i];
+    }
+    if (a.out.Xtilde != nullptr) a.out.Xtilde[e] = (float)gx;
+    if (a.out.delta_G != nullptr) a.out.delta_G[e] = (float)gd;
+    return;
+  }
+  e -= nX;
+  // --- warp hyper-parameters
+  if (e < 2LL * a.V) {
+    const int v = (int)(e >> 1), which = (int)(e & 1), b = a.bidx[v];
+    double gsum = 0.0;
+    if (b >= 0) {
+      gsum = a.dpar_wu[(long long)b * 2 + which];
+      if (a.dpar_wf != nullptr) gsum += a.dpar_wf[(long long)b * 2 + which];
+      if (which == 1 && a.dvar_ws != nullptr) gsum += a.dvar_ws[b];
+    }
+    float* dst = which == 0 ? a.out.warp_ls : a.out.warp_var;
+    if (dst != nullptr) dst[v] = (float)gsum;
+    return;
+  }
+  e -= 2LL * a.V;
+  // --- Gtilde
+  const long long nG = (long long)a.Mg * D;
+  if (e < nG) {
+    double gsum = a.dZ_du[e];
+    for (int p = 0; p < a.npass; ++p) gsum += a.dZ_df[(long long)p * nG + e];
+    if (a.out.Gtilde != nullptr) a.out.Gtilde[e] = (float)gsum;
+    return;
+  }
+  e -= nG;
+  if (e < 2) {
+    double gsum = a.dpar_du[e];
+    for (int p = 0; p < a.npass; ++p) {
+      gsum += a.dpar_df[(long long)p * 2 + e];
+      if (e == 1) gsum += (double)a.dvar_ds[p];
+    }
+    float* dst = e == 0 ? a.out.data_ls : a.out.data_var;
+    if (dst != nullptr) dst[0] = (float)gsum;
+    return;
+  }
+  e -= 2;
+  // --- delta_F[m] [Mg, L]
+  for (int m = 0; m < a.nm; ++m) {
+    const long long cnt = (long long)a.Mg * a.L[m];
+    if (e < cnt) {
+      if (a.out.delta_F[m] == nullptr) return;
+      const int i = (int)(e / a.L[m]), l = (int)(e - (long long)i * a.L[m]);
+      double gsum = a.ddc_F[m] != nullptr ? (double)a.ddc_F[m][e] : 0.0;
+      if (a.dD_d != nullptr) gsum += a.dD_d[((long long)a.Loff[m] + l) * a.Mg + i];
+      a.out.delta_F[m][e] = (float)gsum;
+      return;
+    }
+    e -= cnt;
+  }
+}
+
+// ---- fused Adam over a list of tensors --------------------------------------------------------------------
+constexpr int ADAM_MAXT = 16;
+struct AdamArgs {
+  float* p[ADAM_MAXT];
+  const float* g[ADAM_MAXT];
+  float* m[ADAM_MAXT];
+  float* v[ADAM_MAXT];
+  long long blk0[ADAM_MAXT + 1];  // first block of tensor i (1024 elements per block)
+  long long n[ADAM_MAXT];
+  int nt;
+  double lr, b1, b2, eps;
+};
+
+__global__ void adam_tick_kernel(float* step) { step[0] += 1.f; }
+
+// torch.optim.Adam's update in its fp32 arithmetic (torch/optim/adam.py, single-tensor path):
+//   m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g g;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ void __launch_bounds__(256) adam_kernel(AdamArgs a, const float* __restrict__ step) {
+  int t = 0;
+  while (t + 1 < a.nt && (long long)blockIdx.x >= a.blk0[t + 1]) ++t;
+  // the scalars are formed in double, as Python does for torch's optimiser, then used in fp32 tensor arithmetic
+  const double tt = (double)step[0];
+  const float step_size = (float)(a.lr / (1.0 - pow(a.b1, tt))), rs2 = (float)sqrt(1.0 - pow(a.b2, tt));
+  const float w1 = (float)(1.0 - a.b1), b2 = (float)a.b2, w2 = (float)(1.0 - a.b2), eps = (float)a.eps;
+  const long long base = ((long long)blockIdx.x - a.blk0[t]) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i < a.n[t]) {
+      const float g = a.g[t][i];
+      float m = a.m[t][i], v = a.v[t][i];
+      m = m + w1 * (g - m);
+      v = b2 * v + w2 * g * g;
+      a.m[t][i] = m;
+      a.v[t][i] = v;
+      const float denom = sqrtf(v) / rs2 + eps;
+      a.p[t][i] = a.p[t][i] - step_size * (m / denom);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the plan
+// ---------------------------------------------------------------------------------------------------------
+struct Group {  // matrices of one size, factorised together: the priors first, then the variational ones
+  int M = 0, n_prior = 0, n_omega = 0, kl_off = 0;
+  // offsets into the saved arena (bytes)
+  long long o_mats = 0, o_inv = 0, o_logdet = 0, o_info = 0, o_D = 0, o_KD = 0;
+  // device index tables of the grouped KL kernels
+  int *om_idx = nullptr, *pr_idx = nullptr, *pr_list = nullptr, *grp_off = nullptr, *order = nullptr;
+  int nb() const { return n_prior + n_omega; }
+};
+
+struct Run { int v0, b0, cnt; };
+
+struct Pass {  // one evaluation of the data GP: a modality's own spots, or its G_test
+  int m = 0;
+  bool test = false;
+  long long C = 0;          // columns = S * rows
+  long long o_alpha = 0, o_sigma = 0;
+};
+
+struct Plan {
+  gpsa_step_desc d;
+  std::vector<int> fixed;
+  std::vector<long long> rows;  // [nm*V]
+  int V, D, S, Mx, Mg, nm, nf;
+  std::vector<int> free_views, bidx;
+  std::vector<long long> nview, epsoff;
+  long long Cs = 0, eps_total = 0;
+  std::vector<Run> runs;
+  bool merged = false;
+  int ng = 0;
+  Group grp[2];
+  int Loff[MAXMODS], Ltot = 0;
+  std::vector<Pass> passes;
+  // saved arena
+  long long o_resid = 0, o_Xv = 0, o_alpha_w = 0, o_Wk = 0, o_G64[MAXMODS], o_bad = 0, saved_bytes = 0;
+  long long nbad = 0;
+  long long scratch_bytes = 0;
+  // device tables
+  char* dev = nullptr;
+  ViewTab tab;
+  int* d_free = nullptr;
+  // optional HIP-event timing of the three contraction launches of the first data-GP pass (bench.py's
+  // roofline figures): slot = step index modulo the ring, 2 events per kernel
+  std::vector<hipEvent_t> tev;
+  int tslots = 0, tfwd = 0, tbwd = 0;
+  void tick(int kernel, int edge, bool fwd, hipStream_t st) {
+    if (tslots == 0) return;
+    const int slot = (fwd ? tfwd : tbwd) % tslots;
+    (void)hipEventRecord(tev[(size_t)(slot * 3 + kernel) * 2 + edge], st);
+  }
+
+  Group& gw() { return grp[0]; }
+  Group& gd() { return merged ? grp[0] : grp[1]; }
+  int pos_Kw(int b) const { return b; }
+  int pos_KF() const { return merged ? nf : 0; }
+  int pos_OmG(int r) const { return grp[0].n_prior + r; }
+  int pos_OmF(int m, int l) const { return merged ? grp[0].n_prior + V * D + Loff[m] + l : 1 + Loff[m] + l; }
+};
+
+static long long align256(long long x) { return (x + 255) & ~255LL; }
+
+static void free_plan(Plan* p) {
+  if (p == nullptr) return;
+  if (p->dev != nullptr) (void)hipFree(p->dev);
+  for (hipEvent_t e : p->tev) (void)hipEventDestroy(e);
+  delete p;
+}
+
+static Plan* make_plan(const gpsa_step_desc* dsc) {
+  if (dsc == nullptr) return nullptr;
+  const int V = dsc->n_views, D = dsc->n_dims, nm = dsc->n_mods, S = dsc->n_samples;
+  if (V < 1 || D < 1 || D > MAXD || nm < 1 || nm > MAXMODS || S < 0 || dsc->m_x < 1 || dsc->m_g < 1)
+    return nullptr;
+  if (dsc->view_fixed == nullptr || dsc->view_rows == nullptr) return nullptr;
+  Plan* p = new (std::nothrow) Plan();
+  if (p == nullptr) return nullptr;
+  p->d = *dsc;
+  p->fixed.assign(dsc->view_fixed, dsc->view_fixed + V);
+  p->rows.assign(dsc->view_rows, dsc->view_rows + (long long)nm * V);
+  p->d.view_fixed = nullptr;
+  p->d.view_rows = nullptr;
+  p->V = V; p->D = D; p->S = S; p->Mx = dsc->m_x; p->Mg = dsc->m_g; p->nm = nm;
+  p->bidx.assign(V, -1);
+  p->nview.assign(V, 0);
+  p->epsoff.assign(V, 0);
+  for (int m = 0; m < nm; ++m) {
+    long long tot = 0;
+    for (int v = 0; v < V; ++v) {
+      if (p->rows[(long long)m * V + v] < 0) { free_plan(p); return nullptr; }
+      tot += p->rows[(long long)m * V + v];
+    }
+    if (tot != dsc->n_rows[m] || dsc->n_latent[m] < 1 || dsc->n_out[m] < 1) { free_plan(p); return nullptr; }
+    if (!dsc->has_lmc[m] && dsc->n_latent[m] != dsc->n_out[m]) { free_plan(p); return nullptr; }
+  }
+  long long maxn = 0;
+  for (int v = 0; v < V; ++v) {
+    for (int m = 0; m < nm; ++m) p->nview[v] += p->rows[(long long)m * V + v];
+    if (!p->fixed[v]) {
+      p->bidx[v] = (int)p->free_views.size();
+      p->free_views.push_back(v);
+      p->epsoff[v] = p->eps_total;
+      p->eps_total += (long long)S * p->nview[v] * D;
+      if (p->nview[v] > maxn) maxn = p->nview[v];
+    }
+  }
+  p->nf = (int)p->free_views.size();
+  p->Cs = (maxn + 63) / 64 * 64;
+  // maximal runs of consecutive free views (uniform strides in the per-view parameter arrays), <= 16 each
+  for (int b = 0; b < p->nf;) {
+    int e = b + 1;
+    while (e < p->nf && p->free_views[e] == p->free_views[e - 1] + 1 && e - b < KM_MAXB_STEP) ++e;
+    p->runs.push_back(Run{p->free_views[b], b, e - b});
+    b = e;
+  }
+  p->Ltot = 0;
+  for (int m = 0; m < nm; ++m) {
+    p->Loff[m] = p->Ltot;
+    p->Ltot += dsc->n_latent[m];
+  }
+  for (int m = nm; m < MAXMODS; ++m) p->Loff[m] = p->Ltot;
+  p->merged = p->Mx == p->Mg;
+  if (p->merged) {
+    p->ng = 1;
+    p->grp[0].M = p->Mx;
+    p->grp[0].n_prior = p->nf + 1;
+    p->grp[0].n_omega = V * D + p->Ltot;
+    p->grp[0].kl_off = 0;
+  } else {
+    p->ng = 2;
+    p->grp[0].M = p->Mx; p->grp[0].n_prior = p->nf; p->grp[0].n_omega = V * D; p->grp[0].kl_off = 0;
+    p->grp[1].M = p->Mg; p->grp[1].n_prior = 1; p->grp[1].n_omega = p->Ltot; p->grp[1].kl_off = V * D;
+  }
+  // data-GP passes
+  for (int m = 0; m < nm; ++m)
+    if (dsc->n_rows[m] > 0 && S > 0) {
+      Pass q; q.m = m; q.test = false; q.C = (long long)S * dsc->n_rows[m];
+      p->passes.push_back(q);
+    }
+  if (dsc->s_test > 0)
+    for (int m = 0; m < nm; ++m)
+      if (dsc->n_test[m] > 0) {
+        Pass q; q.m = m; q.test = true; q.C = (long long)dsc->s_test * dsc->n_test[m];
+        p->passes.push_back(q);
+      }
+  // ---- saved arena layout
+  long long o = 0;
+  auto take = [&](long long bytes) { long long r = o; o = align256(o + bytes); return r; };
+  for (int g = 0; g < p->ng; ++g) {
+    Group& G = p->grp[g];
+    const long long mm = (long long)G.M * G.M;
+    G.o_mats = take(G.nb() * mm * 8);
+    G.o_inv = take(G.nb() * mm * 8);
+    G.o_logdet = take(G.nb() * 8LL);
+    G.o_info = take(G.nb() * 4LL);
+    G.o_D = take((long long)G.n_omega * G.M * 8);
+    G.o_KD = take((long long)G.n_omega * G.M * 8);
+  }
+  p->o_resid = take((long long)V * p->Mx * D * 8);
+  p->o_Xv = take((long long)p->nf * p->Cs * D * 4);
+  p->o_alpha_w = take((long long)p->nf * p->Mx * p->Cs * 8);
+  p->o_Wk = take((long long)p->nf * D * p->Mx * p->Cs * 8);
+  for (int m = 0; m < nm; ++m) p->o_G64[m] = take((long long)S * dsc->n_rows[m] * D * 8);
+  p->nbad = 0;
+  for (int m = 0; m < nm; ++m) p->nbad += (dsc->n_rows[m] + 255) / 256;
+  p->o_bad = take((p->nbad + 1) * 4);
+  for (auto& q : p->passes) {
+    q.o_alpha = take((long long)p->Mg * q.C * 4);
+    q.o_sigma = take((long long)dsc->n_latent[q.m] * q.C * 4);
+  }
+  p->saved_bytes = o + 256;
+  // ---- device tables
+  const long long n_ll = (long long)nm * (V + 1) + (long long)nm * V + V + V;  // vstart, colbase, nview, epsoff
+  long long n_int = V /*bidx*/ + p->nf /*free*/;
+  for (int g = 0; g < p->ng; ++g) {
+    const Group& G = p->grp[g];
+    n_int += 2 * G.n_omega + G.n_prior + (G.n_prior + 2) + G.n_omega;
+  }
+  const long long bytes = n_ll * 8 + n_int * 4 + 64;
+  std::vector<char> host((size_t)bytes, 0);
+  long long* hl = reinterpret_cast<long long*>(host.data());
+  int* hi = reinterpret_cast<int*>(host.data() + n_ll * 8);
+  if (hipMalloc(reinterpret_cast<void**>(&p->dev), (size_t)bytes) != hipSuccess) { p->dev = nullptr; free_plan(p); return nullptr; }
+  long long* dl = reinterpret_cast<long long*>(p->dev);
+  int* di = reinterpret_cast<int*>(p->dev + n_ll * 8);
+  long long lo = 0, io = 0;
+  // vstart [nm][V+1], colbase [nm][V]
+  p->tab.vstart = dl + lo;
+  for (int m = 0; m < nm; ++m) {
+    long long acc = 0;
+    for (int v = 0; v <= V; ++v) {
+      hl[lo++] = acc;
+      if (v < V) acc += p->rows[(long long)m * V + v];
+    }
+  }
+  p->tab.colbase = dl + lo;
+  for (int m = 0; m < nm; ++m)
+    for (int v = 0; v < V; ++v) {
+      long long acc = 0;
+      for (int mm = 0; mm < m; ++mm) acc += p->rows[(long long)mm * V + v];
+      hl[lo++] = acc;
+    }
+  p->tab.nview = dl + lo;
+  for (int v = 0; v < V; ++v) hl[lo++] = p->nview[v];
+  p->tab.epsoff = dl + lo;
+  for (int v = 0; v < V; ++v) hl[lo++] = p->epsoff[v];
+  p->tab.bidx = di + io;
+  for (int v = 0; v < V; ++v) hi[io++] = p->bidx[v];
+  p->d_free = di + io;
+  for (int b = 0; b < p->nf; ++b) hi[io++] = p->free_views[b];
+  for (int g = 0; g < p->ng; ++g) {
+    Group& G = p->grp[g];
+    // prior of term t of this group (position among the group's priors), -1: absent (fixed view)
+    std::vector<int> prior(G.n_omega, -1);
+    for (int t = 0; t < G.n_omega; ++t) {
+      if (g == 0 && t < V * D) prior[t] = p->bidx[t % V];  // quirk 2: row r pairs with view r % V
+      else prior[t] = p->merged ? p->nf : 0;
+    }
+    G.om_idx = di + io;
+    for (int t = 0; t < G.n_omega; ++t) hi[io++] = G.n_prior + t;
+    G.pr_idx = di + io;
+    for (int t = 0; t < G.n_omega; ++t) hi[io++] = prior[t];
+    G.pr_list = di + io;
+    for (int q = 0; q < G.n_prior; ++q) hi[io++] = q;
+    std::vector<int> order, off(1, 0);
+    for (int q = 0; q <= G.n_prior; ++q) {
+      const int want = q < G.n_prior ? q : -1;
+      for (int t = 0; t < G.n_omega; ++t)
+        if (prior[t] == want) order.push_back(t);
+      off.push_back((int)order.size());
+    }
+    G.grp_off = di + io;
+    for (int q = 0; q < G.n_prior + 2; ++q) hi[io++] = off[q];
+    G.order = di + io;
+    for (int t = 0; t < G.n_omega; ++t) hi[io++] = order[t];
+  }
+  if (hipMemcpy(p->dev, host.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { free_plan(p); return nullptr; }
+  p->tab.V = V; p->tab.D = D; p->tab.S = S; p->tab.nm = nm; p->tab.nf = p->nf; p->tab.Cs = p->Cs;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sequencing helpers
+// ---------------------------------------------------------------------------------------------------------
+static inline int splitk_for(long long k, int m, int n) {  // ops.HipOps.pick_splitk
+  const long long tiles = cdiv(m, 64) * cdiv(n, 64);
+  long long s = cdiv(512, tiles > 0 ? tiles : 1);
+  if (s > 256) s = 256;
+  if (s > k / 64) s = k / 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+static inline int splitk_small(long long k, int m, int n, int batch) {  // ops.HipOps.gemm's latency rule
+  if (batch == 1 && k >= 128 && k <= 1024 && cdiv(m, 64) * cdiv(n, 64) <= 32) {
+    int s = (int)(k / 48);
+    return s > 4 ? 4 : (s < 1 ? 1 : s);
+  }
+  return 1;
+}
+
+struct Ctx {
+  Plan& P;
+  const gpsa_step_params& prm;
+  const gpsa_step_io& io;
+  char* saved;
+  Arena& sc;
+  hipStream_t st;
+  bool dry;
+  void* stv() const { return (void*)st; }
+  template <typename T> T* sv(long long off) const { return reinterpret_cast<T*>(saved + off); }
+  double* mats(const Group& G, int pos) const { return sv<double>(G.o_mats) + (long long)pos * G.M * G.M; }
+  double* inv(const Group& G, int pos) const { return sv<double>(G.o_inv) + (long long)pos * G.M * G.M; }
+};
+
+// fp64 product through gemm_launch<double> with workspace from the scratch arena
+static int gemm64(Ctx& c, int ta, int tb, int m, int n, long long k, double alpha, const double* A, long long lda,
+                  long long sA, const double* B, long long ldb, long long sB, double beta, double* C,
+                  long long ldc, long long sC, int batch, int splitk) {
+  const bool dry = c.dry;
+  const long long mk = c.sc.mark();
+  void* ws = nullptr;
+  long long wsb = 0;
+  if (splitk > 1) {
+    wsb = (long long)batch * splitk * m * n * 8;
+    ws = c.sc.get<char>(wsb);
+  }
+  GPSA_RUN(gemm_launch<double>(ta, tb, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, splitk,
+                               ws, wsb, c.st));
+  c.sc.release(mk);
+  return 0;
+}
+static int gemm32(Ctx& c, int ta, int tb, int m, int n, long long k, double alpha, const float* A, long long lda,
+                  long long sA, const float* B, long long ldb, long long sB, double beta, float* C,
+                  long long ldc, long long sC, int batch, int splitk) {
+  const bool dry = c.dry;
+  const long long mk = c.sc.mark();
+  void* ws = nullptr;
+  long long wsb = 0;
+  if (splitk > 1) {
+    wsb = (long long)batch * splitk * m * n * 4;
+    ws = c.sc.get<char>(wsb);
+  }
+  GPSA_RUN(gemm_launch<float>(ta, tb, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, splitk,
+                              ws, wsb, c.st));
+  c.sc.release(mk);
+  return 0;
+}
+template <typename TIA, typename TIB, typename TO>
+static int gemmx(Ctx& c, int ta, int tb, int m, int n, long long k, double alpha, const TIA* A, long long lda,
+                 long long sA, const TIB* B, long long ldb, long long sB, double beta, TO* C, long long ldc,
+                 long long sC, int batch, int splitk) {
+  const bool dry = c.dry;
+  const long long mk = c.sc.mark();
+  void* ws = nullptr;
+  long long wsb = 0;
+  if (splitk > 1) {
+    wsb = (long long)batch * splitk * m * n * 8;
+    ws = c.sc.get<char>(wsb);
+  }
+  GPSA_RUN((gemm64_launch<TIA, TIB, TO>(ta, tb, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch,
+                                        splitk, ws, wsb, c.st)));
+  c.sc.release(mk);
+  return 0;
+}
+
+// ---- M x M stage: every prior covariance and variational covariance of the step, factorised together ------
+static int mm_stage_fwd(Ctx& c) {
+  Plan& P = c.P;
+  const bool dry = c.dry;
+  const int V = P.V, D = P.D, Mx = P.Mx, Mg = P.Mg;
+  Group& GW = P.gw();
+  Group& GD = P.gd();
+  const bool kl = P.d.want_kl != 0;
+  // mean function at the inducing points, residuals, the KL terms' mean differences
+  {
+    PrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Xtilde = c.prm.Xtilde; a.delta_G = c.prm.delta_G; a.slopes = c.prm.slopes; a.intercepts = c.prm.intercepts;
+    for (int m = 0; m < P.nm; ++m) { a.delta_F[m] = c.prm.delta_F[m]; a.L[m] = P.d.n_latent[m]; a.Loff[m] = P.Loff[m]; }
+    a.V = V; a.D = D; a.Mx = Mx; a.Mg = Mg; a.nm = P.nm;
+    a.bidx = P.tab.bidx;
+    a.mu_z = c.io.mu_z;
+    a.resid = c.sv<double>(P.o_resid);
+    a.Dw = kl ? c.sv<double>(GW.o_D) : nullptr;
+    a.Dd = kl ? c.sv<double>(GD.o_D) + (P.merged ? (long long)V * D * Mx : 0) : nullptr;
+    const long long nd = kl ? cdiv((long long)P.Ltot * Mg, 256) : 0;
+    if (!dry) {
+      step_prep_kernel<<<(unsigned)(V + nd), 256, 0, c.st>>>(a);
+      GPSA_LAUNCH_CHECK();
+    }
+  }
+  // prior covariances K_uu + 1e-5 I of the free views (batched over runs) and of the data GP
+  for (const Run& r : P.runs)
+    GPSA_RUN(gpsa_kmat_batched(P.d.kind_warp, c.prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
+                               c.prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx, D,
+                               c.prm.warp_ls + r.v0, c.prm.warp_var + r.v0, 1, nullptr, r.cnt, 1e-5,
+                               c.mats(GW, P.pos_Kw(r.b0)), (long long)Mx * Mx, c.stv()));
+  GPSA_RUN(gpsa_kmat_batched(P.d.kind_data, c.prm.Gtilde, 0, Mg, c.prm.Gtilde, 0, Mg, D, c.prm.data_ls,
+                             c.prm.data_var, 0, nullptr, 1, 1e-5, c.mats(GD, P.pos_KF()), 0, c.stv()));
+  // variational covariances Omega = A A^T + 1e-5 I straight from the fp32 parameters
+  GPSA_RUN(gpsa_omega_fwd(c.prm.Omega_sqt_G, Mx, V * D, 1e-5, c.mats(GW, P.pos_OmG(0)), c.stv()));
+  for (int m = 0; m < P.nm; ++m)
+    GPSA_RUN(gpsa_omega_fwd(c.prm.Omega_sqt_F[m], Mg, P.d.n_latent[m], 1e-5, c.mats(GD, P.pos_OmF(m, 0)), c.stv()));
+  // factorise: the priors always; the variational covariances only when the KL terms are wanted (the
+  // layers use Omega itself, never its factor)
+  for (int g = 0; g < P.ng; ++g) {
+    Group& G = P.grp[g];
+    const int nb = kl ? G.nb() : G.n_prior;
+    if (nb == 0) continue;
+    const long long mm = (long long)G.M * G.M;
+    const long long mk = c.sc.mark();
+    double* Linv = c.sc.get<double>(nb * mm);
+    double* logdet = c.sv<double>(G.o_logdet);
+    int* info = c.sv<int>(G.o_info);
+    if (G.M > 256) {
+      const long long wsb = gpsa_chol_inv_blocked_workspace(G.M, nb);
+      void* ws = c.sc.get<char>(wsb);
+      GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, 0), Linv, G.M, nb, logdet, info, ws, wsb, c.stv()));
+    } else {
+      GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, 0), Linv, G.M, nb, logdet, info, c.stv()));
+    }
+    // K^-1 = L^-T L^-1 for the whole batch in one product
+    GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M, mm, nb,
+                   splitk_small(G.M, G.M, G.M, nb)));
+    c.sc.release(mk);
+    if (kl && G.n_omega > 0)
+      GPSA_RUN(gpsa_mvn_kl_grouped_fwd(c.mats(G, 0), c.inv(G, 0), logdet, G.om_idx, G.pr_idx, c.sv<double>(G.o_D),
+                                       G.M, G.n_omega, c.io.kl + G.kl_off, c.sv<double>(G.o_KD), c.stv()));
+  }
+  return 0;
+}
+
+// ---- warp GPs of all free views ---------------------------------------------------------------------------
+static ModPtrs mod_ptrs(Ctx& c, const gpsa_step_out_grads* og, const double* const* dG64) {
+  ModPtrs p;
+  memset(&p, 0, sizeof(p));
+  for (int m = 0; m < c.P.nm; ++m) {
+    p.X[m] = c.io.X[m];
+    p.Gm[m] = c.io.G_means[m];
+    p.Gs[m] = c.io.G_samples[m];
+    p.G64[m] = c.sv<double>(c.P.o_G64[m]);
+    p.N[m] = c.P.d.n_rows[m];
+    if (og != nullptr) {
+      p.dGm[m] = og->dG_means[m];
+      p.dGs[m] = og->dG_samples[m];
+    }
+    if (dG64 != nullptr) p.dG64[m] = dG64[m];
+  }
+  return p;
+}
+
+// alpha = K^-1 K_uf and q = k^T alpha for ``cnt`` fp64 panels (projection kernel, or plain products beyond
+// its size)
+static int project_views(Ctx& c, const double* Kinv, const double* Kuf, int M, long long Cs, double* alpha,
+                         double* q, int cnt) {
+  const bool dry = c.dry;
+  const long long wsb1 = gpsa_whiten_workspace(M);
+  if (wsb1 > 0) {
+    const long long mk = c.sc.mark();
+    void* ws = c.sc.get<char>(wsb1 * cnt);
+    GPSA_RUN(gpsa_whiten_batched_f64(Kinv, (long long)M * M, Kuf, M, Cs, (long long)M * Cs, alpha, q, cnt, ws,
+                                     wsb1 * cnt, c.stv()));
+    c.sc.release(mk);
+    return 0;
+  }
+  GPSA_CK(gemm64(c, 0, 0, M, (int)Cs, M, 1.0, Kinv, M, (long long)M * M, Kuf, Cs, (long long)M * Cs, 0.0, alpha,
+                 Cs, (long long)M * Cs, cnt, 1));
+  if (q != nullptr && !dry) {
+    dim3 grid((unsigned)cdiv(Cs, 256), (unsigned)cnt);
+    coldot2_kernel<<<grid, 256, 0, c.st>>>(Kuf, alpha, M, Cs, q);
+    GPSA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int warp_stage_fwd(Ctx& c) {
+  Plan& P = c.P;
+  const bool dry = c.dry;
+  const int V = P.V, D = P.D, Mx = P.Mx, nf = P.nf;
+  const long long Cs = P.Cs;
+  Group& GW = P.gw();
+  (void)V;
+  const long long mk = c.sc.mark();
+  double* meanT = nullptr;
+  double* vq = nullptr;
+  double* q = nullptr;
+  if (nf > 0 && Cs > 0) {
+    float* Xv = c.sv<float>(P.o_Xv);
+    double* alpha = c.sv<double>(P.o_alpha_w);
+    double* Wk = c.sv<double>(P.o_Wk);
+    meanT = c.sc.get<double>((long long)nf * D * Cs);
+    vq = c.sc.get<double>((long long)nf * D * Cs);
+    q = c.sc.get<double>((long long)nf * Cs);
+    double* Kuf = c.sc.get<double>((long long)nf * Mx * Cs);
+    if (!dry) {
+      dim3 grid((unsigned)cdiv(Cs, 256), (unsigned)nf);
+      warp_gather_kernel<<<grid, 256, 0, c.st>>>(P.tab, P.d_free, mod_ptrs(c, nullptr, nullptr), Xv);
+      GPSA_LAUNCH_CHECK();
+    }
+    for (const Run& r : P.runs) {
+      long long nlive[KM_MAXB_STEP];
+      for (int i = 0; i < r.cnt; ++i) nlive[i] = P.nview[r.v0 + i];
+      GPSA_RUN(gpsa_kmat_batched(P.d.kind_warp, c.prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
+                                 Xv + (long long)r.b0 * Cs * D, Cs * D, Cs, D, c.prm.warp_ls + r.v0,
+                                 c.prm.warp_var + r.v0, 1, nlive, r.cnt, 0.0, Kuf + (long long)r.b0 * Mx * Cs,
+                                 (long long)Mx * Cs, c.stv()));
+      GPSA_CK(project_views(c, c.inv(GW, P.pos_Kw(r.b0)), Kuf + (long long)r.b0 * Mx * Cs, Mx, Cs,
+                            alpha + (long long)r.b0 * Mx * Cs, q + (long long)r.b0 * Cs, r.cnt));
+      // quirk 2: the forward of view v reads the Omega rows v*D + j
+      GPSA_RUN(gpsa_quadform_fwd_keep_batched_f64(
+          alpha + (long long)r.b0 * Mx * Cs, c.mats(GW, P.pos_OmG(r.v0 * D)), Mx, Cs, D,
+          vq + (long long)r.b0 * D * Cs, Wk + (long long)r.b0 * D * Mx * Cs,
+          c.sv<double>(P.o_resid) + (long long)r.v0 * Mx * D, meanT + (long long)r.b0 * D * Cs, r.cnt, c.stv()));
+    }
+  }
+  // draws of every modality's rows (fixed views pass their coordinates through)
+  int* bad = c.sv<int>(P.o_bad);
+  long long boff = 0;
+  for (int m = 0; m < P.nm; ++m) {
+    const long long N = P.d.n_rows[m];
+    if (N == 0) continue;
+    const long long nb = cdiv(N, 256);
+    if (!dry) {
+      warp_sample_views_fwd_kernel<<<(unsigned)nb, 256, 0, c.st>>>(
+          P.tab, m, c.io.X[m], meanT, vq, q, c.prm.warp_var, c.prm.slopes, c.prm.intercepts, c.io.eps_G, N,
+          c.io.G_means[m], c.io.G_samples[m], c.sv<double>(P.o_G64[m]), bad + boff);
+      GPSA_LAUNCH_CHECK();
+    }
+    boff += nb;
+  }
+  c.sc.release(mk);
+  // one word for the host: Cholesky infos and variance flags
+  if (c.io.flag != nullptr && !dry) {
+    Group& G0 = P.grp[0];
+    // infos of the two groups are not contiguous: reduce group 0 + flags, then fold group 1 in
+    const int n0 = P.d.want_kl ? G0.nb() : G0.n_prior;
+    flag_reduce_kernel<<<1, 256, 0, c.st>>>(c.sv<int>(G0.o_info), n0, bad, P.nbad, c.io.flag);
+    GPSA_LAUNCH_CHECK();
+    if (P.ng == 2) {
+      Group& G1 = P.grp[1];
+      const int n1 = P.d.want_kl ? G1.nb() : G1.n_prior;
+      flag_reduce_kernel<<<1, 256, 0, c.st>>>(c.sv<int>(G1.o_info), n1, c.io.flag, 1, c.io.flag);
+      GPSA_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+// ---- data GP ----------------------------------------------------------------------------------------------
+static int data_pass_fwd(Ctx& c, const Pass& ps) {
+  Plan& P = c.P;
+  const bool dry = c.dry;
+  const int m = ps.m, Mg = P.Mg, D = P.D, L = P.d.n_latent[m], Pm = P.d.n_out[m];
+  const long long C = ps.C;
+  Group& GD = P.gd();
+  const double* Kinv = c.inv(GD, P.pos_KF());
+  const double* Om = c.mats(GD, P.pos_OmF(m, 0));
+  float* alpha = c.sv<float>(ps.o_alpha);
+  float* Sigma = c.sv<float>(ps.o_sigma);
+  const float* eps = ps.test ? c.io.eps_F_test[m] : c.io.eps_F[m];
+  float* F = ps.test ? c.io.F_latent_test[m] : c.io.F_latent[m];
+  float* Fo = ps.test ? c.io.F_obs_test[m] : c.io.F_obs[m];
+  const long long mk = c.sc.mark();
+  double* q = c.sc.get<double>(C);
+  {
+    const long long mk2 = c.sc.mark();
+    double* Kuf = c.sc.get<double>((long long)Mg * C);
+    // covariance on the warp GP's UNROUNDED draws (fp64), fp32 parameters as stored; G_test is the caller's fp32
+    if (ps.test)
+      GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D, c.prm.data_ls,
+                         c.prm.data_var, 0.0, Kuf, c.stv()));
+    else
+      GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32_X64, P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D,
+                         c.prm.data_ls, c.prm.data_var, 0.0, Kuf, c.stv()));
+    const long long wsb = gpsa_whiten_workspace(Mg);
+    if (wsb > 0) {
+      void* ws = c.sc.get<char>(wsb);
+      GPSA_RUN(gpsa_whiten_f64(Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb, c.stv()));
+    } else {  // beyond the projection kernel: alpha (fp64) = K^-1 K_uf, q from it, then rounded
+      double* a64 = c.sc.get<double>((long long)Mg * C);
+      GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, Kuf, C, 0, 0.0, a64, C, 0, 1, 1));
+      if (!dry) {
+        coldot2_kernel<<<dim3((unsigned)cdiv(C, 256), 1), 256, 0, c.st>>>(Kuf, a64, Mg, C, q);
+        GPSA_LAUNCH_CHECK();
+        convert_kernel_step<double, float><<<(unsigned)cdiv((long long)Mg * C, 256), 256, 0, c.st>>>(
+            a64, (long long)Mg * C, alpha);
+        GPSA_LAUNCH_CHECK();
+      }
+    }
+    c.sc.release(mk2);
+  }
+  float* meanT = c.sc.get<float>((long long)L * C);
+  float* v = c.sc.get<float>((long long)L * C);
+  // mean[l,c] = sum_m delta_F[m,l] alpha[m,c]   (mu_z = 0 for the data GP)
+  GPSA_CK(gemm32(c, 1, 0, L, (int)C, Mg, 1.0, c.prm.delta_F[m], L, 0, alpha, C, 0, 0.0, meanT, C, 0, 1, 1));
+  {
+    const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
+    void* ws = c.sc.get<char>(wsb);
+    const bool timed = !dry && &ps == &P.passes[0];
+    if (timed) P.tick(0, 0, true, c.st);
+    GPSA_RUN(gpsa_quadform_fwd(GPSA_F32, GPSA_F64, alpha, Om, Mg, C, L, v, ws, wsb, c.stv()));
+    if (timed) { P.tick(0, 1, true, c.st); ++P.tfwd; }
+  }
+  GPSA_RUN(gpsa_data_sample_fwd(meanT, v, q, c.prm.data_var, eps, C, L, F, Sigma, c.stv()));
+  if (P.d.has_lmc[m] && Fo != nullptr)
+    GPSA_CK(gemm32(c, 0, 0, (int)C, Pm, L, 1.0, F, L, 0, c.prm.W[m], Pm, 0, 0.0, Fo, Pm, 0, 1, 1));
+  c.sc.release(mk);
+  return 0;
+}
+
+static int step_forward(Plan& P, const gpsa_step_params& prm, const gpsa_step_io& io, char* saved, Arena& sc,
+                        hipStream_t st, int stages) {
+  Ctx c{P, prm, io, saved, sc, st, sc.dry};
+  if (stages & 1) {
+    GPSA_CK(mm_stage_fwd(c));
+    GPSA_CK(warp_stage_fwd(c));
+  }
+  if (stages & 2)
+    for (const Pass& ps : P.passes) GPSA_CK(data_pass_fwd(c, ps));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------
+struct BwdBufs {          // fp64 pieces of the parameter gradients (scratch, alive for the whole backward)
+  double* dstack[2];      // gradient wrt every matrix of the groups' batches
+  double *dZ_wf, *dZ_wu, *dpar_wf, *dpar_wu, *dvar_ws, *dresid;
+  double *dZ_df, *dpar_df, *dZ_du, *dpar_du;
+  float* dvar_ds;
+  float* ddc_F[MAXMODS];
+  double* dG64[MAXMODS];
+  double* dD[2];
+  bool have_dG[MAXMODS];
+  bool have_ddc[MAXMODS];
+};
+
+static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_in, const float* dFo_in,
+                         BwdBufs& B, const gpsa_step_param_grads& out, bool first_for_mod) {
+  Plan& P = c.P;
+  const bool dry = c.dry;
+  const int m = ps.m, Mg = P.Mg, D = P.D, L = P.d.n_latent[m], Pm = P.d.n_out[m];
+  const long long C = ps.C, mm = (long long)Mg * Mg;
+  Group& GD = P.gd();
+  const double* Kinv = c.inv(GD, P.pos_KF());
+  const double* Om = c.mats(GD, P.pos_OmF(m, 0));
+  double* dOm = B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(m, 0) * mm;
+  double* dKuu = B.dstack[P.merged ? 0 : 1] + (long long)P.pos_KF() * mm;
+  const float* alpha = c.sv<float>(ps.o_alpha);
+  const float* Sigma = c.sv<float>(ps.o_sigma);
+  const float* eps = ps.test ? c.io.eps_F_test[m] : c.io.eps_F[m];
+  const float* F = ps.test ? c.io.F_latent_test[m] : c.io.F_latent[m];
+  const long long mk = c.sc.mark();
+  // gradient wrt the latent draws: the caller's own plus the LMC's F_obs = F W (vgpsa.py:428-432)
+  const float* dFl = dFl_in;
+  if (P.d.has_lmc[m] && dFo_in != nullptr) {
+    float* buf = c.sc.get<float>(C * L);
+    if (dFl_in != nullptr) GPSA_RUN((int)hipMemcpyAsync(buf, dFl_in, (size_t)(C * L * 4), hipMemcpyDeviceToDevice, c.st));
+    GPSA_CK(gemm32(c, 0, 1, (int)C, L, Pm, 1.0, dFo_in, Pm, 0, c.prm.W[m], Pm, 0, dFl_in != nullptr ? 1.0 : 0.0, buf, L,
+                   0, 1, 1));
+    if (out.W[m] != nullptr)  // dW = F^T dF_obs
+      GPSA_CK(gemm32(c, 1, 0, L, Pm, C, 1.0, F, L, 0, dFo_in, Pm, 0, first_for_mod ? 0.0 : 1.0, out.W[m], Pm, 0, 1,
+                     splitk_for(C, L, Pm)));
+    dFl = buf;
+  } else if (!P.d.has_lmc[m] && dFo_in != nullptr && dFl_in != nullptr && dFo_in != dFl_in) {
+    return GPSA_EINVAL;  // without LMC F_obs IS F_latent: one gradient
+  } else if (dFl == nullptr) {
+    dFl = dFo_in;
+  }
+  float* g_ext = c.sc.get<float>((long long)(L + 1) * C);
+  float* dmeanT = c.sc.get<float>((long long)L * C);
+  float* qbar = g_ext + (long long)L * C;
+  {
+    const long long wsb = 8 * (C / 32 + 2);
+    void* ws = c.sc.get<char>(wsb);
+    GPSA_RUN(gpsa_data_sample_bwd(dFl, eps, Sigma, c.prm.data_var, C, L, g_ext, dmeanT, qbar,
+                                  B.dvar_ds + pass_idx, ws, wsb, c.stv()));
+  }
+  // abar = delta_F dmean + 2 sum_l g_l Omega_l alpha
+  float* abar = c.sc.get<float>((long long)Mg * C);
+  {
+    const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
+    const long long mk2 = c.sc.mark();
+    void* ws = c.sc.get<char>(wsb);
+    const bool timed = !dry && &ps == &P.passes[0];
+    if (timed) P.tick(1, 0, false, c.st);
+    GPSA_RUN(gpsa_quadform_bwd_alpha(GPSA_F32, GPSA_F64, alpha, Om, g_ext, Mg, C, L, abar, ws, wsb, c.stv()));
+    if (timed) P.tick(1, 1, false, c.st);
+    c.sc.release(mk2);
+  }
+  GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
+  // d delta_F = alpha dmean^T
+  GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
+                 splitk_for(C, Mg, L)));
+  B.have_ddc[m] = true;
+  // gamma = K^-1 abar (fp64 product on the fp32 panel)
+  float* gamma = c.sc.get<float>((long long)Mg * C);
+  {
+    const long long wsb = gpsa_whiten_workspace(Mg);
+    if (wsb > 0) {
+      const long long mk2 = c.sc.mark();
+      void* ws = c.sc.get<char>(wsb);
+      GPSA_RUN(gpsa_whiten_f64(Kinv, GPSA_F32, abar, Mg, C, GPSA_F32, gamma, nullptr, ws, wsb, c.stv()));
+      c.sc.release(mk2);
+    } else {
+      GPSA_CK((gemmx<double, float, float>(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, abar, C, 0, 0.0, gamma, C, 0, 1, 1)));
+    }
+  }
+  // dOmega_l = sum_c g_l alpha alpha^T (fp32 matrix cores, fp64 result)
+  {
+    const long long mk2 = c.sc.mark();
+    const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
+    void* ws = c.sc.get<char>(wsb);
+    double* dst = first_for_mod ? dOm : c.sc.get<double>((long long)L * mm);
+    const bool timed = !dry && &ps == &P.passes[0];
+    if (timed) P.tick(2, 0, false, c.st);
+    int rc = dry ? 0 : gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F64, alpha, g_ext, Mg, C, L, dst, ws, wsb, c.stv());
+    if (timed) { P.tick(2, 1, false, c.st); ++P.tbwd; }
+    if (rc == GPSA_EUNSUPPORTED) {  // generic path stores in the compute type: convert
+      float* tmp = c.sc.get<float>((long long)L * mm);
+      GPSA_RUN(gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F32, alpha, g_ext, Mg, C, L, tmp, ws, wsb, c.stv()));
+      if (!dry) {
+        convert_kernel_step<float, double><<<(unsigned)cdiv((long long)L * mm, 256), 256, 0, c.st>>>(
+            tmp, (long long)L * mm, dst);
+        GPSA_LAUNCH_CHECK();
+      }
+    } else if (rc != 0) {
+      return rc;
+    }
+    if (dry) (void)c.sc.get<float>((long long)L * mm);
+    if (!first_for_mod && !dry) {
+      add_inplace_kernel<<<(unsigned)cdiv((long long)L * mm, 256), 256, 0, c.st>>>(dOm, dst, (long long)L * mm);
+      GPSA_LAUNCH_CHECK();
+    }
+    // dK_uu
+    if (C >= 4LL * L * Mg) {
+      // dK_uu = -(gamma + qbar a) a^T without a second C-long product (engine.py:_layer_backward):
+      //   gamma a^T = K^-1 (abar a^T),  abar a^T = dc ddc^T + 2 sum_l Omega_l dOmega_l,  (qbar a) a^T = -sum_l dOmega_l
+      // on THIS pass's dOmega (dst) and ddc
+      double* Pm_ = c.sc.get<double>(mm);
+      float* ddc_p = B.ddc_F[m];
+      if (!first_for_mod) {  // this pass's own ddc (the accumulated one holds earlier passes too)
+        ddc_p = c.sc.get<float>((long long)Mg * L);
+        GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, 0.0, ddc_p, L, 0, 1, splitk_for(C, Mg, L)));
+      }
+      GPSA_CK(gemm64(c, 1, 0, Mg, Mg, (long long)L * Mg, 2.0, Om, Mg, 0, dst, Mg, 0, 0.0, Pm_, Mg, 0, 1,
+                     splitk_for((long long)L * Mg, Mg, Mg)));
+      GPSA_CK((gemmx<float, float, double>(c, 0, 1, Mg, Mg, L, 1.0, c.prm.delta_F[m], L, 0, ddc_p, L, 0, 1.0, Pm_, Mg, 0,
+                                           1, 1)));
+      double* sumOm = c.sc.get<double>(mm);
+      if (!dry) {
+        reduce_rows_kernel<double, double><<<(unsigned)cdiv(mm, 64), 256, 0, c.st>>>(dst, L, mm, mm, sumOm, 1.0);
+        GPSA_LAUNCH_CHECK();
+      }
+      GPSA_CK(gemm64(c, 0, 0, Mg, Mg, Mg, -1.0, Kinv, Mg, 0, Pm_, Mg, 0, 1.0, sumOm, Mg, 0, 1, splitk_small(Mg, Mg, Mg, 1)));
+      if (!dry) {  // the gradient buffer starts at zero: every pass adds its share
+        add_inplace_kernel<<<(unsigned)cdiv(mm, 256), 256, 0, c.st>>>(dKuu, sumOm, mm);
+        GPSA_LAUNCH_CHECK();
+      }
+      GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 2.0, Mg, C, gamma, c.stv()));  // dK_uf = gamma + 2 qbar a
+    } else {
+      // few columns: W = gamma + qbar a;  dK_uu = -W a^T ADDED in fp64;  dK_uf = W + qbar a
+      GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 1.0, Mg, C, gamma, c.stv()));
+      GPSA_CK((gemmx<float, float, double>(c, 0, 1, Mg, Mg, C, -1.0, gamma, C, 0, alpha, C, 0, 1.0, dKuu, Mg, 0, 1,
+                                           splitk_for(C, Mg, Mg))));
+      GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 1.0, Mg, C, gamma, c.stv()));
+    }
+    c.sc.release(mk2);
+  }
+  // covariance backward: fp32 panel, fp64 arithmetic and results; the coordinates' gradient goes back to
+  // the warp GPs in fp64
+  {
+    const long long wsb = gpsa_kmat_bwd_workspace(GPSA_F64, Mg, C, D);
+    void* ws = c.sc.get<char>(wsb);
+    double* dZ = B.dZ_df + (long long)pass_idx * Mg * D;
+    double* dpar = B.dpar_df + (long long)pass_idx * 2;
+    if (ps.test) {
+      GPSA_RUN(gpsa_kmat_bwd(GPSA_F64, GPSA_F32_ACC64, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D,
+                             c.prm.data_ls, c.prm.data_var, gamma, 0, dZ, nullptr, dpar, ws, wsb, c.stv()));
+    } else {
+      GPSA_RUN(gpsa_kmat_bwd_x64(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
+                                 c.prm.data_var, gamma, dZ, B.dG64[m], dpar, ws, wsb, c.stv()));
+      B.have_dG[m] = true;
+    }
+  }
+  c.sc.release(mk);
+  return 0;
+}
+
+static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
+  Plan& P = c.P;
+  const bool dry = c.dry;
+  const int D = P.D, Mx = P.Mx, nf = P.nf;
+  const long long Cs = P.Cs, mm = (long long)Mx * Mx;
+  Group& GW = P.gw();
+  if (nf == 0 || Cs == 0) return 0;
+  const long long mk = c.sc.mark();
+  const float* Xv = c.sv<float>(P.o_Xv);
+  const double* alpha = c.sv<double>(P.o_alpha_w);
+  const double* Wk = c.sv<double>(P.o_Wk);
+  double* dmeanT = c.sc.get<double>((long long)nf * D * Cs);
+  double* g = c.sc.get<double>((long long)nf * D * Cs);
+  double* qbar = c.sc.get<double>((long long)nf * Cs);
+  const long long nblk = cdiv(Cs, 256);
+  double* part = c.sc.get<double>((long long)nf * nblk);
+  if (!dry) {
+    const double* dG64[MAXMODS];
+    for (int m = 0; m < MAXMODS; ++m) dG64[m] = (m < P.nm && B.have_dG[m]) ? B.dG64[m] : nullptr;
+    dim3 grid((unsigned)nblk, (unsigned)nf);
+    warp_sample_views_bwd_kernel<<<grid, 256, 0, c.st>>>(P.tab, P.d_free, mod_ptrs(c, &og, dG64), c.io.eps_G, dmeanT,
+                                                         g, qbar, part);
+    GPSA_LAUNCH_CHECK();
+    warp_sample_views_bwd_finish_kernel<<<nf, 64, 0, c.st>>>(part, nblk, P.d_free, c.prm.warp_var, B.dvar_ws);
+    GPSA_LAUNCH_CHECK();
+  }
+  double* abar = c.sc.get<double>((long long)nf * Mx * Cs);   // abar, then gamma's right-hand side
+  double* gamma = c.sc.get<double>((long long)nf * Mx * Cs);
+  for (const Run& r : P.runs) {
+    const long long oMC = (long long)r.b0 * Mx * Cs, oDC = (long long)r.b0 * D * Cs;
+    const double* resid = c.sv<double>(P.o_resid) + (long long)r.v0 * Mx * D;
+    // abar = 2 sum_j g_j o W_j + dc dmean
+    GPSA_RUN(gpsa_quadform_bwd_alpha_kept_batched_f64(Wk + (long long)r.b0 * D * Mx * Cs, g + oDC, Mx, Cs, D, resid,
+                                                      dmeanT + oDC, abar + oMC, r.cnt, c.stv()));
+    // d resid = alpha dmean^T  (the layer's share; the KL's is added by the finalize kernel)
+    GPSA_CK(gemm64(c, 0, 1, Mx, D, Cs, 1.0, alpha + oMC, Cs, (long long)Mx * Cs, dmeanT + oDC, Cs, (long long)D * Cs,
+                   0.0, B.dresid + (long long)r.v0 * Mx * D, D, (long long)Mx * D, r.cnt, splitk_for(Cs, Mx, D)));
+    // gamma = K^-1 abar
+    GPSA_CK(project_views(c, c.inv(GW, P.pos_Kw(r.b0)), abar + oMC, Mx, Cs, gamma + oMC, nullptr, r.cnt));
+    // dOmega rows v*D + j (quirk 2)
+    {
+      const long long mk2 = c.sc.mark();
+      const long long wsb = gpsa_gram_batched_workspace(Mx, Cs, D, r.cnt);
+      void* ws = c.sc.get<char>(wsb);
+      GPSA_RUN(gpsa_gram_batched_f64(alpha + oMC, g + oDC, Mx, Cs, D, B.dstack[0] + (long long)P.pos_OmG(r.v0 * D) * mm,
+                                     r.cnt, ws, wsb, c.stv()));
+      c.sc.release(mk2);
+    }
+    // W = gamma + qbar a;  dK_uu = -W a^T;  dK_uf = W + qbar a
+    GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 1.0, Mx, Cs, gamma + oMC,
+                                       r.cnt, c.stv()));
+    GPSA_CK(gemm64(c, 0, 1, Mx, Mx, Cs, -1.0, gamma + oMC, Cs, (long long)Mx * Cs, alpha + oMC, Cs, (long long)Mx * Cs,
+                   0.0, B.dstack[0] + (long long)P.pos_Kw(r.b0) * mm, Mx, mm, r.cnt, splitk_for(Cs, Mx, Mx)));
+    GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 1.0, Mx, Cs, gamma + oMC,
+                                       r.cnt, c.stv()));
+    // covariance backward of K_uf
+    {
+      const long long mk2 = c.sc.mark();
+      long long nlive[KM_MAXB_STEP];
+      for (int i = 0; i < r.cnt; ++i) nlive[i] = P.nview[r.v0 + i];
+      const long long wsb = gpsa_kmat_bwd_batched_workspace(Mx, Cs, D, r.cnt);
+      void* ws = c.sc.get<char>(wsb);
+      GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_warp, c.prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
+                                     Xv + (long long)r.b0 * Cs * D, Cs * D, Cs, D, c.prm.warp_ls + r.v0,
+                                     c.prm.warp_var + r.v0, 1, nlive, r.cnt, gamma + oMC, (long long)Mx * Cs, 0,
+                                     B.dZ_wf + (long long)r.b0 * Mx * D, (long long)Mx * D,
+                                     B.dpar_wf + (long long)r.b0 * 2, ws, wsb, c.stv()));
+      c.sc.release(mk2);
+    }
+  }
+  c.sc.release(mk);
+  return 0;
+}
+
+static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_io& io,
+                         const gpsa_step_out_grads& og, char* saved, Arena& sc, const gpsa_step_param_grads& out,
+                         hipStream_t st) {
+  Ctx c{P, prm, io, saved, sc, st, sc.dry};
+  const bool dry = c.dry;
+  const int V = P.V, D = P.D, Mx = P.Mx, Mg = P.Mg, nf = P.nf, npass = (int)P.passes.size();
+  BwdBufs B;
+  memset(&B, 0, sizeof(B));
+  for (int g = 0; g < P.ng; ++g) {
+    Group& G = P.grp[g];
+    const long long n = (long long)G.nb() * G.M * G.M;
+    B.dstack[g] = sc.get<double>(n);
+    if (!dry) GPSA_CK((int)hipMemsetAsync(B.dstack[g], 0, (size_t)(n * 8), st));
+    B.dD[g] = sc.get<double>((long long)G.n_omega * G.M);
+  }
+  const long long nwz = (long long)(nf > 0 ? nf : 1) * Mx * D;
+  B.dZ_wf = sc.get<double>(nwz); B.dZ_wu = sc.get<double>(nwz);
+  B.dpar_wf = sc.get<double>(2LL * (nf > 0 ? nf : 1)); B.dpar_wu = sc.get<double>(2LL * (nf > 0 ? nf : 1));
+  B.dvar_ws = sc.get<double>(nf > 0 ? nf : 1);
+  B.dresid = sc.get<double>((long long)V * Mx * D);
+  B.dZ_df = sc.get<double>((long long)(npass > 0 ? npass : 1) * Mg * D);
+  B.dpar_df = sc.get<double>(2LL * (npass > 0 ? npass : 1));
+  B.dvar_ds = sc.get<float>(npass > 0 ? npass : 1);
+  B.dZ_du = sc.get<double>((long long)Mg * D); B.dpar_du = sc.get<double>(2);
+  for (int m = 0; m < P.nm; ++m) {
+    B.ddc_F[m] = sc.get<float>((long long)Mg * P.d.n_latent[m]);
+    B.dG64[m] = sc.get<double>((long long)P.S * P.d.n_rows[m] * D);
+  }
+  if (!dry) {  // pieces that may stay unwritten (no gradient reached them)
+    GPSA_CK((int)hipMemsetAsync(B.dresid, 0, (size_t)((long long)V * Mx * D * 8), st));
+    GPSA_CK((int)hipMemsetAsync(B.dZ_wf, 0, (size_t)(nwz * 8), st));
+    GPSA_CK((int)hipMemsetAsync(B.dpar_wf, 0, (size_t)(2LL * (nf > 0 ? nf : 1) * 8), st));
+    GPSA_CK((int)hipMemsetAsync(B.dvar_ws, 0, (size_t)((nf > 0 ? nf : 1) * 8), st));
+    GPSA_CK((int)hipMemsetAsync(B.dZ_df, 0, (size_t)((long long)(npass > 0 ? npass : 1) * Mg * D * 8), st));
+    GPSA_CK((int)hipMemsetAsync(B.dpar_df, 0, (size_t)(2LL * (npass > 0 ? npass : 1) * 8), st));
+    GPSA_CK((int)hipMemsetAsync(B.dvar_ds, 0, (size_t)((npass > 0 ? npass : 1) * 4), st));
+  }
+  // ---- data GP passes
+  bool seen[MAXMODS] = {false, false, false, false};
+  for (int pi = 0; pi < npass; ++pi) {
+    const Pass& ps = P.passes[pi];
+    const float* dFl = ps.test ? og.dF_latent_test[ps.m] : og.dF_latent[ps.m];
+    const float* dFo = ps.test ? og.dF_obs_test[ps.m] : og.dF_obs[ps.m];
+    if (dFl == nullptr && dFo == nullptr) continue;  // no gradient reached this pass's draws
+    // pi selects this pass's slot of the per-pass pieces; the first pass of a modality writes its shared
+    // pieces (dOmega rows, d delta_F, dW), later ones add to them
+    GPSA_CK(data_pass_bwd(c, ps, pi, dFl, dFo, B, out, !seen[ps.m]));
+    seen[ps.m] = true;
+  }
+  // ---- warp GPs
+  GPSA_CK(warp_stage_bwd(c, og, B));
+  // ---- KL terms: dOmega += , dK_p += 0.5 K_p^-1 S_p K_p^-1, dD
+  const bool kl = P.d.want_kl != 0 && og.dkl != nullptr;
+  for (int g = 0; g < P.ng && kl; ++g) {
+    Group& G = P.grp[g];
+    if (G.n_omega == 0 || G.n_prior == 0) continue;
+    const long long mm = (long long)G.M * G.M;
+    const long long mk = sc.mark();
+    double* S = sc.get<double>((long long)G.n_prior * mm);
+    double* T1 = sc.get<double>((long long)G.n_prior * mm);
+    GPSA_RUN(gpsa_mvn_kl_grouped_bwd_acc(c.mats(G, 0), c.inv(G, 0), G.om_idx, G.pr_list, G.grp_off, G.order,
+                                         c.sv<double>(G.o_D), c.sv<double>(G.o_KD), og.dkl + G.kl_off, G.M, G.n_omega,
+                                         G.n_prior, B.dstack[g] + (long long)G.n_prior * mm, B.dD[g], S, 1, c.stv()));
+    GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 1.0, c.inv(G, 0), G.M, mm, S, G.M, mm, 0.0, T1, G.M, mm, G.n_prior,
+                   splitk_small(G.M, G.M, G.M, G.n_prior)));
+    GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 0.5, T1, G.M, mm, c.inv(G, 0), G.M, mm, 1.0, B.dstack[g], G.M, mm, G.n_prior,
+                   splitk_small(G.M, G.M, G.M, G.n_prior)));
+    sc.release(mk);
+  }
+  // ---- prior covariances: K_uu of the free views and of the data GP
+  {
+    Group& GW = P.gw();
+    Group& GD = P.gd();
+    for (const Run& r : P.runs) {
+      const long long mk = sc.mark();
+      const long long wsb = gpsa_kmat_bwd_batched_workspace(Mx, Mx, D, r.cnt);
+      void* ws = sc.get<char>(wsb);
+      GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_warp, prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
+                                     prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx, D, prm.warp_ls + r.v0,
+                                     prm.warp_var + r.v0, 1, nullptr, r.cnt,
+                                     B.dstack[0] + (long long)P.pos_Kw(r.b0) * Mx * Mx, (long long)Mx * Mx, 1,
+                                     B.dZ_wu + (long long)r.b0 * Mx * D, (long long)Mx * D, B.dpar_wu + (long long)r.b0 * 2,
+                                     ws, wsb, c.stv()));
+      sc.release(mk);
+    }
+    {
+      const long long mk = sc.mark();
+      const long long wsb = gpsa_kmat_bwd_batched_workspace(Mg, Mg, D, 1);
+      void* ws = sc.get<char>(wsb);
+      GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_data, prm.Gtilde, 0, Mg, prm.Gtilde, 0, Mg, D, prm.data_ls, prm.data_var, 0,
+                                     nullptr, 1, B.dstack[P.merged ? 0 : 1] + (long long)P.pos_KF() * Mg * Mg, 0, 1,
+                                     B.dZ_du, 0, B.dpar_du, ws, wsb, c.stv()));
+      sc.release(mk);
+    }
+    // variational covariances: d Omega_sqt = (G + G^T) A = 2 G A (every gradient that reaches Omega is symmetric)
+    if (out.Omega_sqt_G != nullptr)
+      GPSA_RUN(gpsa_omega_bwd(B.dstack[0] + (long long)P.pos_OmG(0) * Mx * Mx, prm.Omega_sqt_G, Mx, V * D, 1,
+                              out.Omega_sqt_G, c.stv()));
+    for (int m = 0; m < P.nm; ++m)
+      if (out.Omega_sqt_F[m] != nullptr)
+        GPSA_RUN(gpsa_omega_bwd(B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(m, 0) * Mg * Mg, prm.Omega_sqt_F[m], Mg,
+                                P.d.n_latent[m], 1, out.Omega_sqt_F[m], c.stv()));
+    (void)GW; (void)GD;
+  }
+  // ---- small parameters
+  {
+    FinalArgs a;
+    memset(&a, 0, sizeof(a));
+    a.V = V; a.D = D; a.Mx = Mx; a.Mg = Mg; a.nm = P.nm; a.nf = nf; a.npass = npass;
+    a.bidx = P.tab.bidx;
+    a.slopes = prm.slopes;
+    a.dZ_wf = B.dZ_wf; a.dZ_wu = B.dZ_wu; a.dpar_wf = B.dpar_wf; a.dpar_wu = B.dpar_wu; a.dvar_ws = B.dvar_ws;
+    a.dresid = B.dresid;
+    a.dD_w = kl ? B.dD[0] : nullptr;
+    a.dZ_df = B.dZ_df; a.dpar_df = B.dpar_df; a.dvar_ds = B.dvar_ds; a.dZ_du = B.dZ_du; a.dpar_du = B.dpar_du;
+    a.dD_d = kl ? (P.merged ? B.dD[0] + (long long)V * D * Mx : B.dD[1]) : nullptr;
+    long long tot = (long long)V * Mx * D + 2LL * V + (long long)Mg * D + 2;
+    for (int m = 0; m < P.nm; ++m) {
+      a.ddc_F[m] = B.have_ddc[m] ? B.ddc_F[m] : nullptr;
+      a.L[m] = P.d.n_latent[m];
+      a.Loff[m] = P.Loff[m];
+      tot += (long long)Mg * P.d.n_latent[m];
+    }
+    a.out = out;
+    if (!dry) {
+      step_finalize_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(a);
+      GPSA_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+}  // namespace gpsa
+
+extern "C" {
+
+void* gpsa_step_create(const gpsa_step_desc* desc) {
+  using namespace gpsa;
+  Plan* p = make_plan(desc);
+  if (p == nullptr) return nullptr;
+  // scratch requirement = high-water mark of a dry run of the forward and of the backward
+  Arena a;
+  a.dry = true;
+  gpsa_step_params prm;
+  gpsa_step_io io;
+  gpsa_step_out_grads og;
+  gpsa_step_param_grads pg;
+  memset(&prm, 0, sizeof(prm)); memset(&io, 0, sizeof(io)); memset(&og, 0, sizeof(og)); memset(&pg, 0, sizeof(pg));
+  // pretend every gradient is present so that the dry run walks every branch
+  static const float dummy = 0.f;
+  static const double dummyd = 0.0;
+  for (int m = 0; m < p->nm; ++m) {
+    og.dF_latent[m] = &dummy;
+    if (p->d.has_lmc[m]) og.dF_obs[m] = &dummy;
+    og.dF_latent_test[m] = &dummy;
+    if (p->d.has_lmc[m]) og.dF_obs_test[m] = &dummy;
+    pg.W[m] = const_cast<float*>(&dummy);
+    io.F_obs[m] = const_cast<float*>(&dummy);
+    io.F_obs_test[m] = const_cast<float*>(&dummy);
+  }
+  og.dkl = &dummyd;
+  if (step_forward(*p, prm, io, nullptr, a, nullptr, 3) != 0) { free_plan(p); return nullptr; }
+  a.off = 0;
+  if (step_backward(*p, prm, io, og, nullptr, a, pg, nullptr) != 0) { free_plan(p); return nullptr; }
+  p->scratch_bytes = a.high + 4096;
+  return p;
+}
+
+void gpsa_step_destroy(void* plan) { gpsa::free_plan(reinterpret_cast<gpsa::Plan*>(plan)); }
+long long gpsa_step_saved_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->saved_bytes : -1; }
+long long gpsa_step_scratch_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->scratch_bytes : -1; }
+int gpsa_step_n_kl(const void* plan) {
+  if (!plan) return -1;
+  const gpsa::Plan* p = reinterpret_cast<const gpsa::Plan*>(plan);
+  return p->V * p->D + p->Ltot;
+}
+long long gpsa_step_eps_g_numel(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->eps_total : -1; }
+
+/* timing of the contraction kernels (diagnostic; bench.py): events around gpsa_quadform_fwd / _bwd_alpha /
+ * _bwd_omega of the first data-GP pass for the next ``slots`` steps (a ring); 0 switches it off */
+int gpsa_step_timing(void* plan, int slots) {
+  using namespace gpsa;
+  if (!plan || slots < 0) return GPSA_EINVAL;
+  Plan& P = *reinterpret_cast<Plan*>(plan);
+  for (hipEvent_t e : P.tev) (void)hipEventDestroy(e);
+  P.tev.clear();
+  P.tslots = 0;
+  P.tfwd = P.tbwd = 0;
+  for (int i = 0; i < slots * 6; ++i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return GPSA_EINVAL;
+    P.tev.push_back(e);
+  }
+  P.tslots = slots;
+  return 0;
+}
+
+/* ms[3 * n]: per recorded step (oldest first, n = min(steps since gpsa_step_timing, slots)) the duration of
+ * the three kernels; the caller has synchronised the stream.  Returns n or a negative error. */
+int gpsa_step_timing_read(void* plan, float* ms, int max_steps) {
+  using namespace gpsa;
+  if (!plan || !ms) return GPSA_EINVAL;
+  Plan& P = *reinterpret_cast<Plan*>(plan);
+  if (P.tslots == 0) return 0;
+  int n = P.tfwd < P.tbwd ? P.tfwd : P.tbwd;
+  if (n > P.tslots) n = P.tslots;
+  if (n > max_steps) n = max_steps;
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const int stepno = (k == 0 ? P.tfwd : P.tbwd) - n + i;
+      const int slot = stepno % P.tslots;
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, P.tev[(size_t)(slot * 3 + k) * 2], P.tev[(size_t)(slot * 3 + k) * 2 + 1]) != hipSuccess)
+        return GPSA_EINVAL;
+      ms[i * 3 + k] = t;
+    }
+  return n;
+}
+
+int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_step_io* io, void* saved, void* scratch,
+                      int stages, void* stream) {
+  using namespace gpsa;
+  if (!plan || !params || !io || !saved || !scratch) return GPSA_EINVAL;
+  Plan& P = *reinterpret_cast<Plan*>(plan);
+  if (P.d.want_kl && io->kl == nullptr) return GPSA_EINVAL;
+  Arena a;
+  a.base = reinterpret_cast<char*>(scratch);
+  return step_forward(P, *params, *io, reinterpret_cast<char*>(saved), a, as_stream(stream), stages);
+}
+
+int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_step_io* io,
+                       const gpsa_step_out_grads* og, void* saved, void* scratch, const gpsa_step_param_grads* grads,
+                       void* stream) {
+  using namespace gpsa;
+  if (!plan || !params || !io || !og || !saved || !scratch || !grads) return GPSA_EINVAL;
+  Plan& P = *reinterpret_cast<Plan*>(plan);
+  Arena a;
+  a.base = reinterpret_cast<char*>(scratch);
+  return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, as_stream(stream));
+}
+
+/* ---- likelihood + ELBO: one host call each way ------------------------------------------------------------- */
+int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                       const int* S, const long long* N, const int* P, const double* kl, int n_kl, double kl_scale,
+                       float* loss, double* ll_out, void* workspace, long long workspace_bytes, void* stream) {
+  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !loss || !ll_out) return GPSA_EINVAL;
+  if (workspace_bytes < 8LL * 4100) return GPSA_EWORKSPACE;
+  for (int i = 0; i < n_ll; ++i) {
+    int rc = gpsa_loglik_fwd(F[i], Y[i], noise_u[i], S[i], N[i], P[i], ll_out + i, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return gpsa_elbo_fwd(ll_out, n_ll, kl, kl ? n_kl : 0, kl_scale, loss, stream);
+}
+
+int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                       const int* S, const long long* N, const int* P, const float* gloss, int n_kl, double kl_scale,
+                       float* const* dF, float* const* dnoise, double* dkl, void* workspace, long long workspace_bytes,
+                       void* stream) {
+  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !gloss || !dF || !dnoise)
+    return GPSA_EINVAL;
+  if (workspace_bytes < 8LL * 4100 + 64) return GPSA_EWORKSPACE;
+  // dll[i] = -gloss (fp64 device scalars at the head of the workspace), dkl[t] = kl_scale * gloss
+  double* dll = reinterpret_cast<double*>(workspace);
+  int rc = gpsa_elbo_bwd(gloss, n_ll, dkl ? n_kl : 0, kl_scale, dll, dkl, stream);
+  if (rc) return rc;
+  char* ws = reinterpret_cast<char*>(workspace) + 64;
+  for (int i = 0; i < n_ll; ++i) {
+    rc = gpsa_loglik_bwd(F[i], Y[i], noise_u[i], dll + i, S[i], N[i], P[i], dF[i], dnoise[i], ws, workspace_bytes - 64,
+                         stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int gpsa_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const long long* numel, double lr, double beta1, double beta2, double eps,
+                   float* step, void* stream) {
+  using namespace gpsa;
+  if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !step) return GPSA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  adam_tick_kernel<<<1, 1, 0, st>>>(step);
+  GPSA_LAUNCH_CHECK();
+  for (int i0 = 0; i0 < n; i0 += ADAM_MAXT) {
+    AdamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nt = n - i0 < ADAM_MAXT ? n - i0 : ADAM_MAXT;
+    long long blk = 0;
+    for (int t = 0; t < a.nt; ++t) {
+      a.p[t] = params[i0 + t]; a.g[t] = grads[i0 + t]; a.m[t] = exp_avg[i0 + t]; a.v[t] = exp_avg_sq[i0 + t];
+      a.n[t] = numel[i0 + t];
+      a.blk0[t] = blk;
+      blk += cdiv(numel[i0 + t], 1024);
+    }
+    a.blk0[a.nt] = blk;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    if (blk > 0) {
+      adam_kernel<<<(unsigned)blk, 256, 0, st>>>(a, step);
+      GPSA_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

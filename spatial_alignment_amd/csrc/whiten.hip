@@ -30,10 +30,13 @@ __device__ __forceinline__ void glds16_f64(const double* gsrc, unsigned lds_base
 
 // Kinv [M][M] row-major -> Apk[kc][ks][rt][lane] = Kinv[16 rt + (lane&15)][16 kc + 4 ks + (lane>>4)]
 // (zero padded to MP = 16 MB): the A-operand fragment of every MFMA is one lane-linear 512-byte row.
-__global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int MB, double* __restrict__ Apk) {
+__global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int MB, double* __restrict__ Apk,
+                                   long long sKinv) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long tot = (long long)MB * 4 * MB * 64;
   if (idx >= tot) return;
+  Kinv += blockIdx.y * sKinv;  // problem blockIdx.y of a batch (the views' warp GPs)
+  Apk += blockIdx.y * tot;
   const int lane = (int)(idx & 63);
   long long t = idx >> 6;
   const int rt = (int)(t % MB);
@@ -54,9 +57,15 @@ __global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int M
 // registers, one workgroup per CU -- the shorter dependency chain when the grid does not fill the chip.
 template <int MB, typename TI, typename TO, bool STREAM>
 __global__ void __launch_bounds__(256, (MB >= (STREAM ? 14 : 13)) ? 1 : 2)
-whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int M, long long C,
-                   TO* __restrict__ alpha, double* __restrict__ q) {
+whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, int M, long long C,
+                   TO* __restrict__ alpha0, double* __restrict__ q0, long long sX) {
   constexpr int CHUNK = 4 * MB * 64;          // doubles per K chunk (2*MB pieces of 1 KiB)
+  // problem blockIdx.y of a batch: its own packed inverse, panels at stride sX, q at stride C
+  const long long pb = blockIdx.y;
+  const double* __restrict__ Apk = Apk0 + pb * (long long)MB * CHUNK;
+  const TI* __restrict__ X = X0 + pb * sX;
+  TO* __restrict__ alpha = alpha0 + pb * sX;
+  double* __restrict__ q = q0 + pb * C;  // only dereferenced when q0 != nullptr
   constexpr int NPIECE = 2 * MB;
   constexpr int NPW = (NPIECE + 3) / 4;       // LDS-DMA operations per wave per stage (uniform)
   constexpr int BUFD = NPW * 4 * 128;         // doubles per ring slot (incl. dummy pieces)
@@ -68,6 +77,8 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
   const long long c = blockIdx.x * 64LL + w * 16 + j;
   const bool okc = c < C;
   const TI* xcol = X + (okc ? c : 0);
+  // LDS byte address of the ring, taken ONCE from the array's base (one foldable address-space cast)
+  const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr64_t)(&lds[0][0]);
 
 #define GPSA_WSTAGE(Q, BUF)                                                                    \
   {                                                                                            \
@@ -75,8 +86,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
     _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
       const int piece = pc * 4 + w;                                                            \
       glds16_f64(src__ + (piece < NPIECE ? piece : NPIECE - 1) * 128,                          \
-                 __builtin_amdgcn_readfirstlane(                                               \
-                     (unsigned)(unsigned long long)(lds_ptr64_t)(&lds[BUF][piece * 128])));    \
+                 __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((BUF) * BUFD + piece * 128) * 8))); \
     }                                                                                          \
   }
 #define GPSA_WLOADB(DST, KC, T)                                                                \
@@ -135,7 +145,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
   for (int rt = 0; rt < MB; ++rt) {
     double kb[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (STREAM) {
-      if (q != nullptr) GPSA_WLOADB(kb, rt, double)
+      if (q0 != nullptr) GPSA_WLOADB(kb, rt, double)
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) kb[r] = xb[STREAM ? 0 : rt][r];
@@ -149,7 +159,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk, const TI* __restrict__ X, int
     }
   }
 #undef GPSA_WLOADB
-  if (q != nullptr) {
+  if (q0 != nullptr) {
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     if (kq == 0 && okc) q[c] = s;
@@ -169,21 +179,21 @@ static inline int whiten_mb_for(int M) {
 
 template <typename TI, typename TO>
 static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
-                         double* q, hipStream_t st) {
-  const unsigned grid = (unsigned)cdiv(C, 64);
-  bool stream = q == nullptr || (long long)grid > num_cus();
+                         double* q, hipStream_t st, int batch = 1, long long sX = 0) {
+  const dim3 grid((unsigned)cdiv(C, 64), (unsigned)batch);
+  bool stream = q == nullptr || (long long)grid.x * batch > num_cus();
   if (const char* e = getenv("GPSA_WHITEN_STREAM")) stream = atoi(e) != 0;
   if (MB > 16) stream = true;
 #define GPSA_WCASE(V)                                                                     \
   case V:                                                                                 \
     if (stream)                                                                           \
-      whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);  \
-    else                                                                                  \
-      whiten_mfma_kernel<V, TI, TO, false><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q); \
+      whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX);  \
+    else                                                                                      \
+      whiten_mfma_kernel<V, TI, TO, false><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX); \
     break;
 #define GPSA_WCASE_STREAM(V)                                                              \
   case V:                                                                                 \
-    whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q);    \
+    whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX); \
     break;
   switch (MB) {
     GPSA_WCASE(2)
@@ -223,7 +233,7 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
   hipStream_t st = as_stream(stream);
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
-  pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk);
+  pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
   GPSA_LAUNCH_CHECK();
   if (in_dtype == GPSA_F64) {
     if (alpha_dtype == GPSA_F32)
@@ -233,6 +243,26 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
   if (alpha_dtype == GPSA_F32)
     return whiten_launch<float, float>(MB, Apk, (const float*)Kuf, M, C, (float*)alpha, q, st);
   return whiten_launch<float, double>(MB, Apk, (const float*)Kuf, M, C, (double*)alpha, q, st);
+}
+
+/* batch of fp64 -> fp64 projections with one inverse each (the views' warp GPs): problem b reads
+ * Kinv + b strideKinv and Kuf + b strideX ([M,C] blocks, strideX >= M*C), writes alpha + b strideX and
+ * q + b C (q may be NULL).  workspace >= batch * gpsa_whiten_workspace(M). */
+int gpsa_whiten_batched_f64(const double* Kinv, long long strideKinv, const double* Kuf, int M, long long C,
+                            long long strideX, double* alpha, double* q, int batch, void* workspace,
+                            long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || batch < 1 || Kinv == nullptr || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
+  const int MB = whiten_mb_for(M);
+  if (MB == 0) return GPSA_EUNSUPPORTED;
+  if (workspace_bytes < gpsa_whiten_workspace(M) * batch) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* Apk = (double*)workspace;
+  const long long tot = (long long)MB * 4 * MB * 64;
+  dim3 pgrid((unsigned)cdiv(tot, 256), (unsigned)batch);
+  pack_whiten_kernel<<<pgrid, 256, 0, st>>>(Kinv, M, MB, Apk, strideKinv);
+  GPSA_LAUNCH_CHECK();
+  return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha, q, st, batch, strideX);
 }
 
 }  // extern "C"

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine as E
+from .. import step_engine as SE
 from ..kernels import builtin_kind, rbf_kernel
 from .gpsa import GPSA
 
@@ -41,6 +42,7 @@ class _StepCache:
         self.Omega_F_fac = {}  # mod -> (Omega_F^-1, logdet)
         self.flags = []  # device int tensors: Cholesky info / non-positive variance flags
         self.mu_z = self.dG_v = self.resid = None  # per-view prior means / variational means / their difference
+        self.kl = None  # step engine: the per-term KL vector (a differentiable output of the forward node)
         self.batch = self.free = None  # (matrices, inverses, logdets) of the whole factorisation batch
         self.Om_fwd = self.Om_kl = None  # per-view row groups of Omega_G
 
@@ -100,6 +102,9 @@ class VariationalGPSA(GPSA):
         # warp GPs of different views on side HIP streams: pays under hipGraph replay (-0.2 ms at the
         # headline config), costs CPU time per launch in eager mode, so train.GraphedTrainStep turns it on
         self.overlap_views = False
+        # forward as ONE node whose launch sequence is enqueued from C++ (step_engine.py, csrc/step.hip);
+        # False: one node per layer driven from Python (the path arbitrary plug-in covariance callables take)
+        self.use_step_engine = True
         self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
         self._cache = None
 
@@ -246,9 +251,9 @@ class VariationalGPSA(GPSA):
     @property
     def mu_z_G(self):
         cache = self.__dict__.get("_cache")
-        if cache is None or not cache.mu_z:
+        if cache is None or cache.mu_z is None or (isinstance(cache.mu_z, list) and not cache.mu_z):
             raise AttributeError("mu_z_G is available after forward")
-        return torch.stack(cache.mu_z)
+        return cache.mu_z if torch.is_tensor(cache.mu_z) else torch.stack(cache.mu_z)
 
     def _side_streams(self, n, device):
         pool = self.__dict__.setdefault("_stream_pool", [])
@@ -269,6 +274,10 @@ class VariationalGPSA(GPSA):
         V, D = self.n_views, self.n_spatial_dims
         f64 = torch.float64
         noise, self._noise = self._noise, None
+        if self.use_step_engine and dev.type == "cuda" and SE.eligible(self, X_spatial, view_idx, G_test):
+            rows = SE.view_rows(self, view_idx, Ns)
+            if rows is not None:
+                return self._forward_engine(X_spatial, rows, S, G_test, noise, prediction_mode)
         cache = _StepCache()
 
         # per-view slices of the parameters, unbound once (one autograd node per parameter instead of
@@ -501,6 +510,84 @@ class VariationalGPSA(GPSA):
             )
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
+    def _forward_engine(self, X_spatial, rows, S, G_test, noise, prediction_mode):
+        """forward through the C++ step engine: one autograd node, one host call each way"""
+        dev = self.Xtilde.device
+        mods = self.modality_names
+        V, D = self.n_views, self.n_spatial_dims
+        f32 = torch.float32
+        test_shapes = None
+        if G_test is not None:
+            Gt = [G_test[m].to(device=dev, dtype=f32).contiguous() for m in mods]
+            test_shapes = (int(Gt[0].shape[0]), tuple(int(g.shape[1]) for g in Gt))
+        plan = SE.get_plan(self, rows, S, test_shapes, want_kl=not prediction_mode)
+        # draws: one buffer for the warp GPs of all free, non-empty views (order of vgpsa.py:346-348)
+        if noise is not None and noise["G"] is not None:
+            eps_G = torch.cat([e.to(device=dev, dtype=f32).reshape(-1) for e in noise["G"]]) if noise["G"] else \
+                torch.empty(0, dtype=f32, device=dev)
+            if eps_G.numel() != plan.eps_g_numel:
+                raise ValueError(f"injected eps_G has {eps_G.numel()} values, the free views need {plan.eps_g_numel}")
+        else:
+            eps_G = self._draw([plan.eps_g_numel], dev, "G")
+        eps_F, eps_Ft = [], []
+        for i, m in enumerate(mods):
+            shape = [S, plan.N[i], plan.L[i]]
+            if noise is not None and noise["F"] is not None:
+                eps_F.append(noise["F"][m].to(device=dev, dtype=f32).reshape(shape).contiguous())
+            else:
+                eps_F.append(self._draw(shape, dev, "F"))
+            if G_test is not None:
+                tshape = [plan.s_test, plan.n_test[i], plan.L[i]]
+                if noise is not None and noise["F_test"] is not None:
+                    eps_Ft.append(noise["F_test"][m].to(device=dev, dtype=f32).reshape(tshape).contiguous())
+                else:
+                    eps_Ft.append(self._draw(tshape, dev, "F"))
+        aux = dict(plan=plan, model=self, X=[X_spatial[m].contiguous() for m in mods], eps_G=eps_G, eps_F=eps_F,
+                   G_test=Gt if G_test is not None else None, eps_F_test=eps_Ft,
+                   slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
+                   want_kl=not prediction_mode, check=bool(self.check_numerics))
+        outs = SE.StepFn.apply(aux, *SE._param_list(self))
+        nm = len(mods)
+        lmc = [i for i in range(nm) if plan.lmc[i]]
+        k = 0
+        take = lambda n: outs[k:k + n]
+        Gm, k = outs[k:k + nm], k + nm
+        Gs, k = outs[k:k + nm], k + nm
+        Fl, k = outs[k:k + nm], k + nm
+        Fo, k = outs[k:k + len(lmc)], k + len(lmc)
+        Flt, Fot = (), ()
+        if G_test is not None:
+            Flt, k = outs[k:k + nm], k + nm
+            Fot, k = outs[k:k + len(lmc)], k + len(lmc)
+        cache = _StepCache()
+        cache.kl = outs[k] if not prediction_mode else None
+        cache.mu_z, cache.engine_flag = aux["mu_z"], aux["flag"]
+        G_means = {m: Gm[i] for i, m in enumerate(mods)}
+        G_samples = {m: Gs[i] for i, m in enumerate(mods)}
+        self.F_latent_samples = {m: Fl[i] for i, m in enumerate(mods)}
+        # the same tensor object without LMC (quirk 10)
+        self.F_observed_samples = {m: (Fo[lmc.index(i)] if plan.lmc[i] else Fl[i]) for i, m in enumerate(mods)}
+        self._cache = cache
+        if aux["pending"] is not None:
+            self._raise_on_flags(aux["pending"])
+        if G_test is not None:
+            self.F_latent_samples_test = {m: Flt[i] for i, m in enumerate(mods)}
+            self.F_observed_samples_test = {m: (Fot[lmc.index(i)] if plan.lmc[i] else Flt[i])
+                                            for i, m in enumerate(mods)}
+            return (G_means, G_samples, self.F_latent_samples, self.F_observed_samples,
+                    self.F_latent_samples_test, self.F_observed_samples_test)
+        return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
+
+    def _post_flag(self, flag):
+        """one device word -> host, asynchronously; returns what _raise_on_flags waits on"""
+        host = self.__dict__.get("_flag_host")
+        if host is None:
+            host = self.__dict__["_flag_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(flag.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
     def _post_flags(self, cache):
         """max |flag| of this forward -> host, asynchronously; returns what _raise_on_flags waits on"""
         if not cache.flags:
@@ -561,6 +648,16 @@ class VariationalGPSA(GPSA):
         if cache is None:
             raise AttributeError("loss_fn called before forward (no factorisations cached)")
         V, D = self.n_views, self.n_spatial_dims
+        if cache.kl is not None:  # forward ran through the step engine: the KL terms came out of its node
+            kl = cache.kl
+            if self.kl_weight_G != 1.0:  # output-sharded rank: its share of the warp GPs' terms
+                kl = torch.cat([kl[: V * D] * self.kl_weight_G, kl[V * D:]])
+            nn_ = self.noise_variance.numel()
+            aux = dict(Y=[data_dict[m]["outputs"] for m in self.modality_names],
+                       noise_idx=[nn_ - self.n_modalities + i for i in range(self.n_modalities)],  # quirk 5
+                       kl_scale=self.kl_scale)
+            loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *[F_samples[m] for m in self.modality_names])
+            return loss.to(self.Xtilde.dtype)
         f64 = torch.float64
         kl = None
         grouped = cache.batch is not None

@@ -1,0 +1,352 @@
+"""Host side of the C++ step engine (csrc/step.hip, declared in include/gpsa_hip.h).
+
+``forward`` of the model becomes ONE autograd node whose forward and backward are one C call each
+(``gpsa_step_forward`` / ``gpsa_step_backward``): the launch sequence of the whole step is enqueued from
+C++, the warp GPs of all free views share their launches, and every parameter gradient is accumulated in
+fp64 and rounded once.  ``loss_fn`` is a second node (``gpsa_elbo_loss_fwd`` / ``_bwd``).
+
+PyTorch remains plumbing: it owns the tensors (parameters, outputs, the two arenas), the stream and the
+autograd bookkeeping between the two nodes and the optimiser.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import ops as _ops_mod
+from .kernels import builtin_kind
+
+MAXM = _lib.MAX_MODS
+KINDS = _ops_mod.KINDS
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class StepPlan:
+    """a ``gpsa_step_create`` handle + the shape it was made for"""
+
+    def __init__(self, lib, key, desc, keep):
+        self.lib, self.key, self._keep = lib, key, keep
+        self.handle = lib.gpsa_step_create(C.byref(desc))
+        if not self.handle:
+            raise _lib.GpsaHipError(f"gpsa_step_create refused the problem description {key}")
+        self.saved_bytes = int(lib.gpsa_step_saved_bytes(self.handle))
+        self.scratch_bytes = int(lib.gpsa_step_scratch_bytes(self.handle))
+        self.n_kl = int(lib.gpsa_step_n_kl(self.handle))
+        self.eps_g_numel = int(lib.gpsa_step_eps_g_numel(self.handle))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.gpsa_step_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def eligible(model, X_spatial, view_idx, G_test):
+    """the engine covers: built-in covariance functions, fp32 HIP tensors, views that are consecutive row
+    blocks covering each modality (what create_view_idx_dict produces), <= 4 modalities"""
+    if builtin_kind(model.kernel_func_warp) is None or builtin_kind(model.kernel_func_data) is None:
+        return False
+    mods = model.modality_names
+    if len(mods) > MAXM or model.n_spatial_dims > 4:
+        return False
+    if not model.Xtilde.is_cuda or model.Xtilde.dtype != torch.float32:
+        return False
+    for m in mods:
+        x = X_spatial[m]
+        if not x.is_cuda or x.dtype != torch.float32 or x.requires_grad:
+            return False
+        if G_test is not None and G_test[m].requires_grad:
+            return False
+    return True
+
+
+def view_rows(model, view_idx, Ns):
+    """rows of view v in modality m when the views are consecutive row blocks covering 0..N, else None"""
+    import numpy as np
+
+    V = model.n_views
+    out = []
+    for m in model.modality_names:
+        edge = 0
+        for v in range(V):
+            idx = view_idx[m][v]
+            a = np.asarray(idx.cpu() if torch.is_tensor(idx) else idx)
+            n = int(a.shape[0])
+            if n > 0 and (int(a[0]) != edge or int(a[-1]) != edge + n - 1 or
+                          (n > 1 and not bool(np.all(np.diff(a) == 1)))):
+                return None
+            out.append(n)
+            edge += n
+        if edge != int(Ns[m]):
+            return None
+    return tuple(out)
+
+
+def get_plan(model, rows, S, test_shapes, want_kl):
+    """plan for this model / data shape (cached on the model)"""
+    mods = model.modality_names
+    V, D = model.n_views, model.n_spatial_dims
+    fixed = tuple(1 if model._is_fixed(v) else 0 for v in range(V))
+    L = tuple(int(model.n_latent_outputs[m]) for m in mods)
+    P = tuple(int(model.Ps[m]) for m in mods)
+    lmc = tuple(1 if model.n_latent_gps[m] is not None else 0 for m in mods)
+    N = tuple(sum(rows[i * V:(i + 1) * V]) for i in range(len(mods)))
+    s_test = test_shapes[0] if test_shapes else 0
+    n_test = tuple(test_shapes[1]) if test_shapes else tuple(0 for _ in mods)
+    kw, kd = KINDS[builtin_kind(model.kernel_func_warp)], KINDS[builtin_kind(model.kernel_func_data)]
+    key = (V, D, len(mods), int(S), int(model.Xtilde.shape[1]), int(model.Gtilde.shape[0]), kw, kd, L, P, lmc, N,
+           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index)
+    cache = model.__dict__.setdefault("_step_plans", {})
+    plan = cache.get(key)
+    if plan is not None:
+        return plan
+    d = _lib.StepDesc()
+    d.n_views, d.n_dims, d.n_mods, d.n_samples = V, D, len(mods), int(S)
+    d.m_x, d.m_g, d.kind_warp, d.kind_data = key[4], key[5], kw, kd
+    for i in range(len(mods)):
+        d.n_latent[i], d.n_out[i], d.has_lmc[i], d.n_rows[i], d.n_test[i] = L[i], P[i], lmc[i], N[i], n_test[i]
+    d.s_test, d.want_kl = int(s_test), int(bool(want_kl))
+    vf = (C.c_int * V)(*fixed)
+    vr = (C.c_longlong * len(rows))(*rows)
+    d.view_fixed, d.view_rows = vf, vr
+    with torch.cuda.device(model.Xtilde.device):
+        plan = StepPlan(_lib.load(), key, d, (vf, vr))
+    plan.mods, plan.V, plan.D, plan.S, plan.L, plan.P, plan.lmc, plan.N = mods, V, D, int(S), L, P, lmc, N
+    plan.s_test, plan.n_test, plan.fixed, plan.rows = s_test, n_test, fixed, rows
+    cache[key] = plan
+    return plan
+
+
+def _param_list(model):
+    """the tensors the step differentiates, in gpsa_step_params order"""
+    mods = model.modality_names
+    ps = [model.Xtilde, model.delta_G_list, model.Omega_sqt_G_list, model.warp_kernel_lengthscales,
+          model.warp_kernel_variances, model.Gtilde, model.data_kernel_lengthscale, model.data_kernel_variance]
+    ps += [model.Omega_sqt_F_dict[m] for m in mods]
+    ps += [model.delta_F_dict[m] for m in mods]
+    ps += [model.W_dict[m] for m in mods if model.n_latent_gps[m] is not None]
+    return ps
+
+
+def _fill_params(st, tensors, model, plan):
+    nm = len(plan.mods)
+    (st.Xtilde, st.delta_G, st.Omega_sqt_G, st.warp_ls, st.warp_var, st.Gtilde, st.data_ls,
+     st.data_var) = (_p(t) for t in tensors[:8])
+    for i in range(nm):
+        st.Omega_sqt_F[i] = _p(tensors[8 + i])
+        st.delta_F[i] = _p(tensors[8 + nm + i])
+    k = 8 + 2 * nm
+    for i in range(nm):
+        if plan.lmc[i]:
+            st.W[i] = _p(tensors[k])
+            k += 1
+    return st
+
+
+class StepFn(torch.autograd.Function):
+    """(parameters) -> G_means[m].., G_samples[m].., F_latent[m].., F_obs[m] (LMC).., test draws.., kl [T].
+    ``aux``: everything that is not differentiated (plan, coordinates, draws, stream policy)."""
+
+    @staticmethod
+    def forward(ctx, aux, *tensors):
+        plan, model = aux["plan"], aux["model"]
+        lib = plan.lib
+        dev = tensors[0].device
+        nm, S, D = len(plan.mods), plan.S, plan.D
+        f32 = torch.float32
+        for t in tensors:
+            if t.dtype != f32 or not t.is_contiguous():
+                raise _lib.GpsaHipError("step engine: parameters must be contiguous fp32 tensors")
+        o = _ops_mod.get_ops()
+        prm = _fill_params(_lib.StepParams(), tensors, model, plan)
+        prm.slopes, prm.intercepts = _p(aux["slopes"]), _p(aux["intercepts"])
+        io = _lib.StepIO()
+        empty = lambda *sh: torch.empty(*sh, dtype=f32, device=dev)
+        outs = {"Gm": [], "Gs": [], "Fl": [], "Fo": [], "Flt": [], "Fot": []}
+        for i, m in enumerate(plan.mods):
+            N, L, P = plan.N[i], plan.L[i], plan.P[i]
+            io.X[i] = _p(aux["X"][i])
+            io.eps_F[i] = _p(aux["eps_F"][i])
+            Gm, Gs, Fl = empty(N, D), empty(S, N, D), empty(S, N, L)
+            outs["Gm"].append(Gm); outs["Gs"].append(Gs); outs["Fl"].append(Fl)
+            io.G_means[i], io.G_samples[i], io.F_latent[i] = _p(Gm), _p(Gs), _p(Fl)
+            if plan.lmc[i]:
+                Fo = empty(S, N, P)
+                outs["Fo"].append(Fo)
+                io.F_obs[i] = _p(Fo)
+            if plan.s_test:
+                io.G_test[i], io.eps_F_test[i] = _p(aux["G_test"][i]), _p(aux["eps_F_test"][i])
+                Flt = empty(plan.s_test, plan.n_test[i], L)
+                outs["Flt"].append(Flt)
+                io.F_latent_test[i] = _p(Flt)
+                if plan.lmc[i]:
+                    Fot = empty(plan.s_test, plan.n_test[i], P)
+                    outs["Fot"].append(Fot)
+                    io.F_obs_test[i] = _p(Fot)
+        io.eps_G = _p(aux["eps_G"])
+        mu_z = empty(plan.V, model.Xtilde.shape[1], D)
+        kl = torch.empty(plan.n_kl, dtype=torch.float64, device=dev) if aux["want_kl"] else None
+        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        io.mu_z, io.kl, io.flag = _p(mu_z), _p(kl), _p(flag)
+        saved = torch.empty(plan.saved_bytes, dtype=torch.uint8, device=dev)
+        scratch = o._ws(plan.scratch_bytes, saved)
+        stream = _raw_stream(dev.index)
+        pending = None
+        if aux["check"]:
+            # the flag depends on the factorisations and the warp GPs only: ship it to the host behind an event
+            # BEFORE the data GPs are queued, so that the check waits for the short part of the forward and the
+            # host keeps queueing while the long part runs
+            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 1,
+                                             stream), "gpsa_step_forward")
+            pending = model._post_flag(flag)
+            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 2,
+                                             stream), "gpsa_step_forward")
+        else:
+            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 3,
+                                             stream), "gpsa_step_forward")
+        aux["pending"], aux["mu_z"], aux["flag"] = pending, mu_z, flag
+        ctx.aux, ctx.io, ctx.prm = aux, io, prm
+        ctx.arena = saved
+        ctx.keep = outs  # F_latent is an input of the backward (dW of the LMC); the rest keeps the pointers alive
+        ctx.save_for_backward(*tensors)
+        ctx.n_in = len(tensors)
+        flat = outs["Gm"] + outs["Gs"] + outs["Fl"] + outs["Fo"] + outs["Flt"] + outs["Fot"]
+        ctx.layout = [len(outs[k]) for k in ("Gm", "Gs", "Fl", "Fo", "Flt", "Fot")]
+        ctx.set_materialize_grads(False)
+        if kl is None:
+            return tuple(flat)
+        return tuple(flat) + (kl,)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        aux = ctx.aux
+        plan, model = aux["plan"], aux["model"]
+        lib = plan.lib
+        tensors = ctx.saved_tensors
+        dev = tensors[0].device
+        nm = len(plan.mods)
+        f32 = torch.float32
+        o = _ops_mod.get_ops()
+        og = _lib.StepOutGrads()
+        keep = []
+
+        def grad_ptr(g):
+            if g is None:
+                return 0
+            g = g if (g.dtype == f32 and g.is_contiguous()) else g.to(f32).contiguous()
+            keep.append(g)
+            return g.data_ptr()
+
+        k = 0
+        nGm, nGs, nFl, nFo, nFlt, nFot = ctx.layout
+        lmc_idx = [i for i in range(nm) if plan.lmc[i]]
+        for i in range(nGm):
+            og.dG_means[i] = grad_ptr(gouts[k]); k += 1
+        for i in range(nGs):
+            og.dG_samples[i] = grad_ptr(gouts[k]); k += 1
+        for i in range(nFl):
+            og.dF_latent[i] = grad_ptr(gouts[k]); k += 1
+        for j in range(nFo):
+            og.dF_obs[lmc_idx[j]] = grad_ptr(gouts[k]); k += 1
+        for i in range(nFlt):
+            og.dF_latent_test[i] = grad_ptr(gouts[k]); k += 1
+        for j in range(nFot):
+            og.dF_obs_test[lmc_idx[j]] = grad_ptr(gouts[k]); k += 1
+        if aux["want_kl"]:
+            gk = gouts[k]
+            if gk is not None:
+                gk = gk if (gk.dtype == torch.float64 and gk.is_contiguous()) else gk.double().contiguous()
+                keep.append(gk)
+                og.dkl = gk.data_ptr()
+        # ONE flat fp32 buffer for every parameter gradient: the gradients handed to autograd are views of it
+        # (a ready-made all-reduce bucket and a single region for the optimiser to stream through)
+        sizes = [t.numel() for t in tensors]
+        flat = torch.empty(sum(sizes), dtype=f32, device=dev)
+        views = list(flat.split(sizes))
+        grads = _lib.StepParamGrads()
+        (grads.Xtilde, grads.delta_G, grads.Omega_sqt_G, grads.warp_ls, grads.warp_var, grads.Gtilde, grads.data_ls,
+         grads.data_var) = (_p(v) for v in views[:8])
+        for i in range(nm):
+            grads.Omega_sqt_F[i] = _p(views[8 + i])
+            grads.delta_F[i] = _p(views[8 + nm + i])
+        kk = 8 + 2 * nm
+        for i in range(nm):
+            if plan.lmc[i]:
+                grads.W[i] = _p(views[kk])
+                if og.dF_obs[i] is None and og.dF_obs_test[i] is None:
+                    views[kk].zero_()  # no gradient reached F_obs: the engine leaves dW untouched
+                kk += 1
+        scratch = o._ws(plan.scratch_bytes, flat)
+        _lib.check(lib.gpsa_step_backward(plan.handle, C.byref(ctx.prm), C.byref(ctx.io), C.byref(og),
+                                          _p(ctx.arena), _p(scratch), C.byref(grads), _raw_stream(dev.index)),
+                   "gpsa_step_backward")
+        out = [None]
+        for i, t in enumerate(tensors):
+            out.append(views[i].view(t.shape) if ctx.needs_input_grad[1 + i] else None)
+        return tuple(out)
+
+
+class ElboLossFn(torch.autograd.Function):
+    """loss = -(sum_i LL_i) + kl_scale * sum(kl_w * kl)   (vgpsa.py:532-540) as one C call each way.
+    inputs: noise_variance [n], kl [T] or None, F_0 .. F_{n_ll-1};  aux: Y tensors, noise indices, kl_scale"""
+
+    @staticmethod
+    def forward(ctx, aux, noise, kl, *Fs):
+        lib = _lib.load()
+        o = _ops_mod.get_ops()
+        n = len(Fs)
+        dev = Fs[0].device
+        Fc = [f.detach() if (f.dtype == torch.float32 and f.is_contiguous()) else f.detach().float().contiguous()
+              for f in Fs]
+        Yc = [y if (y.dtype == torch.float32 and y.is_contiguous()) else y.float().contiguous() for y in aux["Y"]]
+        nz = noise.detach()
+        nz = nz if (nz.dtype == torch.float32 and nz.is_contiguous()) else nz.float().contiguous()
+        arr = lambda vals: (C.c_void_p * n)(*vals)
+        Fp, Yp = arr([f.data_ptr() for f in Fc]), arr([y.data_ptr() for y in Yc])
+        Np = arr([nz.data_ptr() + 4 * j for j in aux["noise_idx"]])
+        Sa = (C.c_int * n)(*[int(f.shape[0]) for f in Fc])
+        Na = (C.c_longlong * n)(*[int(f.shape[1]) for f in Fc])
+        Pa = (C.c_int * n)(*[int(f.shape[2]) for f in Fc])
+        klc = None
+        if kl is not None:
+            klc = kl.detach()
+            klc = klc if (klc.dtype == torch.float64 and klc.is_contiguous()) else klc.double().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ll = torch.empty(n, dtype=torch.float64, device=dev)
+        ws = o._ws(8 * 4100 + 64, loss)
+        stream = _raw_stream(dev.index)
+        _lib.check(lib.gpsa_elbo_loss_fwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(klc), 0 if klc is None else klc.numel(),
+                                          float(aux["kl_scale"]), _p(loss), _p(ll), _p(ws), ws.numel(), stream),
+                   "gpsa_elbo_loss_fwd")
+        ctx.aux, ctx.args = aux, (Fc, Yc, nz, Fp, Yp, Np, Sa, Na, Pa)
+        ctx.n_kl = 0 if klc is None else klc.numel()
+        ctx.noise_meta = (noise.shape, noise.dtype)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        lib = _lib.load()
+        o = _ops_mod.get_ops()
+        aux = ctx.aux
+        Fc, Yc, nz, Fp, Yp, Np, Sa, Na, Pa = ctx.args
+        n = len(Fc)
+        dev = Fc[0].device
+        g = gloss.detach().reshape(1)
+        g = g if g.dtype == torch.float32 else g.float()
+        dF = [torch.empty_like(f) for f in Fc]
+        dnoise = torch.zeros(nz.numel(), dtype=torch.float32, device=dev)
+        dkl = torch.empty(ctx.n_kl, dtype=torch.float64, device=dev) if ctx.n_kl else None
+        dFp = (C.c_void_p * n)(*[t.data_ptr() for t in dF])
+        dNp = (C.c_void_p * n)(*[dnoise.data_ptr() + 4 * j for j in aux["noise_idx"]])
+        ws = o._ws(8 * 4100 + 64, g)
+        _lib.check(lib.gpsa_elbo_loss_bwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(g), ctx.n_kl, float(aux["kl_scale"]), dFp, dNp,
+                                          _p(dkl), _p(ws), ws.numel(), _raw_stream(dev.index)),
+                   "gpsa_elbo_loss_bwd")
+        shape, dt = ctx.noise_meta
+        return (None, dnoise.reshape(shape).to(dt), dkl) + tuple(dF)

@@ -35,9 +35,12 @@ def fit(model, data_dict, n_epochs, lr=1e-2, S=5, optimizer=None, checker=None, 
     model.train()
     view_idx, Ns, _, _ = model.create_view_idx_dict(data_dict)
     if optimizer is None:
-        dev_is_gpu = next(model.parameters()).is_cuda
-        optimizer = torch.optim.Adam(model.parameters(), lr=lr, **({"capturable": True} if graphed else
-                                                                    {"fused": True} if dev_is_gpu else {}))
+        if next(model.parameters()).is_cuda:  # torch.optim.Adam's update as one HIP launch (capturable)
+            from .optim import FusedAdam
+
+            optimizer = FusedAdam(model.parameters(), lr=lr)
+        else:
+            optimizer = torch.optim.Adam(model.parameters(), lr=lr)
     stepper = GraphedTrainStep(model, optimizer, data_dict, view_idx, Ns, S=S) if graphed else None
     trace, pending = [], []
 
@@ -68,7 +71,7 @@ class GraphedTrainStep:
     * the per-forward numerics check cannot sync inside a capture: every replay folds its flags (a
       non-positive pivot, a non-positive warp variance, a non-finite loss) into a STICKY device word, and
       ``check()`` raises if any step since the last check tripped it (call it every N steps);
-    * the optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``);
+    * the optimizer must be capturable (``optim.FusedAdam`` or ``torch.optim.Adam(..., capturable=True)``);
     * single-GPU only (an all-reduce inside the graph is not attempted here).
     """
 

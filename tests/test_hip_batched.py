@@ -1,0 +1,178 @@
+"""The batched entry points of the C ABI (the warp GPs of several views in one launch) against loops over
+their single-problem forms, which tests/test_hip_kernels.py pins to the fp64 contracts."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+f64, f32 = torch.float64, torch.float32
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from spatial_alignment_amd.ops import get_ops
+
+    return get_ops()
+
+
+def rnd(*shape, dtype=f32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=f64) * scale).to(dtype)
+
+
+def stream():
+    return _raw_stream(0)
+
+
+def p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+KIND = {"rbf": 0, "matern12": 1, "matern32": 2}
+
+
+@pytest.mark.parametrize("kind,M,D,B,Cs,nl", [("rbf", 20, 2, 3, 128, [100, 128, 0]), ("matern32", 200, 3, 2, 320, [300, 257]),
+                                             ("matern12", 7, 1, 5, 64, [64, 1, 33, 64, 10])])
+def test_kmat_batched_fwd_bwd(hip, kind, M, D, B, Cs, nl):
+    Z = rnd(B, M, D, seed=1, scale=3).to(DEV)
+    X = rnd(B, Cs, D, seed=2, scale=3).to(DEV)
+    ls, var = rnd(B, seed=3, scale=0.3).to(DEV), rnd(B, seed=4, scale=0.3).to(DEV)
+    nlive = (C.c_longlong * B)(*nl)
+    K = torch.full((B, M, Cs), 7.0, dtype=f64, device=DEV)
+    rc = hip.lib.gpsa_kmat_batched(KIND[kind], p(Z), M * D, M, p(X), Cs * D, Cs, D, p(ls), p(var), 1, nlive, B, 0.0,
+                                   p(K), M * Cs, stream())
+    assert rc == 0
+    for b in range(B):
+        want = hip.kmat(kind, Z[b], X[b], ls[b:b + 1], var[b:b + 1], 0.0, dtype=f64)
+        assert torch.equal(K[b][:, : nl[b]], want[:, : nl[b]])
+        assert float(K[b][:, nl[b]:].abs().max()) == 0.0 if nl[b] < Cs else True
+    # backward: panels with garbage in the padding columns (must be ignored)
+    Kbar = rnd(B, M, Cs, dtype=f64, seed=5).to(DEV)
+    dZ = torch.empty(B, M, D, dtype=f64, device=DEV)
+    dpar = torch.empty(B, 2, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_kmat_bwd_batched_workspace(M, Cs, D, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.lib.gpsa_kmat_bwd_batched(KIND[kind], p(Z), M * D, M, p(X), Cs * D, Cs, D, p(ls), p(var), 1, nlive, B,
+                                       p(Kbar), M * Cs, 0, p(dZ), M * D, p(dpar), p(ws), wsb, stream())
+    assert rc == 0
+    for b in range(B):
+        if nl[b] == 0:
+            assert float(dZ[b].abs().max()) == 0.0 and float(dpar[b].abs().max()) == 0.0
+            continue
+        wZ, _, wp = hip.kmat_bwd(kind, Z[b], X[b][: nl[b]].contiguous(), ls[b:b + 1], var[b:b + 1],
+                                 Kbar[b][:, : nl[b]].contiguous(), need_dX=False, out_dtype=f64)
+        assert (dZ[b] - wZ).norm() <= 1e-12 * wZ.norm() and (dpar[b] - wp).norm() <= 1e-12 * wp.norm()
+
+
+@pytest.mark.parametrize("kind,M,D,B", [("rbf", 50, 2, 3), ("matern32", 200, 2, 2)])
+def test_kmat_batched_same_points(hip, kind, M, D, B):
+    """K_uu of several views: X = Z, jitter on the diagonal, backward folds the X-side sums into dZ"""
+    Z = rnd(B, M, D, seed=1, scale=3).to(DEV)
+    ls, var = rnd(B, seed=3, scale=0.3).to(DEV), rnd(B, seed=4, scale=0.3).to(DEV)
+    K = torch.empty(B, M, M, dtype=f64, device=DEV)
+    rc = hip.lib.gpsa_kmat_batched(KIND[kind], p(Z), M * D, M, p(Z), M * D, M, D, p(ls), p(var), 1, None, B, 1e-5, p(K),
+                                   M * M, stream())
+    assert rc == 0
+    Kbar = rnd(B, M, M, dtype=f64, seed=5).to(DEV)
+    dZ = torch.empty(B, M, D, dtype=f64, device=DEV)
+    dpar = torch.empty(B, 2, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_kmat_bwd_batched_workspace(M, M, D, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.lib.gpsa_kmat_bwd_batched(KIND[kind], p(Z), M * D, M, p(Z), M * D, M, D, p(ls), p(var), 1, None, B, p(Kbar),
+                                       M * M, 1, p(dZ), M * D, p(dpar), p(ws), wsb, stream())
+    assert rc == 0
+    for b in range(B):
+        assert torch.equal(K[b], hip.kmat(kind, Z[b], Z[b], ls[b:b + 1], var[b:b + 1], 1e-5, dtype=f64))
+        wZ, _, wp = hip.kmat_bwd(kind, Z[b], Z[b], ls[b:b + 1], var[b:b + 1], Kbar[b], same=True, out_dtype=f64)
+        assert (dZ[b] - wZ).norm() <= 1e-12 * wZ.norm() and (dpar[b] - wp).norm() <= 1e-12 * wp.norm()
+
+
+@pytest.mark.parametrize("M,D,C", [(200, 2, 5000), (30, 3, 777)])
+def test_kmat_bwd_x64(hip, M, D, C):
+    """the data GP's covariance backward: fp32 inducing points / panel, fp64 coordinates, fp64 results"""
+    Z, X64 = rnd(M, D, seed=1, scale=3).to(DEV), rnd(C, D, dtype=f64, seed=2, scale=3).to(DEV)
+    ls, var = rnd(1, seed=3, scale=0.3).to(DEV), rnd(1, seed=4, scale=0.3).to(DEV)
+    Kbar = rnd(M, C, seed=5).to(DEV)
+    dZ, dX = torch.empty(M, D, dtype=f64, device=DEV), torch.empty(C, D, dtype=f64, device=DEV)
+    dpar = torch.empty(2, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_kmat_bwd_workspace(1, M, C, D))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.lib.gpsa_kmat_bwd_x64(0, p(Z), M, p(X64), C, D, p(ls), p(var), p(Kbar), p(dZ), p(dX), p(dpar), p(ws), wsb,
+                                   stream())
+    assert rc == 0
+    wZ, wX, wp = hip.kmat_bwd("rbf", Z.double(), X64, ls.double(), var.double(), Kbar.double())
+    for a, w in ((dZ, wZ), (dX, wX), (dpar, wp)):
+        assert (a - w).norm() <= 1e-12 * w.norm()
+
+
+@pytest.mark.parametrize("M,Cs,B", [(200, 640, 3), (50, 64, 5), (300, 128, 2)])
+def test_whiten_batched(hip, M, Cs, B):
+    A = rnd(B, M, M, dtype=f64, seed=1).to(DEV)
+    Kinv = (A @ A.transpose(1, 2) / M + torch.eye(M, dtype=f64, device=DEV)).contiguous()
+    Kuf = rnd(B, M, Cs, dtype=f64, seed=2).to(DEV)
+    alpha = torch.empty_like(Kuf)
+    q = torch.empty(B, Cs, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_whiten_workspace(M)) * B
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.lib.gpsa_whiten_batched_f64(p(Kinv), M * M, p(Kuf), M, Cs, M * Cs, p(alpha), p(q), B, p(ws), wsb, stream())
+    assert rc == 0
+    for b in range(B):
+        wa, wq = hip.whiten(Kinv[b], Kuf[b], f64)
+        assert (alpha[b] - wa).norm() <= 1e-13 * wa.norm() and (q[b] - wq).norm() <= 1e-13 * wq.norm()
+        ref = Kinv[b] @ Kuf[b]
+        assert (alpha[b] - ref).norm() <= 1e-12 * ref.norm()
+
+
+@pytest.mark.parametrize("M,Cs,L,B", [(200, 320, 2, 3), (40, 64, 3, 2)])
+def test_keep_forms_batched(hip, M, Cs, L, B):
+    alpha = rnd(B, M, Cs, dtype=f64, seed=1).to(DEV)
+    Om = rnd(B, L, M, M, dtype=f64, seed=2).to(DEV)
+    Om = (Om + Om.transpose(-1, -2)).contiguous()
+    dcT = rnd(B, M, L, dtype=f64, seed=3).to(DEV)
+    v = torch.empty(B, L, Cs, dtype=f64, device=DEV)
+    W = torch.empty(B, L, M, Cs, dtype=f64, device=DEV)
+    meanT = torch.empty(B, L, Cs, dtype=f64, device=DEV)
+    assert hip.lib.gpsa_quadform_fwd_keep_batched_f64(p(alpha), p(Om), M, Cs, L, p(v), p(W), p(dcT), p(meanT), B,
+                                                      stream()) == 0
+    g, dm = rnd(B, L, Cs, dtype=f64, seed=4).to(DEV), rnd(B, L, Cs, dtype=f64, seed=5).to(DEV)
+    dal = torch.empty(B, M, Cs, dtype=f64, device=DEV)
+    assert hip.lib.gpsa_quadform_bwd_alpha_kept_batched_f64(p(W), p(g), M, Cs, L, p(dcT), p(dm), p(dal), B, stream()) == 0
+    d = rnd(B, Cs, dtype=f64, seed=6).to(DEV)
+    ax = torch.empty(B, M, Cs, dtype=f64, device=DEV)
+    assert hip.lib.gpsa_col_axpy_batched_f64(p(dal), p(alpha), p(d), 0.7, M, Cs, p(ax), B, stream()) == 0
+    dOm = torch.empty(B, L, M, M, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_gram_batched_workspace(M, Cs, L, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    assert hip.lib.gpsa_gram_batched_f64(p(alpha), p(g), M, Cs, L, p(dOm), B, p(ws), wsb, stream()) == 0
+    close = lambda a, w, tol=1e-12: (a - w).norm() <= tol * w.norm()
+    for b in range(B):
+        wv, wW, wm = hip.quadform_fwd_keep(alpha[b], Om[b], dcT[b])
+        assert close(v[b], wv) and close(W[b], wW) and close(meanT[b], wm)
+        assert close(dal[b], hip.quadform_bwd_alpha_kept(W[b], g[b], dcT[b], dm[b]))
+        assert close(ax[b], dal[b] + 0.7 * d[b].unsqueeze(0) * alpha[b])
+        want = torch.einsum("lc,mc,kc->lmk", g[b], alpha[b], alpha[b])
+        assert close(dOm[b], want, 1e-11)
+
+
+def test_fused_adam_matches_torch():
+    """gpsa_adam_step against torch.optim.Adam (the optimiser of the reference loop) over several steps"""
+    from spatial_alignment_amd.optim import FusedAdam
+
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(3, 200, 200), (17,), (1,), (200, 2), (5, 40, 40)]
+    p0 = [torch.randn(*s, generator=gen) for s in shapes]
+    ref = [torch.nn.Parameter(t.clone()) for t in p0]
+    got = [torch.nn.Parameter(t.clone().to(DEV)) for t in p0]
+    o_ref = torch.optim.Adam(ref, lr=1e-2)
+    o_got = FusedAdam(got, lr=1e-2)
+    for it in range(7):
+        gs = [torch.randn(*s, generator=gen) * (10.0 ** (it % 3 - 1)) for s in shapes]
+        for a, b, g in zip(ref, got, gs):
+            a.grad, b.grad = g.clone(), g.clone().to(DEV)
+        o_ref.step()
+        o_got.step()
+    for a, b in zip(ref, got):
+        assert (b.detach().cpu() - a.detach()).abs().max() <= 2e-6 * max(1.0, float(a.detach().abs().max()))

@@ -1,0 +1,89 @@
+"""The C++ step engine (forward / backward as one host call each) against the per-layer path it replaces and
+against the reference's fp64 run, on every golden case; injected noise, so both paths see the same draws."""
+import numpy as np
+import pytest
+import torch
+
+from golden_io import CASES, Golden, rel
+from model_util import build_model, compare, run_step
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_engine_matches_per_layer_path(name):
+    g = Golden(name)
+    res = {}
+    for eng in (True, False):
+        model, dd = build_model(g, device=DEV)
+        model.use_step_engine = eng
+        res[eng] = run_step(model, dd, g, device=DEV)
+        assert (model._cache.kl is not None) == eng  # the path that ran is the one that was asked for
+    big = bool(g.cfg.get("summary_only"))
+    worst = {}
+    for k, want in res[False].items():
+        got = res[True][k]
+        assert got.shape == want.shape, k
+        if np.isnan(want).any() or np.linalg.norm(want.astype(np.float64)) == 0:
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.nan_to_num(np.abs(got)).max() == 0 \
+                or np.allclose(np.nan_to_num(got), np.nan_to_num(want)), k
+            continue
+        worst[k] = rel(got, want)
+    print(name, {k: f"{v:.1e}" for k, v in worst.items()})
+    for k, e in worst.items():
+        tol = (3e-3 if big else 1e-4) if k.startswith("grad/") else 2e-6
+        assert e <= tol, (k, e)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_engine_matches_reference_fp64(name):
+    g = Golden(name)
+    model, dd = build_model(g, device=DEV)
+    assert model.use_step_engine
+    res = run_step(model, dd, g, device=DEV)
+    assert model._cache.kl is not None
+    big = bool(g.cfg.get("summary_only"))
+    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4 if not big else 3e-3)
+    print(name, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert not bad, bad
+
+
+def test_engine_unequal_views_and_user_loss_on_G():
+    """views of different sizes (padding columns of the view blocks), a loss that also uses G_means and
+    G_samples directly, S = 1"""
+    import spatial_alignment_amd as gp
+
+    gen = torch.Generator().manual_seed(3)
+    ns = [37, 90, 5]
+    N = sum(ns)
+    X = (10 * torch.rand(N, 2, generator=gen)).to(DEV)
+    Y = torch.randn(N, 4, generator=gen).to(DEV)
+    dd = {"expression": {"spatial_coords": X, "outputs": Y, "n_samples_list": ns}}
+    outs = {}
+    for eng in (True, False):
+        torch.manual_seed(1)
+        np.random.seed(1)
+        model = gp.VariationalGPSA({"expression": {"spatial_coords": X.cpu(), "outputs": Y.cpu(), "n_samples_list": ns}},
+                                   m_X_per_view=9, m_G=11, data_init=False, n_latent_gps={"expression": None},
+                                   fixed_view_idx=None).to(DEV)
+        with torch.no_grad():
+            model.delta_G_list.add_(0.1 * torch.randn(model.delta_G_list.shape, generator=gen).to(DEV) * 0 + 0.05)
+        model.use_step_engine = eng
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        g2 = torch.Generator().manual_seed(11)
+        eps_G = [torch.randn(1, n, 2, generator=g2) for n in ns]
+        eps_F = {"expression": torch.randn(1, N, 4, generator=g2)}
+        model.inject_noise(eps_G, eps_F)
+        Gm, Gs, Fl, Fo = model.forward({"expression": X}, view_idx, Ns, S=1)
+        loss = model.loss_fn(dd, Fo) + 3.0 * (Gm["expression"] ** 2).sum() + (Gs["expression"].sin()).sum()
+        loss.backward()
+        outs[eng] = dict(loss=loss.detach().cpu().numpy(), Gm=Gm["expression"].detach().cpu().numpy(),
+                         F=Fo["expression"].detach().cpu().numpy(),
+                         **{f"grad/{k}": p.grad.detach().cpu().numpy() for k, p in model.named_parameters()
+                            if p.grad is not None})
+    for k, want in outs[False].items():
+        if np.linalg.norm(want) == 0:
+            assert np.abs(outs[True][k]).max() == 0, k
+            continue
+        assert rel(outs[True][k], want) <= (1e-4 if k.startswith("grad/") else 2e-6), (k, rel(outs[True][k], want))
