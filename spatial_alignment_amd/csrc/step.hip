@@ -13,6 +13,7 @@
 // Math and precision plan: as spatial_alignment_amd/engine.py documents (fp64 factorisations, fp64 warp GP,
 // fp64 projection + fp32 matrix-core contractions in the data GP, fp64 gradient sums).
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -517,6 +518,10 @@ struct Plan {
   char* dev = nullptr;
   ViewTab tab;
   int* d_free = nullptr;
+  // side stream for the work only the KL terms need (factorising / inverting the variational covariances,
+  // the KL kernels and their backward): forked from and joined to the caller's stream inside every call
+  hipStream_t side = nullptr;
+  hipEvent_t sev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // optional HIP-event timing of the three contraction launches of the first data-GP pass (bench.py's
   // roofline figures): slot = step index modulo the ring, 2 events per kernel
   std::vector<hipEvent_t> tev;
@@ -541,6 +546,9 @@ static void free_plan(Plan* p) {
   if (p == nullptr) return;
   if (p->dev != nullptr) (void)hipFree(p->dev);
   for (hipEvent_t e : p->tev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->sev)
+    if (e != nullptr) (void)hipEventDestroy(e);
+  if (p->side != nullptr) (void)hipStreamDestroy(p->side);
   delete p;
 }
 
@@ -713,6 +721,17 @@ static Plan* make_plan(const gpsa_step_desc* dsc) {
   }
   if (hipMemcpy(p->dev, host.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { free_plan(p); return nullptr; }
   p->tab.V = V; p->tab.D = D; p->tab.S = S; p->tab.nm = nm; p->tab.nf = p->nf; p->tab.Cs = p->Cs;
+  {
+    // off by default: measured on MI355X (profiles/r02_*), the fork buys nothing - the side stream's kernels
+    // cannot co-reside with the persistent full-chip contraction kernels (one wave per SIMD holding the whole
+    // register file), and next to the latency-bound small kernels they only trade places
+    const char* e = getenv("GPSA_STEP_SIDE");
+    if ((e && e[0] == '1') && dsc->want_kl) {
+      bool ok = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess;
+      for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreateWithFlags(&p->sev[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { free_plan(p); return nullptr; }
+    }
+  }
   return p;
 }
 
@@ -839,31 +858,75 @@ static int mm_stage_fwd(Ctx& c) {
   for (int m = 0; m < P.nm; ++m)
     GPSA_RUN(gpsa_omega_fwd(c.prm.Omega_sqt_F[m], Mg, P.d.n_latent[m], 1e-5, c.mats(GD, P.pos_OmF(m, 0)), c.stv()));
   // factorise: the priors always; the variational covariances only when the KL terms are wanted (the
-  // layers use Omega itself, never its factor)
+  // layers use Omega itself, never its factor) - and then on the side stream, next to the priors: neither
+  // the layers nor the warp GPs wait for them
+  const bool fork = kl && P.side != nullptr && !dry;
+  hipStream_t sst = fork ? P.side : c.st;
+  if (fork) {
+    GPSA_CK((int)hipEventRecord(P.sev[0], c.st));
+    GPSA_CK((int)hipStreamWaitEvent(P.side, P.sev[0], 0));
+  }
+  // buffers the side stream owns for the whole call (never handed back to the bump allocator before the join)
+  double* LinvO[2] = {nullptr, nullptr};
+  void* wsO[2] = {nullptr, nullptr};
+  long long wsOb[2] = {0, 0};
+  if (kl && P.side != nullptr)
+    for (int g = 0; g < P.ng; ++g) {
+      Group& G = P.grp[g];
+      if (G.n_omega == 0) continue;
+      LinvO[g] = c.sc.get<double>((long long)G.n_omega * G.M * G.M);
+      if (G.M > 256) {
+        wsOb[g] = gpsa_chol_inv_blocked_workspace(G.M, G.n_omega);
+        wsO[g] = c.sc.get<char>(wsOb[g]);
+      }
+      wsOb[g] += 0;
+    }
   for (int g = 0; g < P.ng; ++g) {
     Group& G = P.grp[g];
-    const int nb = kl ? G.nb() : G.n_prior;
-    if (nb == 0) continue;
     const long long mm = (long long)G.M * G.M;
-    const long long mk = c.sc.mark();
-    double* Linv = c.sc.get<double>(nb * mm);
     double* logdet = c.sv<double>(G.o_logdet);
     int* info = c.sv<int>(G.o_info);
-    if (G.M > 256) {
-      const long long wsb = gpsa_chol_inv_blocked_workspace(G.M, nb);
-      void* ws = c.sc.get<char>(wsb);
-      GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, 0), Linv, G.M, nb, logdet, info, ws, wsb, c.stv()));
-    } else {
-      GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, 0), Linv, G.M, nb, logdet, info, c.stv()));
+    const bool split = kl && P.side != nullptr;  // priors on the caller's stream, the rest on the side stream
+    const int nb_main = split ? G.n_prior : (kl ? G.nb() : G.n_prior);
+    if (nb_main > 0) {
+      const long long mk = c.sc.mark();
+      double* Linv = c.sc.get<double>(nb_main * mm);
+      if (G.M > 256) {
+        const long long wsb = gpsa_chol_inv_blocked_workspace(G.M, nb_main);
+        void* ws = c.sc.get<char>(wsb);
+        GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, 0), Linv, G.M, nb_main, logdet, info, ws, wsb, c.stv()));
+      } else {
+        GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, 0), Linv, G.M, nb_main, logdet, info, c.stv()));
+      }
+      // K^-1 = L^-T L^-1 for the whole batch in one product
+      GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M, mm, nb_main,
+                     splitk_small(G.M, G.M, G.M, nb_main)));
+      c.sc.release(mk);
     }
-    // K^-1 = L^-T L^-1 for the whole batch in one product
-    GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M, mm, nb,
-                   splitk_small(G.M, G.M, G.M, nb)));
-    c.sc.release(mk);
-    if (kl && G.n_omega > 0)
-      GPSA_RUN(gpsa_mvn_kl_grouped_fwd(c.mats(G, 0), c.inv(G, 0), logdet, G.om_idx, G.pr_idx, c.sv<double>(G.o_D),
-                                       G.M, G.n_omega, c.io.kl + G.kl_off, c.sv<double>(G.o_KD), c.stv()));
+    if (split && G.n_omega > 0) {
+      const int np = G.n_prior;
+      if (G.M > 256)
+        GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, np), LinvO[g], G.M, G.n_omega, logdet + np, info + np, wsO[g],
+                                           wsOb[g], (void*)sst));
+      else
+        GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, np), LinvO[g], G.M, G.n_omega, logdet + np, info + np, (void*)sst));
+      GPSA_RUN((gemm_launch<double>(1, 0, G.M, G.M, G.M, 1.0, LinvO[g], G.M, mm, LinvO[g], G.M, mm, 0.0, c.inv(G, np),
+                                    G.M, mm, G.n_omega, 1, nullptr, 0, sst)));
+    }
   }
+  if (fork) {  // the KL kernels read the priors' inverses too
+    GPSA_CK((int)hipEventRecord(P.sev[1], c.st));
+    GPSA_CK((int)hipStreamWaitEvent(P.side, P.sev[1], 0));
+  }
+  if (kl)
+    for (int g = 0; g < P.ng; ++g) {
+      Group& G = P.grp[g];
+      if (G.n_omega > 0)
+        GPSA_RUN(gpsa_mvn_kl_grouped_fwd(c.mats(G, 0), c.inv(G, 0), c.sv<double>(G.o_logdet), G.om_idx, G.pr_idx,
+                                         c.sv<double>(G.o_D), G.M, G.n_omega, c.io.kl + G.kl_off,
+                                         c.sv<double>(G.o_KD), (void*)sst));
+    }
+  if (fork) GPSA_CK((int)hipEventRecord(P.sev[2], P.side));
   return 0;
 }
 
@@ -966,6 +1029,8 @@ static int warp_stage_fwd(Ctx& c) {
     boff += nb;
   }
   c.sc.release(mk);
+  // join the side stream (KL terms, factorisation infos of the variational covariances)
+  if (P.d.want_kl && P.side != nullptr && !dry) GPSA_CK((int)hipStreamWaitEvent(c.st, P.sev[2], 0));
   // one word for the host: Cholesky infos and variance flags
   if (c.io.flag != nullptr && !dry) {
     Group& G0 = P.grp[0];
@@ -1306,35 +1371,63 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   const int V = P.V, D = P.D, Mx = P.Mx, Mg = P.Mg, nf = P.nf, npass = (int)P.passes.size();
   BwdBufs B;
   memset(&B, 0, sizeof(B));
+  const bool kl = P.d.want_kl != 0 && og.dkl != nullptr;
+  const bool fork = kl && P.side != nullptr && !dry;
+  // the KL terms' backward runs on the side stream into buffers of its own (dKL: same layout as dstack)
+  double* dKL[2] = {nullptr, nullptr};
+  double* Skl[2] = {nullptr, nullptr};
+  double* Tkl[2] = {nullptr, nullptr};
   for (int g = 0; g < P.ng; ++g) {
     Group& G = P.grp[g];
-    const long long n = (long long)G.nb() * G.M * G.M;
-    B.dstack[g] = sc.get<double>(n);
-    if (!dry) GPSA_CK((int)hipMemsetAsync(B.dstack[g], 0, (size_t)(n * 8), st));
     B.dD[g] = sc.get<double>((long long)G.n_omega * G.M);
+    if (kl && P.side != nullptr) {
+      dKL[g] = sc.get<double>((long long)G.nb() * G.M * G.M);
+      Skl[g] = sc.get<double>((long long)G.n_prior * G.M * G.M);
+      Tkl[g] = sc.get<double>((long long)G.n_prior * G.M * G.M);
+    }
+  }
+  // everything that must start at zero sits in ONE contiguous region: one fill
+  const long long z0 = (sc.off + 255) & ~255LL;
+  for (int g = 0; g < P.ng; ++g) {
+    Group& G = P.grp[g];
+    B.dstack[g] = sc.get<double>((long long)G.nb() * G.M * G.M);
   }
   const long long nwz = (long long)(nf > 0 ? nf : 1) * Mx * D;
-  B.dZ_wf = sc.get<double>(nwz); B.dZ_wu = sc.get<double>(nwz);
-  B.dpar_wf = sc.get<double>(2LL * (nf > 0 ? nf : 1)); B.dpar_wu = sc.get<double>(2LL * (nf > 0 ? nf : 1));
+  B.dZ_wf = sc.get<double>(nwz);
+  B.dpar_wf = sc.get<double>(2LL * (nf > 0 ? nf : 1));
   B.dvar_ws = sc.get<double>(nf > 0 ? nf : 1);
   B.dresid = sc.get<double>((long long)V * Mx * D);
   B.dZ_df = sc.get<double>((long long)(npass > 0 ? npass : 1) * Mg * D);
   B.dpar_df = sc.get<double>(2LL * (npass > 0 ? npass : 1));
   B.dvar_ds = sc.get<float>(npass > 0 ? npass : 1);
+  const long long z1 = sc.off;
+  if (!dry) GPSA_CK((int)hipMemsetAsync(sc.base + z0, 0, (size_t)(z1 - z0), st));
+  B.dZ_wu = sc.get<double>(nwz);
+  B.dpar_wu = sc.get<double>(2LL * (nf > 0 ? nf : 1));
   B.dZ_du = sc.get<double>((long long)Mg * D); B.dpar_du = sc.get<double>(2);
   for (int m = 0; m < P.nm; ++m) {
     B.ddc_F[m] = sc.get<float>((long long)Mg * P.d.n_latent[m]);
     B.dG64[m] = sc.get<double>((long long)P.S * P.d.n_rows[m] * D);
   }
-  if (!dry) {  // pieces that may stay unwritten (no gradient reached them)
-    GPSA_CK((int)hipMemsetAsync(B.dresid, 0, (size_t)((long long)V * Mx * D * 8), st));
-    GPSA_CK((int)hipMemsetAsync(B.dZ_wf, 0, (size_t)(nwz * 8), st));
-    GPSA_CK((int)hipMemsetAsync(B.dpar_wf, 0, (size_t)(2LL * (nf > 0 ? nf : 1) * 8), st));
-    GPSA_CK((int)hipMemsetAsync(B.dvar_ws, 0, (size_t)((nf > 0 ? nf : 1) * 8), st));
-    GPSA_CK((int)hipMemsetAsync(B.dZ_df, 0, (size_t)((long long)(npass > 0 ? npass : 1) * Mg * D * 8), st));
-    GPSA_CK((int)hipMemsetAsync(B.dpar_df, 0, (size_t)(2LL * (npass > 0 ? npass : 1) * 8), st));
-    GPSA_CK((int)hipMemsetAsync(B.dvar_ds, 0, (size_t)((npass > 0 ? npass : 1) * 4), st));
+  // ---- KL terms: dOmega, dK_p = 0.5 K_p^-1 S_p K_p^-1, dD   (side stream when there is one)
+  if (fork) {
+    GPSA_CK((int)hipEventRecord(P.sev[3], st));
+    GPSA_CK((int)hipStreamWaitEvent(P.side, P.sev[3], 0));
   }
+  for (int g = 0; g < P.ng && kl && P.side != nullptr; ++g) {
+    Group& G = P.grp[g];
+    if (G.n_omega == 0 || G.n_prior == 0) continue;
+    const long long mm = (long long)G.M * G.M;
+    hipStream_t sst = dry ? st : P.side;
+    GPSA_RUN(gpsa_mvn_kl_grouped_bwd_acc(c.mats(G, 0), c.inv(G, 0), G.om_idx, G.pr_list, G.grp_off, G.order,
+                                         c.sv<double>(G.o_D), c.sv<double>(G.o_KD), og.dkl + G.kl_off, G.M, G.n_omega,
+                                         G.n_prior, dKL[g] + (long long)G.n_prior * mm, B.dD[g], Skl[g], 0, (void*)sst));
+    GPSA_RUN((gemm_launch<double>(0, 0, G.M, G.M, G.M, 1.0, c.inv(G, 0), G.M, mm, Skl[g], G.M, mm, 0.0, Tkl[g], G.M, mm,
+                                  G.n_prior, 1, nullptr, 0, sst)));
+    GPSA_RUN((gemm_launch<double>(0, 0, G.M, G.M, G.M, 0.5, Tkl[g], G.M, mm, c.inv(G, 0), G.M, mm, 0.0, dKL[g], G.M, mm,
+                                  G.n_prior, 1, nullptr, 0, sst)));
+  }
+  if (fork) GPSA_CK((int)hipEventRecord(P.sev[4], P.side));
   // ---- data GP passes
   bool seen[MAXMODS] = {false, false, false, false};
   for (int pi = 0; pi < npass; ++pi) {
@@ -1349,9 +1442,18 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   }
   // ---- warp GPs
   GPSA_CK(warp_stage_bwd(c, og, B));
-  // ---- KL terms: dOmega += , dK_p += 0.5 K_p^-1 S_p K_p^-1, dD
-  const bool kl = P.d.want_kl != 0 && og.dkl != nullptr;
-  for (int g = 0; g < P.ng && kl; ++g) {
+  // ---- KL terms
+  if (kl && P.side != nullptr) {  // join: add the side stream's share (same layout as dstack) in one pass
+    if (fork) GPSA_CK((int)hipStreamWaitEvent(st, P.sev[4], 0));
+    for (int g = 0; g < P.ng; ++g) {
+      Group& G = P.grp[g];
+      if (G.n_omega == 0 || G.n_prior == 0 || dry) continue;
+      const long long n = (long long)G.nb() * G.M * G.M;
+      add_inplace_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(B.dstack[g], dKL[g], n);
+      GPSA_LAUNCH_CHECK();
+    }
+  }
+  for (int g = 0; g < P.ng && kl && P.side == nullptr; ++g) {  // single stream: accumulate in place
     Group& G = P.grp[g];
     if (G.n_omega == 0 || G.n_prior == 0) continue;
     const long long mm = (long long)G.M * G.M;

@@ -92,7 +92,12 @@ class VariationalGPSA(GPSA):
             for m in self.modality_names
         }
         self.fixed_view_idx = fixed_view_idx
-        self.check_numerics = True  # one host sync per forward; raises like the reference would
+        # True: forward raises (torch.linalg.LinAlgError) on a non-positive-definite covariance or a non-positive
+        # warp variance, as the reference does - one host wait per forward.  With gradients enabled and the step
+        # engine the wait is DEFERRED to the start of this forward's backward (still before any gradient or
+        # parameter is touched; a forward whose backward never runs is checked at the next forward): the host
+        # keeps queueing the ELBO while the warp GPs run.  "strict": always wait inside forward.  False: never.
+        self.check_numerics = True
         self.kl_scale = 1.0  # data-parallel ranks add 1/world of the KL each (parallel.py)
         # output-sharded ranks (parallel.shard_outputs) own their outputs' KL terms in full and share the
         # warp GPs': weight of the warp-GP KL terms inside the KL sum, and separate generators for the
@@ -542,10 +547,21 @@ class VariationalGPSA(GPSA):
                     eps_Ft.append(noise["F_test"][m].to(device=dev, dtype=f32).reshape(tshape).contiguous())
                 else:
                     eps_Ft.append(self._draw(tshape, dev, "F"))
+        stale = self.__dict__.get("_pending_flag")
+        if stale is not None:  # an earlier forward's deferred check whose backward never ran
+            self._pending_flag = None
+            self._raise_on_flags(stale)
+        check = self.check_numerics
+        if check is True and torch.is_grad_enabled() and any(p.requires_grad for p in SE._param_list(self)):
+            check = "deferred"
+        elif check == "strict":
+            check = True
         aux = dict(plan=plan, model=self, X=[X_spatial[m].contiguous() for m in mods], eps_G=eps_G, eps_F=eps_F,
                    G_test=Gt if G_test is not None else None, eps_F_test=eps_Ft,
                    slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
-                   want_kl=not prediction_mode, check=bool(self.check_numerics))
+                   want_kl=not prediction_mode, check=check,
+                   flag_slot=self.__dict__.get("_flag_slot", 0))
+        self.__dict__["_flag_slot"] = 1 - aux["flag_slot"]  # two pinned words: consecutive forwards never share one
         outs = SE.StepFn.apply(aux, *SE._param_list(self))
         nm = len(mods)
         lmc = [i for i in range(nm) if plan.lmc[i]]
@@ -568,6 +584,8 @@ class VariationalGPSA(GPSA):
         # the same tensor object without LMC (quirk 10)
         self.F_observed_samples = {m: (Fo[lmc.index(i)] if plan.lmc[i] else Fl[i]) for i, m in enumerate(mods)}
         self._cache = cache
+        if aux.get("deferred") is not None:
+            self.__dict__["_pending_flag"] = aux["deferred"]
         if aux["pending"] is not None:
             self._raise_on_flags(aux["pending"])
         if G_test is not None:
@@ -578,11 +596,12 @@ class VariationalGPSA(GPSA):
                     self.F_latent_samples_test, self.F_observed_samples_test)
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
-    def _post_flag(self, flag):
+    def _post_flag(self, flag, slot=0):
         """one device word -> host, asynchronously; returns what _raise_on_flags waits on"""
-        host = self.__dict__.get("_flag_host")
-        if host is None:
-            host = self.__dict__["_flag_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        hosts = self.__dict__.get("_flag_hosts")
+        if hosts is None:
+            hosts = self.__dict__["_flag_hosts"] = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        host = hosts[slot]
         host.copy_(flag.reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

@@ -97,23 +97,65 @@ def setup_output_sharding(model, rank, world, seed=0):
 
 class GradAllReducer:
     """One fused all-reduce(sum) of all parameter gradients per step (bucket = everything: 8.6 MB at
-    the headline config, latency-bound on xGMI, so a single flat buffer is the right shape)."""
+    the headline config, latency-bound on xGMI, so a single flat buffer is the right shape).
 
-    def __init__(self, params):
+    The step engine hands autograd ONE flat gradient buffer whose views are the parameters' ``.grad``
+    (step_engine.StepFn.backward), with spare room at its end: when that is what the parameters hold, the
+    few gradients from elsewhere (the likelihood's noise parameter) are copied into the spare room and the
+    buffer itself is reduced in place - no pack, no unpack.  Otherwise: pack, reduce, unpack.
+    Every call inside it (copies, the RCCL all-reduce) is capturable into a hipGraph."""
+
+    def __init__(self, params, always=False):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.always = always  # reduce even in a 1-rank group (tests of the capture path)
+
+    def _engine_bucket(self):
+        """(flat buffer, parameters outside it) when the gradients are views of one step-engine buffer"""
+        from .step_engine import LAST_FLAT
+
+        p0 = self.params[0]
+        flat = LAST_FLAT.get(p0.device.index) if p0.is_cuda else None
+        if flat is None:
+            return None
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        inside, outside = [], []
+        for p in self.params:
+            g = p.grad
+            if g is not None and g.is_contiguous() and g.dtype == flat.dtype and lo <= g.data_ptr() < hi:
+                inside.append(p)
+            else:
+                outside.append(p)
+        used = sum(p.numel() for p in inside)
+        if sum(p.numel() for p in outside) > flat.numel() - used:
+            return None
+        return flat, used, outside
 
     def __call__(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() == 1 and not self.always:
+            return
+        for p in self.params:  # a parameter the step did not touch contributes zeros
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        bucket = self._engine_bucket()
+        if bucket is not None:
+            flat, used, outside = bucket
+            if outside:
+                tail = flat[used: used + sum(p.numel() for p in outside)]
+                torch.cat([p.grad.view(-1) for p in outside], out=tail)
+                dist.all_reduce(flat[: used + tail.numel()], op=dist.ReduceOp.SUM)
+                torch._foreach_copy_([p.grad.view(-1) for p in outside],
+                                     list(tail.split([p.numel() for p in outside])))
+            else:
+                dist.all_reduce(flat[:used], op=dist.ReduceOp.SUM)
             return
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
             self.flat = torch.empty(self.numel, dtype=p0.dtype, device=p0.device)
             self.views = list(self.flat.split([p.numel() for p in self.params]))
-        for p in self.params:  # a parameter the step did not touch contributes zeros
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
         # pack (one batched launch), reduce, unpack (one batched launch): not one copy per parameter
         # view(-1), not reshape(-1): a non-contiguous .grad must raise here, not be reduced into a temporary
         torch.cat([p.grad.view(-1) for p in self.params], out=self.flat)

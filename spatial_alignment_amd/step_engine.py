@@ -16,6 +16,10 @@ from . import _lib
 from . import ops as _ops_mod
 from .kernels import builtin_kind
 
+# the flat gradient buffer of the most recent backward per device (its views are the parameters' .grad):
+# parallel.GradAllReducer reduces it in place
+LAST_FLAT = {}
+
 MAXM = _lib.MAX_MODS
 KINDS = _ops_mod.KINDS
 _raw_stream = torch._C._cuda_getCurrentRawStream
@@ -198,7 +202,15 @@ class StepFn(torch.autograd.Function):
         scratch = o._ws(plan.scratch_bytes, saved)
         stream = _raw_stream(dev.index)
         pending = None
-        if aux["check"]:
+        if aux["check"] == "deferred":
+            # training: the word is shipped behind an event as below, but nobody waits for it inside forward -
+            # the backward of this node does, before it touches a gradient (see StepFn.backward)
+            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 1,
+                                             stream), "gpsa_step_forward")
+            aux["deferred"] = model._post_flag(flag, slot=aux.get("flag_slot", 0))
+            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 2,
+                                             stream), "gpsa_step_forward")
+        elif aux["check"]:
             # the flag depends on the factorisations and the warp GPs only: ship it to the host behind an event
             # BEFORE the data GPs are queued, so that the check waits for the short part of the forward and the
             # host keeps queueing while the long part runs
@@ -227,6 +239,10 @@ class StepFn(torch.autograd.Function):
     def backward(ctx, *gouts):
         aux = ctx.aux
         plan, model = aux["plan"], aux["model"]
+        if aux.get("deferred") is not None:  # the forward's numerics word: raise before any gradient exists
+            pend, aux["deferred"] = aux["deferred"], None
+            model._pending_flag = None
+            model._raise_on_flags(pend)
         lib = plan.lib
         tensors = ctx.saved_tensors
         dev = tensors[0].device
@@ -267,8 +283,8 @@ class StepFn(torch.autograd.Function):
         # ONE flat fp32 buffer for every parameter gradient: the gradients handed to autograd are views of it
         # (a ready-made all-reduce bucket and a single region for the optimiser to stream through)
         sizes = [t.numel() for t in tensors]
-        flat = torch.empty(sum(sizes), dtype=f32, device=dev)
-        views = list(flat.split(sizes))
+        flat = torch.empty(sum(sizes) + 64, dtype=f32, device=dev)  # spare room: see parallel.GradAllReducer
+        views = list(flat[: sum(sizes)].split(sizes))
         grads = _lib.StepParamGrads()
         (grads.Xtilde, grads.delta_G, grads.Omega_sqt_G, grads.warp_ls, grads.warp_var, grads.Gtilde, grads.data_ls,
          grads.data_var) = (_p(v) for v in views[:8])
@@ -289,6 +305,7 @@ class StepFn(torch.autograd.Function):
         out = [None]
         for i, t in enumerate(tensors):
             out.append(views[i].view(t.shape) if ctx.needs_input_grad[1 + i] else None)
+        LAST_FLAT[dev.index] = flat
         return tuple(out)
 
 

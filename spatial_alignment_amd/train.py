@@ -72,10 +72,11 @@ class GraphedTrainStep:
       non-positive pivot, a non-positive warp variance, a non-finite loss) into a STICKY device word, and
       ``check()`` raises if any step since the last check tripped it (call it every N steps);
     * the optimizer must be capturable (``optim.FusedAdam`` or ``torch.optim.Adam(..., capturable=True)``);
-    * single-GPU only (an all-reduce inside the graph is not attempted here).
+    * ``reducer`` (parallel.GradAllReducer): the data-parallel all-reduce of the gradients is captured too -
+      RCCL collectives are capturable - so every rank of a sharded job replays ONE graph per step.
     """
 
-    def __init__(self, model, optimizer, data_dict, view_idx, Ns, S=5, warmup=3):
+    def __init__(self, model, optimizer, data_dict, view_idx, Ns, S=5, warmup=3, reducer=None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a HIP device")
         self.model, self.optimizer = model, optimizer
@@ -93,12 +94,15 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up off the default stream, as torch's capture rules ask
             for _ in range(warmup):
-                train_step(model, optimizer, data_dict, view_idx, Ns, S, static_grads=True)
+                train_step(model, optimizer, data_dict, view_idx, Ns, S, reducer=reducer, static_grads=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = train_step(model, optimizer, data_dict, view_idx, Ns, S, static_grads=True)
+        # with a collective inside, other threads (the process group's watchdog polling its events) must stay
+        # legal during the capture: thread-local capture mode
+        mode = {"capture_error_mode": "thread_local"} if reducer is not None else {}
+        with torch.cuda.graph(self.graph, **mode):
+            self.loss = train_step(model, optimizer, data_dict, view_idx, Ns, S, reducer=reducer, static_grads=True)
             flags = [f.reshape(-1).to(torch.int32) for f in model._cache.flags]
             flags.append((~torch.isfinite(self.loss.detach())).reshape(-1).to(torch.int32))
             self.sticky.copy_(torch.maximum(self.sticky, torch.cat(flags).abs().max()))

@@ -80,3 +80,47 @@ def test_row_sharded_hip_step_equals_full_hip_step():
     for k, p in model.named_parameters():
         a, b = p.grad.detach().cpu().numpy(), g2[k]
         assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
+
+
+def _graph_worker(port, q):
+    """EXPERIMENT (tools/try_graph_step.py), not a test: one rank, RCCL backend, the sharded step WITH its
+    all-reduce captured into one hipGraph.  A bare all-reduce captures and replays fine on this build
+    (tools/try_graph_allreduce.py); inside the whole step torch's process-group watchdog polls an event that
+    was recorded in the capturing stream (hipErrorCapturedEvent) and aborts.  The eager step is the multi-GPU
+    path: its host cost (1 ms) is below its GPU time at every shard size, so a graph has nothing to win."""
+    import __graft_entry__ as ge
+    from spatial_alignment_amd.optim import FusedAdam
+    from spatial_alignment_amd.parallel import GradAllReducer
+    from spatial_alignment_amd.train import GraphedTrainStep, train_step
+
+    ge.build()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    res = []
+    eG, eF = _noise()
+    eG, eF = [e.to(dev) for e in eG], eF.to(dev)
+    for mode in ("eager", "graph"):
+        dd, model = _problem(dev)
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        opt = FusedAdam(model.parameters(), lr=1e-2)
+        reducer = GradAllReducer(model.parameters(), always=True)
+        orig = model.forward
+
+        def fwd(*a, _orig=orig, _m=model, **k):  # same injected noise on every call
+            _m.inject_noise(eG, {"expression": eF})
+            return _orig(*a, **k)
+
+        model.forward = fwd
+        if mode == "eager":
+            for _ in range(4):
+                loss = train_step(model, opt, dd, view_idx, Ns, S=3, reducer=reducer)
+        else:
+            gs = GraphedTrainStep(model, opt, dd, view_idx, Ns, S=3, warmup=3, reducer=reducer)
+            loss = gs.step()
+            gs.check()
+        torch.cuda.synchronize()
+        res.append((float(loss), {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
+    q.put(res)
+    dist.destroy_process_group()

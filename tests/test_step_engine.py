@@ -87,3 +87,39 @@ def test_engine_unequal_views_and_user_loss_on_G():
             assert np.abs(outs[True][k]).max() == 0, k
             continue
         assert rel(outs[True][k], want) <= (1e-4 if k.startswith("grad/") else 2e-6), (k, rel(outs[True][k], want))
+
+
+def test_numerics_check_raises_like_the_reference():
+    """a non-positive-definite covariance: torch.linalg.LinAlgError from forward (no gradients wanted, or
+    check_numerics == "strict"), from the backward of the same step before any gradient exists (training:
+    the wait is deferred so that the host keeps queueing), never with check_numerics == False"""
+    g = Golden("c2_three_free_views")
+
+    def broken():
+        model, dd = build_model(g, device=DEV)
+        with torch.no_grad():
+            model.Xtilde[1, 3, 0] = float("nan")  # K_uu of view 1 loses positive definiteness
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+        return model, dd, Xs, view_idx, Ns
+
+    model, dd, Xs, view_idx, Ns = broken()
+    with torch.no_grad(), pytest.raises(torch.linalg.LinAlgError):
+        model.forward(Xs, view_idx, Ns, S=2)
+    model, dd, Xs, view_idx, Ns = broken()
+    model.check_numerics = "strict"
+    with pytest.raises(torch.linalg.LinAlgError):
+        model.forward(Xs, view_idx, Ns, S=2)
+    model, dd, Xs, view_idx, Ns = broken()
+    out = model.forward(Xs, view_idx, Ns, S=2)  # training: deferred
+    loss = model.loss_fn(dd, out[3])
+    with pytest.raises(torch.linalg.LinAlgError):
+        loss.backward()
+    assert all(p.grad is None for p in model.parameters())
+    model, dd, Xs, view_idx, Ns = broken()
+    out = model.forward(Xs, view_idx, Ns, S=2)  # backward never runs: the next forward reports it
+    with pytest.raises(torch.linalg.LinAlgError):
+        model.forward(Xs, view_idx, Ns, S=2)
+    model, dd, Xs, view_idx, Ns = broken()
+    model.check_numerics = False
+    model.forward(Xs, view_idx, Ns, S=2)

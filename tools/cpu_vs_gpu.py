@@ -17,10 +17,12 @@ dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"]
 model.check_numerics = False
 view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
 Xs = {m: d["spatial_coords"] for m, d in dd.items()}
-opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+from spatial_alignment_amd.optim import FusedAdam
+opt = FusedAdam(model.parameters(), lr=1e-2)
+S = int(os.environ.get("GPSA_S", "5"))
 
 def step():
-    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=5)
+    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=S)
     loss = model.loss_fn(dd, out[3])
     opt.zero_grad(set_to_none=True)
     loss.backward()
