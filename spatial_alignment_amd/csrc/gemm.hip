@@ -7,6 +7,7 @@
 namespace gpsa {
 
 constexpr int GB_M = 64, GB_N = 64, GB_K = 16;
+enum { GEMM_TRI_NONE = 0, GEMM_TRI_UPPER_A = 1, GEMM_TRI_LOWER_C = 2 };
 
 template <typename T, bool TA, bool TB>
 __global__ void __launch_bounds__(256, 4)
@@ -166,7 +167,12 @@ __global__ void __launch_bounds__(256, 4)
 gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A, long long lda,
                  long long sA, const TIB* __restrict__ B, long long ldb, long long sB, TC beta,
                  TO* __restrict__ C, long long ldc, long long sC, int splitk, TC* __restrict__ part,
-                 TC diag = TC(0)) {
+                 TC diag = TC(0), int tri = 0) {
+  // tri = GEMM_TRI_UPPER_A: op(A) is upper triangular (square, m == k): block row m0 contracts k >= m0 only
+  //       (the symmetric quadratic form a^T Omega a = a^T (diag + 2 strict-upper) a at half the flops);
+  // tri = GEMM_TRI_LOWER_C: only the blocks of C that touch its lower triangle are computed (a symmetric
+  //       product such as sum_c g a a^T; the caller mirrors them) - the others are left untouched.
+  if (tri == GEMM_TRI_LOWER_C && (int)(blockIdx.x * GB_N) > (int)(blockIdx.y * GB_M) + GB_M - 1) return;
   typedef typename MfmaTile<TC>::vec acc_t;
   // K tile of 16 (32 was tried: fewer resident workgroups, 20-40 % slower on every shape used here)
   constexpr int GK = 16, NG = GK / 16;
@@ -178,8 +184,9 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
   const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
   long long kchunk = (k + splitk - 1) / splitk;
   kchunk = (kchunk + GK - 1) / GK * GK;
-  const long long kbeg = (long long)sp * kchunk;
+  long long kbeg = (long long)sp * kchunk;
   const long long kend = (kbeg + kchunk < k) ? kbeg + kchunk : k;
+  if (tri == GEMM_TRI_UPPER_A && kbeg < m0) kbeg = m0;  // m0 is a multiple of the K tile
   const TIA* Ab = A + (long long)b * sA;
   const TIB* Bb = B + (long long)b * sB;
   acc_t acc[2][2];
@@ -318,11 +325,27 @@ static inline bool gemm_force_vector() {
 }
 
 template <typename T>
+int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                    long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
+                    T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
+                    long long ws_bytes, hipStream_t st, int tri);
+
+template <typename T>
 int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
                 long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
                 T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
                 long long ws_bytes, hipStream_t st) {
+  return gemm_launch_tri<T>(transA, transB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, splitk,
+                            ws, ws_bytes, st, GEMM_TRI_NONE);
+}
+
+template <typename T>
+int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                    long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
+                    T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
+                    long long ws_bytes, hipStream_t st, int tri) {
   if (m < 1 || n < 1 || k < 1 || batch < 1 || splitk < 1) return GPSA_EINVAL;
+  if (tri != GEMM_TRI_NONE && (splitk != 1 && tri == GEMM_TRI_UPPER_A)) return GPSA_EINVAL;
   if ((long long)batch * splitk > 65535) return GPSA_EINVAL;
   T* part = nullptr;
   if (splitk > 1) {
@@ -335,9 +358,10 @@ int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha,
                                                (T)beta, C, ldc, sC, splitk, part)
 #define GPSA_GEMMX_CASE(TA, TB)                                                                     \
   gemm_mfma_kernel<T, TA, TB><<<grid, 256, 0, st>>>(m, n, k, (T)alpha, A, lda, sA, B, ldb, sB, (T)beta, \
-                                                    C, ldc, sC, splitk, part)
-  // products with at least one MFMA tile in each direction run on the matrix cores
-  const bool mfma = m >= 16 && n >= 16 && !gemm_force_vector();
+                                                    C, ldc, sC, splitk, part, T(0), tri)
+  // products with at least one MFMA tile in each direction run on the matrix cores (always with a triangle
+  // mode: only that kernel knows them)
+  const bool mfma = (m >= 16 && n >= 16 && !gemm_force_vector()) || tri != GEMM_TRI_NONE;
   if (mfma) {
     if (!transA && !transB) GPSA_GEMMX_CASE(false, false);
     else if (transA && !transB) GPSA_GEMMX_CASE(true, false);
@@ -435,6 +459,12 @@ GPSA_G64_INST(double, double, float)  // alpha = K^-1 K_uf stored fp32 beyond th
 #undef GPSA_G64_INST
 
 // explicit instantiations used from other translation units
+template int gemm_launch_tri<float>(int, int, int, int, long long, double, const float*, long long,
+                                    long long, const float*, long long, long long, double, float*,
+                                    long long, long long, int, int, void*, long long, hipStream_t, int);
+template int gemm_launch_tri<double>(int, int, int, int, long long, double, const double*, long long,
+                                     long long, const double*, long long, long long, double, double*,
+                                     long long, long long, int, int, void*, long long, hipStream_t, int);
 template int gemm_launch<float>(int, int, int, int, long long, double, const float*, long long,
                                 long long, const float*, long long, long long, double, float*,
                                 long long, long long, int, int, void*, long long, hipStream_t);

@@ -23,6 +23,33 @@ int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha,
                 long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
                 T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
                 long long ws_bytes, hipStream_t st);
+// the same with a triangle mode (gemm.hip): 1 = op(A) upper triangular, 2 = lower-triangle blocks of C only
+template <typename T>
+int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                    long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
+                    T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
+                    long long ws_bytes, hipStream_t st, int tri);
+
+// U[l] = diag(Omega_l) + 2 * strict upper triangle of Omega_l (zeros below), stored as TD:
+// a^T Omega a = a^T U a for symmetric Omega, and U a costs half the products of Omega a
+template <typename TS, typename TD>
+__global__ void tri_upper_kernel(const TS* __restrict__ src, int M, long long n, TD* __restrict__ dst) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= n) return;
+  const long long e = idx % ((long long)M * M);
+  const int i = (int)(e / M), k = (int)(e % M);
+  dst[idx] = k > i ? (TD)(2.0 * (double)src[idx]) : (k == i ? (TD)src[idx] : TD(0));
+}
+
+// C[b][i][k] = C[b][k][i] for k > i (mirror the lower triangle of each M x M block)
+template <typename T>
+__global__ void mirror_lower_kernel(T* __restrict__ Cm, int M, long long n) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= n) return;
+  const long long mm = (long long)M * M, b = idx / mm, e = idx % mm;
+  const int i = (int)(e / M), k = (int)(e % M);
+  if (k > i) Cm[idx] = Cm[b * mm + (long long)k * M + i];
+}
 
 // ------------------------------------------------------------------------------------------------
 // generic helpers
@@ -206,9 +233,10 @@ int generic_quadform_fwd(const T* alpha, const T* Omega, int M, long long C, int
   T* Tm = reinterpret_cast<T*>(ws);
   for (int l0 = 0; l0 < L; l0 += lc) {
     const int nb = (L - l0 < lc) ? L - l0 : lc;
-    int rc = gemm_launch<T>(0, 0, M, (int)C, M, 1.0, Omega + (long long)l0 * M * M, M,
-                            (long long)M * M, alpha, C, 0, 0.0, Tm, C, (long long)M * C, nb, 1,
-                            nullptr, 0, st);
+    // Omega holds U_l = diag + 2 strict-upper (tri_upper_kernel): block row m0 contracts k >= m0 only
+    int rc = gemm_launch_tri<T>(0, 0, M, (int)C, M, 1.0, Omega + (long long)l0 * M * M, M,
+                                (long long)M * M, alpha, C, 0, 0.0, Tm, C, (long long)M * C, nb, 1,
+                                nullptr, 0, st, 1);
     if (rc) return rc;
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)nb);
     coldot_kernel<T><<<grid, 256, 0, st>>>(alpha, Tm, M, C, v + (long long)l0 * C, C);
@@ -261,10 +289,14 @@ int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, i
     dim3 grid((unsigned)cdiv(C, 256), (unsigned)((M < 64) ? M : 64), (unsigned)nb);
     colscale_batched_kernel<T><<<grid, 256, 0, st>>>(alpha, g + (long long)l0 * C, M, C, tmp);
     GPSA_LAUNCH_CHECK();
-    int rc = gemm_launch<T>(0, 1, M, M, C, 1.0, tmp, C, (long long)M * C, alpha, C, 0, 0.0,
-                            dOmega + (long long)l0 * M * M, M, (long long)M * M, nb, sk, part,
-                            (long long)nb * part_b, st);
+    // symmetric result: only the blocks touching the lower triangle are computed, then mirrored
+    int rc = gemm_launch_tri<T>(0, 1, M, M, C, 1.0, tmp, C, (long long)M * C, alpha, C, 0, 0.0,
+                                dOmega + (long long)l0 * M * M, M, (long long)M * M, nb, sk, part,
+                                (long long)nb * part_b, st, 2);
     if (rc) return rc;
+    const long long nn = (long long)nb * M * M;
+    mirror_lower_kernel<T><<<(unsigned)cdiv(nn, 256), 256, 0, st>>>(dOmega + (long long)l0 * M * M, M, nn);
+    GPSA_LAUNCH_CHECK();
   }
   return 0;
 }
@@ -1319,6 +1351,29 @@ static int operand_as(int p_dtype, const void* P, long long n, const T** out, vo
 
 }  // namespace gpsa
 
+namespace gpsa {
+// the triangular operand U of the generic quadratic form, always a copy at the head of the workspace
+template <typename T>
+static int tri_operand(int p_dtype, const void* P, int M, int L, const T** out, void** ws, long long* ws_bytes,
+                       hipStream_t st) {
+  const long long n = (long long)L * M * M;
+  const long long need = (n * (long long)sizeof(T) + 255) / 256 * 256;
+  if (*ws_bytes < need) return GPSA_EWORKSPACE;
+  T* dst = reinterpret_cast<T*>(*ws);
+  if (p_dtype == GPSA_F32)
+    tri_upper_kernel<float, T><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)P, M, n, dst);
+  else if (p_dtype == GPSA_F64)
+    tri_upper_kernel<double, T><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const double*)P, M, n, dst);
+  else
+    return GPSA_EINVAL;
+  GPSA_LAUNCH_CHECK();
+  *ws = reinterpret_cast<char*>(*ws) + need;
+  *ws_bytes -= need;
+  *out = dst;
+  return 0;
+}
+}  // namespace gpsa
+
 extern "C" {
 
 long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
@@ -1359,14 +1414,14 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
                                           nullptr, 1.f, nullptr, st);
     }
     const float* Om;
-    int rc = operand_as<float>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
+    int rc = tri_operand<float>(omega_dtype, Omega, M, L, &Om, &workspace, &workspace_bytes, st);
     if (rc) return rc;
     return generic_quadform_fwd<float>((const float*)alpha, Om, M, C, L, (float*)v, workspace,
                                        workspace_bytes, st);
   }
   if (dtype == GPSA_F64) {
     const double* Om;
-    int rc = operand_as<double>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
+    int rc = tri_operand<double>(omega_dtype, Omega, M, L, &Om, &workspace, &workspace_bytes, st);
     if (rc) return rc;
     return generic_quadform_fwd<double>((const double*)alpha, Om, M, C, L, (double*)v, workspace,
                                         workspace_bytes, st);
