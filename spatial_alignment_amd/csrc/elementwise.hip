@@ -326,11 +326,14 @@ loglik_fwd_kernel(const float* __restrict__ F, const float* __restrict__ Y,
 __global__ void __launch_bounds__(256)
 loglik_bwd_kernel(const float* __restrict__ F, const float* __restrict__ Y,
                   const float* __restrict__ noise_u, const double* __restrict__ gout, int S,
-                  long long tot, long long NP, float* __restrict__ dF, double* __restrict__ part) {
+                  long long tot, long long NP, float* __restrict__ dF, double* __restrict__ part,
+                  const float* __restrict__ gloss = nullptr) {
   __shared__ double red[4];
   const double s = exp((double)noise_u[0]) + 1e-5;
   const float inv = (float)(1.0 / s);
-  const float coef = (float)(gout[0] / (s * s * (double)S));
+  // upstream gradient of this log-likelihood: gout[0], or -gloss[0] when the ELBO glue is fused in
+  const double up = gloss != nullptr ? -(double)gloss[0] : gout[0];
+  const float coef = (float)(up / (s * s * (double)S));
   double acc = 0.0;  // sum z^2 - 1 ; dLL/ds = acc / s / S
   for (long long i0 = blockIdx.x * 256LL * 4; i0 < tot; i0 += (long long)gridDim.x * 256 * 4) {
     float a = 0.f;
@@ -354,15 +357,50 @@ loglik_bwd_kernel(const float* __restrict__ F, const float* __restrict__ Y,
 __global__ void loglik_bwd_finish_kernel(const double* __restrict__ part, int n,
                                          const float* __restrict__ noise_u,
                                          const double* __restrict__ gout, int S,
-                                         float* __restrict__ dnoise_u) {
+                                         float* __restrict__ dnoise_u, const float* __restrict__ gloss = nullptr,
+                                         double* __restrict__ dkl = nullptr, int n_kl = 0,
+                                         double kl_scale = 0.0) {
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) {
     const double e = exp((double)noise_u[0]), sc = e + 1e-5;
-    dnoise_u[0] = (float)(gout[0] * s / sc / (double)S * e);
+    const double up = gloss != nullptr ? -(double)gloss[0] : gout[0];
+    dnoise_u[0] = (float)(up * s / sc / (double)S * e);
   }
+  if (dkl != nullptr)  // fused ELBO glue: dkl[t] = kl_scale * gloss
+    for (int t = threadIdx.x; t < n_kl; t += blockDim.x) dkl[t] = kl_scale * (double)gloss[0];
+}
+
+// fused forward finish: ll[i] = sum(part_i) / S_i for every likelihood term, then
+// loss = kl_scale * sum(kl) - sum_i ll[i]   (vgpsa.py:540); one block
+struct ElboFinishArgs {
+  const double* part[GPSA_MAX_MODS];
+  int nb[GPSA_MAX_MODS], S[GPSA_MAX_MODS];
+  int n_ll, n_kl;
+  const double* kl;
+  double kl_scale;
+  double* ll;
+  float* loss;
+};
+__global__ void __launch_bounds__(256) elbo_loss_finish_kernel(ElboFinishArgs a) {
+  __shared__ double red[4];
+  double lsum = 0.0;
+  for (int i = 0; i < a.n_ll; ++i) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < a.nb[i]; k += 256) s += a.part[i][k];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+      const double v = s / (double)a.S[i];
+      a.ll[i] = v;
+      lsum += v;
+    }
+  }
+  double k = 0.0;
+  for (int t = threadIdx.x; t < a.n_kl; t += 256) k += a.kl[t];
+  k = block_sum(k, red);
+  if (threadIdx.x == 0) a.loss[0] = (float)(a.kl_scale * k - lsum);
 }
 
 static inline int loglik_blocks(long long tot) {
@@ -514,6 +552,57 @@ int gpsa_elbo_bwd(const float* gloss, int n_ll, int n_kl, double kl_scale, doubl
   if (n_ll < 1 || n_kl < 0) return GPSA_EINVAL;
   const int n = n_ll > n_kl ? n_ll : n_kl;
   gpsa::elbo_bwd_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(gloss, n_ll, n_kl, kl_scale, dll, dkl);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+/* ---- likelihood + ELBO fused: one host call each way, one finishing launch for all of it ------------------ */
+int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                       const int* S, const long long* N, const int* P, const double* kl, int n_kl, double kl_scale,
+                       float* loss, double* ll_out, void* workspace, long long workspace_bytes, void* stream) {
+  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !loss || !ll_out) return GPSA_EINVAL;
+  if (workspace_bytes < 8LL * 4100 * n_ll) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  gpsa::ElboFinishArgs a;
+  a.n_ll = n_ll;
+  a.n_kl = kl ? n_kl : 0;
+  a.kl = kl;
+  a.kl_scale = kl_scale;
+  a.ll = ll_out;
+  a.loss = loss;
+  for (int i = 0; i < n_ll; ++i) {
+    if (S[i] < 1 || N[i] < 1 || P[i] < 1) return GPSA_EINVAL;
+    const long long NP = N[i] * P[i], tot = NP * S[i];
+    const int nb = gpsa::loglik_blocks(tot);
+    double* part = reinterpret_cast<double*>(workspace) + 4100LL * i;
+    gpsa::loglik_fwd_kernel<<<nb, 256, 0, st>>>(F[i], Y[i], noise_u[i], tot, NP, part);
+    a.part[i] = part;
+    a.nb[i] = nb;
+    a.S[i] = S[i];
+  }
+  gpsa::elbo_loss_finish_kernel<<<1, 256, 0, st>>>(a);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                       const int* S, const long long* N, const int* P, const float* gloss, int n_kl, double kl_scale,
+                       float* const* dF, float* const* dnoise, double* dkl, void* workspace, long long workspace_bytes,
+                       void* stream) {
+  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !gloss || !dF || !dnoise)
+    return GPSA_EINVAL;
+  if (workspace_bytes < 8LL * 4100 * n_ll) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  for (int i = 0; i < n_ll; ++i) {
+    if (S[i] < 1 || N[i] < 1 || P[i] < 1) return GPSA_EINVAL;
+    const long long NP = N[i] * P[i], tot = NP * S[i];
+    const int nb = gpsa::loglik_blocks(tot);
+    double* part = reinterpret_cast<double*>(workspace) + 4100LL * i;
+    gpsa::loglik_bwd_kernel<<<nb, 256, 0, st>>>(F[i], Y[i], noise_u[i], nullptr, S[i], tot, NP, dF[i], part, gloss);
+    // the first term's finishing launch also writes dkl
+    gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(part, nb, noise_u[i], nullptr, S[i], dnoise[i], gloss,
+                                                      i == 0 ? dkl : nullptr, n_kl, kl_scale);
+  }
   GPSA_LAUNCH_CHECK();
   return 0;
 }

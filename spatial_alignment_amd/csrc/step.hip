@@ -1641,39 +1641,6 @@ int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_st
   return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, as_stream(stream));
 }
 
-/* ---- likelihood + ELBO: one host call each way ------------------------------------------------------------- */
-int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
-                       const int* S, const long long* N, const int* P, const double* kl, int n_kl, double kl_scale,
-                       float* loss, double* ll_out, void* workspace, long long workspace_bytes, void* stream) {
-  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !loss || !ll_out) return GPSA_EINVAL;
-  if (workspace_bytes < 8LL * 4100) return GPSA_EWORKSPACE;
-  for (int i = 0; i < n_ll; ++i) {
-    int rc = gpsa_loglik_fwd(F[i], Y[i], noise_u[i], S[i], N[i], P[i], ll_out + i, workspace, workspace_bytes, stream);
-    if (rc) return rc;
-  }
-  return gpsa_elbo_fwd(ll_out, n_ll, kl, kl ? n_kl : 0, kl_scale, loss, stream);
-}
-
-int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
-                       const int* S, const long long* N, const int* P, const float* gloss, int n_kl, double kl_scale,
-                       float* const* dF, float* const* dnoise, double* dkl, void* workspace, long long workspace_bytes,
-                       void* stream) {
-  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !gloss || !dF || !dnoise)
-    return GPSA_EINVAL;
-  if (workspace_bytes < 8LL * 4100 + 64) return GPSA_EWORKSPACE;
-  // dll[i] = -gloss (fp64 device scalars at the head of the workspace), dkl[t] = kl_scale * gloss
-  double* dll = reinterpret_cast<double*>(workspace);
-  int rc = gpsa_elbo_bwd(gloss, n_ll, dkl ? n_kl : 0, kl_scale, dll, dkl, stream);
-  if (rc) return rc;
-  char* ws = reinterpret_cast<char*>(workspace) + 64;
-  for (int i = 0; i < n_ll; ++i) {
-    rc = gpsa_loglik_bwd(F[i], Y[i], noise_u[i], dll + i, S[i], N[i], P[i], dF[i], dnoise[i], ws, workspace_bytes - 64,
-                         stream);
-    if (rc) return rc;
-  }
-  return 0;
-}
-
 int gpsa_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const long long* numel, double lr, double beta1, double beta2, double eps,
                    float* step, void* stream) {

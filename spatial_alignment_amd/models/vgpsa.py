@@ -526,27 +526,46 @@ class VariationalGPSA(GPSA):
             Gt = [G_test[m].to(device=dev, dtype=f32).contiguous() for m in mods]
             test_shapes = (int(Gt[0].shape[0]), tuple(int(g.shape[1]) for g in Gt))
         plan = SE.get_plan(self, rows, S, test_shapes, want_kl=not prediction_mode)
-        # draws: one buffer for the warp GPs of all free, non-empty views (order of vgpsa.py:346-348)
-        if noise is not None and noise["G"] is not None:
-            eps_G = torch.cat([e.to(device=dev, dtype=f32).reshape(-1) for e in noise["G"]]) if noise["G"] else \
-                torch.empty(0, dtype=f32, device=dev)
-            if eps_G.numel() != plan.eps_g_numel:
-                raise ValueError(f"injected eps_G has {eps_G.numel()} values, the free views need {plan.eps_g_numel}")
+        # draws: one buffer for the warp GPs of all free, non-empty views (order of vgpsa.py:346-348), one per
+        # modality for the data GP; without injected noise or per-purpose generators ALL of them come out of a
+        # single launch
+        nm_ = len(mods)
+        shapes_F = [[S, plan.N[i], plan.L[i]] for i in range(nm_)]
+        shapes_Ft = [[plan.s_test, plan.n_test[i], plan.L[i]] for i in range(nm_)] if G_test is not None else []
+        eps_G, eps_F, eps_Ft = None, [], []
+        if noise is None and self.noise_generators is None:
+            sizes = [plan.eps_g_numel] + [s_[0] * s_[1] * s_[2] for s_ in shapes_F + shapes_Ft]
+            # 64-float (256-byte) aligned pieces of one buffer
+            offs, tot = [], 0
+            for n_ in sizes:
+                offs.append(tot)
+                tot += (n_ + 63) // 64 * 64
+            buf = self._draw([max(tot, 1)], dev, "G")
+            eps_G = buf[: sizes[0]]
+            for i in range(nm_):
+                eps_F.append(buf[offs[1 + i]: offs[1 + i] + sizes[1 + i]].view(shapes_F[i]))
+            for i in range(len(shapes_Ft)):
+                k_ = 1 + nm_ + i
+                eps_Ft.append(buf[offs[k_]: offs[k_] + sizes[k_]].view(shapes_Ft[i]))
         else:
-            eps_G = self._draw([plan.eps_g_numel], dev, "G")
-        eps_F, eps_Ft = [], []
-        for i, m in enumerate(mods):
-            shape = [S, plan.N[i], plan.L[i]]
-            if noise is not None and noise["F"] is not None:
-                eps_F.append(noise["F"][m].to(device=dev, dtype=f32).reshape(shape).contiguous())
+            if noise is not None and noise["G"] is not None:
+                eps_G = torch.cat([e.to(device=dev, dtype=f32).reshape(-1) for e in noise["G"]]) if noise["G"] else \
+                    torch.empty(0, dtype=f32, device=dev)
+                if eps_G.numel() != plan.eps_g_numel:
+                    raise ValueError(f"injected eps_G has {eps_G.numel()} values, the free views need "
+                                     f"{plan.eps_g_numel}")
             else:
-                eps_F.append(self._draw(shape, dev, "F"))
-            if G_test is not None:
-                tshape = [plan.s_test, plan.n_test[i], plan.L[i]]
-                if noise is not None and noise["F_test"] is not None:
-                    eps_Ft.append(noise["F_test"][m].to(device=dev, dtype=f32).reshape(tshape).contiguous())
+                eps_G = self._draw([plan.eps_g_numel], dev, "G")
+            for i, m in enumerate(mods):
+                if noise is not None and noise["F"] is not None:
+                    eps_F.append(noise["F"][m].to(device=dev, dtype=f32).reshape(shapes_F[i]).contiguous())
                 else:
-                    eps_Ft.append(self._draw(tshape, dev, "F"))
+                    eps_F.append(self._draw(shapes_F[i], dev, "F"))
+                if G_test is not None:
+                    if noise is not None and noise["F_test"] is not None:
+                        eps_Ft.append(noise["F_test"][m].to(device=dev, dtype=f32).reshape(shapes_Ft[i]).contiguous())
+                    else:
+                        eps_Ft.append(self._draw(shapes_Ft[i], dev, "F"))
         stale = self.__dict__.get("_pending_flag")
         if stale is not None:  # an earlier forward's deferred check whose backward never ran
             self._pending_flag = None

@@ -336,7 +336,7 @@ class ElboLossFn(torch.autograd.Function):
             klc = klc if (klc.dtype == torch.float64 and klc.is_contiguous()) else klc.double().contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         ll = torch.empty(n, dtype=torch.float64, device=dev)
-        ws = o._ws(8 * 4100 + 64, loss)
+        ws = o._ws(8 * 4100 * n + 64, loss)
         stream = _raw_stream(dev.index)
         _lib.check(lib.gpsa_elbo_loss_fwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(klc), 0 if klc is None else klc.numel(),
                                           float(aux["kl_scale"]), _p(loss), _p(ll), _p(ws), ws.numel(), stream),
@@ -361,7 +361,7 @@ class ElboLossFn(torch.autograd.Function):
         dkl = torch.empty(ctx.n_kl, dtype=torch.float64, device=dev) if ctx.n_kl else None
         dFp = (C.c_void_p * n)(*[t.data_ptr() for t in dF])
         dNp = (C.c_void_p * n)(*[dnoise.data_ptr() + 4 * j for j in aux["noise_idx"]])
-        ws = o._ws(8 * 4100 + 64, g)
+        ws = o._ws(8 * 4100 * n + 64, g)
         _lib.check(lib.gpsa_elbo_loss_bwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(g), ctx.n_kl, float(aux["kl_scale"]), dFp, dNp,
                                           _p(dkl), _p(ws), ws.numel(), _raw_stream(dev.index)),
                    "gpsa_elbo_loss_bwd")
