@@ -405,6 +405,9 @@ typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar 
 } gpsa_step_out_grads;
 
 void* gpsa_step_create(const gpsa_step_desc* desc);   /* NULL: invalid / unsupported description */
+/* the same plan described on the host only (no device): out[6] = saved bytes, scratch bytes, KL terms, floats of
+ * eps_G, batched runs of free views, column stride of the view blocks */
+int gpsa_step_describe(const gpsa_step_desc* desc, long long* out);
 void gpsa_step_destroy(void* plan);
 long long gpsa_step_saved_bytes(const void* plan);
 long long gpsa_step_scratch_bytes(const void* plan);

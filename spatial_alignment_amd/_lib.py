@@ -127,6 +127,7 @@ SIGNATURES.update({
     "gpsa_mvn_kl_grouped_bwd_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i,
                                          _vp]),
     "gpsa_step_create": (_vp, [C.POINTER(StepDesc)]),
+    "gpsa_step_describe": (_i, [C.POINTER(StepDesc), C.POINTER(_ll)]),
     "gpsa_step_destroy": (None, [_vp]),
     "gpsa_step_saved_bytes": (_ll, [_vp]),
     "gpsa_step_scratch_bytes": (_ll, [_vp]),

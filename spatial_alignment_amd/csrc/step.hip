@@ -552,7 +552,7 @@ static void free_plan(Plan* p) {
   delete p;
 }
 
-static Plan* make_plan(const gpsa_step_desc* dsc) {
+static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
   if (dsc == nullptr) return nullptr;
   const int V = dsc->n_views, D = dsc->n_dims, nm = dsc->n_mods, S = dsc->n_samples;
   if (V < 1 || D < 1 || D > MAXD || nm < 1 || nm > MAXMODS || S < 0 || dsc->m_x < 1 || dsc->m_g < 1)
@@ -665,7 +665,9 @@ static Plan* make_plan(const gpsa_step_desc* dsc) {
   std::vector<char> host((size_t)bytes, 0);
   long long* hl = reinterpret_cast<long long*>(host.data());
   int* hi = reinterpret_cast<int*>(host.data() + n_ll * 8);
-  if (hipMalloc(reinterpret_cast<void**>(&p->dev), (size_t)bytes) != hipSuccess) { p->dev = nullptr; free_plan(p); return nullptr; }
+  // host_only (gpsa_step_describe): the tables are built but never uploaded; the pointers into them are only
+  // ever handed to launches, which a dry run skips
+  if (!host_only && hipMalloc(reinterpret_cast<void**>(&p->dev), (size_t)bytes) != hipSuccess) { p->dev = nullptr; free_plan(p); return nullptr; }
   long long* dl = reinterpret_cast<long long*>(p->dev);
   int* di = reinterpret_cast<int*>(p->dev + n_ll * 8);
   long long lo = 0, io = 0;
@@ -719,14 +721,14 @@ static Plan* make_plan(const gpsa_step_desc* dsc) {
     G.order = di + io;
     for (int t = 0; t < G.n_omega; ++t) hi[io++] = order[t];
   }
-  if (hipMemcpy(p->dev, host.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { free_plan(p); return nullptr; }
+  if (!host_only && hipMemcpy(p->dev, host.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { free_plan(p); return nullptr; }
   p->tab.V = V; p->tab.D = D; p->tab.S = S; p->tab.nm = nm; p->tab.nf = p->nf; p->tab.Cs = p->Cs;
   {
     // off by default: measured on MI355X (profiles/r02_*), the fork buys nothing - the side stream's kernels
     // cannot co-reside with the persistent full-chip contraction kernels (one wave per SIMD holding the whole
     // register file), and next to the latency-bound small kernels they only trade places
     const char* e = getenv("GPSA_STEP_SIDE");
-    if ((e && e[0] == '1') && dsc->want_kl) {
+    if (!host_only && (e && e[0] == '1') && dsc->want_kl) {
       bool ok = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess;
       for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreateWithFlags(&p->sev[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { free_plan(p); return nullptr; }
@@ -1536,9 +1538,30 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
 
 extern "C" {
 
-void* gpsa_step_create(const gpsa_step_desc* desc) {
+static gpsa::Plan* plan_with_sizes(const gpsa_step_desc* desc, bool host_only);
+
+void* gpsa_step_create(const gpsa_step_desc* desc) { return plan_with_sizes(desc, false); }
+
+/* host-only description of a plan (no device needed): out[0..5] = saved bytes, scratch bytes, KL terms, floats
+ * of eps_G, batched runs of free views, column stride of the view blocks.  0, or GPSA_EINVAL for a description
+ * gpsa_step_create would refuse. */
+int gpsa_step_describe(const gpsa_step_desc* desc, long long* out) {
+  if (!out) return GPSA_EINVAL;
+  gpsa::Plan* p = plan_with_sizes(desc, true);
+  if (p == nullptr) return GPSA_EINVAL;
+  out[0] = p->saved_bytes;
+  out[1] = p->scratch_bytes;
+  out[2] = (long long)p->V * p->D + p->Ltot;
+  out[3] = p->eps_total;
+  out[4] = (long long)p->runs.size();
+  out[5] = p->Cs;
+  gpsa::free_plan(p);
+  return 0;
+}
+
+static gpsa::Plan* plan_with_sizes(const gpsa_step_desc* desc, bool host_only) {
   using namespace gpsa;
-  Plan* p = make_plan(desc);
+  Plan* p = make_plan(desc, host_only);
   if (p == nullptr) return nullptr;
   // scratch requirement = high-water mark of a dry run of the forward and of the backward
   Arena a;
