@@ -289,6 +289,11 @@ int gpsa_kmat_bwd_batched(int kind, const float* Z, long long strideZ, int M, co
 int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
                       const float* var_u, const float* Kbar, double* dZ, double* dX, double* dparams,
                       void* workspace, long long workspace_bytes, void* stream);
+/* gpsa_whiten_f64 on an fp32 panel with gpsa_col_axpy fused into its store:
+ *   out[m,c] = (Kinv X)[m,c] + s * d[c] * X2[m,c]      (X, X2, out [M,C] fp32; d [C] fp32; fp64 arithmetic)
+ * the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) in one pass. */
+int gpsa_whiten_axpy_f32(const double* Kinv, const float* X, int M, long long C, const float* X2, const float* d,
+                         double s, float* out, void* workspace, long long workspace_bytes, void* stream);
 /* gpsa_whiten_f64 for a batch of fp64 panels with one inverse each: problem b reads Kinv + b strideKinv and
  * Kuf + b strideX, writes alpha + b strideX and q + b C (q may be NULL).
  * workspace >= batch * gpsa_whiten_workspace(M). */

@@ -1197,14 +1197,26 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
                  splitk_for(C, Mg, L)));
   B.have_ddc[m] = true;
-  // gamma = K^-1 abar (fp64 product on the fp32 panel)
+  // gamma = K^-1 abar (fp64 product on the fp32 panel).  With many columns dK_uu comes from the identity below
+  // and only dK_uf = gamma + 2 qbar a is needed: the column-scaled update rides in the solve's store
   float* gamma = c.sc.get<float>((long long)Mg * C);
+  const bool identity = C >= 4LL * L * Mg;
+  bool fused_axpy = false;
   {
     const long long wsb = gpsa_whiten_workspace(Mg);
     if (wsb > 0) {
       const long long mk2 = c.sc.mark();
       void* ws = c.sc.get<char>(wsb);
-      GPSA_RUN(gpsa_whiten_f64(Kinv, GPSA_F32, abar, Mg, C, GPSA_F32, gamma, nullptr, ws, wsb, c.stv()));
+      // measured (bench.py A/B in one run, twice): the fused store makes the step 37 us SLOWER (8.939 vs 8.901
+      // ms): its row-strided reads of alpha in the projection kernel's epilogue cost more than the separate
+      // streaming pass saves.  Kept behind GPSA_FUSED_AXPY=1.
+      static const bool fuse = [] { const char* e = getenv("GPSA_FUSED_AXPY"); return e && e[0] == '1'; }();
+      if (identity && fuse) {
+        GPSA_RUN(gpsa_whiten_axpy_f32(Kinv, abar, Mg, C, alpha, qbar, 2.0, gamma, ws, wsb, c.stv()));
+        fused_axpy = true;
+      } else {
+        GPSA_RUN(gpsa_whiten_f64(Kinv, GPSA_F32, abar, Mg, C, GPSA_F32, gamma, nullptr, ws, wsb, c.stv()));
+      }
       c.sc.release(mk2);
     } else {
       GPSA_CK((gemmx<double, float, float>(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, abar, C, 0, 0.0, gamma, C, 0, 1, 1)));
@@ -1237,7 +1249,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       GPSA_LAUNCH_CHECK();
     }
     // dK_uu
-    if (C >= 4LL * L * Mg) {
+    if (identity) {
       // dK_uu = -(gamma + qbar a) a^T without a second C-long product (engine.py:_layer_backward):
       //   gamma a^T = K^-1 (abar a^T),  abar a^T = dc ddc^T + 2 sum_l Omega_l dOmega_l,  (qbar a) a^T = -sum_l dOmega_l
       // on THIS pass's dOmega (dst) and ddc
@@ -1261,7 +1273,8 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
         add_inplace_kernel<<<(unsigned)cdiv(mm, 256), 256, 0, c.st>>>(dKuu, sumOm, mm);
         GPSA_LAUNCH_CHECK();
       }
-      GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 2.0, Mg, C, gamma, c.stv()));  // dK_uf = gamma + 2 qbar a
+      if (!fused_axpy)  // dK_uf = gamma + 2 qbar a
+        GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 2.0, Mg, C, gamma, c.stv()));
     } else {
       // few columns: W = gamma + qbar a;  dK_uu = -W a^T ADDED in fp64;  dK_uf = W + qbar a
       GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 1.0, Mg, C, gamma, c.stv()));

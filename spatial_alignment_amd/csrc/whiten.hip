@@ -55,10 +55,18 @@ __global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int M
 // consume it, so the accumulators are the only resident state and two workgroups share a CU (q then
 // closes against a second, cache-warm read of the column); otherwise the whole 16-column slab stays in
 // registers, one workgroup per CU -- the shorter dependency chain when the grid does not fill the chip.
+// optional fused epilogue: alpha[m,c] = (K^-1 X)[m,c] + s * d[c] * X2[m,c]  (the data GP's backward:
+// dK_uf = K^-1 abar + 2 qbar o alpha in the solve's own pass instead of a second sweep over two panels)
+struct WhitenAxpy {
+  const float* X2;
+  const float* d;
+  float s;
+};
+
 template <int MB, typename TI, typename TO, bool STREAM>
 __global__ void __launch_bounds__(256, (MB >= (STREAM ? 14 : 13)) ? 1 : 2)
 whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, int M, long long C,
-                   TO* __restrict__ alpha0, double* __restrict__ q0, long long sX) {
+                   TO* __restrict__ alpha0, double* __restrict__ q0, long long sX, WhitenAxpy ax) {
   constexpr int CHUNK = 4 * MB * 64;          // doubles per K chunk (2*MB pieces of 1 KiB)
   // problem blockIdx.y of a batch: its own packed inverse, panels at stride sX, q at stride C
   const long long pb = blockIdx.y;
@@ -141,6 +149,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
   // the accumulator row of register r is the row the lane held as B operand (4 r + kq within the
   // tile), so q = k^T alpha closes lane-locally
   double s = 0.0;
+  const double axd = (ax.X2 != nullptr && okc) ? (double)ax.s * (double)ax.d[c] : 0.0;
 #pragma unroll
   for (int rt = 0; rt < MB; ++rt) {
     double kb[4] = {0.0, 0.0, 0.0, 0.0};
@@ -153,9 +162,12 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rt * 16 + 4 * r + kq;
-      const double y = acc[rt][r];
+      double y = acc[rt][r];
       s += y * kb[r];
-      if (okc && row < M) alpha[(long long)row * C + c] = (TO)y;
+      if (okc && row < M) {
+        if (ax.X2 != nullptr) y += axd * (double)ax.X2[(long long)row * C + c];  // uniform branch
+        alpha[(long long)row * C + c] = (TO)y;
+      }
     }
   }
 #undef GPSA_WLOADB
@@ -179,7 +191,8 @@ static inline int whiten_mb_for(int M) {
 
 template <typename TI, typename TO>
 static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
-                         double* q, hipStream_t st, int batch = 1, long long sX = 0) {
+                         double* q, hipStream_t st, int batch = 1, long long sX = 0,
+                         WhitenAxpy ax = WhitenAxpy{nullptr, nullptr, 0.f}) {
   const dim3 grid((unsigned)cdiv(C, 64), (unsigned)batch);
   bool stream = q == nullptr || (long long)grid.x * batch > num_cus();
   if (const char* e = getenv("GPSA_WHITEN_STREAM")) stream = atoi(e) != 0;
@@ -187,13 +200,13 @@ static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long lon
 #define GPSA_WCASE(V)                                                                     \
   case V:                                                                                 \
     if (stream)                                                                           \
-      whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX);  \
+      whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX, ax);  \
     else                                                                                      \
-      whiten_mfma_kernel<V, TI, TO, false><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX); \
+      whiten_mfma_kernel<V, TI, TO, false><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX, ax); \
     break;
 #define GPSA_WCASE_STREAM(V)                                                              \
   case V:                                                                                 \
-    whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX); \
+    whiten_mfma_kernel<V, TI, TO, true><<<grid, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX, ax); \
     break;
   switch (MB) {
     GPSA_WCASE(2)
@@ -243,6 +256,25 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
   if (alpha_dtype == GPSA_F32)
     return whiten_launch<float, float>(MB, Apk, (const float*)Kuf, M, C, (float*)alpha, q, st);
   return whiten_launch<float, double>(MB, Apk, (const float*)Kuf, M, C, (double*)alpha, q, st);
+}
+
+/* gamma = Kinv X (fp32 panel, fp64 arithmetic) with the column-scaled update fused into the store:
+ *   out[m,c] = (Kinv X)[m,c] + s * d[c] * X2[m,c]      (X, X2, out [M,C] fp32; d [C] fp32)
+ * the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) in one pass.
+ * M as gpsa_whiten_f64; workspace >= gpsa_whiten_workspace(M). */
+int gpsa_whiten_axpy_f32(const double* Kinv, const float* X, int M, long long C, const float* X2, const float* d,
+                         double s, float* out, void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || !Kinv || !X || !X2 || !d || !out) return GPSA_EINVAL;
+  const int MB = whiten_mb_for(M);
+  if (MB == 0) return GPSA_EUNSUPPORTED;
+  if (workspace_bytes < gpsa_whiten_workspace(M)) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* Apk = (double*)workspace;
+  const long long tot = (long long)MB * 4 * MB * 64;
+  pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+  GPSA_LAUNCH_CHECK();
+  return whiten_launch<float, float>(MB, Apk, X, M, C, out, nullptr, st, 1, 0, WhitenAxpy{X2, d, (float)s});
 }
 
 /* batch of fp64 -> fp64 projections with one inverse each (the views' warp GPs): problem b reads

@@ -126,6 +126,23 @@ def test_whiten_batched(hip, M, Cs, B):
         assert (alpha[b] - ref).norm() <= 1e-12 * ref.norm()
 
 
+@pytest.mark.parametrize("M,C", [(200, 5000), (50, 333), (300, 1000)])
+def test_whiten_with_fused_column_update(hip, M, C):
+    """gpsa_whiten_axpy_f32 = gpsa_whiten_f64 on an fp32 panel followed by gpsa_col_axpy, in one pass"""
+    A = rnd(M, M, dtype=f64, seed=1).to(DEV)
+    Kinv = (A @ A.t() / M + torch.eye(M, dtype=f64, device=DEV)).contiguous()
+    X, X2, d = rnd(M, C, seed=2).to(DEV), rnd(M, C, seed=3).to(DEV), rnd(C, seed=4).to(DEV)
+    out = torch.empty(M, C, dtype=f32, device=DEV)
+    wsb = int(hip.lib.gpsa_whiten_workspace(M))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    assert hip.lib.gpsa_whiten_axpy_f32(p(Kinv), p(X), M, C, p(X2), p(d), 2.0, p(out), p(ws), wsb, stream()) == 0
+    gamma, _ = hip.whiten(Kinv, X, f32, want_q=False)
+    want = (Kinv @ X.double() + 2.0 * d.double().unsqueeze(0) * X2.double())
+    assert (out.double() - want).norm() <= 2e-7 * want.norm()
+    two_pass = hip.col_axpy(gamma, X2, d, 2.0)
+    assert (out - two_pass).abs().max() <= 4e-7 * float(want.abs().max())  # one rounding instead of two
+
+
 @pytest.mark.parametrize("M,Cs,L,B", [(200, 320, 2, 3), (40, 64, 3, 2)])
 def test_keep_forms_batched(hip, M, Cs, L, B):
     alpha = rnd(B, M, Cs, dtype=f64, seed=1).to(DEV)

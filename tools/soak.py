@@ -21,7 +21,9 @@ model = make_model(dd_cpu, m=200, device=dev)
 dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
           "n_samples_list": d["n_samples_list"]} for m, d in dd_cpu.items()}
 view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
-opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+from spatial_alignment_amd.optim import FusedAdam  # noqa: E402
+
+opt = FusedAdam(model.parameters(), lr=1e-2)
 torch.manual_seed(0)
 losses = []
 torch.cuda.synchronize()
