@@ -309,6 +309,229 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Blocked form of the fused factorisation (M <= 208): the same register-resident 2-D cyclic layout, but the
+// columns are processed in panels of 16 with TWO block barriers per panel instead of one per column.
+//   (1) the panel's columns t(:, J) and the row block's partial inverse t(J, <J) go to LDS        [barrier]
+//   (2) every wave factorises the 16 x 16 diagonal block for itself (one row per lane, cross-lane reads:
+//       no barrier, no waiting for a designated wave);
+//   (3) one thread per row below the block solves L(i,J) L_JJ^T = A(i,J) (forward substitution over 16
+//       columns), one thread per column k < J_end solves L_JJ X(J,k) = T(J,k) (T = e_k inside the block):
+//       rows + columns = 16 NT <= 256 threads, all independent                                    [barrier]
+//   (4) the row block of t becomes final X(J, :); every row below gets the rank-16 update
+//           t(i,k) (-)= sum_{j in J} L(i,j) w_j(k),   w_j(k) = L(k,j) for k > J,  X(j,k) for k <= J_end
+//       (positions k in J start from zero: L(i,j) leaves, X(i,j) enters) - the same FMAs the per-column
+//       kernel issues, without its 16 barriers and 16 dependent pivot chains.
+// 167 -> (see DESIGN) us for the 57 matrices of a step; the dependent chain per matrix is what a step waits for.
+constexpr int CB_LS = 18;  // LDS row stride (doubles) of the panel buffers: conflict-free 16-byte reads
+
+// LDS-qualified pointers: the helpers below are real functions (one copy for all panels); with generic
+// pointers every access would be a flat load
+typedef __attribute__((address_space(3))) double lds_f64;
+
+// 16 x 16 Cholesky of the diagonal block by ONE wave (lane l holds row l & 15): D row-major, stride CB_LS.
+// Step r: the lanes publish column r (their row's entry) to this wave's 16-double buffer, every lane reads
+// the pivot and the entries of the rows c > r back (broadcast reads, no cross-lane instructions).
+// Writes this wave's copy of the factor (Ld, row-major [16][16]) and the pivots' inverses; returns 0 or
+// 1 + the global column of the first non-positive pivot.
+__device__ __noinline__ int chol16_wave(const lds_f64* D, lds_f64* Ld, lds_f64* dinv, lds_f64* colbuf, int j0,
+                                        int M) {
+  const int lane = threadIdx.x & 63, row = lane & 15;
+  double P[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) P[c] = D[row * CB_LS + c];
+  int bad = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (lane < 16) colbuf[row] = P[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double d = colbuf[r];
+    if (j0 + r >= M) d = 1.0;  // identity padding beyond the matrix
+    if (!(d > 0.0)) {
+      if (!bad) bad = j0 + r + 1;
+      d = 1.0;
+    }
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y0), y0, 1.0);
+    const double inv = fma(y0 * e, fma(0.375, e, 0.5), y0);
+    if (lane == 0) dinv[r] = inv;
+    const double mine = P[r] * inv;
+    P[r] = mine;
+    const double mi = mine * inv;  // L(i,r) L(c,r) = (P(i,r) inv) (P(c,r) inv)
+#pragma unroll
+    for (int c = r + 1; c < 16; ++c) P[c] = fma(-mi, colbuf[c], P[c]);
+    __builtin_amdgcn_wave_barrier();  // the buffer is rewritten by the next step
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Ld[lane * 16 + c] = P[c];
+  }
+  return bad;
+}
+
+// step (3): threads [0, R-16): row 16 + t of the panel; threads [R-16, R+i0): column k = t - (R-16) of X(J, :)
+__device__ __noinline__ void panel_solves(lds_f64* Lp, int R, const lds_f64* Ld, const lds_f64* dinv,
+                                          const lds_f64* Tb, int MP, lds_f64* XpT, int i0) {
+  const int t = threadIdx.x, na = R - 16;
+  if (t < na) {
+    lds_f64* a = Lp + (16 + t) * CB_LS;
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = a[c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {  // (four partial sums per c were measured SLOWER: 33 -> 45 us per 13 panels)
+      double s = x[c];
+#pragma unroll
+      for (int m = 0; m < c; ++m) s = fma(-x[m], Ld[c * 16 + m], s);
+      x[c] = s * dinv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = x[c];
+  } else if (t < na + i0 + 16) {
+    const int k = t - na;
+    double x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = (k < i0) ? Tb[j * MP + k] : ((k - i0 == j) ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double s = x[j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) s = fma(-Ld[j * 16 + m], x[m], s);
+      x[j] = s * dinv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) XpT[k * CB_LS + j] = x[j];
+  }
+}
+
+static inline long long chol_blk_lds_bytes(int NT) {
+  const long long MP = NT * 16;
+  return (3 * MP * CB_LS + 16 * MP + 4 * 256 + 4 * 16 + 4 * 16 + MP + 8) * 8;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Linv,
+                    double* __restrict__ logdet, int* __restrict__ info, int skip) {
+  constexpr int MP = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* Lp0 = sm;                       // [MP][CB_LS]  panel (rows >= i0 of the 16 columns), buffer 0
+  double* Lp1 = Lp0 + MP * CB_LS;         //              buffer 1
+  double* XpT = Lp1 + MP * CB_LS;         // [MP][CB_LS]  XpT[k][jj] = X(i0 + jj, k)
+  double* Tb = XpT + MP * CB_LS;          // [16][MP]     partial inverse rows of the block
+  double* Ldw = Tb + 16 * MP;             // [4][256]     per-wave copy of the diagonal block's factor
+  double* dinvw = Ldw + 4 * 256;          // [4][16]
+  double* colw = dinvw + 4 * 16;          // [4][16]     per-wave column buffer of the block factorisation
+  double* sdiag = colw + 4 * 16;          // [MP]
+  __shared__ double red[16];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* G = A + (long long)blockIdx.x * M * M;
+  double* O = Linv + (long long)blockIdx.x * M * M;
+  double t[NT][NT];
+#pragma unroll
+  for (int qa = 0; qa < NT; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+      const int i = 16 * qa + ty, k = 16 * qb + tx;
+      t[qa][qb] = (qb <= qa) ? ((i < M && k < M) ? G[(long long)i * M + k] : (i == k ? 1.0 : 0.0)) : 0.0;
+    }
+  int bad = 0;
+#pragma unroll
+  for (int q0 = 0; q0 < NT; ++q0) {
+    const int i0 = 16 * q0;
+    if (i0 >= M || bad) break;  // uniform
+    double* Lp = (q0 & 1) ? Lp1 : Lp0;
+    const int R = MP - i0;
+    // (1) publish the panel and the row block's partial inverse
+#pragma unroll
+    for (int qa = q0; qa < NT; ++qa) Lp[((qa - q0) * 16 + ty) * CB_LS + tx] = t[qa][q0];
+#pragma unroll
+    for (int qb = 0; qb < q0; ++qb) Tb[ty * MP + 16 * qb + tx] = t[q0][qb];
+    __syncthreads();
+    // (2) diagonal block, every wave for itself
+    if (!(skip & 1)) bad = chol16_wave((const lds_f64*)Lp, (lds_f64*)(Ldw + w * 256), (lds_f64*)(dinvw + w * 16),
+                      (lds_f64*)(colw + w * 16), i0, M);
+    if (tid < 16) sdiag[i0 + tid] = dinvw[tid];  // wave 0's copy (written by its lane 0 above; same wave)
+    if (bad) break;  // uniform: every wave factorised the same block
+    // (3) panel rows and X columns, one thread each
+    if (!(skip & 2)) panel_solves((lds_f64*)Lp, R, (const lds_f64*)(Ldw + w * 256), (const lds_f64*)(dinvw + w * 16),
+                 (const lds_f64*)Tb, MP, (lds_f64*)XpT, i0);
+    __syncthreads();
+    // (4) the row block of t is final; rank-16 update of the rows below
+#pragma unroll
+    for (int qb = 0; qb <= q0; ++qb) t[q0][qb] = XpT[(16 * qb + tx) * CB_LS + ty];
+    if (q0 + 1 < NT && !(skip & 4)) {
+#pragma unroll
+      for (int qa = q0 + 1; qa < NT; ++qa) t[qa][q0] = 0.0;  // L(i,J) left for LDS, X(i,J) accumulates from zero
+#pragma unroll 1
+      for (int jj = 0; jj < 16; jj += 2) {
+        double2 li[NT], wv[NT];
+#pragma unroll
+        for (int qa = q0 + 1; qa < NT; ++qa)
+          li[qa] = *reinterpret_cast<const double2*>(&Lp[((qa - q0) * 16 + ty) * CB_LS + jj]);
+#pragma unroll
+        for (int qb = 0; qb < NT; ++qb) {
+          if (qb > q0) wv[qb] = *reinterpret_cast<const double2*>(&Lp[((qb - q0) * 16 + tx) * CB_LS + jj]);
+          else wv[qb] = *reinterpret_cast<const double2*>(&XpT[(16 * qb + tx) * CB_LS + jj]);
+        }
+#pragma unroll
+        for (int qa = q0 + 1; qa < NT; ++qa)
+#pragma unroll
+          for (int qb = 0; qb <= qa; ++qb)
+            t[qa][qb] = fma(-li[qa].y, wv[qb].y, fma(-li[qa].x, wv[qb].x, t[qa][qb]));
+      }
+    }
+  }
+  __syncthreads();
+  double lg = 0.0;
+  if (!bad)
+    for (int j = tid; j < M; j += 256) lg -= log(sdiag[j]);  // sdiag = 1 / L(j,j)
+  lg = block_sum(lg, red);
+  if (tid == 0) {
+    logdet[blockIdx.x] = bad ? __builtin_nan("") : 2.0 * lg;
+    info[blockIdx.x] = bad;
+  }
+#pragma unroll
+  for (int qa = 0; qa < NT; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+      const int i = 16 * qa + ty, k = 16 * qb + tx;
+      if (i < M && k < M) O[(long long)i * M + k] = (qb <= qa && k <= i) ? t[qa][qb] : 0.0;
+    }
+}
+
+template <int NT>
+static int chol_inv_blk_launch_nt(const double* A, int M, double* Linv, double* logdet, int* info, int batch,
+                                  hipStream_t st) {
+  static bool attr_set = false;
+  const long long lds = chol_blk_lds_bytes(NT);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_blk_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GPSA_EUNSUPPORTED;
+    attr_set = true;
+  }
+  // timing-only experiments (results are then wrong): bit 0 skips the block factorisation, 1 the solves, 2 the update
+  static const int skip = [] { const char* e = getenv("GPSA_CHOL_SKIP"); return e ? atoi(e) : 0; }();
+  chol_inv_blk_kernel<NT><<<batch, 256, (size_t)lds, st>>>(A, M, Linv, logdet, info, skip);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+// contiguous batch, M <= 208: the blocked kernel (GPSA_CHOL_BLOCKED=0 falls back to one barrier per column)
+static int chol_inv_blk_launch(const double* A, int M, double* Linv, double* logdet, int* info, int batch,
+                               hipStream_t st) {
+  const int nt = (M + 15) / 16;
+  if (nt <= 2) return chol_inv_blk_launch_nt<2>(A, M, Linv, logdet, info, batch, st);
+  if (nt <= 4) return chol_inv_blk_launch_nt<4>(A, M, Linv, logdet, info, batch, st);
+  if (nt <= 7) return chol_inv_blk_launch_nt<7>(A, M, Linv, logdet, info, batch, st);
+  if (nt <= 10) return chol_inv_blk_launch_nt<10>(A, M, Linv, logdet, info, batch, st);
+  if (nt <= 13) return chol_inv_blk_launch_nt<13>(A, M, Linv, logdet, info, batch, st);
+  return GPSA_EUNSUPPORTED;
+}
+
 // out[b] = sum_i A[b,i]*B[b,i]; grid (batch, nsplit): partial sums per split in part[b*nsplit+s], then summed
 template <typename T>
 __global__ void bdot_kernel(const T* __restrict__ A, long long sA, const T* __restrict__ B,
@@ -482,6 +705,11 @@ int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet,
                       void* stream) {
   using namespace gpsa;
   if (M < 1 || batch < 1) return GPSA_EINVAL;
+  static const bool blocked = [] { const char* e = getenv("GPSA_CHOL_BLOCKED"); return !(e && e[0] == '0'); }();
+  if (blocked && M <= 208) {
+    int rc = chol_inv_blk_launch((const double*)A, M, (double*)Linv, (double*)logdet, info, batch, as_stream(stream));
+    if (rc != GPSA_EUNSUPPORTED) return rc;
+  }
   return chol_inv_reg_launch((const double*)A, M, (double*)Linv, (double*)logdet, info, M,
                              (long long)M * M, M, (long long)M * M, 0, 0, batch, as_stream(stream));
 }
