@@ -167,7 +167,11 @@ __global__ void __launch_bounds__(256, 4)
 gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A, long long lda,
                  long long sA, const TIB* __restrict__ B, long long ldb, long long sB, TC beta,
                  TO* __restrict__ C, long long ldc, long long sC, int splitk, TC* __restrict__ part,
-                 TC diag = TC(0), int tri = 0) {
+                 TC diag = TC(0), int tri = 0, const TIB* __restrict__ kscale = nullptr, long long sKs = 0,
+                 const TIB* __restrict__ cscale = nullptr, long long sCs = 0) {
+  // kscale (with !TA): the left operand is A[m][k] * kscale[b][k] (a column-scaled panel alpha o g contracted
+  //   along its columns without materialising it: the Gram product sum_c g a a^T);
+  // cscale: the result's column n is scaled by cscale[b][n] (Omega (alpha o g) = (Omega alpha) o g).
   // tri = GEMM_TRI_UPPER_A: op(A) is upper triangular (square, m == k): block row m0 contracts k >= m0 only
   //       (the symmetric quadratic form a^T Omega a = a^T (diag + 2 strict-upper) a at half the flops);
   // tri = GEMM_TRI_LOWER_C: only the blocks of C that touch its lower triangle are computed (a symmetric
@@ -215,6 +219,10 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
     const long long lim_a = TA ? ((gk < kend) ? (long long)m - gr : 0)                    \
                                : ((gr < m) ? kend - gk : 0);                              \
     load4<TIA, TC>(pa, va_ok, lim_a, ra[g_]);                                             \
+    if (!TA && kscale != nullptr) {                                                       \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
+        if (i < lim_a) ra[g_][i] *= (TC)kscale[(long long)b * sKs + gk + i];              \
+    }                                                                                     \
     if (SYMA) {                                                                           \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
         if (i < lim_a) ra[g_][i] += (TC)(TA ? Ab[(gr + i) * lda + gk] : Ab[(gk + i) * lda + gr]); \
@@ -271,7 +279,8 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm + tm * 16 + MfmaTile<TC>::row(kq, r), col = n0 + wn + tn * 16 + j;
         if (row < m && col < n) {
-          const TC y = acc[tm][tn][r];
+          TC y = acc[tm][tn][r];
+          if (cscale != nullptr) y *= (TC)cscale[(long long)b * sCs + col];
           if (splitk == 1) {
             TO* p = C + (long long)b * sC + (long long)row * ldc + col;
             TC v = (beta == TC(0)) ? alpha * y : alpha * y + beta * (TC)(*p);
@@ -329,6 +338,12 @@ int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double al
                     long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
                     T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
                     long long ws_bytes, hipStream_t st, int tri);
+template <typename T>
+int gemm_launch_scaled(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                       long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
+                       T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
+                       long long ws_bytes, hipStream_t st, int tri, const T* kscale, long long sKs,
+                       const T* cscale, long long sCs);
 
 template <typename T>
 int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
@@ -344,7 +359,19 @@ int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double al
                     long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
                     T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
                     long long ws_bytes, hipStream_t st, int tri) {
+  return gemm_launch_scaled<T>(transA, transB, m, n, k, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch,
+                               splitk, ws, ws_bytes, st, tri, nullptr, 0, nullptr, 0);
+}
+
+// + kscale [batch][k] on the (non-transposed) left operand's K index, cscale [batch][n] on the result's columns
+template <typename T>
+int gemm_launch_scaled(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
+                       long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
+                       T* C, long long ldc, long long sC, int batch, int splitk, void* ws,
+                       long long ws_bytes, hipStream_t st, int tri, const T* kscale, long long sKs,
+                       const T* cscale, long long sCs) {
   if (m < 1 || n < 1 || k < 1 || batch < 1 || splitk < 1) return GPSA_EINVAL;
+  if (kscale != nullptr && transA) return GPSA_EINVAL;
   if (tri != GEMM_TRI_NONE && (splitk != 1 && tri == GEMM_TRI_UPPER_A)) return GPSA_EINVAL;
   if ((long long)batch * splitk > 65535) return GPSA_EINVAL;
   T* part = nullptr;
@@ -358,10 +385,12 @@ int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double al
                                                (T)beta, C, ldc, sC, splitk, part)
 #define GPSA_GEMMX_CASE(TA, TB)                                                                     \
   gemm_mfma_kernel<T, TA, TB><<<grid, 256, 0, st>>>(m, n, k, (T)alpha, A, lda, sA, B, ldb, sB, (T)beta, \
-                                                    C, ldc, sC, splitk, part, T(0), tri)
+                                                    C, ldc, sC, splitk, part, T(0), tri, kscale, sKs, cscale, sCs)
   // products with at least one MFMA tile in each direction run on the matrix cores (always with a triangle
-  // mode: only that kernel knows them)
-  const bool mfma = (m >= 16 && n >= 16 && !gemm_force_vector()) || tri != GEMM_TRI_NONE;
+  // mode or a scale vector: only that kernel knows them)
+  const bool mfma = (m >= 16 && n >= 16 && !gemm_force_vector()) || tri != GEMM_TRI_NONE || kscale != nullptr ||
+                    cscale != nullptr;
+  if (cscale != nullptr && splitk != 1) return GPSA_EINVAL;  // the split-K reduce does not know the scale
   if (mfma) {
     if (!transA && !transB) GPSA_GEMMX_CASE(false, false);
     else if (transA && !transB) GPSA_GEMMX_CASE(true, false);
@@ -459,6 +488,14 @@ GPSA_G64_INST(double, double, float)  // alpha = K^-1 K_uf stored fp32 beyond th
 #undef GPSA_G64_INST
 
 // explicit instantiations used from other translation units
+template int gemm_launch_scaled<float>(int, int, int, int, long long, double, const float*, long long, long long,
+                                       const float*, long long, long long, double, float*, long long, long long,
+                                       int, int, void*, long long, hipStream_t, int, const float*, long long,
+                                       const float*, long long);
+template int gemm_launch_scaled<double>(int, int, int, int, long long, double, const double*, long long, long long,
+                                        const double*, long long, long long, double, double*, long long, long long,
+                                        int, int, void*, long long, hipStream_t, int, const double*, long long,
+                                        const double*, long long);
 template int gemm_launch_tri<float>(int, int, int, int, long long, double, const float*, long long,
                                     long long, const float*, long long, long long, double, float*,
                                     long long, long long, int, int, void*, long long, hipStream_t, int);

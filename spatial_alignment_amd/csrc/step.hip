@@ -1231,7 +1231,6 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     const bool timed = !dry && &ps == &P.passes[0];
     if (timed) P.tick(2, 0, false, c.st);
     int rc = dry ? 0 : gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F64, alpha, g_ext, Mg, C, L, dst, ws, wsb, c.stv());
-    if (timed) { P.tick(2, 1, false, c.st); ++P.tbwd; }
     if (rc == GPSA_EUNSUPPORTED) {  // generic path stores in the compute type: convert
       float* tmp = c.sc.get<float>((long long)L * mm);
       GPSA_RUN(gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F32, alpha, g_ext, Mg, C, L, tmp, ws, wsb, c.stv()));
@@ -1243,6 +1242,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     } else if (rc != 0) {
       return rc;
     }
+    if (timed) { P.tick(2, 1, false, c.st); ++P.tbwd; }
     if (dry) (void)c.sc.get<float>((long long)L * mm);
     if (!first_for_mod && !dry) {
       add_inplace_kernel<<<(unsigned)cdiv((long long)L * mm, 256), 256, 0, c.st>>>(dOm, dst, (long long)L * mm);

@@ -16,7 +16,7 @@ import spatial_alignment_amd as gp  # noqa: E402
 from spatial_alignment_amd.synthetic import make_grid_problem, make_model  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dev = torch.device("cuda:0")
 CFG = {
     # 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2 warp / RBF data
@@ -31,6 +31,8 @@ model = make_model(dd_cpu, m=CFG["M"], n_latent_gps={"expression": CFG["latent"]
                    device=dev, kernel_func_warp=CFG["warp"], kernel_func_data=gp.rbf_kernel)
 dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
           "n_samples_list": d["n_samples_list"]} for m, d in dd_cpu.items()}
+if os.environ.get("GPSA_NOCHECK") == "1":
+    model.check_numerics = False
 view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
 Xs = {m: d["spatial_coords"] for m, d in dd.items()}
 from spatial_alignment_amd.optim import FusedAdam  # noqa: E402
@@ -47,14 +49,34 @@ def step():
     return loss
 
 
-for _ in range(2):
+for _ in range(4):  # allocator growth and first-use code loading settle within the first steps
     l0 = step()
 torch.cuda.synchronize()
+import ctypes  # noqa: E402
+
+plans = [p for p in model.__dict__.get("_step_plans", {}).values() if p.S == CFG["S"]]
+if os.environ.get("GPSA_NOTIMING") == "1":
+    plans = []
+for p in plans:
+    p.lib.gpsa_step_timing(p.handle, steps)
 t0 = time.perf_counter()
 for _ in range(steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+# the three contraction ops of the (first modality's) data GP, timed by the engine on its launch stream:
+# op-level rates on the nominal 2*C*L*M^2 flops (M > 256: an op is several launches - operand preparation,
+# the tiled product with its triangle mode, the closing reduction)
+for p in plans:
+    buf = (ctypes.c_float * (3 * steps))()
+    n = p.lib.gpsa_step_timing_read(p.handle, buf, steps)
+    p.lib.gpsa_step_timing(p.handle, 0)
+    if n > 0:
+        C_, L_, M_ = CFG["S"] * CFG["views"] * CFG["side"] ** 2, CFG["latent"], CFG["M"]
+        fl = 2.0 * C_ * L_ * M_ * M_
+        for k, name in enumerate(("variance form a^T Omega a", "its alpha-gradient (ACCUM)", "its Omega-gradient (Gram)")):
+            ms = sum(buf[i * 3 + k] for i in range(n)) / n
+            print(f"  {name:32s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TF nominal = {fl / ms / 1e9 / 157.3:.2f} of the fp32-MFMA peak")
 print(f"{which}: {CFG['views']} views x {CFG['side'] ** 2} spots, {CFG['outputs']} outputs via {CFG['latent']} latent GPs, "
       f"M={CFG['M']}, S={CFG['S']}: {dt * 1e3:.2f} ms/step, loss {float(l0):.4g} -> {float(loss):.4g}, "
       f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
