@@ -208,6 +208,7 @@ def main():
               flush=True)
         return
     from spatial_alignment_amd.optim import FusedAdam
+    from spatial_alignment_amd.train import backward as train_backward
 
     opt = FusedAdam(model.parameters(), lr=1e-2)  # torch.optim.Adam's update as one HIP launch
     reducer = GradAllReducer(model.parameters())
@@ -218,7 +219,7 @@ def main():
         out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=args.S)
         loss = model.loss_fn(dd, out[3])
         opt.zero_grad(set_to_none=not args.static_grads)
-        loss.backward()
+        train_backward(loss)  # loss.backward() with the seed gradient kept on the device
         reducer()
         opt.step()
         return loss

@@ -78,6 +78,13 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
 int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omega, void* stream);
 int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, int symmetric, float* dA,
                    void* stream);
+/* The same over TWO parameter tensors in one launch (the warp GPs' Omega_sqt_G_list, vgpsa.py:131-143, and a
+ * modality's Omega_sqt_F_dict entry, :145-153, which share M when m_X_per_view == m_G): segment 0 has n0
+ * matrices, segment 1 n1 (0: absent). */
+int gpsa_omega_fwd2(const float* A0, int n0, double* Omega0, const float* A1, int n1, double* Omega1, int M,
+                    double jitter, void* stream);
+int gpsa_omega_bwd2(const double* G0, const float* A0, float* dA0, int n0, const double* G1, const float* A1,
+                    float* dA1, int n1, int M, int symmetric, void* stream);
 
 /* ---- inducing-point factorisations (fp64, batched, one workgroup per matrix) -----------------
  * gpsa_chol_f64: in-place lower Cholesky of A[b] (upper triangle zeroed); logdet[b] = 2*sum(log diag);
@@ -437,7 +444,9 @@ int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_st
 /* ---- Gaussian likelihood + ELBO in one call each way (vgpsa.py:532-540) ------------------------------------
  * loss[0] = -(sum_i LL_i) + kl_scale * sum_t kl[t],  LL_i = sum log N(Y_i; F_i, exp(noise_u[i]) + 1e-5) / S_i
  * (n_ll likelihood terms: one per modality; F_i [S, N_i, P_i], Y_i [N_i, P_i]; kl [n_kl] fp64 or NULL).
- * backward: dF_i (overwritten), dnoise[i] (overwritten), dkl[t] = kl_scale * gloss.
+ * backward: dF_i (overwritten), dnoise[i] (overwritten), dkl[t] = kl_scale * gloss; dnoise_all [n_noise] or NULL:
+ * the whole noise-gradient vector the dnoise[i] point into, zero-filled first (the reference's noise_variance
+ * holds entries no likelihood term reads, vgpsa.py:217 / :534).
  * workspace >= 8 * 4100 * n_ll bytes. */
 int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
                        const int* S, const long long* N, const int* P, const double* kl, int n_kl,
@@ -445,8 +454,8 @@ int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, c
                        long long workspace_bytes, void* stream);
 int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
                        const int* S, const long long* N, const int* P, const float* gloss, int n_kl,
-                       double kl_scale, float* const* dF, float* const* dnoise, double* dkl, void* workspace,
-                       long long workspace_bytes, void* stream);
+                       double kl_scale, float* const* dF, float* const* dnoise, float* dnoise_all, int n_noise,
+                       double* dkl, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- fused Adam over a list of tensors (torch.optim.Adam, no weight decay / amsgrad; the optimiser step of
  * the reference loop, examples/grid_example.py:59-78), ONE launch: for every element

@@ -24,6 +24,8 @@ SIGNATURES = {
                        _i, _i, _vp, _ll, _vp]),
     "gpsa_omega_fwd": (_i, [_vp, _i, _i, _d, _vp, _vp]),
     "gpsa_omega_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gpsa_omega_fwd2": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _d, _vp]),
+    "gpsa_omega_bwd2": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gpsa_chol_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -142,7 +144,7 @@ SIGNATURES.update({
     "gpsa_elbo_loss_fwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _vp, _i, _d, _vp,
                                 _vp, _vp, _ll, _vp]),
     "gpsa_elbo_loss_bwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _vp, _i, _d, _pp, _pp,
-                                _vp, _vp, _ll, _vp]),
+                                _vp, _i, _vp, _vp, _ll, _vp]),
     "gpsa_adam_step": (_i, [_i, _pp, _pp, _pp, _pp, C.POINTER(_ll), _d, _d, _d, _d, _vp, _vp]),
 })
 

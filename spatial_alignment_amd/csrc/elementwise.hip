@@ -359,8 +359,13 @@ __global__ void loglik_bwd_finish_kernel(const double* __restrict__ part, int n,
                                          const double* __restrict__ gout, int S,
                                          float* __restrict__ dnoise_u, const float* __restrict__ gloss = nullptr,
                                          double* __restrict__ dkl = nullptr, int n_kl = 0,
-                                         double kl_scale = 0.0) {
+                                         double kl_scale = 0.0, float* __restrict__ zero_base = nullptr,
+                                         int zero_n = 0) {
   __shared__ double red[4];
+  if (zero_base != nullptr) {  // the whole noise-gradient vector starts at zero (entries no term names stay so)
+    for (int t = threadIdx.x; t < zero_n; t += blockDim.x) zero_base[t] = 0.f;
+    __syncthreads();
+  }
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
   s = block_sum(s, red);
@@ -587,8 +592,8 @@ int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, c
 
 int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
                        const int* S, const long long* N, const int* P, const float* gloss, int n_kl, double kl_scale,
-                       float* const* dF, float* const* dnoise, double* dkl, void* workspace, long long workspace_bytes,
-                       void* stream) {
+                       float* const* dF, float* const* dnoise, float* dnoise_all, int n_noise, double* dkl,
+                       void* workspace, long long workspace_bytes, void* stream) {
   if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !gloss || !dF || !dnoise)
     return GPSA_EINVAL;
   if (workspace_bytes < 8LL * 4100 * n_ll) return GPSA_EWORKSPACE;
@@ -601,7 +606,8 @@ int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, c
     gpsa::loglik_bwd_kernel<<<nb, 256, 0, st>>>(F[i], Y[i], noise_u[i], nullptr, S[i], tot, NP, dF[i], part, gloss);
     // the first term's finishing launch also writes dkl
     gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(part, nb, noise_u[i], nullptr, S[i], dnoise[i], gloss,
-                                                      i == 0 ? dkl : nullptr, n_kl, kl_scale);
+                                                      i == 0 ? dkl : nullptr, n_kl, kl_scale,
+                                                      i == 0 ? dnoise_all : nullptr, n_noise);
   }
   GPSA_LAUNCH_CHECK();
   return 0;

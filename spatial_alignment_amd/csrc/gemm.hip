@@ -2,12 +2,21 @@
 // Used for the small M x M inducing-point algebra (fp64) and as the shape-generic path next to the
 // MFMA panel kernels in quadform.hip.  Replaces torch.matmul / torch.mm calls of
 // gpsa/models/vgpsa.py:179-196, 207-210, 227, 302, 430.
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace gpsa {
 
 constexpr int GB_M = 64, GB_N = 64, GB_K = 16;
-enum { GEMM_TRI_NONE = 0, GEMM_TRI_UPPER_A = 1, GEMM_TRI_LOWER_C = 2 };
+
+// second segment of a batch: problems b >= nb0 take their operands / result from these bases (index b - nb0,
+// same strides and leading dimensions): one launch over matrices that live in two separate parameter tensors
+template <typename TIA, typename TIB, typename TO>
+struct GemmSeg2 {
+  int nb0;
+  const TIA* A;
+  const TIB* B;
+  TO* C;
+};
 
 template <typename T, bool TA, bool TB>
 __global__ void __launch_bounds__(256, 4)
@@ -168,7 +177,8 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
                  long long sA, const TIB* __restrict__ B, long long ldb, long long sB, TC beta,
                  TO* __restrict__ C, long long ldc, long long sC, int splitk, TC* __restrict__ part,
                  TC diag = TC(0), int tri = 0, const TIB* __restrict__ kscale = nullptr, long long sKs = 0,
-                 const TIB* __restrict__ cscale = nullptr, long long sCs = 0) {
+                 const TIB* __restrict__ cscale = nullptr, long long sCs = 0,
+                 GemmSeg2<TIA, TIB, TO> seg2 = GemmSeg2<TIA, TIB, TO>{0x7fffffff, nullptr, nullptr, nullptr}) {
   // kscale (with !TA): the left operand is A[m][k] * kscale[b][k] (a column-scaled panel alpha o g contracted
   //   along its columns without materialising it: the Gram product sum_c g a a^T);
   // cscale: the result's column n is scaled by cscale[b][n] (Omega (alpha o g) = (Omega alpha) o g).
@@ -176,21 +186,34 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
   //       (the symmetric quadratic form a^T Omega a = a^T (diag + 2 strict-upper) a at half the flops);
   // tri = GEMM_TRI_LOWER_C: only the blocks of C that touch its lower triangle are computed (a symmetric
   //       product such as sum_c g a a^T; the caller mirrors them) - the others are left untouched.
-  if (tri == GEMM_TRI_LOWER_C && (int)(blockIdx.x * GB_N) > (int)(blockIdx.y * GB_M) + GB_M - 1) return;
+  // tri = GEMM_TRI_LTL (TA, !TB, A == B square lower triangular, split-K 1): C = A^T A contracts k >= max(i, j)
+  //       only; the blocks touching the lower triangle are computed and written to both halves
+  //       (K^-1 = L^-T L^-1 at a third of the block products).
+  if ((tri == GEMM_TRI_LOWER_C || tri == GEMM_TRI_LTL) &&
+      (int)(blockIdx.x * GB_N) > (int)(blockIdx.y * GB_M) + GB_M - 1)
+    return;
   typedef typename MfmaTile<TC>::vec acc_t;
-  // K tile of 16 (32 was tried: fewer resident workgroups, 20-40 % slower on every shape used here)
+  // K tile of 16 (32 was tried: fewer resident workgroups, 20-40 % slower on every shape used here; fetching TWO
+  // tiles ahead through a second register set was tried too: 10 % slower at M = 1000, no gain on the small batches)
   constexpr int GK = 16, NG = GK / 16;
   __shared__ TC As[2][GK][GB_M + 4];  // double-buffered: one barrier per K tile
   __shared__ TC Bs[2][GK][GB_N + 4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32, wn = (w & 1) * 32, j = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.z / splitk, sp = blockIdx.z % splitk;
+  int b = blockIdx.z / splitk;
+  const int sp = blockIdx.z % splitk;
+  if (b >= seg2.nb0) {  // block-uniform
+    b -= seg2.nb0;
+    A = seg2.A;
+    B = seg2.B;
+    C = seg2.C;
+  }
   const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
   long long kchunk = (k + splitk - 1) / splitk;
   kchunk = (kchunk + GK - 1) / GK * GK;
   long long kbeg = (long long)sp * kchunk;
   const long long kend = (kbeg + kchunk < k) ? kbeg + kchunk : k;
-  if (tri == GEMM_TRI_UPPER_A && kbeg < m0) kbeg = m0;  // m0 is a multiple of the K tile
+  if ((tri == GEMM_TRI_UPPER_A || tri == GEMM_TRI_LTL) && kbeg < m0) kbeg = m0;  // m0: a multiple of the K tile
   const TIA* Ab = A + (long long)b * sA;
   const TIB* Bb = B + (long long)b * sB;
   acc_t acc[2][2];
@@ -286,6 +309,7 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
             TC v = (beta == TC(0)) ? alpha * y : alpha * y + beta * (TC)(*p);
             if (row == col) v += diag;
             *p = (TO)v;
+            if (tri == GEMM_TRI_LTL) C[(long long)b * sC + (long long)col * ldc + row] = (TO)v;
           } else {
             part[((long long)blockIdx.z * m + row) * n + col] = y;
           }
@@ -372,7 +396,8 @@ int gemm_launch_scaled(int transA, int transB, int m, int n, long long k, double
                        const T* cscale, long long sCs) {
   if (m < 1 || n < 1 || k < 1 || batch < 1 || splitk < 1) return GPSA_EINVAL;
   if (kscale != nullptr && transA) return GPSA_EINVAL;
-  if (tri != GEMM_TRI_NONE && (splitk != 1 && tri == GEMM_TRI_UPPER_A)) return GPSA_EINVAL;
+  if (splitk != 1 && (tri == GEMM_TRI_UPPER_A || tri == GEMM_TRI_LTL)) return GPSA_EINVAL;
+  if (tri == GEMM_TRI_LTL && (!transA || transB || m != n || m != k || A != B)) return GPSA_EINVAL;
   if ((long long)batch * splitk > 65535) return GPSA_EINVAL;
   T* part = nullptr;
   if (splitk > 1) {
@@ -536,11 +561,19 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
 
 /* Omega[b] = A[b] A[b]^T + jitter I in fp64 from the fp32 parameter, one launch */
 int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omega, void* stream) {
-  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  return gpsa_omega_fwd2(A, batch, Omega, nullptr, 0, nullptr, M, jitter, stream);
+}
+
+/* the same over two parameter tensors in ONE launch (the warp GPs' and a modality's variational factors):
+ * Omega0[b] from A0[b], b < n0; Omega1[b] from A1[b], b < n1 (n1 == 0: one segment) */
+int gpsa_omega_fwd2(const float* A0, int n0, double* Omega0, const float* A1, int n1, double* Omega1, int M,
+                    double jitter, void* stream) {
+  if (M < 1 || n0 < 1 || n1 < 0) return GPSA_EINVAL;
   const long long mm = (long long)M * M;
-  dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
+  dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)(n0 + n1));
+  gpsa::GemmSeg2<float, float, double> seg{n1 > 0 ? n0 : 0x7fffffff, A1, A1, Omega1};
   gpsa::gemm_mfma_kernel<double, false, true, float, float, double, false><<<grid, 256, 0, as_stream(stream)>>>(
-      M, M, M, 1.0, A, M, mm, A, M, mm, 0.0, Omega, M, mm, 1, nullptr, jitter);
+      M, M, M, 1.0, A0, M, mm, A0, M, mm, 0.0, Omega0, M, mm, 1, nullptr, jitter, 0, nullptr, 0, nullptr, 0, seg);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -551,15 +584,22 @@ int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omeg
  * reads of G^T. */
 int gpsa_omega_bwd(const double* G, const float* A, int M, int batch, int symmetric, float* dA,
                    void* stream) {
-  if (M < 1 || batch < 1) return GPSA_EINVAL;
+  return gpsa_omega_bwd2(G, A, dA, batch, nullptr, nullptr, nullptr, 0, M, symmetric, stream);
+}
+
+/* two segments in one launch, as gpsa_omega_fwd2 */
+int gpsa_omega_bwd2(const double* G0, const float* A0, float* dA0, int n0, const double* G1, const float* A1,
+                    float* dA1, int n1, int M, int symmetric, void* stream) {
+  if (M < 1 || n0 < 1 || n1 < 0) return GPSA_EINVAL;
   const long long mm = (long long)M * M;
-  dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)batch);
+  dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)(n0 + n1));
+  gpsa::GemmSeg2<double, float, float> seg{n1 > 0 ? n0 : 0x7fffffff, G1, A1, dA1};
   if (symmetric)
     gpsa::gemm_mfma_kernel<double, false, false, double, float, float, false><<<grid, 256, 0, as_stream(stream)>>>(
-        M, M, M, 2.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
+        M, M, M, 2.0, G0, M, mm, A0, M, mm, 0.0, dA0, M, mm, 1, nullptr, 0.0, 0, nullptr, 0, nullptr, 0, seg);
   else
     gpsa::gemm_mfma_kernel<double, false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
-        M, M, M, 1.0, G, M, mm, A, M, mm, 0.0, dA, M, mm, 1, nullptr, 0.0);
+        M, M, M, 1.0, G0, M, mm, A0, M, mm, 0.0, dA0, M, mm, 1, nullptr, 0.0, 0, nullptr, 0, nullptr, 0, seg);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

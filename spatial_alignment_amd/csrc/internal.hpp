@@ -9,6 +9,12 @@ template <typename T>
 int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A, long long lda,
                 long long sA, const T* B, long long ldb, long long sB, double beta, T* C, long long ldc,
                 long long sC, int batch, int splitk, void* ws, long long ws_bytes, hipStream_t st);
+// triangle modes of the MFMA product (gemm.hip documents them at the kernel)
+enum { GEMM_TRI_NONE = 0, GEMM_TRI_UPPER_A = 1, GEMM_TRI_LOWER_C = 2, GEMM_TRI_LTL = 3 };
+template <typename T>
+int gemm_launch_tri(int transA, int transB, int m, int n, long long k, double alpha, const T* A, long long lda,
+                    long long sA, const T* B, long long ldb, long long sB, double beta, T* C, long long ldc,
+                    long long sC, int batch, int splitk, void* ws, long long ws_bytes, hipStream_t st, int tri);
 // the same accumulated in fp64 from operands / into results of either precision (instantiated for
 // (double,float,float), (float,float,double), (double,double,float))
 template <typename TIA, typename TIB, typename TO>

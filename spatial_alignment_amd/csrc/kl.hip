@@ -110,15 +110,21 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
   const long long mm = (long long)M * M, e = blockIdx.x * 256LL + threadIdx.x;
   const int y = blockIdx.y;
   if (y < T) {
-    if (e >= mm) return;
     const int t = y;
-    int p = -1;  // prior of term t: the group that lists it (uniform over the block; group P = absent terms)
-    for (int pg = 0; pg < P && p < 0; ++pg)
-      for (int q = grp_off[pg]; q < grp_off[pg + 1]; ++q)
-        if (order[q] == t) {
-          p = pr_list[pg];
-          break;
-        }
+    // prior of term t: the group that lists it (group P = the absent terms).  The listed positions are searched
+    // by the block's threads in parallel (a serial scan was up to T dependent scalar loads in every block)
+    __shared__ int p_sh;
+    if (threadIdx.x == 0) p_sh = -1;
+    __syncthreads();
+    for (int q = threadIdx.x; q < grp_off[P]; q += 256)
+      if (order[q] == t) {
+        int pg = 0;
+        while (q >= grp_off[pg + 1]) ++pg;
+        p_sh = pr_list[pg];
+      }
+    __syncthreads();
+    const int p = p_sh;
+    if (e >= mm) return;
     double dom = 0.0;
     if (p >= 0) dom = 0.5 * g[t] * (inv[(long long)p * mm + e] - inv[(long long)om_idx[t] * mm + e]);
     // accumulate: dOmega already holds the layers' share of the gradient (the step engine's buffer)
@@ -142,20 +148,26 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
     }
   if (e >= mm) return;
   const int i = (int)(e / M), j = (int)(e % M);
+  // eight terms' loads in flight at a time (the term indices are block-uniform); a plain loop over the 50 terms
+  // of the data prior was 25 dependent load latencies, 50 of the kernel's 65 us
   double s0 = 0.0, s1 = 0.0, gs = 0.0;
-  int q = t0;
-  for (; q + 1 < t1; q += 2) {  // two independent chains
-    const int ta = order[q], tb = order[q + 1];
-    const double ga = g[ta], gb = g[tb];
-    gs += ga + gb;
-    s0 += ga * (mats[(long long)om_idx[ta] * mm + e] + D[(long long)ta * M + i] * D[(long long)ta * M + j]);
-    s1 += gb * (mats[(long long)om_idx[tb] * mm + e] + D[(long long)tb * M + i] * D[(long long)tb * M + j]);
-  }
-  if (q < t1) {
-    const int ta = order[q];
-    const double ga = g[ta];
-    gs += ga;
-    s0 += ga * (mats[(long long)om_idx[ta] * mm + e] + D[(long long)ta * M + i] * D[(long long)ta * M + j]);
+  for (int q = t0; q < t1; q += 8) {
+    double ga[8], om[8], di[8], dj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool on = q + u < t1;
+      const int ta = order[on ? q + u : t0];
+      ga[u] = on ? g[ta] : 0.0;
+      om[u] = mats[(long long)om_idx[ta] * mm + e];
+      di[u] = D[(long long)ta * M + i];
+      dj[u] = D[(long long)ta * M + j];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      gs += ga[u] + ga[u + 1];
+      s0 += ga[u] * (om[u] + di[u] * dj[u]);
+      s1 += ga[u + 1] * (om[u + 1] + di[u + 1] * dj[u + 1]);
+    }
   }
   S[(long long)pg * mm + e] = gs * mats[(long long)p * mm + e] - (s0 + s1);
 }

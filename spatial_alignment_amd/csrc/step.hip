@@ -856,8 +856,14 @@ static int mm_stage_fwd(Ctx& c) {
   GPSA_RUN(gpsa_kmat_batched(P.d.kind_data, c.prm.Gtilde, 0, Mg, c.prm.Gtilde, 0, Mg, D, c.prm.data_ls,
                              c.prm.data_var, 0, nullptr, 1, 1e-5, c.mats(GD, P.pos_KF()), 0, c.stv()));
   // variational covariances Omega = A A^T + 1e-5 I straight from the fp32 parameters
-  GPSA_RUN(gpsa_omega_fwd(c.prm.Omega_sqt_G, Mx, V * D, 1e-5, c.mats(GW, P.pos_OmG(0)), c.stv()));
-  for (int m = 0; m < P.nm; ++m)
+  // (the warp GPs' factors and the first modality's in one launch when the sizes agree)
+  const int m_first = (Mx == Mg && P.nm > 0) ? 1 : 0;
+  if (m_first)
+    GPSA_RUN(gpsa_omega_fwd2(c.prm.Omega_sqt_G, V * D, c.mats(GW, P.pos_OmG(0)), c.prm.Omega_sqt_F[0], P.d.n_latent[0],
+                             c.mats(GD, P.pos_OmF(0, 0)), Mx, 1e-5, c.stv()));
+  else
+    GPSA_RUN(gpsa_omega_fwd(c.prm.Omega_sqt_G, Mx, V * D, 1e-5, c.mats(GW, P.pos_OmG(0)), c.stv()));
+  for (int m = m_first; m < P.nm; ++m)
     GPSA_RUN(gpsa_omega_fwd(c.prm.Omega_sqt_F[m], Mg, P.d.n_latent[m], 1e-5, c.mats(GD, P.pos_OmF(m, 0)), c.stv()));
   // factorise: the priors always; the variational covariances only when the KL terms are wanted (the
   // layers use Omega itself, never its factor) - and then on the side stream, next to the priors: neither
@@ -901,8 +907,13 @@ static int mm_stage_fwd(Ctx& c) {
         GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, 0), Linv, G.M, nb_main, logdet, info, c.stv()));
       }
       // K^-1 = L^-T L^-1 for the whole batch in one product
-      GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M, mm, nb_main,
-                     splitk_small(G.M, G.M, G.M, nb_main)));
+      // (the triangle mode contracts k >= max(i, j) only and mirrors; it needs split-K 1: a large batch)
+      if (splitk_small(G.M, G.M, G.M, nb_main) == 1)
+        GPSA_RUN(gemm_launch_tri<double>(1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M,
+                                         mm, nb_main, 1, nullptr, 0, c.st, GEMM_TRI_LTL));
+      else
+        GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M, mm, nb_main,
+                       splitk_small(G.M, G.M, G.M, nb_main)));
       c.sc.release(mk);
     }
     if (split && G.n_omega > 0) {
@@ -912,8 +923,8 @@ static int mm_stage_fwd(Ctx& c) {
                                            wsOb[g], (void*)sst));
       else
         GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, np), LinvO[g], G.M, G.n_omega, logdet + np, info + np, (void*)sst));
-      GPSA_RUN((gemm_launch<double>(1, 0, G.M, G.M, G.M, 1.0, LinvO[g], G.M, mm, LinvO[g], G.M, mm, 0.0, c.inv(G, np),
-                                    G.M, mm, G.n_omega, 1, nullptr, 0, sst)));
+      GPSA_RUN((gemm_launch_tri<double>(1, 0, G.M, G.M, G.M, 1.0, LinvO[g], G.M, mm, LinvO[g], G.M, mm, 0.0,
+                                        c.inv(G, np), G.M, mm, G.n_omega, 1, nullptr, 0, sst, GEMM_TRI_LTL)));
     }
   }
   if (fork) {  // the KL kernels read the priors' inverses too
@@ -1415,7 +1426,8 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   B.dZ_df = sc.get<double>((long long)(npass > 0 ? npass : 1) * Mg * D);
   B.dpar_df = sc.get<double>(2LL * (npass > 0 ? npass : 1));
   B.dvar_ds = sc.get<float>(npass > 0 ? npass : 1);
-  const long long z1 = sc.off;
+  sc.get<char>(256);  // (round the region up to the arena's 256-byte granule: the runtime fills an unaligned tail
+  const long long z1 = (sc.off + 255) & ~255LL;  //  with a second launch)
   if (!dry) GPSA_CK((int)hipMemsetAsync(sc.base + z0, 0, (size_t)(z1 - z0), st));
   B.dZ_wu = sc.get<double>(nwz);
   B.dpar_wu = sc.get<double>(2LL * (nf > 0 ? nf : 1));
@@ -1510,10 +1522,19 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
       sc.release(mk);
     }
     // variational covariances: d Omega_sqt = (G + G^T) A = 2 G A (every gradient that reaches Omega is symmetric)
-    if (out.Omega_sqt_G != nullptr)
-      GPSA_RUN(gpsa_omega_bwd(B.dstack[0] + (long long)P.pos_OmG(0) * Mx * Mx, prm.Omega_sqt_G, Mx, V * D, 1,
-                              out.Omega_sqt_G, c.stv()));
-    for (int m = 0; m < P.nm; ++m)
+    int m_first = 0;
+    if (out.Omega_sqt_G != nullptr) {
+      if (Mx == Mg && P.nm > 0 && out.Omega_sqt_F[0] != nullptr) {  // one launch with the first modality's
+        m_first = 1;
+        GPSA_RUN(gpsa_omega_bwd2(B.dstack[0] + (long long)P.pos_OmG(0) * Mx * Mx, prm.Omega_sqt_G, out.Omega_sqt_G, V * D,
+                                 B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(0, 0) * Mg * Mg, prm.Omega_sqt_F[0],
+                                 out.Omega_sqt_F[0], P.d.n_latent[0], Mx, 1, c.stv()));
+      } else {
+        GPSA_RUN(gpsa_omega_bwd(B.dstack[0] + (long long)P.pos_OmG(0) * Mx * Mx, prm.Omega_sqt_G, Mx, V * D, 1,
+                                out.Omega_sqt_G, c.stv()));
+      }
+    }
+    for (int m = m_first; m < P.nm; ++m)
       if (out.Omega_sqt_F[m] != nullptr)
         GPSA_RUN(gpsa_omega_bwd(B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(m, 0) * Mg * Mg, prm.Omega_sqt_F[m], Mg,
                                 P.d.n_latent[m], 1, out.Omega_sqt_F[m], c.stv()));

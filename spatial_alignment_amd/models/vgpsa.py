@@ -615,13 +615,15 @@ class VariationalGPSA(GPSA):
                     self.F_latent_samples_test, self.F_observed_samples_test)
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
-    def _post_flag(self, flag, slot=0):
-        """one device word -> host, asynchronously; returns what _raise_on_flags waits on"""
+    def _flag_host(self, slot=0):
+        """one of two pinned (device-mapped) host words the engine's numerics reduction writes into"""
         hosts = self.__dict__.get("_flag_hosts")
         if hosts is None:
             hosts = self.__dict__["_flag_hosts"] = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
-        host = hosts[slot]
-        host.copy_(flag.reshape(1), non_blocking=True)
+        return hosts[slot]
+
+    def _post_flag(self, host):
+        """an event behind the kernel that wrote ``host``; returns what _raise_on_flags waits on"""
         ev = torch.cuda.Event()
         ev.record()
         return host, ev

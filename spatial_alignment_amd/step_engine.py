@@ -196,7 +196,12 @@ class StepFn(torch.autograd.Function):
         io.eps_G = _p(aux["eps_G"])
         mu_z = empty(plan.V, model.Xtilde.shape[1], D)
         kl = torch.empty(plan.n_kl, dtype=torch.float64, device=dev) if aux["want_kl"] else None
-        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        # the numerics word: with a check requested the engine's reduction writes it STRAIGHT into a pinned host word
+        # (device-mapped: no copy launch), otherwise into a device word nobody reads
+        if aux["check"]:
+            flag = model._flag_host(aux.get("flag_slot", 0) if aux["check"] == "deferred" else 0)
+        else:
+            flag = torch.empty(1, dtype=torch.int32, device=dev)
         io.mu_z, io.kl, io.flag = _p(mu_z), _p(kl), _p(flag)
         saved = torch.empty(plan.saved_bytes, dtype=torch.uint8, device=dev)
         scratch = o._ws(plan.scratch_bytes, saved)
@@ -207,7 +212,7 @@ class StepFn(torch.autograd.Function):
             # the backward of this node does, before it touches a gradient (see StepFn.backward)
             _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 1,
                                              stream), "gpsa_step_forward")
-            aux["deferred"] = model._post_flag(flag, slot=aux.get("flag_slot", 0))
+            aux["deferred"] = model._post_flag(flag)
             _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 2,
                                              stream), "gpsa_step_forward")
         elif aux["check"]:
@@ -357,13 +362,13 @@ class ElboLossFn(torch.autograd.Function):
         g = gloss.detach().reshape(1)
         g = g if g.dtype == torch.float32 else g.float()
         dF = [torch.empty_like(f) for f in Fc]
-        dnoise = torch.zeros(nz.numel(), dtype=torch.float32, device=dev)
+        dnoise = torch.empty(nz.numel(), dtype=torch.float32, device=dev)  # zero-filled by the first finishing launch
         dkl = torch.empty(ctx.n_kl, dtype=torch.float64, device=dev) if ctx.n_kl else None
         dFp = (C.c_void_p * n)(*[t.data_ptr() for t in dF])
         dNp = (C.c_void_p * n)(*[dnoise.data_ptr() + 4 * j for j in aux["noise_idx"]])
         ws = o._ws(8 * 4100 * n + 64, g)
         _lib.check(lib.gpsa_elbo_loss_bwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(g), ctx.n_kl, float(aux["kl_scale"]), dFp, dNp,
-                                          _p(dkl), _p(ws), ws.numel(), _raw_stream(dev.index)),
+                                          _p(dnoise), dnoise.numel(), _p(dkl), _p(ws), ws.numel(), _raw_stream(dev.index)),
                    "gpsa_elbo_loss_bwd")
         shape, dt = ctx.noise_meta
         return (None, dnoise.reshape(shape).to(dt), dkl) + tuple(dF)

@@ -6,6 +6,19 @@ launch-bound small configurations (config 1, S=1).
 import torch
 
 
+_SEED = {}
+
+
+def backward(loss):
+    """``loss.backward()`` with the seed gradient (a one) kept on the device between steps: autograd otherwise
+    launches a fill for it at every step."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _SEED.get(key)
+    if one is None:
+        one = _SEED[key] = torch.ones_like(loss)
+    loss.backward(one)
+
+
 def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None, static_grads=False):
     """forward(S) + loss_fn + backward + optimizer step; returns the loss tensor (no host sync).
     ``static_grads``: keep the .grad buffers (zeroed, accumulated into) instead of letting autograd hand
@@ -14,7 +27,7 @@ def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None, sta
     out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=S)
     loss = model.loss_fn(data_dict, out[3])
     optimizer.zero_grad(set_to_none=not static_grads)
-    loss.backward()
+    backward(loss)
     if reducer is not None:
         reducer()
     optimizer.step()

@@ -145,6 +145,27 @@ def test_omega_fwd_bwd(hip, M, B):
     close(hip.omega_bwd(Gs.to(DEV), A.to(DEV), symmetric=True), FK.omega_bwd(Gs, A), 2e-6)
 
 
+@pytest.mark.parametrize("M,n0,n1", [(5, 3, 2), (200, 4, 50), (72, 1, 1)])
+def test_omega_two_segments(hip, M, n0, n1):
+    """gpsa_omega_fwd2 / _bwd2: two parameter tensors in one launch == the two single-segment calls, bit for bit"""
+    A0, A1 = rnd(n0, M, M, seed=M).to(DEV), rnd(n1, M, M, seed=M + 1).to(DEV)
+    st = hip._stream(A0)
+    O0 = torch.empty(n0, M, M, dtype=torch.float64, device=DEV)
+    O1 = torch.empty(n1, M, M, dtype=torch.float64, device=DEV)
+    rc = hip.lib.gpsa_omega_fwd2(A0.data_ptr(), n0, O0.data_ptr(), A1.data_ptr(), n1, O1.data_ptr(), M, 1e-5, st)
+    assert rc == 0
+    assert torch.equal(O0, hip.omega_fwd(A0, 1e-5)) and torch.equal(O1, hip.omega_fwd(A1, 1e-5))
+    G0 = rnd(n0, M, M, dtype=torch.float64, seed=5).to(DEV)
+    G1 = rnd(n1, M, M, dtype=torch.float64, seed=6).to(DEV)
+    for sym in (0, 1):
+        d0, d1 = torch.empty_like(A0), torch.empty_like(A1)
+        rc = hip.lib.gpsa_omega_bwd2(G0.data_ptr(), A0.data_ptr(), d0.data_ptr(), n0, G1.data_ptr(), A1.data_ptr(),
+                                     d1.data_ptr(), n1, M, sym, st)
+        assert rc == 0
+        assert torch.equal(d0, hip.omega_bwd(G0, A0, symmetric=bool(sym)))
+        assert torch.equal(d1, hip.omega_bwd(G1, A1, symmetric=bool(sym)))
+
+
 @pytest.mark.parametrize("M,B", [(1, 2), (5, 3), (50, 4), (200, 6), (233, 2)])
 def test_chol_and_tri_inv(hip, M, B):
     A = rnd(B, M, M, dtype=torch.float64)

@@ -26,14 +26,17 @@ dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"]
           "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
 view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
 Xs = {m: d["spatial_coords"] for m, d in dd.items()}
-opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+from spatial_alignment_amd.optim import FusedAdam  # noqa: E402
+from spatial_alignment_amd.train import backward as train_backward  # noqa: E402
+
+opt = FusedAdam(model.parameters(), lr=1e-2)
 
 
 def step():
     out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=5)
     loss = model.loss_fn(dd, out[3])
     opt.zero_grad(set_to_none=True)
-    loss.backward()
+    train_backward(loss)
     opt.step()
 
 
