@@ -1142,7 +1142,16 @@ panel_slab_reduce_kernel(const float* __restrict__ slab, int M, int MP, int wgco
     if (c >= C) continue;
     const float* p = slab + (long long)row * wgcols + cl;
     float s = 0.f;
-    for (int k = 0; k < n; ++k) s += p[soff[k]];  // workgroup order: bitwise reproducible
+    for (int k = 0; k < n; k += 4) {  // four contributors' loads in flight; added in workgroup order: reproducible
+      const float v0 = p[soff[k]];
+      const float v1 = (k + 1 < n) ? p[soff[k + 1]] : 0.f;
+      const float v2 = (k + 2 < n) ? p[soff[k + 2]] : 0.f;
+      const float v3 = (k + 3 < n) ? p[soff[k + 3]] : 0.f;
+      s += v0;
+      if (k + 1 < n) s += v1;
+      if (k + 2 < n) s += v2;
+      if (k + 3 < n) s += v3;
+    }
     out[(long long)row * C + c] = s;
   }
 }
@@ -1167,7 +1176,8 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
       panel_mfma_kernel<MBV, NCTV, MODE, 4><<<(unsigned)grid, 256, 0, st>>>(                    \
           Ppk, X, g, M, C, L, out, colsq, scale, slab);                                         \
     if (MODE == MODE_ACCUM) {                                                                   \
-      dim3 rg((unsigned)ntiles, 8);                                                             \
+      /* few tiles (a short column range): more blocks per tile, the reduce is latency-bound */ \
+      dim3 rg((unsigned)ntiles, ntiles >= 512 ? 8 : (ntiles >= 128 ? 16 : 32));               \
       panel_slab_reduce_kernel<<<rg, 256, 0, st>>>(slab, M, MBV * 16, 64 * NCTV, C, L, ntiles,  \
                                                    (int)grid, out);                             \
     }                                                                                           \
