@@ -144,7 +144,9 @@ int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const v
  * K_fu K_uu^-1 factors of the conditional mean and covariance of both GP layers,
  * gpsa/models/vgpsa.py:179-183 and 194-196, and - applied to a gradient panel - the K_uu^-1 solve of
  * their backward.  M <= 256; GPSA_EUNSUPPORTED above (callers then chain gpsa_panel_mm).  workspace >=
- * gpsa_whiten_workspace(M) bytes. */
+ * gpsa_whiten_workspace(M) bytes; the call leaves the matrix-core layout of Kinv in it, and a later call with
+ * Kinv == NULL on the same workspace reuses it (the backward's solve against the forward's inverse; the same
+ * holds for gpsa_whiten_axpy_f32 and, per problem, gpsa_whiten_batched_f64). */
 long long gpsa_whiten_workspace(int M);
 int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, long long C,
                     int alpha_dtype, void* alpha, double* q, void* workspace, long long workspace_bytes,

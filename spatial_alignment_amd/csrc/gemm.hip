@@ -196,7 +196,9 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
   // K tile of 16 (32 was tried: fewer resident workgroups, 20-40 % slower on every shape used here; fetching TWO
   // tiles ahead through a second register set was tried too: 10 % slower at M = 1000, no gain on the small batches;
   // a 128 x 128 workgroup tile (4 x 4 MFMA tiles per wave, half the staged bytes per flop) was 2 % slower at
-  // M = 500 and 8 % slower at M = 1000 end to end: the 64-tile is not bound by the operand traffic)
+  // M = 500 and 8 % slower at M = 1000 end to end: the 64-tile is not bound by the operand traffic; an XCD-aware
+  // block order (blocks with equal dispatch index mod 8 on adjacent tiles, short grid edge fastest) gained 7 % on
+  // the alpha-gradient at M = 1000 and lost 8 % on the variance form and more on the fp64 products: not kept)
   constexpr int GK = 16, NG = GK / 16;
   __shared__ TC As[2][GK][GB_M + 4];  // double-buffered: one barrier per K tile
   __shared__ TC Bs[2][GK][GB_N + 4];

@@ -272,7 +272,8 @@ int generic_quadform_bwd_alpha(const T* alpha, const T* Omega, const T* g, int M
 static inline int gram_splitk(long long C, int M) {
   // enough K-splits that a single M x M product still fills the chip (tiles of 64 x 64)
   const long long tiles = cdiv(M, 64) * cdiv(M, 64);
-  long long s = cdiv(512, tiles);
+  static const long long target = [] { const char* e = getenv("GPSA_GRAM_SK_TARGET"); return e ? atoll(e) : 512LL; }();
+  long long s = cdiv(target, tiles);
   const long long cap = C / 256 > 1 ? C / 256 : 1;
   if (s > cap) s = cap;
   if (s > 256) s = 256;

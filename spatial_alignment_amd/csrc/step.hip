@@ -512,6 +512,7 @@ struct Plan {
   std::vector<Pass> passes;
   // saved arena
   long long o_resid = 0, o_Xv = 0, o_alpha_w = 0, o_Wk = 0, o_G64[MAXMODS], o_bad = 0, saved_bytes = 0;
+  long long o_apk_w = 0, o_apk_d = 0;  // packed inverses of the projection kernel: forward packs, backward reuses
   long long nbad = 0;
   long long scratch_bytes = 0;
   // device tables
@@ -653,6 +654,8 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
     q.o_alpha = take((long long)p->Mg * q.C * 4);
     q.o_sigma = take((long long)dsc->n_latent[q.m] * q.C * 4);
   }
+  p->o_apk_w = take(gpsa_whiten_workspace(p->Mx) * (long long)(p->nf > 0 ? p->nf : 1));
+  p->o_apk_d = take(gpsa_whiten_workspace(p->Mg));
   p->saved_bytes = o + 256;
   // ---- device tables
   const long long n_ll = (long long)nm * (V + 1) + (long long)nm * V + V + V;  // vstart, colbase, nview, epsoff
@@ -764,6 +767,7 @@ struct Ctx {
   Arena& sc;
   hipStream_t st;
   bool dry;
+  bool apk_d = false;  // the data GP's packed inverse has been written in this call
   void* stv() const { return (void*)st; }
   template <typename T> T* sv(long long off) const { return reinterpret_cast<T*>(saved + off); }
   double* mats(const Group& G, int pos) const { return sv<double>(G.o_mats) + (long long)pos * G.M * G.M; }
@@ -965,15 +969,14 @@ static ModPtrs mod_ptrs(Ctx& c, const gpsa_step_out_grads* og, const double* con
 // alpha = K^-1 K_uf and q = k^T alpha for ``cnt`` fp64 panels (projection kernel, or plain products beyond
 // its size)
 static int project_views(Ctx& c, const double* Kinv, const double* Kuf, int M, long long Cs, double* alpha,
-                         double* q, int cnt) {
+                         double* q, int cnt, int b0, bool packed) {
+  // packed: the saved arena already holds these views' packed inverses (the forward's call): no second packing
   const bool dry = c.dry;
   const long long wsb1 = gpsa_whiten_workspace(M);
   if (wsb1 > 0) {
-    const long long mk = c.sc.mark();
-    void* ws = c.sc.get<char>(wsb1 * cnt);
-    GPSA_RUN(gpsa_whiten_batched_f64(Kinv, (long long)M * M, Kuf, M, Cs, (long long)M * Cs, alpha, q, cnt, ws,
-                                     wsb1 * cnt, c.stv()));
-    c.sc.release(mk);
+    void* ws = c.sv<char>(c.P.o_apk_w) + wsb1 * b0;
+    GPSA_RUN(gpsa_whiten_batched_f64(packed ? nullptr : Kinv, (long long)M * M, Kuf, M, Cs, (long long)M * Cs, alpha, q,
+                                     cnt, ws, wsb1 * cnt, c.stv()));
     return 0;
   }
   GPSA_CK(gemm64(c, 0, 0, M, (int)Cs, M, 1.0, Kinv, M, (long long)M * M, Kuf, Cs, (long long)M * Cs, 0.0, alpha,
@@ -1018,7 +1021,7 @@ static int warp_stage_fwd(Ctx& c) {
                                  c.prm.warp_var + r.v0, 1, nlive, r.cnt, 0.0, Kuf + (long long)r.b0 * Mx * Cs,
                                  (long long)Mx * Cs, c.stv()));
       GPSA_CK(project_views(c, c.inv(GW, P.pos_Kw(r.b0)), Kuf + (long long)r.b0 * Mx * Cs, Mx, Cs,
-                            alpha + (long long)r.b0 * Mx * Cs, q + (long long)r.b0 * Cs, r.cnt));
+                            alpha + (long long)r.b0 * Mx * Cs, q + (long long)r.b0 * Cs, r.cnt, r.b0, false));
       // quirk 2: the forward of view v reads the Omega rows v*D + j
       GPSA_RUN(gpsa_quadform_fwd_keep_batched_f64(
           alpha + (long long)r.b0 * Mx * Cs, c.mats(GW, P.pos_OmG(r.v0 * D)), Mx, Cs, D,
@@ -1088,9 +1091,10 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
       GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32_X64, P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D,
                          c.prm.data_ls, c.prm.data_var, 0.0, Kuf, c.stv()));
     const long long wsb = gpsa_whiten_workspace(Mg);
-    if (wsb > 0) {
-      void* ws = c.sc.get<char>(wsb);
-      GPSA_RUN(gpsa_whiten_f64(Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb, c.stv()));
+    if (wsb > 0) {  // the packed inverse stays in the saved arena: later passes and the backward reuse it
+      void* ws = c.sv<char>(P.o_apk_d);
+      GPSA_RUN(gpsa_whiten_f64(c.apk_d ? nullptr : Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb, c.stv()));
+      c.apk_d = true;
     } else {  // beyond the projection kernel: alpha (fp64) = K^-1 K_uf, q from it, then rounded
       double* a64 = c.sc.get<double>((long long)Mg * C);
       GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, Kuf, C, 0, 0.0, a64, C, 0, 1, 1));
@@ -1217,16 +1221,16 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     const long long wsb = gpsa_whiten_workspace(Mg);
     if (wsb > 0) {
       const long long mk2 = c.sc.mark();
-      void* ws = c.sc.get<char>(wsb);
+      void* ws = c.sv<char>(P.o_apk_d);  // packed by the forward
       // measured (bench.py A/B in one run, twice): the fused store makes the step 37 us SLOWER (8.939 vs 8.901
       // ms): its row-strided reads of alpha in the projection kernel's epilogue cost more than the separate
       // streaming pass saves.  Kept behind GPSA_FUSED_AXPY=1.
       static const bool fuse = [] { const char* e = getenv("GPSA_FUSED_AXPY"); return e && e[0] == '1'; }();
       if (identity && fuse) {
-        GPSA_RUN(gpsa_whiten_axpy_f32(Kinv, abar, Mg, C, alpha, qbar, 2.0, gamma, ws, wsb, c.stv()));
+        GPSA_RUN(gpsa_whiten_axpy_f32(nullptr, abar, Mg, C, alpha, qbar, 2.0, gamma, ws, wsb, c.stv()));
         fused_axpy = true;
       } else {
-        GPSA_RUN(gpsa_whiten_f64(Kinv, GPSA_F32, abar, Mg, C, GPSA_F32, gamma, nullptr, ws, wsb, c.stv()));
+        GPSA_RUN(gpsa_whiten_f64(nullptr, GPSA_F32, abar, Mg, C, GPSA_F32, gamma, nullptr, ws, wsb, c.stv()));
       }
       c.sc.release(mk2);
     } else {
@@ -1353,7 +1357,7 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
     GPSA_CK(gemm64(c, 0, 1, Mx, D, Cs, 1.0, alpha + oMC, Cs, (long long)Mx * Cs, dmeanT + oDC, Cs, (long long)D * Cs,
                    0.0, B.dresid + (long long)r.v0 * Mx * D, D, (long long)Mx * D, r.cnt, splitk_for(Cs, Mx, D)));
     // gamma = K^-1 abar
-    GPSA_CK(project_views(c, c.inv(GW, P.pos_Kw(r.b0)), abar + oMC, Mx, Cs, gamma + oMC, nullptr, r.cnt));
+    GPSA_CK(project_views(c, c.inv(GW, P.pos_Kw(r.b0)), abar + oMC, Mx, Cs, gamma + oMC, nullptr, r.cnt, r.b0, true));
     // dOmega rows v*D + j (quirk 2)
     {
       const long long mk2 = c.sc.mark();

@@ -237,7 +237,7 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
                     int alpha_dtype, void* alpha, double* q, void* workspace, long long workspace_bytes,
                     void* stream) {
   using namespace gpsa;
-  if (M < 1 || C < 1 || Kinv == nullptr || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
+  if (M < 1 || C < 1 || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
   if (alpha_dtype != GPSA_F32 && alpha_dtype != GPSA_F64) return GPSA_EINVAL;
   if (in_dtype != GPSA_F32 && in_dtype != GPSA_F64) return GPSA_EINVAL;
   const int MB = whiten_mb_for(M);
@@ -246,8 +246,10 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
   hipStream_t st = as_stream(stream);
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
-  pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
-  GPSA_LAUNCH_CHECK();
+  if (Kinv != nullptr) {  // NULL: the workspace still holds the packed inverse of an earlier call
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+    GPSA_LAUNCH_CHECK();
+  }
   if (in_dtype == GPSA_F64) {
     if (alpha_dtype == GPSA_F32)
       return whiten_launch<double, float>(MB, Apk, (const double*)Kuf, M, C, (float*)alpha, q, st);
@@ -265,15 +267,17 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
 int gpsa_whiten_axpy_f32(const double* Kinv, const float* X, int M, long long C, const float* X2, const float* d,
                          double s, float* out, void* workspace, long long workspace_bytes, void* stream) {
   using namespace gpsa;
-  if (M < 1 || C < 1 || !Kinv || !X || !X2 || !d || !out) return GPSA_EINVAL;
+  if (M < 1 || C < 1 || !X || !X2 || !d || !out) return GPSA_EINVAL;
   const int MB = whiten_mb_for(M);
   if (MB == 0) return GPSA_EUNSUPPORTED;
   if (workspace_bytes < gpsa_whiten_workspace(M)) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
-  pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
-  GPSA_LAUNCH_CHECK();
+  if (Kinv != nullptr) {
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+    GPSA_LAUNCH_CHECK();
+  }
   return whiten_launch<float, float>(MB, Apk, X, M, C, out, nullptr, st, 1, 0, WhitenAxpy{X2, d, (float)s});
 }
 
@@ -284,7 +288,7 @@ int gpsa_whiten_batched_f64(const double* Kinv, long long strideKinv, const doub
                             long long strideX, double* alpha, double* q, int batch, void* workspace,
                             long long workspace_bytes, void* stream) {
   using namespace gpsa;
-  if (M < 1 || C < 1 || batch < 1 || Kinv == nullptr || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
+  if (M < 1 || C < 1 || batch < 1 || Kuf == nullptr || alpha == nullptr) return GPSA_EINVAL;
   const int MB = whiten_mb_for(M);
   if (MB == 0) return GPSA_EUNSUPPORTED;
   if (workspace_bytes < gpsa_whiten_workspace(M) * batch) return GPSA_EWORKSPACE;
@@ -292,8 +296,10 @@ int gpsa_whiten_batched_f64(const double* Kinv, long long strideKinv, const doub
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
   dim3 pgrid((unsigned)cdiv(tot, 256), (unsigned)batch);
-  pack_whiten_kernel<<<pgrid, 256, 0, st>>>(Kinv, M, MB, Apk, strideKinv);
-  GPSA_LAUNCH_CHECK();
+  if (Kinv != nullptr) {
+    pack_whiten_kernel<<<pgrid, 256, 0, st>>>(Kinv, M, MB, Apk, strideKinv);
+    GPSA_LAUNCH_CHECK();
+  }
   return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha, q, st, batch, strideX);
 }
 
