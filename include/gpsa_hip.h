@@ -132,6 +132,21 @@ int gpsa_quadform_fwd_keep(int dtype, const void* alpha, const void* Omega, int 
 /* dcT [M,L] / dmeanT [L,C] (both or neither NULL): adds the mean term's share dcT dmeanT to dalpha. */
 int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M, long long C, int L,
                                  const void* dcT, const void* dmeanT, void* dalpha, void* stream);
+/* The data GP's form (many outputs, fp32 matrix cores, M <= 256) with its products kept: v as gpsa_quadform_fwd
+ * and, in the same pass, the products Omega[l] alpha themselves into W - an opaque buffer of
+ * gpsa_quadform_keep_f32_bytes(M, C, L) bytes (about L M C 4) in the kernel's own accumulator order, so that each
+ * wave stores 1 KiB contiguous.  Training's backward is then gpsa_quadform_bwd_alpha_kept_f32:
+ *     dalpha[:,c] = 2 sum_l g[l,c] (Omega[l] alpha)[:,c]
+ * as ONE streaming read of W instead of the L M x M x C products of gpsa_quadform_bwd_alpha (vgpsa.py:192-196
+ * and its autograd; the forward alone loses the symmetric half-price form: without a backward use
+ * gpsa_quadform_fwd).  Omega [L,M,M] stored as omega_dtype.  workspace >= gpsa_quadform_keep_f32_workspace(M, L);
+ * both sizes are 0 when M is beyond the kernel (GPSA_EUNSUPPORTED). */
+long long gpsa_quadform_keep_f32_workspace(int M, int L);
+long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L);
+int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                               float* v, float* W, void* workspace, long long workspace_bytes, void* stream);
+int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, float* dalpha,
+                                     void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
  * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */
@@ -406,6 +421,12 @@ typedef struct gpsa_step_io {
                                                    then every modality's outputs), NULL with want_kl = 0 */
   int* flag;                                /* out [1]: nonzero = a covariance was not positive definite or a
                                                    warp variance not positive (the reference raises there) */
+  int keep_products;                        /* in  nonzero (training): the data GPs' forward keeps its products
+                                                   Omega_l alpha in the saved arena (gpsa_quadform_fwd_keep_f32)
+                                                   and gpsa_step_backward streams them back; needs the arena of
+                                                   gpsa_step_saved_bytes.  0 (no backward to follow): the cheaper
+                                                   forward, gpsa_step_saved_bytes_nokeep suffices, and a backward
+                                                   recomputes the products.  Pass the same value to both calls. */
 } gpsa_step_io;
 
 typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */
@@ -419,11 +440,12 @@ typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar 
 } gpsa_step_out_grads;
 
 void* gpsa_step_create(const gpsa_step_desc* desc);   /* NULL: invalid / unsupported description */
-/* the same plan described on the host only (no device): out[6] = saved bytes, scratch bytes, KL terms, floats of
- * eps_G, batched runs of free views, column stride of the view blocks */
+/* the same plan described on the host only (no device): out[7] = saved bytes, scratch bytes, KL terms, floats of
+ * eps_G, batched runs of free views, column stride of the view blocks, saved bytes without the kept products */
 int gpsa_step_describe(const gpsa_step_desc* desc, long long* out);
 void gpsa_step_destroy(void* plan);
 long long gpsa_step_saved_bytes(const void* plan);
+long long gpsa_step_saved_bytes_nokeep(const void* plan);  /* arena of a forward with io.keep_products == 0 */
 long long gpsa_step_scratch_bytes(const void* plan);
 int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */

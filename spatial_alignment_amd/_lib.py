@@ -100,7 +100,7 @@ class StepIO(C.Structure):
         ("X", _vp * MAX_MODS), ("eps_G", _vp), ("eps_F", _vp * MAX_MODS), ("G_test", _vp * MAX_MODS),
         ("eps_F_test", _vp * MAX_MODS), ("G_means", _vp * MAX_MODS), ("G_samples", _vp * MAX_MODS),
         ("F_latent", _vp * MAX_MODS), ("F_obs", _vp * MAX_MODS), ("F_latent_test", _vp * MAX_MODS),
-        ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp),
+        ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp), ("keep_products", _i),
     ]
 
 
@@ -133,6 +133,11 @@ SIGNATURES.update({
     "gpsa_step_describe": (_i, [C.POINTER(StepDesc), C.POINTER(_ll)]),
     "gpsa_step_destroy": (None, [_vp]),
     "gpsa_step_saved_bytes": (_ll, [_vp]),
+    "gpsa_step_saved_bytes_nokeep": (_ll, [_vp]),
+    "gpsa_quadform_keep_f32_workspace": (_ll, [_i, _i]),
+    "gpsa_quadform_fwd_keep_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_quadform_keep_f32_bytes": (_ll, [_i, _ll, _i]),
+    "gpsa_quadform_bwd_alpha_kept_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp]),
     "gpsa_step_scratch_bytes": (_ll, [_vp]),
     "gpsa_step_n_kl": (_i, [_vp]),
     "gpsa_step_eps_g_numel": (_ll, [_vp]),

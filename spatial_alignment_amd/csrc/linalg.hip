@@ -329,11 +329,71 @@ constexpr int CB_LS = 18;  // LDS row stride (doubles) of the panel buffers: con
 // pointers every access would be a flat load
 typedef __attribute__((address_space(3))) double lds_f64;
 
+// value of ``v`` in lane ``src`` (compile-time constant) for every lane: two v_readlane_b32, no LDS round trip
+template <int SRC>
+__device__ __forceinline__ double lane_bcast(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, SRC);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), SRC);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// P[c] -= mi * (column R entry of row c).  The two columns next to the pivot take that entry by register
+// broadcast (they feed the next pivots: no LDS latency in the chain), the others read it back from the column
+// the lanes published to LDS at the start of the step (their loads are issued early and land under the chain).
+template <int R, int C>
+struct Chol16Col {
+  static __device__ __forceinline__ void run(double (&P)[16], double mi, double colr, const lds_f64* cb) {
+    if (C <= R + 2) P[C] = fma(-mi, lane_bcast<C>(colr), P[C]);
+    else P[C] = fma(-mi, cb[C], P[C]);
+    Chol16Col<R, C + 1>::run(P, mi, colr, cb);
+  }
+};
+template <int R>
+struct Chol16Col<R, 16> {
+  static __device__ __forceinline__ void run(double (&)[16], double, double, const lds_f64*) {}
+};
+
+template <int R>
+struct Chol16Step {
+  static __device__ __forceinline__ void run(double (&P)[16], lds_f64* dinv, lds_f64* colbuf, int j0, int M, int lane,
+                                             int& bad) {
+    const double colr = P[R];          // this row's entry of column R (lanes 0..15 hold rows 0..15, repeated)
+    lds_f64* cb = colbuf + R * 16;     // a buffer per step: no reuse hazards
+    if (R + 3 < 16) {
+      if (lane < 16) cb[lane] = colr;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    double d = lane_bcast<R>(colr);    // the pivot, straight from lane R's register
+    if (j0 + R >= M) d = 1.0;          // identity padding beyond the matrix
+    if (!(d > 0.0)) {
+      if (!bad) bad = j0 + R + 1;
+      d = 1.0;
+    }
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y0), y0, 1.0);
+    const double inv = fma(y0 * e, fma(0.375, e, 0.5), y0);
+    if (lane == 0) dinv[R] = inv;
+    const double mine = colr * inv;
+    P[R] = mine;
+    const double mi = mine * inv;  // L(i,r) L(c,r) = (P(i,r) inv) (P(c,r) inv)
+    Chol16Col<R, R + 1>::run(P, mi, colr, cb);
+    Chol16Step<R + 1>::run(P, dinv, colbuf, j0, M, lane, bad);
+  }
+};
+template <>
+struct Chol16Step<16> {
+  static __device__ __forceinline__ void run(double (&)[16], lds_f64*, lds_f64*, int, int, int, int&) {}
+};
+
 // 16 x 16 Cholesky of the diagonal block by ONE wave (lane l holds row l & 15): D row-major, stride CB_LS.
-// Step r: the lanes publish column r (their row's entry) to this wave's 16-double buffer, every lane reads
-// the pivot and the entries of the rows c > r back (broadcast reads, no cross-lane instructions).
-// Writes this wave's copy of the factor (Ld, row-major [16][16]) and the pivots' inverses; returns 0 or
-// 1 + the global column of the first non-positive pivot.
+// The pivot and the entries of the two columns next to it cross the lanes as v_readlane broadcasts from the
+// owning lane's register, so the 16-step dependency chain holds no LDS round trip (publishing every column
+// through LDS cost a store -> load latency per step on top of the reciprocal square root: 3.7 us per block;
+// broadcasting ALL entries by readlane is 2 instructions per multiply-add: 3.2 us, issue-bound).
+// colbuf: [16][16] doubles of this wave.  Writes this wave's copy of the factor (Ld, row-major [16][16]) and
+// the pivots' inverses; returns 0 or 1 + the global column of the first non-positive pivot.
 __device__ __noinline__ int chol16_wave(const lds_f64* D, lds_f64* Ld, lds_f64* dinv, lds_f64* colbuf, int j0,
                                         int M) {
   const int lane = threadIdx.x & 63, row = lane & 15;
@@ -341,28 +401,7 @@ __device__ __noinline__ int chol16_wave(const lds_f64* D, lds_f64* Ld, lds_f64* 
 #pragma unroll
   for (int c = 0; c < 16; ++c) P[c] = D[row * CB_LS + c];
   int bad = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    if (lane < 16) colbuf[row] = P[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    double d = colbuf[r];
-    if (j0 + r >= M) d = 1.0;  // identity padding beyond the matrix
-    if (!(d > 0.0)) {
-      if (!bad) bad = j0 + r + 1;
-      d = 1.0;
-    }
-    const double y0 = __builtin_amdgcn_rsq(d);
-    const double e = fma(-(d * y0), y0, 1.0);
-    const double inv = fma(y0 * e, fma(0.375, e, 0.5), y0);
-    if (lane == 0) dinv[r] = inv;
-    const double mine = P[r] * inv;
-    P[r] = mine;
-    const double mi = mine * inv;  // L(i,r) L(c,r) = (P(i,r) inv) (P(c,r) inv)
-#pragma unroll
-    for (int c = r + 1; c < 16; ++c) P[c] = fma(-mi, colbuf[c], P[c]);
-    __builtin_amdgcn_wave_barrier();  // the buffer is rewritten by the next step
-  }
+  Chol16Step<0>::run(P, dinv, colbuf, j0, M, lane, bad);
   if (lane < 16) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) Ld[lane * 16 + c] = P[c];
@@ -407,7 +446,7 @@ __device__ __noinline__ void panel_solves(lds_f64* Lp, int R, const lds_f64* Ld,
 
 static inline long long chol_blk_lds_bytes(int NT) {
   const long long MP = NT * 16;
-  return (3 * MP * CB_LS + 16 * MP + 4 * 256 + 4 * 16 + 4 * 16 + MP + 8) * 8;
+  return (3 * MP * CB_LS + 16 * MP + 4 * 256 + 4 * 16 + 4 * 256 + MP + 8) * 8;
 }
 
 template <int NT>
@@ -422,8 +461,8 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   double* Tb = XpT + MP * CB_LS;          // [16][MP]     partial inverse rows of the block
   double* Ldw = Tb + 16 * MP;             // [4][256]     per-wave copy of the diagonal block's factor
   double* dinvw = Ldw + 4 * 256;          // [4][16]
-  double* colw = dinvw + 4 * 16;          // [4][16]     per-wave column buffer of the block factorisation
-  double* sdiag = colw + 4 * 16;          // [MP]
+  double* colw = dinvw + 4 * 16;          // [4][16][16] per-wave column buffers of the block factorisation
+  double* sdiag = colw + 4 * 256;         // [MP]
   __shared__ double red[16];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,7 +491,7 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
     __syncthreads();
     // (2) diagonal block, every wave for itself
     if (!(skip & 1)) bad = chol16_wave((const lds_f64*)Lp, (lds_f64*)(Ldw + w * 256), (lds_f64*)(dinvw + w * 16),
-                      (lds_f64*)(colw + w * 16), i0, M);
+                      (lds_f64*)(colw + w * 256), i0, M);
     if (tid < 16) sdiag[i0 + tid] = dinvw[tid];  // wave 0's copy (written by its lane 0 above; same wave)
     if (bad) break;  // uniform: every wave factorised the same block
     // (3) panel rows and X columns, one thread each

@@ -453,7 +453,8 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
                   float* __restrict__ out,        // QUAD: v [L][C]; ACCUM/STORE: Y [M][C]
                   float* __restrict__ colsq,      // STORE: optional [C]
                   float out_scale,
-                  float* __restrict__ slab) {     // ACCUM: [gridDim.x][2][MP][WGCOLS] partial tiles
+                  float* __restrict__ slab,       // ACCUM: [gridDim.x][2][MP][WGCOLS] partial tiles
+                  float* __restrict__ keep = nullptr) {  // QUAD: optional, the products P_l X in fragment order
   constexpr int MP = MB * 16;
   constexpr int WGCOLS = 64 * NCT;
   constexpr int CHUNK = MP * 16;                    // floats per K chunk (MB pieces of 256 floats)
@@ -607,16 +608,26 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           float s = 0.f;
+          const long long c = cw + ct * 16 + j;
+          // keep: the product Omega_l alpha leaves through HBM once, for the backward's streaming pass, in the
+          // accumulators' own order (one 16-byte store per lane and 16 x 16 block, 1 KiB contiguous per wave;
+          // row-major [M][C] stores of 64-byte segments cost 1.7 ms per 4 GB here):
+          //   keep[l][tile][wave][ct][rt][lane][r]  =  (Omega_l alpha)[16 rt + 4 kq + r][column of (tile, wave, ct, j)]
+          f32x4* kp = nullptr;
+          if (keep != nullptr)  // block-uniform
+            kp = reinterpret_cast<f32x4*>(keep) +
+                 (((((long long)l * ntiles + tile) * 4 + w) * NCT + ct) * MB) * 64 + lane;
 #pragma unroll
-          for (int rt = 0; rt < MB; ++rt)
+          for (int rt = 0; rt < MB; ++rt) {
+            if (kp != nullptr) kp[rt * 64] = acc[rt][ct];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               s += acc[rt][ct][r] * xb[ct][rt][r];
               acc[rt][ct][r] = 0.f;
             }
+          }
           s += __shfl_xor(s, 16, 64);
           s += __shfl_xor(s, 32, 64);
-          const long long c = cw + ct * 16 + j;
           if (kq == 0 && c < C) out[(long long)l * C + c] = s;
         }
       }
@@ -1157,10 +1168,46 @@ panel_slab_reduce_kernel(const float* __restrict__ slab, int M, int MP, int wgco
   }
 }
 
+// Backward of the kept form: out[m,c] = scale * sum_l g[l,c] * (Omega_l alpha)[m,c], streaming the products the
+// forward kept (panel_mfma_kernel<QUAD>'s ``keep``, in its fragment order) exactly once: memory-bound, 13 independent
+// 16-byte loads per thread and output.  Block = the four waves' slots of one (column tile, ct).
+template <int MB, int NCT>
+__global__ void __launch_bounds__(256)
+kept_wsum_kernel(const float* __restrict__ keep, const float* __restrict__ g, int M, long long C, int L,
+                 long long ntiles, float scale, float* __restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const long long tile = blockIdx.x;
+  const int ct = blockIdx.y;
+  const long long c = tile * (64 * NCT) + (long long)w * (16 * NCT) + ct * 16 + j;
+  f32x4 acc[MB];
+#pragma unroll
+  for (int rt = 0; rt < MB; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4* kp = reinterpret_cast<const f32x4*>(keep) + (((tile * 4 + w) * NCT + ct) * MB) * 64 + lane;
+  const long long lstride = ntiles * 4 * NCT * MB * 64;  // f32x4 elements between consecutive l
+  for (int l = 0; l < L; ++l) {
+    const float gv = (c < C) ? g[(long long)l * C + c] : 0.f;
+    const f32x4* p = kp + (long long)l * lstride;
+#pragma unroll
+    for (int rt = 0; rt < MB; ++rt) {
+      const f32x4 u = p[rt * 64];
+      acc[rt] += gv * u;
+    }
+  }
+  if (c < C) {
+#pragma unroll
+    for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + kq * 4 + r;
+        if (row < M) out[(long long)row * C + c] = scale * acc[rt][r];
+      }
+  }
+}
+
 template <int MODE>
 int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* g, int M,
                       long long C, int L, float* out, float* colsq, float scale, float* slab,
-                      hipStream_t st) {
+                      hipStream_t st, float* keep = nullptr) {
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
   case MBV:                                                                                     \
     if constexpr (MBV <= 16 || MODE == MODE_ACCUM) {  /* 24 / 32 row tiles: accumulate only */  \
@@ -1172,10 +1219,10 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
     constexpr int RLV = (MODE == MODE_QUAD) ? 4 : 2;                                            \
     if (RLV == 2 && M - 16 * (MBV - 1) <= 8)                                                    \
       panel_mfma_kernel<MBV, NCTV, MODE, RLV><<<(unsigned)grid, 256, 0, st>>>(                  \
-          Ppk, X, g, M, C, L, out, colsq, scale, slab);                                         \
+          Ppk, X, g, M, C, L, out, colsq, scale, slab, keep);                                   \
     else                                                                                        \
       panel_mfma_kernel<MBV, NCTV, MODE, 4><<<(unsigned)grid, 256, 0, st>>>(                    \
-          Ppk, X, g, M, C, L, out, colsq, scale, slab);                                         \
+          Ppk, X, g, M, C, L, out, colsq, scale, slab, keep);                                   \
     if (MODE == MODE_ACCUM) {                                                                   \
       /* few tiles (a short column range): more blocks per tile, the reduce is latency-bound */ \
       dim3 rg((unsigned)ntiles, ntiles >= 512 ? 8 : (ntiles >= 128 ? 16 : 32));               \
@@ -1448,6 +1495,61 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
                                         workspace_bytes, st);
   }
   return GPSA_EINVAL;
+}
+
+long long gpsa_quadform_keep_f32_workspace(int M, int L) {
+  const int MB = gpsa::mfma_mb_for(M);
+  if (!MB || MB > 16 || gpsa::force_generic()) return 0;  // the full-product form kernel holds M <= 256
+  return (long long)L * MB * 16 * MB * 16 * 4;
+}
+
+long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L) {
+  const int MB = gpsa::mfma_mb_for(M);
+  if (!MB || MB > 16 || gpsa::force_generic() || C < 1 || L < 1) return 0;
+  const long long wgcols = 64LL * gpsa::panel_nct_for(MB);
+  return (long long)L * cdiv(C, wgcols) * wgcols * MB * 16 * 4;
+}
+
+int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                               float* v, float* W, void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || L < 1 || !alpha || !Omega || !v || !W) return GPSA_EINVAL;
+  const long long need = gpsa_quadform_keep_f32_workspace(M, L);
+  if (need == 0) return GPSA_EUNSUPPORTED;
+  if (workspace_bytes < need) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int MB = mfma_mb_for(M);
+  float* Ppk = (float*)workspace;
+  int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, 0);
+  if (rc) return rc;
+  return panel_mfma_launch<MODE_QUAD>(MB, Ppk, alpha, nullptr, M, C, L, v, nullptr, 1.f, nullptr, st, W);
+}
+
+int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, float* dalpha,
+                                     void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || L < 1 || !W || !g || !dalpha) return GPSA_EINVAL;
+  const int MB = mfma_mb_for(M);
+  if (!MB || MB > 16 || force_generic()) return GPSA_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+#define GPSA_KEPT_CASE(MBV, NCTV)                                                                        \
+  case MBV: {                                                                                            \
+    const long long ntiles = cdiv(C, 64 * NCTV);                                                         \
+    kept_wsum_kernel<MBV, NCTV><<<dim3((unsigned)ntiles, NCTV), 256, 0, st>>>(W, g, M, C, L, ntiles, 2.f, dalpha); \
+    break;                                                                                               \
+  }
+  switch (MB) {
+    GPSA_KEPT_CASE(2, 4)
+    GPSA_KEPT_CASE(4, 4)
+    GPSA_KEPT_CASE(7, 4)
+    GPSA_KEPT_CASE(13, 3)
+    GPSA_KEPT_CASE(16, 2)
+    default:
+      return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_KEPT_CASE
+  GPSA_LAUNCH_CHECK();
+  return 0;
 }
 
 int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const void* Omega,

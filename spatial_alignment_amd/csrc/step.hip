@@ -494,6 +494,7 @@ struct Pass {  // one evaluation of the data GP: a modality's own spots, or its 
   bool test = false;
   long long C = 0;          // columns = S * rows
   long long o_alpha = 0, o_sigma = 0;
+  long long o_keep = -1;  // [L][Mg][C] fp32 products Omega_l alpha kept for the backward (-1: not kept)
 };
 
 struct Plan {
@@ -512,6 +513,7 @@ struct Plan {
   std::vector<Pass> passes;
   // saved arena
   long long o_resid = 0, o_Xv = 0, o_alpha_w = 0, o_Wk = 0, o_G64[MAXMODS], o_bad = 0, saved_bytes = 0;
+  long long saved_bytes_nokeep = 0;   // arena without the kept products (they sit at its end)
   long long o_apk_w = 0, o_apk_d = 0;  // packed inverses of the projection kernel: forward packs, backward reuses
   long long nbad = 0;
   long long scratch_bytes = 0;
@@ -656,6 +658,22 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
   }
   p->o_apk_w = take(gpsa_whiten_workspace(p->Mx) * (long long)(p->nf > 0 ? p->nf : 1));
   p->o_apk_d = take(gpsa_whiten_workspace(p->Mg));
+  p->saved_bytes_nokeep = o + 256;
+  // The data GPs' products Omega_l alpha, kept by a training forward so that the backward streams them instead
+  // of recomputing L M x M x C products.  At the END of the arena (a forward without a backward allocates only
+  // the part before them); only while they stay within GPSA_KEEP_GB (default 48) GiB in total.
+  {
+    static const double keep_gb = [] { const char* e = getenv("GPSA_KEEP_GB"); return e ? atof(e) : 48.0; }();
+    long long tot = 0;
+    bool ok = true;
+    for (auto& q : p->passes) {
+      const long long b = gpsa_quadform_keep_f32_bytes(p->Mg, q.C, dsc->n_latent[q.m]);
+      if (b == 0) ok = false;
+      tot += b;
+    }
+    if (ok && (double)tot <= keep_gb * 1073741824.0)
+      for (auto& q : p->passes) q.o_keep = take(gpsa_quadform_keep_f32_bytes(p->Mg, q.C, dsc->n_latent[q.m]));
+  }
   p->saved_bytes = o + 256;
   // ---- device tables
   const long long n_ll = (long long)nm * (V + 1) + (long long)nm * V + V + V;  // vstart, colbase, nview, epsoff
@@ -1117,7 +1135,10 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
     void* ws = c.sc.get<char>(wsb);
     const bool timed = !dry && &ps == &P.passes[0];
     if (timed) P.tick(0, 0, true, c.st);
-    GPSA_RUN(gpsa_quadform_fwd(GPSA_F32, GPSA_F64, alpha, Om, Mg, C, L, v, ws, wsb, c.stv()));
+    if (c.io.keep_products && ps.o_keep >= 0)  // training: the full product, kept for the backward
+      GPSA_RUN(gpsa_quadform_fwd_keep_f32(GPSA_F64, alpha, Om, Mg, C, L, v, c.sv<float>(ps.o_keep), ws, wsb, c.stv()));
+    else
+      GPSA_RUN(gpsa_quadform_fwd(GPSA_F32, GPSA_F64, alpha, Om, Mg, C, L, v, ws, wsb, c.stv()));
     if (timed) { P.tick(0, 1, true, c.st); ++P.tfwd; }
   }
   GPSA_RUN(gpsa_data_sample_fwd(meanT, v, q, c.prm.data_var, eps, C, L, F, Sigma, c.stv()));
@@ -1203,7 +1224,11 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     void* ws = c.sc.get<char>(wsb);
     const bool timed = !dry && &ps == &P.passes[0];
     if (timed) P.tick(1, 0, false, c.st);
-    GPSA_RUN(gpsa_quadform_bwd_alpha(GPSA_F32, GPSA_F64, alpha, Om, g_ext, Mg, C, L, abar, ws, wsb, c.stv()));
+    const bool kept = c.io.keep_products && ps.o_keep >= 0;
+    if (kept)  // one streaming pass over the products the forward kept
+      GPSA_RUN(gpsa_quadform_bwd_alpha_kept_f32(c.sv<float>(ps.o_keep), g_ext, Mg, C, L, abar, c.stv()));
+    else
+      GPSA_RUN(gpsa_quadform_bwd_alpha(GPSA_F32, GPSA_F64, alpha, Om, g_ext, Mg, C, L, abar, ws, wsb, c.stv()));
     if (timed) P.tick(1, 1, false, c.st);
     c.sc.release(mk2);
   }
@@ -1593,6 +1618,7 @@ int gpsa_step_describe(const gpsa_step_desc* desc, long long* out) {
   out[3] = p->eps_total;
   out[4] = (long long)p->runs.size();
   out[5] = p->Cs;
+  out[6] = p->saved_bytes_nokeep;
   gpsa::free_plan(p);
   return 0;
 }
@@ -1631,6 +1657,9 @@ static gpsa::Plan* plan_with_sizes(const gpsa_step_desc* desc, bool host_only) {
 
 void gpsa_step_destroy(void* plan) { gpsa::free_plan(reinterpret_cast<gpsa::Plan*>(plan)); }
 long long gpsa_step_saved_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->saved_bytes : -1; }
+long long gpsa_step_saved_bytes_nokeep(const void* plan) {
+  return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->saved_bytes_nokeep : -1;
+}
 long long gpsa_step_scratch_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->scratch_bytes : -1; }
 int gpsa_step_n_kl(const void* plan) {
   if (!plan) return -1;

@@ -38,6 +38,7 @@ class StepPlan:
         if not self.handle:
             raise _lib.GpsaHipError(f"gpsa_step_create refused the problem description {key}")
         self.saved_bytes = int(lib.gpsa_step_saved_bytes(self.handle))
+        self.saved_bytes_nokeep = int(lib.gpsa_step_saved_bytes_nokeep(self.handle))
         self.scratch_bytes = int(lib.gpsa_step_scratch_bytes(self.handle))
         self.n_kl = int(lib.gpsa_step_n_kl(self.handle))
         self.eps_g_numel = int(lib.gpsa_step_eps_g_numel(self.handle))
@@ -203,7 +204,11 @@ class StepFn(torch.autograd.Function):
         else:
             flag = torch.empty(1, dtype=torch.int32, device=dev)
         io.mu_z, io.kl, io.flag = _p(mu_z), _p(kl), _p(flag)
-        saved = torch.empty(plan.saved_bytes, dtype=torch.uint8, device=dev)
+        # training (a backward will follow): the data GPs keep their products Omega_l alpha in the arena and the
+        # backward streams them back; otherwise the cheaper forward and the smaller arena
+        keep = any(ctx.needs_input_grad[1:]) and not aux.get("no_keep", False)  # (all False under no_grad)
+        io.keep_products = 1 if keep else 0
+        saved = torch.empty(plan.saved_bytes if keep else plan.saved_bytes_nokeep, dtype=torch.uint8, device=dev)
         scratch = o._ws(plan.scratch_bytes, saved)
         stream = _raw_stream(dev.index)
         pending = None
@@ -248,6 +253,9 @@ class StepFn(torch.autograd.Function):
             pend, aux["deferred"] = aux["deferred"], None
             model._pending_flag = None
             model._raise_on_flags(pend)
+        if ctx.arena is None:
+            raise RuntimeError("GPSA step: backward through the same forward a second time - its saved arena was "
+                               "released after the first backward (run forward again)")
         lib = plan.lib
         tensors = ctx.saved_tensors
         dev = tensors[0].device
@@ -311,6 +319,10 @@ class StepFn(torch.autograd.Function):
         for i, t in enumerate(tensors):
             out.append(views[i].view(t.shape) if ctx.needs_input_grad[1 + i] else None)
         LAST_FLAT[dev.index] = flat
+        # the arena (gigabytes when the data GPs keep their products) goes back to the allocator NOW: the node sits
+        # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
+        # would break, steps later
+        ctx.arena = None
         return tuple(out)
 
 

@@ -145,6 +145,37 @@ def test_omega_fwd_bwd(hip, M, B):
     close(hip.omega_bwd(Gs.to(DEV), A.to(DEV), symmetric=True), FK.omega_bwd(Gs, A), 2e-6)
 
 
+@pytest.mark.parametrize("M,C,L", [(200, 1000, 50), (64, 333, 7), (16, 70, 5), (256, 513, 6), (130, 4099, 10)])
+def test_quadform_keep_f32(hip, M, C, L):
+    """the data GP's form with its products kept (gpsa_quadform_fwd_keep_f32, opaque buffer) and the streaming
+    backward over them (gpsa_quadform_bwd_alpha_kept_f32) against the recomputing pair"""
+    al = rnd(M, C, seed=1)
+    A = rnd(L, M, M, seed=2, dtype=torch.float64) / M ** 0.5
+    Om = A @ A.transpose(1, 2) + 1e-5 * torch.eye(M, dtype=torch.float64)
+    g = rnd(L, C, seed=3)
+    ald, Omd, gd = al.to(DEV), Om.to(DEV), g.to(DEV)
+    st = hip._stream(ald)
+    wsb = hip.lib.gpsa_quadform_keep_f32_workspace(M, L)
+    nb = hip.lib.gpsa_quadform_keep_f32_bytes(M, C, L)
+    assert wsb > 0 and L * M * C * 4 <= nb <= 1.6 * L * (M + 16) * (C + 256) * 4
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    v = torch.empty(L, C, device=DEV)
+    W = torch.full((nb // 4,), float("nan"), device=DEV)
+    rc = hip.lib.gpsa_quadform_fwd_keep_f32(1, ald.data_ptr(), Omd.data_ptr(), M, C, L, v.data_ptr(), W.data_ptr(),
+                                            ws.data_ptr(), wsb, st)
+    assert rc == 0
+    Wr = torch.einsum("lmk,kc->lmc", Om, al.double())
+    close(v, (Wr * al.double()[None]).sum(1), 2e-6)
+    close(hip.quadform_fwd(ald, Omd), v, 3e-6)        # the cheap forward agrees with the kept one
+    out = torch.full((M, C), float("nan"), device=DEV)
+    rc = hip.lib.gpsa_quadform_bwd_alpha_kept_f32(W.data_ptr(), gd.data_ptr(), M, C, L, out.data_ptr(), st)
+    assert rc == 0
+    close(out, 2.0 * torch.einsum("lc,lmc->mc", g.double(), Wr), 2e-6)
+    close(out, hip.quadform_bwd_alpha(ald, Omd, gd), 3e-6)
+    assert hip.lib.gpsa_quadform_keep_f32_workspace(300, 3) == 0   # beyond the kernel: callers recompute
+    assert hip.lib.gpsa_quadform_keep_f32_bytes(300, 1000, 3) == 0
+
+
 @pytest.mark.parametrize("M,n0,n1", [(5, 3, 2), (200, 4, 50), (72, 1, 1)])
 def test_omega_two_segments(hip, M, n0, n1):
     """gpsa_omega_fwd2 / _bwd2: two parameter tensors in one launch == the two single-segment calls, bit for bit"""

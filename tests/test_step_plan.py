@@ -23,13 +23,13 @@ def describe(V=2, D=2, S=5, mx=200, mg=200, mods=((50, 50, 0, (10000, 10000)),),
     fx = (C.c_int * V)(*(fixed or [0] * V))
     rw = (C.c_longlong * len(rows))(*rows)
     d.view_fixed, d.view_rows = fx, rw
-    out = (C.c_longlong * 6)()
+    out = (C.c_longlong * 7)()
     rc = lib.gpsa_step_describe(C.byref(d), out)
-    return rc, list(out)
+    return rc, list(out)[:6], int(out[6])
 
 
 def test_headline_plan():
-    rc, (saved, scratch, n_kl, eps, runs, Cs) = describe()
+    rc, (saved, scratch, n_kl, eps, runs, Cs), nokeep = describe()
     assert rc == 0
     assert n_kl == 2 * 2 + 50                      # Omega_G rows + the data GP's outputs
     assert eps == 2 * 5 * 10000 * 2                # S draws [n_v, D] per free view
@@ -37,12 +37,15 @@ def test_headline_plan():
     # saved: alpha fp32 [M, S N] + Sigma [L, S N] + the warp GPs' fp64 alpha and D kept products + the batch
     C_ = 5 * 20000
     floor = 200 * C_ * 4 + 50 * C_ * 4 + 2 * 200 * Cs * 8 * (1 + 2) + 2 * 57 * 200 * 200 * 8
-    assert floor <= saved <= 1.15 * floor
+    assert floor <= nokeep <= 1.15 * floor
+    # a training forward also keeps the data GP's products Omega_l alpha behind everything else: [L, M, S N] fp32,
+    # padded to the kernel's tiles (208 rows, 192-column tiles)
+    assert 0 <= saved - nokeep - 50 * 208 * 100032 * 4 <= 4096
     assert scratch >= 200 * C_ * 8                  # the fp64 covariance panel of the data GP is in there
 
 
 def test_fixed_views_split_runs_and_kl_terms():
-    rc, (_, _, n_kl, eps, runs, Cs) = describe(V=5, S=2, mx=30, mg=20, mods=((7, 7, 0, (10, 20, 30, 40, 50)),),
+    rc, (_, _, n_kl, eps, runs, Cs), _nk = describe(V=5, S=2, mx=30, mg=20, mods=((7, 7, 0, (10, 20, 30, 40, 50)),),
                                               fixed=[0, 0, 1, 0, 0])
     assert rc == 0
     assert n_kl == 5 * 2 + 7                       # fixed views keep their (absent) terms' slots
@@ -51,15 +54,15 @@ def test_fixed_views_split_runs_and_kl_terms():
 
 
 def test_many_views_are_batched_by_sixteen():
-    rc, out = describe(V=40, S=1, mx=16, mg=16, mods=((3, 3, 0, tuple([8] * 40)),))
+    rc, out, _nk = describe(V=40, S=1, mx=16, mg=16, mods=((3, 3, 0, tuple([8] * 40)),))
     assert rc == 0 and out[4] == 3 and out[2] == 40 * 2 + 3
 
 
 def test_two_modalities_lmc_and_test_pass():
-    rc, (saved, scratch, n_kl, eps, runs, Cs) = describe(
+    rc, (saved, scratch, n_kl, eps, runs, Cs), _nk = describe(
         V=2, D=3, S=3, mx=16, mg=18, mods=((7, 7, 0, (64, 64)), (2, 4, 1, (36, 36))), s_test=1, n_test=(17, 5))
     assert rc == 0 and n_kl == 2 * 3 + 7 + 2 and eps == 3 * 3 * (100 + 100) and Cs == 128
-    rc2, (saved2, scratch2, *_r) = describe(
+    rc2, (saved2, scratch2, *_r), _nk2 = describe(
         V=2, D=3, S=3, mx=16, mg=18, mods=((7, 7, 0, (64, 64)), (2, 4, 1, (36, 36))))
     assert saved > saved2                          # the test passes keep their own alpha / Sigma
 
@@ -83,6 +86,6 @@ def test_row_total_must_match():
     d.n_latent[0], d.n_out[0], d.n_rows[0], d.want_kl = 3, 3, 99, 1
     fx, rw = (C.c_int * 2)(0, 0), (C.c_longlong * 2)(10, 20)
     d.view_fixed, d.view_rows = fx, rw
-    out = (C.c_longlong * 6)()
+    out = (C.c_longlong * 7)()
     assert lib.gpsa_step_describe(C.byref(d), out) == _lib.GPSA_EINVAL
     assert lib.gpsa_step_describe(C.byref(d), None) == _lib.GPSA_EINVAL
