@@ -316,6 +316,17 @@ def main():
             "quadform_bwd_omega": "gram_mfma_kernel (gpsa_quadform_bwd_omega; lower-triangle tiles: executes "
                                   "0.58x of the nominal flops)",
         }
+        # training keeps the data GP's products Omega_l alpha (step engine, io.keep_products): the forward is then
+        # the FULL product (rows and contraction padded to 16 MB), the alpha-gradient one streaming read of them
+        kept = any(p.saved_bytes > p.saved_bytes_nokeep for p in timer.plans)
+        keep_bytes = 0
+        if kept:
+            executed_ratio["quadform_fwd"] = (16.0 * MB / args.M) ** 2
+            kernel_of["quadform_fwd"] = ("panel_mfma_kernel<MODE_QUAD> with kept products (gpsa_quadform_fwd_keep_f32: "
+                                         "the full 2*C*L*M^2 product, stored once for the backward)")
+            kernel_of["quadform_bwd_alpha"] = ("kept_wsum_kernel (gpsa_quadform_bwd_alpha_kept_f32: one streaming read "
+                                               "of the kept products; HBM-bound, no matrix-core work)")
+            keep_bytes = sum(p.saved_bytes - p.saved_bytes_nokeep for p in timer.plans)
         roof = None
         if ks:
             # the dominant kernel = the contraction with the longest launch
@@ -339,6 +350,12 @@ def main():
                                                nominal_tflops=v["tflops"],
                                                nominal_frac=v["tflops"] / PEAK_F32_MFMA_TFLOPS)
                                        for k, v in ks.items() if k != dname})
+            if kept and "quadform_bwd_alpha" in roof["other_kernels"]:  # a streaming kernel: bytes, not flops
+                o = roof["other_kernels"]["quadform_bwd_alpha"]
+                gbs = keep_bytes / (o["avg_ms"] * 1e-3) / 1e9
+                roof["other_kernels"]["quadform_bwd_alpha"] = dict(
+                    kernel=o["kernel"], avg_ms=o["avg_ms"], bound="hbm", bytes_per_launch=keep_bytes,
+                    achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0)
             # step level: algorithmic flops of a whole step / step time / peak
             Mq, Cq, Lq = args.M, args.S * N, args.outputs
             step_flops = 3.0 * (2.0 * Cq * Mq * Mq * (Lq + 1) + 2.0 * Cq * Mq * Lq

@@ -38,7 +38,7 @@ def main():
         pm = re.search(r"panel_mfma_kernel<\d+, \d+, (\d+)", k)  # third argument: 0 QUAD, 1 ACCUM, 2 STORE
         if "quad_sym_mfma_kernel" in k or (pm and pm.group(1) == "0"):
             bl["quadform_fwd"] = fb + wb
-        elif pm and pm.group(1) == "1":
+        elif (pm and pm.group(1) == "1") or "kept_wsum_kernel" in k:
             bl["quadform_bwd_alpha"] = fb + wb
         elif "gram_mfma_kernel" in k:
             bl["quadform_bwd_omega"] = fb + wb

@@ -473,6 +473,7 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   if (it0 >= it1) return;
 
   float xb[NCT][MB][4];
+  float xl[NCT][4];  // QUAD with RL < 4: the last chunk's B operand in K-step order (see PACK_KSTEP_LAST)
   f32x4 acc[MB][NCT];
   // K chunk Q of the packed left operand -> LDS buffer BUF by LDS-DMA (no VGPR staging, no ds_write):
   // wave w moves pieces w, w+4, ... (1 KiB each, lane-linear); every wave issues exactly NPW
@@ -556,6 +557,13 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
           const int row = t * 16 + ((MODE == MODE_QUAD) ? kq * 4 + r : r * 4 + kq);
           xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
+      if (MODE == MODE_QUAD && RL < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (MB - 1) * 16 + r * 4 + kq;
+          xl[ct][r] = (r < RL && c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < MB; ++rt)
@@ -579,7 +587,8 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            bv[ct][r] = (MODE == MODE_ACCUM) ? xb[ct][kc][r] * gv[ct] : xb[ct][kc][r];
+            bv[ct][r] = (MODE == MODE_ACCUM) ? xb[ct][kc][r] * gv[ct]
+                        : ((MODE == MODE_QUAD && RL < 4 && kc == MB - 1) ? xl[ct][r] : xb[ct][kc][r]);
         const float* base = &lds[buf][lane * 4];
         // A fragments are read one row tile ahead of the MFMAs that consume them (LDS latency
         // hides under the previous tile's 4*NCT MFMAs instead of stalling the matrix pipe)
@@ -1171,35 +1180,55 @@ panel_slab_reduce_kernel(const float* __restrict__ slab, int M, int MP, int wgco
 // Backward of the kept form: out[m,c] = scale * sum_l g[l,c] * (Omega_l alpha)[m,c], streaming the products the
 // forward kept (panel_mfma_kernel<QUAD>'s ``keep``, in its fragment order) exactly once: memory-bound, 13 independent
 // 16-byte loads per thread and output.  Block = the four waves' slots of one (column tile, ct).
-template <int MB, int NCT>
+template <int MB, int NCT, int RTB>
 __global__ void __launch_bounds__(256)
 kept_wsum_kernel(const float* __restrict__ keep, const float* __restrict__ g, int M, long long C, int L,
                  long long ntiles, float scale, float* __restrict__ out) {
+  // blockIdx.z: a group of RTB row tiles (more blocks and fewer registers than one thread per column: a short
+  // column range otherwise leaves the chip with one block per CU and a chain of L load latencies each)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const long long tile = blockIdx.x;
-  const int ct = blockIdx.y;
+  const int ct = blockIdx.y, rt0 = blockIdx.z * RTB;
   const long long c = tile * (64 * NCT) + (long long)w * (16 * NCT) + ct * 16 + j;
-  f32x4 acc[MB];
+  f32x4 acc[RTB];
 #pragma unroll
-  for (int rt = 0; rt < MB; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const f32x4* kp = reinterpret_cast<const f32x4*>(keep) + (((tile * 4 + w) * NCT + ct) * MB) * 64 + lane;
+  for (int i = 0; i < RTB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4* kp = reinterpret_cast<const f32x4*>(keep) + (((tile * 4 + w) * NCT + ct) * MB + rt0) * 64 + lane;
   const long long lstride = ntiles * 4 * NCT * MB * 64;  // f32x4 elements between consecutive l
-  for (int l = 0; l < L; ++l) {
-    const float gv = (c < C) ? g[(long long)l * C + c] : 0.f;
-    const f32x4* p = kp + (long long)l * lstride;
+  int l = 0;
+  for (; l + 1 < L; l += 2) {  // two outputs' loads in flight
+    const float g0 = (c < C) ? g[(long long)l * C + c] : 0.f;
+    const float g1 = (c < C) ? g[(long long)(l + 1) * C + c] : 0.f;
+    const f32x4* p0 = kp + (long long)l * lstride;
+    const f32x4* p1 = p0 + lstride;
+    f32x4 u0[RTB], u1[RTB];
 #pragma unroll
-    for (int rt = 0; rt < MB; ++rt) {
-      const f32x4 u = p[rt * 64];
-      acc[rt] += gv * u;
-    }
+    for (int i = 0; i < RTB; ++i)
+      if (rt0 + i < MB) {
+        u0[i] = p0[i * 64];
+        u1[i] = p1[i * 64];
+      }
+#pragma unroll
+    for (int i = 0; i < RTB; ++i)
+      if (rt0 + i < MB) {
+        acc[i] += g0 * u0[i];
+        acc[i] += g1 * u1[i];
+      }
+  }
+  if (l < L) {
+    const float g0 = (c < C) ? g[(long long)l * C + c] : 0.f;
+    const f32x4* p0 = kp + (long long)l * lstride;
+#pragma unroll
+    for (int i = 0; i < RTB; ++i)
+      if (rt0 + i < MB) acc[i] += g0 * p0[i * 64];
   }
   if (c < C) {
 #pragma unroll
-    for (int rt = 0; rt < MB; ++rt)
+    for (int i = 0; i < RTB; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + kq * 4 + r;
-        if (row < M) out[(long long)row * C + c] = scale * acc[rt][r];
+        const int row = (rt0 + i) * 16 + kq * 4 + r;
+        if (rt0 + i < MB && row < M) out[(long long)row * C + c] = scale * acc[i][r];
       }
   }
 }
@@ -1216,7 +1245,7 @@ int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* 
     long long grid = (long long)num_cus() * wgs_per_cu;                                         \
     if (MODE == MODE_STORE) grid = T;              /* L == 1: one item per tile */              \
     if (grid > T) grid = T;                                                                     \
-    constexpr int RLV = (MODE == MODE_QUAD) ? 4 : 2;                                            \
+    constexpr int RLV = 2;  /* QUAD: the caller packs the last chunk in K-step order (PACK_KSTEP_LAST) */ \
     if (RLV == 2 && M - 16 * (MBV - 1) <= 8)                                                    \
       panel_mfma_kernel<MBV, NCTV, MODE, RLV><<<(unsigned)grid, 256, 0, st>>>(                  \
           Ppk, X, g, M, C, L, out, colsq, scale, slab, keep);                                   \
@@ -1472,10 +1501,12 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
     if (MB && MB <= MB_MAX_QUAD && !force_generic()) {
       if (workspace_bytes < (long long)L * MB * 16 * MB * 16 * 4) return GPSA_EWORKSPACE;
       float* Ppk = (float*)workspace;
-      static const bool full = [] { const char* e = getenv("GPSA_QUAD_FULL"); return e && e[0] == '1'; }();
+      static const bool full_env = [] { const char* e = getenv("GPSA_QUAD_FULL"); return e && e[0] == '1'; }();
+      const bool full = full_env && MB <= 16;  // (the full-product kernel holds M <= 256)
       // (the last chunk goes in K-step order exactly when quad_sym_launch picks the step-skipping kernel)
       const int sym = PACK_SYM_UPPER | ((M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0);
-      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, full ? 0 : sym);
+      const int klast = (M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0;  // matches panel_mfma_launch's RL choice
+      int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, full ? klast : sym);
       if (rc) return rc;
       if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
@@ -1520,7 +1551,8 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
   hipStream_t st = as_stream(stream);
   const int MB = mfma_mb_for(M);
   float* Ppk = (float*)workspace;
-  int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, 0);
+  const int klast = (M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0;  // matches panel_mfma_launch's RL choice
+  int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, klast);
   if (rc) return rc;
   return panel_mfma_launch<MODE_QUAD>(MB, Ppk, alpha, nullptr, M, C, L, v, nullptr, 1.f, nullptr, st, W);
 }
@@ -1535,7 +1567,9 @@ int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long
 #define GPSA_KEPT_CASE(MBV, NCTV)                                                                        \
   case MBV: {                                                                                            \
     const long long ntiles = cdiv(C, 64 * NCTV);                                                         \
-    kept_wsum_kernel<MBV, NCTV><<<dim3((unsigned)ntiles, NCTV), 256, 0, st>>>(W, g, M, C, L, ntiles, 2.f, dalpha); \
+    constexpr int RTB = 4;                                                                                \
+    kept_wsum_kernel<MBV, NCTV, RTB><<<dim3((unsigned)ntiles, NCTV, (MBV + RTB - 1) / RTB), 256, 0, st>>>( \
+        W, g, M, C, L, ntiles, 2.f, dalpha);                                                             \
     break;                                                                                               \
   }
   switch (MB) {

@@ -19,8 +19,8 @@ open(os.path.join(O, f"{tag}_pmc_fetch_write_summary.txt"), "w").write(
     "--no-cpu-baseline --no-graph --no-s1\n(profiles/pmc_summarize.py: KiB -> bytes, FETCH doubled per "
     "MI355X_MICROARCH.md; per-launch averages, top 12 by fetch)\n\n" + fw)
 
-keys = {"panel_mfma_kernel<13, 3, 1, 2>": "panel_mfma_kernel<13,3,ACCUM,2>  (dominant)",
-        "quad_sym_mfma_kernel": "quad_sym_mfma_kernel<13,3,2>",
+keys = {"panel_mfma_kernel<13, 3, 0, 4>": "panel_mfma_kernel<13,3,QUAD,4> + kept products  (dominant)",
+        "kept_wsum_kernel": "kept_wsum_kernel<13,3,4>  (streaming, no MFMA)",
         "gram_mfma_kernel": "gram_mfma_kernel<13,true,2>  (2 outputs per WG)",
         "whiten_mfma_kernel<13, double, float, true>": "whiten_mfma_kernel<13,double,float,stream> (fp64 MFMA)",
         "whiten_mfma_kernel<13, float, float, true>": "whiten_mfma_kernel<13,float,float,stream>  (fp64 MFMA)"}
@@ -34,6 +34,8 @@ for r in csv.DictReader(open(os.path.join(P, "busy", "b_counter_collection.csv")
 rows = []
 for key, label in keys.items():
     ds = [d for (k, _), d in per.items() if k == key]
+    if not ds:
+        continue
     if key == "gram_mfma_kernel":
         ds = [d for d in ds if d["dur"] > 1e6]  # the data layer's launches (the warp layers' are ~70 us)
     G = sum(d["GRBM_GUI_ACTIVE"] for d in ds) / len(ds)
