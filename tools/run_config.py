@@ -74,9 +74,15 @@ for p in plans:
     if n > 0:
         C_, L_, M_ = CFG["S"] * CFG["views"] * CFG["side"] ** 2, CFG["latent"], CFG["M"]
         fl = 2.0 * C_ * L_ * M_ * M_
-        for k, name in enumerate(("variance form a^T Omega a", "its alpha-gradient (ACCUM)", "its Omega-gradient (Gram)")):
+        kept = p.saved_bytes - p.saved_bytes_nokeep  # training keeps the products Omega_l alpha (M <= 256)
+        names = ("variance form a^T Omega a" + (" (full product, kept)" if kept else ""),
+                 "its alpha-gradient (" + ("streams the kept products" if kept else "ACCUM") + ")", "its Omega-gradient (Gram)")
+        for k, name in enumerate(names):
             ms = sum(buf[i * 3 + k] for i in range(n)) / n
-            print(f"  {name:32s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TF nominal = {fl / ms / 1e9 / 157.3:.2f} of the fp32-MFMA peak")
+            if kept and k == 1:
+                print(f"  {name:46s} {ms:8.3f} ms   {kept / ms / 1e6:7.0f} GB/s = {kept / ms / 1e6 / 8000:.2f} of the HBM peak")
+            else:
+                print(f"  {name:46s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TF nominal = {fl / ms / 1e9 / 157.3:.2f} of the fp32-MFMA peak")
 print(f"{which}: {CFG['views']} views x {CFG['side'] ** 2} spots, {CFG['outputs']} outputs via {CFG['latent']} latent GPs, "
       f"M={CFG['M']}, S={CFG['S']}: {dt * 1e3:.2f} ms/step, loss {float(l0):.4g} -> {float(loss):.4g}, "
       f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
