@@ -628,7 +628,7 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
                  (((((long long)l * ntiles + tile) * 4 + w) * NCT + ct) * MB) * 64 + lane;
 #pragma unroll
           for (int rt = 0; rt < MB; ++rt) {
-            if (kp != nullptr) kp[rt * 64] = acc[rt][ct];
+            if (kp != nullptr) __builtin_nontemporal_store(acc[rt][ct], &kp[rt * 64]);  // written once, read once, much later
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               s += acc[rt][ct][r] * xb[ct][rt][r];
@@ -1205,8 +1205,8 @@ kept_wsum_kernel(const float* __restrict__ keep, const float* __restrict__ g, in
 #pragma unroll
     for (int i = 0; i < RTB; ++i)
       if (rt0 + i < MB) {
-        u0[i] = p0[i * 64];
-        u1[i] = p1[i * 64];
+        u0[i] = __builtin_nontemporal_load(&p0[i * 64]);
+        u1[i] = __builtin_nontemporal_load(&p1[i * 64]);
       }
 #pragma unroll
     for (int i = 0; i < RTB; ++i)
@@ -1220,7 +1220,7 @@ kept_wsum_kernel(const float* __restrict__ keep, const float* __restrict__ g, in
     const f32x4* p0 = kp + (long long)l * lstride;
 #pragma unroll
     for (int i = 0; i < RTB; ++i)
-      if (rt0 + i < MB) acc[i] += g0 * p0[i * 64];
+      if (rt0 + i < MB) acc[i] += g0 * __builtin_nontemporal_load(&p0[i * 64]);
   }
   if (c < C) {
 #pragma unroll
