@@ -136,7 +136,8 @@ int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M,
  * and, in the same pass, the products Omega[l] alpha themselves into W - an opaque buffer of
  * gpsa_quadform_keep_f32_bytes(M, C, L) bytes (about L M C 4) in the kernel's own accumulator order, so that each
  * wave stores 1 KiB contiguous.  Training's backward is then gpsa_quadform_bwd_alpha_kept_f32:
- *     dalpha[:,c] = 2 sum_l g[l,c] (Omega[l] alpha)[:,c]
+ *     dalpha[:,c] = 2 sum_l g[l,c] (Omega[l] alpha)[:,c]  ( + dcT dmeanT: the mean term's share, dcT [M,L] and
+ *     dmeanT [L,C] both or neither NULL, as in gpsa_quadform_bwd_alpha_kept )
  * as ONE streaming read of W instead of the L M x M x C products of gpsa_quadform_bwd_alpha (vgpsa.py:192-196
  * and its autograd; the forward alone loses the symmetric half-price form: without a backward use
  * gpsa_quadform_fwd).  Omega [L,M,M] stored as omega_dtype.  workspace >= gpsa_quadform_keep_f32_workspace(M, L);
@@ -145,8 +146,8 @@ long long gpsa_quadform_keep_f32_workspace(int M, int L);
 long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L);
 int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
                                float* v, float* W, void* workspace, long long workspace_bytes, void* stream);
-int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, float* dalpha,
-                                     void* stream);
+int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, const float* dcT,
+                                     const float* dmeanT, float* dalpha, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
  * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */

@@ -137,7 +137,7 @@ SIGNATURES.update({
     "gpsa_quadform_keep_f32_workspace": (_ll, [_i, _i]),
     "gpsa_quadform_fwd_keep_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_keep_f32_bytes": (_ll, [_i, _ll, _i]),
-    "gpsa_quadform_bwd_alpha_kept_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp]),
+    "gpsa_quadform_bwd_alpha_kept_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     "gpsa_step_scratch_bytes": (_ll, [_vp]),
     "gpsa_step_n_kl": (_i, [_vp]),
     "gpsa_step_eps_g_numel": (_ll, [_vp]),

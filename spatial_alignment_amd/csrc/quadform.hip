@@ -1183,7 +1183,8 @@ panel_slab_reduce_kernel(const float* __restrict__ slab, int M, int MP, int wgco
 template <int MB, int NCT, int RTB>
 __global__ void __launch_bounds__(256)
 kept_wsum_kernel(const float* __restrict__ keep, const float* __restrict__ g, int M, long long C, int L,
-                 long long ntiles, float scale, float* __restrict__ out) {
+                 long long ntiles, float scale, const float* __restrict__ A, const float* __restrict__ dm,
+                 float* __restrict__ out) {
   // blockIdx.z: a group of RTB row tiles (more blocks and fewer registers than one thread per column: a short
   // column range otherwise leaves the chip with one block per CU and a chain of L load latencies each)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
@@ -1222,13 +1223,32 @@ kept_wsum_kernel(const float* __restrict__ keep, const float* __restrict__ g, in
     for (int i = 0; i < RTB; ++i)
       if (rt0 + i < MB) acc[i] += g0 * __builtin_nontemporal_load(&p0[i * 64]);
   }
+  // the mean term's share  sum_l A[m,l] dm[l,c]  (A = delta [M,L], dm = d mean [L,C]) on the matrix cores: the
+  // thread's accumulators are already MFMA C-layout tiles (row 4 kq + r, column j), so each 16 x 16 tile takes
+  // ceil(L / 4) MFMA steps with A[16 rt + j][4 s + kq] and dm[4 s + kq][c_j] as operands - no separate product
+  // and no second pass over the [M,C] panel
+  f32x4 tacc[RTB];
+#pragma unroll
+  for (int i = 0; i < RTB; ++i) tacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (A != nullptr) {  // uniform
+    for (int l0 = 0; l0 < L; l0 += 4) {
+      const int ll = l0 + kq;
+      const float b = (ll < L && c < C) ? dm[(long long)ll * C + c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < RTB; ++i) {
+        const int row = (rt0 + i) * 16 + j;
+        const float a = (rt0 + i < MB && ll < L && row < M) ? A[(long long)row * L + ll] : 0.f;
+        tacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, tacc[i], 0, 0, 0);
+      }
+    }
+  }
   if (c < C) {
 #pragma unroll
     for (int i = 0; i < RTB; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = (rt0 + i) * 16 + kq * 4 + r;
-        if (rt0 + i < MB && row < M) out[(long long)row * C + c] = scale * acc[i][r];
+        if (rt0 + i < MB && row < M) out[(long long)row * C + c] = fmaf(scale, acc[i][r], tacc[i][r]);
       }
   }
 }
@@ -1557,10 +1577,11 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
   return panel_mfma_launch<MODE_QUAD>(MB, Ppk, alpha, nullptr, M, C, L, v, nullptr, 1.f, nullptr, st, W);
 }
 
-int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, float* dalpha,
-                                     void* stream) {
+int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, const float* dcT,
+                                     const float* dmeanT, float* dalpha, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1 || !W || !g || !dalpha) return GPSA_EINVAL;
+  if ((dcT == nullptr) != (dmeanT == nullptr)) return GPSA_EINVAL;
   const int MB = mfma_mb_for(M);
   if (!MB || MB > 16 || force_generic()) return GPSA_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
@@ -1569,7 +1590,7 @@ int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long
     const long long ntiles = cdiv(C, 64 * NCTV);                                                         \
     constexpr int RTB = 4;                                                                                \
     kept_wsum_kernel<MBV, NCTV, RTB><<<dim3((unsigned)ntiles, NCTV, (MBV + RTB - 1) / RTB), 256, 0, st>>>( \
-        W, g, M, C, L, ntiles, 2.f, dalpha);                                                             \
+        W, g, M, C, L, ntiles, 2.f, dcT, dmeanT, dalpha);                                                \
     break;                                                                                               \
   }
   switch (MB) {

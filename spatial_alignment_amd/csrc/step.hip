@@ -1225,14 +1225,16 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     const bool timed = !dry && &ps == &P.passes[0];
     if (timed) P.tick(1, 0, false, c.st);
     const bool kept = c.io.keep_products && ps.o_keep >= 0;
-    if (kept)  // one streaming pass over the products the forward kept
-      GPSA_RUN(gpsa_quadform_bwd_alpha_kept_f32(c.sv<float>(ps.o_keep), g_ext, Mg, C, L, abar, c.stv()));
+    if (kept)  // one streaming pass over the products the forward kept, the mean term's share in the same pass
+      GPSA_RUN(gpsa_quadform_bwd_alpha_kept_f32(c.sv<float>(ps.o_keep), g_ext, Mg, C, L, c.prm.delta_F[m], dmeanT, abar,
+                                                c.stv()));
     else
       GPSA_RUN(gpsa_quadform_bwd_alpha(GPSA_F32, GPSA_F64, alpha, Om, g_ext, Mg, C, L, abar, ws, wsb, c.stv()));
     if (timed) P.tick(1, 1, false, c.st);
     c.sc.release(mk2);
+    if (!kept)
+      GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
   }
-  GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
   // d delta_F = alpha dmean^T
   GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
                  splitk_for(C, Mg, L)));

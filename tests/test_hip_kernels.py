@@ -36,6 +36,11 @@ def close(got, want, tol):
 TOL = {torch.float32: 2e-5, torch.float64: 1e-11}
 
 
+def _lib_einval():
+    from spatial_alignment_amd import _lib
+    return _lib.GPSA_EINVAL
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32"])
 @pytest.mark.parametrize("M,C,D", [(7, 300, 2), (25, 1000, 1), (200, 777, 3), (33, 33, 2)])
@@ -168,10 +173,21 @@ def test_quadform_keep_f32(hip, M, C, L):
     close(v, (Wr * al.double()[None]).sum(1), 2e-6)
     close(hip.quadform_fwd(ald, Omd), v, 3e-6)        # the cheap forward agrees with the kept one
     out = torch.full((M, C), float("nan"), device=DEV)
-    rc = hip.lib.gpsa_quadform_bwd_alpha_kept_f32(W.data_ptr(), gd.data_ptr(), M, C, L, out.data_ptr(), st)
+    rc = hip.lib.gpsa_quadform_bwd_alpha_kept_f32(W.data_ptr(), gd.data_ptr(), M, C, L, None, None, out.data_ptr(), st)
     assert rc == 0
-    close(out, 2.0 * torch.einsum("lc,lmc->mc", g.double(), Wr), 2e-6)
+    want = 2.0 * torch.einsum("lc,lmc->mc", g.double(), Wr)
+    close(out, want, 2e-6)
     close(out, hip.quadform_bwd_alpha(ald, Omd, gd), 3e-6)
+    # with the mean term's share dcT dmeanT in the same pass
+    dc, dm = rnd(M, L, seed=5), rnd(L, C, seed=6)
+    dcd, dmd = dc.to(DEV), dm.to(DEV)
+    out2 = torch.full((M, C), float("nan"), device=DEV)
+    rc = hip.lib.gpsa_quadform_bwd_alpha_kept_f32(W.data_ptr(), gd.data_ptr(), M, C, L, dcd.data_ptr(), dmd.data_ptr(),
+                                                  out2.data_ptr(), st)
+    assert rc == 0
+    close(out2, want + dc.double() @ dm.double(), 2e-6)
+    assert hip.lib.gpsa_quadform_bwd_alpha_kept_f32(W.data_ptr(), gd.data_ptr(), M, C, L, dcd.data_ptr(), None,
+                                                    out2.data_ptr(), st) == _lib_einval()
     assert hip.lib.gpsa_quadform_keep_f32_workspace(300, 3) == 0   # beyond the kernel: callers recompute
     assert hip.lib.gpsa_quadform_keep_f32_bytes(300, 1000, 3) == 0
 
