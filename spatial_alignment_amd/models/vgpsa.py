@@ -110,6 +110,10 @@ class VariationalGPSA(GPSA):
         # forward as ONE node whose launch sequence is enqueued from C++ (step_engine.py, csrc/step.hip);
         # False: one node per layer driven from Python (the path arbitrary plug-in covariance callables take)
         self.use_step_engine = True
+        # training forwards keep the data GPs' products Omega_l alpha for the backward (L M C 4 bytes of HBM,
+        # one product less per step); False: recompute them in the backward (the memory-lean path, also taken
+        # by itself when M > 256 or the products exceed GPSA_KEEP_GB)
+        self.keep_products = True
         self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
         self._cache = None
 
@@ -578,7 +582,7 @@ class VariationalGPSA(GPSA):
         aux = dict(plan=plan, model=self, X=[X_spatial[m].contiguous() for m in mods], eps_G=eps_G, eps_F=eps_F,
                    G_test=Gt if G_test is not None else None, eps_F_test=eps_Ft,
                    slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
-                   want_kl=not prediction_mode, check=check,
+                   want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,
                    flag_slot=self.__dict__.get("_flag_slot", 0))
         self.__dict__["_flag_slot"] = 1 - aux["flag_slot"]  # two pinned words: consecutive forwards never share one
         outs = SE.StepFn.apply(aux, *SE._param_list(self))

@@ -248,14 +248,14 @@ class StepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         aux = ctx.aux
+        if aux is None or ctx.arena is None:
+            raise RuntimeError("GPSA step: backward through the same forward a second time - its saved arena was "
+                               "released after the first backward (run forward again)")
         plan, model = aux["plan"], aux["model"]
         if aux.get("deferred") is not None:  # the forward's numerics word: raise before any gradient exists
             pend, aux["deferred"] = aux["deferred"], None
             model._pending_flag = None
             model._raise_on_flags(pend)
-        if ctx.arena is None:
-            raise RuntimeError("GPSA step: backward through the same forward a second time - its saved arena was "
-                               "released after the first backward (run forward again)")
         lib = plan.lib
         tensors = ctx.saved_tensors
         dev = tensors[0].device
@@ -323,6 +323,7 @@ class StepFn(torch.autograd.Function):
         # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
         # would break, steps later
         ctx.arena = None
+        ctx.aux = ctx.io = ctx.prm = ctx.keep = None  # ... and the cycle is cut here for everything else it holds
         return tuple(out)
 
 

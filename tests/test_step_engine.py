@@ -49,6 +49,66 @@ def test_engine_matches_reference_fp64(name):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name", [c for c in CASES if c.startswith(("c2", "c3", "c4", "c9"))])
+def test_kept_products_match_recomputed(name):
+    """training's forward keeps the data GPs' products Omega_l alpha and the backward streams them; with
+    ``keep_products = False`` the forward is the half-price symmetric form and the backward recomputes them:
+    same outputs and gradients (different kernels, so to rounding), and the arena is the smaller one"""
+    g = Golden(name)
+    res, arena = {}, {}
+    for keep in (True, False):
+        model, dd = build_model(g, device=DEV)
+        model.keep_products = keep
+        res[keep] = run_step(model, dd, g, device=DEV)
+        plan = next(iter(model._step_plans.values()))
+        arena[keep] = (plan.saved_bytes, plan.saved_bytes_nokeep)
+    assert arena[True][0] > arena[True][1]  # this plan CAN keep (M <= 256)
+    big = bool(g.cfg.get("summary_only"))
+    for k, want in res[False].items():
+        got = res[True][k]
+        if np.isnan(want).any() or np.linalg.norm(want.astype(np.float64)) == 0:
+            continue
+        e = rel(got, want)
+        assert e <= ((3e-3 if big else 3e-5) if k.startswith("grad/") else 2e-6), (k, e)
+
+
+def test_arenas_do_not_pile_up():
+    """no backward to follow: nothing is kept and nothing leaks between calls; a training step hands its arena back
+    right after backward (the autograd node sits in a reference cycle only the cyclic collector would break)"""
+    import gc
+
+    g = Golden("c7_m200_conditioning")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {m: d["spatial_coords"] for m, d in dd.items()}
+    gc.disable()
+    try:
+        with torch.no_grad():
+            model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
+            base = torch.cuda.memory_allocated()
+            for _ in range(3):
+                model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
+            assert torch.cuda.memory_allocated() <= base + (1 << 20)
+        used = []
+        for _ in range(5):
+            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
+            loss = model.loss_fn(dd, out[3])
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            del out, loss
+            used.append(torch.cuda.memory_allocated())
+        plan = [p for p in model._step_plans.values() if p.S == 2][0]
+        assert plan.saved_bytes - plan.saved_bytes_nokeep > (4 << 20)
+        assert used[-1] <= used[1] + (1 << 20), used
+    finally:
+        gc.enable()
+    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
+    loss = model.loss_fn(dd, out[3])
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+
+
 def test_engine_unequal_views_and_user_loss_on_G():
     """views of different sizes (padding columns of the view blocks), a loss that also uses G_means and
     G_samples directly, S = 1"""
