@@ -281,12 +281,65 @@ static inline int gram_splitk(long long C, int M) {
   return (int)s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gram sums beyond the register-resident kernel (M > 256: BASELINE configs 4 / 5), fp32 matrix cores:
+//     P[l][i][j] = sum_c g[l,c] alpha[i,c] alpha[j,c]       for the 128 x 128 blocks touching the lower triangle
+// One workgroup = one block pair (bi >= bj), one output l, one slice of the columns.  Both operands are rows of
+// alpha, contiguous along the contracted index c: a chunk of 16 columns of the 128 + 128 rows moves to LDS by
+// LDS-DMA as sixteen 1-KiB pieces in MFMA-fragment order (lane j + 16 kq holds alpha[16 p + j][c0 + 4 kq .. +3]),
+// so a fragment read is one conflict-free ds_read_b128 and nothing is staged through registers or transposed
+// through ds_write (the generic tiled product spends 45 % of its LDS cycles in bank conflicts on exactly that,
+// and ran this shape at 0.35 matrix-pipe utilisation).  g scales the left fragment as it is read (no [M, C]
+// scaled copy of alpha per output).  Three-slot ring, two stages in flight, one barrier per 64 MFMAs per wave.
+// The forward declarations of glds16 / lds_addr / GPSA_DMA_* are below (panel kernels); this kernel is
+// instantiated after them.
+struct GramBigArgs {
+  const float* alpha;  // [M][C]
+  const float* g;      // [L][Cpad], zero beyond C (Cpad = a multiple of 16)
+  float* part;         // [L][nsplit][M][M]   (lower blocks written)
+  int M, L, nsplit, nblk;
+  long long C, Cpad;
+};
+__global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
+                                float* __restrict__ gpad);
+__global__ void gram_big_kernel(GramBigArgs a);
+template <typename TO>
+__global__ void gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit, TO* __restrict__ out);
+static inline bool gram_big_off() {
+  static const bool v = [] { const char* e = getenv("GPSA_GRAM_BIG"); return e && e[0] == '0'; }();
+  return v;
+}
+
 template <typename T>
 int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, int L, T* dOmega,
                                void* ws, long long ws_bytes, hipStream_t st) {
   // up to 4 outputs per pass: one scaling launch and one batched split-K product for the group.  (Scaling the
   // left operand by g along the contracted index INSIDE the product - gemm_launch_scaled's kscale - was
   // measured slower than this materialised copy: 26.5 vs 25.1 ms at M = 500, 55 vs 43 ms at M = 1000.)
+  if constexpr (sizeof(T) == 4) {
+    // fp32: the LDS-DMA Gram kernel (16-byte aligned rows; its partial slabs must fit the workspace)
+    const int nblk = (int)cdiv(M, 128), pairs = nblk * (nblk + 1) / 2;
+    long long ns = cdiv(1024, (long long)pairs * L);
+    const long long nch = cdiv(C, 16);
+    if (ns > nch / 8) ns = nch / 8 > 0 ? nch / 8 : 1;
+    if (ns > 16) ns = 16;
+    if (ns < 1) ns = 1;
+    const long long Cpad = nch * 16, part_b = (long long)L * ns * M * M * 4;
+    const long long need = part_b + (long long)L * Cpad * 4;
+    if (!gram_big_off() && (C & 3) == 0 && C >= 16 && (reinterpret_cast<uintptr_t>(alpha) & 15) == 0 && need <= ws_bytes &&
+        L <= 65535) {
+      float* gpad = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_b);
+      pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, gpad);
+      GPSA_LAUNCH_CHECK();
+      GramBigArgs a{alpha, gpad, reinterpret_cast<float*>(ws), M, L, (int)ns, nblk, C, Cpad};
+      gram_big_kernel<<<dim3((unsigned)pairs, (unsigned)ns, (unsigned)L), 256, 0, st>>>(a);
+      GPSA_LAUNCH_CHECK();
+      gram_big_reduce_kernel<float><<<dim3((unsigned)cdiv((long long)M * M, 256), (unsigned)L), 256, 0, st>>>(
+          a.part, M, (int)ns, dOmega);
+      GPSA_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const int sk = gram_splitk(C, M);
   const long long tmp_b = (long long)M * C * (long long)sizeof(T);
   const long long part_b = (sk > 1) ? (long long)sk * M * M * (long long)sizeof(T) : 0;
@@ -396,6 +449,110 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
 #define GPSA_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(lds_ptr_t)(p);
+}
+
+__global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
+  __shared__ __attribute__((aligned(16))) float sg[3][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
+  // block pair t -> (bi, bj), bj <= bi, row-major over the lower triangle
+  int bi = 0, t = blockIdx.x;
+  while (t > bi) {
+    t -= bi + 1;
+    ++bi;
+  }
+  const int bj = t, l = blockIdx.z, sp = blockIdx.y;
+  const int M = a.M;
+  const long long C = a.C;
+  const long long nch = (C + 15) / 16;
+  const long long ch0 = (long long)sp * nch / a.nsplit, ch1 = (long long)(sp + 1) * nch / a.nsplit;
+  const float* gl = a.g + (long long)l * a.Cpad;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // stage chunk CH into ring slot BUF: wave w moves pieces w, w+4, w+8, w+12 (0..7: rows of block bi, 8..15: bj);
+  // rows >= M are clamped (they only feed outputs >= M, never stored), columns beyond C to the last aligned group
+  // (they meet g == 0: g is zero-padded to whole chunks).  The chunk's 16 values of g ride along as a fifth
+  // operation of every wave (all four write the same 64 bytes): a counted vmcnt(5) then means "everything but the
+  // newest stage has landed".
+#define GPSA_GB_STAGE(CH, BUF)                                                                \
+  {                                                                                           \
+    long long col__ = (long long)(CH) * 16 + kq * 4;                                          \
+    col__ = col__ < C - 4 ? col__ : C - 4;                                                    \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) {                                        \
+      const int piece = pc * 4 + w;                                                           \
+      int row__ = ((piece < 8) ? bi * 128 + piece * 16 : bj * 128 + (piece - 8) * 16) + j;    \
+      row__ = row__ < M ? row__ : M - 1;                                                      \
+      glds16(a.alpha + (long long)row__ * C + col__,                                          \
+             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));               \
+    }                                                                                         \
+    if (lane < 4)                                                                             \
+      glds16(gl + (long long)(CH) * 16 + lane * 4, __builtin_amdgcn_readfirstlane(lds_addr(&sg[BUF][0]))); \
+  }
+  if (ch0 < ch1) {
+    GPSA_GB_STAGE(ch0, 0)
+    GPSA_GB_STAGE(ch0 + 1 < ch1 ? ch0 + 1 : ch0, 1)
+  }
+  GPSA_DMA_WAIT(5);
+  __syncthreads();
+  int buf = 0;
+  for (long long ch = ch0; ch < ch1; ++ch) {
+    // slot (buf + 2) % 3 held chunk ch - 1: everyone left it before the barrier that ended that iteration
+    GPSA_GB_STAGE(ch + 2 < ch1 ? ch + 2 : ch1 - 1, buf == 0 ? 2 : buf - 1)
+    const float* base = &lds[buf][lane * 4];
+    const float4 gk = *reinterpret_cast<const float4*>(&sg[buf][kq * 4]);
+    float4 av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 x = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
+      av[i] = make_float4(x.x * gk.x, x.y * gk.y, x.z * gk.z, x.w * gk.w);
+      bv[i] = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+    }
+#define GPSA_GB_MMA(F)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                             \
+      acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, bv[k].F, acc[i][k], 0, 0, 0);
+    GPSA_GB_MMA(x)
+    GPSA_GB_MMA(y)
+    GPSA_GB_MMA(z)
+    GPSA_GB_MMA(w)
+#undef GPSA_GB_MMA
+    GPSA_DMA_WAIT(5);
+    __syncthreads();
+    buf = (buf == 2) ? 0 : buf + 1;
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_GB_STAGE
+  float* P = a.part + ((long long)l * a.nsplit + sp) * M * M;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi * 128 + wr * 64 + i * 16 + kq * 4 + r, col = bj * 128 + wc * 64 + k * 16 + j;
+        if (row < M && col < M) P[(long long)row * M + col] = acc[i][k][r];
+      }
+}
+
+// out[l][i][j] = out[l][j][i] = sum_s part[l][s][max(i,j)][min(i,j)]  (the lower blocks hold every i >= j)
+template <typename TO>
+__global__ void __launch_bounds__(256) gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit,
+                                                              TO* __restrict__ out) {
+  const long long mm = (long long)M * M, e = blockIdx.x * 256LL + threadIdx.x;
+  if (e >= mm) return;
+  const int l = blockIdx.y, i = (int)(e / M), jj = (int)(e % M);
+  const long long src = (jj <= i) ? e : (long long)jj * M + i;
+  const float* p = part + (long long)l * nsplit * mm + src;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * mm];
+  out[(long long)l * mm + e] = (TO)s;
 }
 
 // Visiting order of a workgroup's column tiles.  The item range [it0, it1) covers tiles tile0..tile1;
