@@ -140,8 +140,10 @@ int gpsa_quadform_bwd_alpha_kept(int dtype, const void* W, const void* g, int M,
  *     dmeanT [L,C] both or neither NULL, as in gpsa_quadform_bwd_alpha_kept )
  * as ONE streaming read of W instead of the L M x M x C products of gpsa_quadform_bwd_alpha (vgpsa.py:192-196
  * and its autograd; the forward alone loses the symmetric half-price form: without a backward use
- * gpsa_quadform_fwd).  Omega [L,M,M] stored as omega_dtype.  workspace >= gpsa_quadform_keep_f32_workspace(M, L);
- * both sizes are 0 when M is beyond the kernel (GPSA_EUNSUPPORTED). */
+ * gpsa_quadform_fwd).  Omega [L,M,M] stored as omega_dtype.  workspace >= gpsa_quadform_keep_f32_workspace(M, L).
+ * M <= 256: the register-resident full-product kernel; beyond (configs 4 / 5): one tiled product per output into
+ * a row-major [L][M][C] buffer, streamed back by a row-blocked kernel - the same entry points, the same sizes
+ * queries. */
 long long gpsa_quadform_keep_f32_workspace(int M, int L);
 long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L);
 int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,

@@ -18,6 +18,8 @@
 
 namespace gpsa {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 template <typename T>
 int gemm_launch(int transA, int transB, int m, int n, long long k, double alpha, const T* A,
                 long long lda, long long sA, const T* B, long long ldb, long long sB, double beta,
@@ -152,6 +154,66 @@ __global__ void col_wsum_kernel(const T* __restrict__ W, const T* __restrict__ g
       if (A != nullptr) t += A[(long long)m * L + l] * dm[(long long)l * C + c];
     }
     out[(long long)m * C + c] = T(2) * s + t;
+  }
+}
+
+// The same sum over products kept ROW-MAJOR [L][M][C] (the large-M data GP, M > 256), fp32: one thread = 4 columns x
+// RB rows, so that g / dm are read once per RB rows and RB independent 16-byte loads of W are in flight per
+// output; W is read exactly once (nontemporal: it does not come back).
+template <int RB>
+__global__ void __launch_bounds__(256)
+col_wsum_rows_kernel(const float* __restrict__ W, const float* __restrict__ g, int M, long long C, int L,
+                     const float* __restrict__ A, const float* __restrict__ dm, float* __restrict__ out) {
+  const long long c = (blockIdx.x * 256LL + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int m0 = blockIdx.y * RB;
+  f32x4_t acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool full = c + 4 <= C && (C & 3) == 0;  // aligned 16-byte accesses
+  for (int l = 0; l < L; ++l) {
+    f32x4_t gv, dv = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (full) {
+      gv = *reinterpret_cast<const f32x4_t*>(g + (long long)l * C + c);
+      if (A != nullptr) dv = *reinterpret_cast<const f32x4_t*>(dm + (long long)l * C + c);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gv[i] = (c + i < C) ? g[(long long)l * C + c + i] : 0.f;
+        dv[i] = (A != nullptr && c + i < C) ? dm[(long long)l * C + c + i] : 0.f;
+      }
+    }
+    gv *= 2.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int m = m0 + r;
+      if (m < M) {  // block-uniform
+        const float* wp = W + ((long long)l * M + m) * C + c;
+        f32x4_t w;
+        if (full) {
+          w = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(wp));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = (c + i < C) ? wp[i] : 0.f;
+        }
+        const float a = (A != nullptr) ? A[(long long)m * L + l] : 0.f;
+        acc[r] += gv * w + a * dv;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int m = m0 + r;
+    if (m < M) {
+      float* op = out + (long long)m * C + c;
+      if (full) {
+        *reinterpret_cast<f32x4_t*>(op) = acc[r];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c + i < C) op[i] = acc[r][i];
+      }
+    }
   }
 }
 
@@ -1705,33 +1767,61 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
   return GPSA_EINVAL;
 }
 
-long long gpsa_quadform_keep_f32_workspace(int M, int L) {
+// M <= 256: the register-resident full-product kernel, products in its accumulator order;
+// beyond: one tiled product per output into a row-major [L][M][C] buffer (the generic MFMA product)
+static inline bool keep_mfma_path(int M) {
   const int MB = gpsa::mfma_mb_for(M);
-  if (!MB || MB > 16 || gpsa::force_generic()) return 0;  // the full-product form kernel holds M <= 256
-  return (long long)L * MB * 16 * MB * 16 * 4;
+  return MB && MB <= 16 && !gpsa::force_generic();
+}
+
+long long gpsa_quadform_keep_f32_workspace(int M, int L) {
+  if (M < 1 || L < 1) return 0;
+  if (keep_mfma_path(M)) {
+    const int MB = gpsa::mfma_mb_for(M);
+    return (long long)L * MB * 16 * MB * 16 * 4;
+  }
+  return (long long)L * M * M * 4 + 256;  // fp32 copy of Omega
 }
 
 long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L) {
-  const int MB = gpsa::mfma_mb_for(M);
-  if (!MB || MB > 16 || gpsa::force_generic() || C < 1 || L < 1) return 0;
-  const long long wgcols = 64LL * gpsa::panel_nct_for(MB);
-  return (long long)L * cdiv(C, wgcols) * wgcols * MB * 16 * 4;
+  if (M < 1 || C < 1 || L < 1) return 0;
+  if (keep_mfma_path(M)) {
+    const int MB = gpsa::mfma_mb_for(M);
+    const long long wgcols = 64LL * gpsa::panel_nct_for(MB);
+    return (long long)L * cdiv(C, wgcols) * wgcols * MB * 16 * 4;
+  }
+  return (long long)L * M * C * 4;
 }
 
 int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
                                float* v, float* W, void* workspace, long long workspace_bytes, void* stream) {
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1 || !alpha || !Omega || !v || !W) return GPSA_EINVAL;
-  const long long need = gpsa_quadform_keep_f32_workspace(M, L);
-  if (need == 0) return GPSA_EUNSUPPORTED;
-  if (workspace_bytes < need) return GPSA_EWORKSPACE;
+  if (workspace_bytes < gpsa_quadform_keep_f32_workspace(M, L)) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const int MB = mfma_mb_for(M);
-  float* Ppk = (float*)workspace;
-  const int klast = (M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0;  // matches panel_mfma_launch's RL choice
-  int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, klast);
+  if (keep_mfma_path(M)) {
+    const int MB = mfma_mb_for(M);
+    float* Ppk = (float*)workspace;
+    const int klast = (M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0;  // matches panel_mfma_launch's RL choice
+    int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, klast);
+    if (rc) return rc;
+    return panel_mfma_launch<MODE_QUAD>(MB, Ppk, alpha, nullptr, M, C, L, v, nullptr, 1.f, nullptr, st, W);
+  }
+  if (C > 0x7fffffffLL) return GPSA_EINVAL;
+  const float* Om;
+  int rc = operand_as<float>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
   if (rc) return rc;
-  return panel_mfma_launch<MODE_QUAD>(MB, Ppk, alpha, nullptr, M, C, L, v, nullptr, 1.f, nullptr, st, W);
+  // W[l] = Omega[l] alpha: batches of outputs (grid.z <= 65535)
+  for (int l0 = 0; l0 < L; l0 += 16384) {
+    const int nb = (L - l0 < 16384) ? L - l0 : 16384;
+    rc = gemm_launch<float>(0, 0, M, (int)C, M, 1.0, Om + (long long)l0 * M * M, M, (long long)M * M, alpha, C, 0, 0.0,
+                            W + (long long)l0 * M * C, C, (long long)M * C, nb, 1, nullptr, 0, st);
+    if (rc) return rc;
+    coldot_kernel<float><<<dim3((unsigned)cdiv(C, 64), (unsigned)nb), 256, 0, st>>>(
+        alpha, W + (long long)l0 * M * C, M, C, v + (long long)l0 * C, C);
+    GPSA_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, const float* dcT,
@@ -1739,9 +1829,15 @@ int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long
   using namespace gpsa;
   if (M < 1 || C < 1 || L < 1 || !W || !g || !dalpha) return GPSA_EINVAL;
   if ((dcT == nullptr) != (dmeanT == nullptr)) return GPSA_EINVAL;
-  const int MB = mfma_mb_for(M);
-  if (!MB || MB > 16 || force_generic()) return GPSA_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
+  if (!keep_mfma_path(M)) {  // row-major products
+    constexpr int RB = 8;
+    col_wsum_rows_kernel<RB><<<dim3((unsigned)cdiv(C, 1024), (unsigned)cdiv(M, RB)), 256, 0, st>>>(
+        W, g, M, C, L, dcT, dmeanT, dalpha);
+    GPSA_LAUNCH_CHECK();
+    return 0;
+  }
+  const int MB = mfma_mb_for(M);
 #define GPSA_KEPT_CASE(MBV, NCTV)                                                                        \
   case MBV: {                                                                                            \
     const long long ntiles = cdiv(C, 64 * NCTV);                                                         \

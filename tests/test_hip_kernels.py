@@ -150,7 +150,8 @@ def test_omega_fwd_bwd(hip, M, B):
     close(hip.omega_bwd(Gs.to(DEV), A.to(DEV), symmetric=True), FK.omega_bwd(Gs, A), 2e-6)
 
 
-@pytest.mark.parametrize("M,C,L", [(200, 1000, 50), (64, 333, 7), (16, 70, 5), (256, 513, 6), (130, 4099, 10)])
+@pytest.mark.parametrize("M,C,L", [(200, 1000, 50), (64, 333, 7), (16, 70, 5), (256, 513, 6), (130, 4099, 10),
+                                   (300, 1000, 3), (500, 1302, 4), (1000, 640, 2)])
 def test_quadform_keep_f32(hip, M, C, L):
     """the data GP's form with its products kept (gpsa_quadform_fwd_keep_f32, opaque buffer) and the streaming
     backward over them (gpsa_quadform_bwd_alpha_kept_f32) against the recomputing pair"""
@@ -188,8 +189,8 @@ def test_quadform_keep_f32(hip, M, C, L):
     close(out2, want + dc.double() @ dm.double(), 2e-6)
     assert hip.lib.gpsa_quadform_bwd_alpha_kept_f32(W.data_ptr(), gd.data_ptr(), M, C, L, dcd.data_ptr(), None,
                                                     out2.data_ptr(), st) == _lib_einval()
-    assert hip.lib.gpsa_quadform_keep_f32_workspace(300, 3) == 0   # beyond the kernel: callers recompute
-    assert hip.lib.gpsa_quadform_keep_f32_bytes(300, 1000, 3) == 0
+    if M > 256:  # beyond the register-resident kernel the products are kept row-major
+        assert nb == L * M * C * 4
 
 
 @pytest.mark.parametrize("M,n0,n1", [(5, 3, 2), (200, 4, 50), (72, 1, 1)])
@@ -287,7 +288,8 @@ def test_chol_flags_indefinite(hip):
 
 
 QF = [(10, 100, 3), (25, 1000, 5), (50, 333, 2), (100, 500, 4), (200, 2100, 7), (256, 300, 2), (16, 64, 1),
-      (300, 130, 2), (200, 50001, 3), (13, 7, 1), (380, 1000, 3), (392, 200, 2), (500, 700, 3), (513, 100, 2)]
+      (300, 130, 2), (200, 50001, 3), (13, 7, 1), (380, 1000, 3), (392, 200, 2), (500, 700, 3), (513, 100, 2),
+      (1000, 1040, 2), (641, 4100, 1)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
