@@ -365,6 +365,15 @@ struct GramBigArgs {
 __global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
                                 float* __restrict__ gpad);
 __global__ void gram_big_kernel(GramBigArgs a);
+// W[l] = P[l] X for large M (see prod_big_kernel)
+struct ProdBigArgs {
+  const float* P;  // [L][M][Mp], zero for k >= M (Mp = a multiple of 16)
+  const float* X;  // [M][C]
+  float* W;        // [L][M][C]
+  int M, Mp, L;
+  long long C;
+};
+__global__ void prod_big_kernel(ProdBigArgs a);
 template <typename TO>
 __global__ void gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit, TO* __restrict__ out);
 static inline bool gram_big_off() {
@@ -601,6 +610,109 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
         const int row = bi * 128 + wr * 64 + i * 16 + kq * 4 + r, col = bj * 128 + wc * 64 + k * 16 + j;
         if (row < M && col < M) P[(long long)row * M + col] = acc[i][k][r];
       }
+}
+
+// The large-M full product W[l] = P[l] X  ([M,M] x [M,C], fp32 matrix cores) with both operands staged by LDS-DMA
+// in MFMA-fragment order, like gram_big_kernel.  P rows are contiguous along the contracted index: a piece is
+// 16 rows x 16 k, lane j + 16 kq holding P[16 p + j][k0 + 4 kq .. +3] (component F = MFMA step F, which contracts
+// k0 + {F, 4+F, 8+F, 12+F}).  X rows are contiguous along the OUTPUT index: piece F of a 64-column group is the
+// four rows k0 + 4 kq + F with lane j holding columns 4 j .. 4 j + 3, so component G feeds the MFMA tile of the
+// columns {4 j + G} - and the four tiles' results of a lane are four CONSECUTIVE columns: one 16-byte store.
+// One workgroup = a 128 x 128 tile of one output; grid (row blocks, outputs, column tiles): the workgroups that
+// run together share the column tile of X.  P is zero-padded along k (garbage rows of X beyond M meet zeros).
+__global__ void __launch_bounds__(256, 2) prod_big_kernel(ProdBigArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
+  const int M = a.M, Mp = a.Mp, l = blockIdx.y;
+  const long long C = a.C;
+  const int m0 = blockIdx.x * 128;
+  const long long c0 = (long long)blockIdx.z * 128;
+  const float* Pl = a.P + (long long)l * M * Mp;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // pieces 0..7: rows m0 + 16 p of P; 8..15: X piece (group = (p - 8) >> 2, F = (p - 8) & 3)
+#define GPSA_PB_STAGE(CH, BUF)                                                                \
+  {                                                                                           \
+    const int k0__ = (CH) * 16;                                                               \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) {                                        \
+      const int piece = pc * 4 + w;                                                           \
+      const float* src__;                                                                     \
+      if (piece < 8) {                                                                        \
+        int row__ = m0 + piece * 16 + j;                                                      \
+        row__ = row__ < M ? row__ : M - 1;                                                    \
+        src__ = Pl + (long long)row__ * Mp + k0__ + kq * 4;                                   \
+      } else {                                                                                \
+        const int grp__ = (piece - 8) >> 2, F__ = (piece - 8) & 3;                            \
+        int krow__ = k0__ + kq * 4 + F__;                                                     \
+        krow__ = krow__ < M ? krow__ : M - 1;                                                 \
+        long long col__ = c0 + grp__ * 64 + j * 4;                                            \
+        col__ = col__ < C - 4 ? col__ : C - 4;                                                \
+        src__ = a.X + (long long)krow__ * C + col__;                                          \
+      }                                                                                       \
+      glds16(src__, __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));       \
+    }                                                                                         \
+  }
+  const int nch = Mp / 16;
+  GPSA_PB_STAGE(0, 0)
+  GPSA_PB_STAGE(nch > 1 ? 1 : 0, 1)
+  GPSA_DMA_WAIT(4);
+  __syncthreads();
+  int buf = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    GPSA_PB_STAGE(ch + 2 < nch ? ch + 2 : nch - 1, buf == 0 ? 2 : buf - 1)
+    const float* base = &lds[buf][lane * 4];
+    float4 av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
+      bv[i] = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+    }
+    // step F: A = av[rt].F ; B tile G = bv[F].G
+#define GPSA_PB_MMA(F, BF)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.x, acc[i][0], 0, 0, 0);      \
+    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.y, acc[i][1], 0, 0, 0);      \
+    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.z, acc[i][2], 0, 0, 0);      \
+    acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.w, acc[i][3], 0, 0, 0);      \
+  }
+    GPSA_PB_MMA(x, bv[0])
+    GPSA_PB_MMA(y, bv[1])
+    GPSA_PB_MMA(z, bv[2])
+    GPSA_PB_MMA(w, bv[3])
+#undef GPSA_PB_MMA
+    GPSA_DMA_WAIT(4);
+    __syncthreads();
+    buf = (buf == 2) ? 0 : buf + 1;
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_PB_STAGE
+  float* Wl = a.W + (long long)l * M * C;
+  const long long col = c0 + wc * 64 + j * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wr * 64 + i * 16 + kq * 4 + r;
+      if (row < M && col < C) {  // C % 4 == 0: the four columns are in or out together
+        const f32x4 o = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Wl + (long long)row * C + col));
+      }
+    }
+}
+
+// P [n][M][M] (TS) -> fp32 [n][M][Mp], zero for k >= M
+template <typename TS>
+__global__ void pad_k_kernel(const TS* __restrict__ src, int M, int Mp, long long n, float* __restrict__ dst) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= n * M * Mp) return;
+  const int k = (int)(idx % Mp);
+  const long long rowi = idx / Mp;
+  dst[idx] = k < M ? (float)src[rowi * M + k] : 0.f;
 }
 
 // out[l][i][j] = out[l][j][i] = sum_s part[l][s][max(i,j)][min(i,j)]  (the lower blocks hold every i >= j)
@@ -1780,7 +1892,7 @@ long long gpsa_quadform_keep_f32_workspace(int M, int L) {
     const int MB = gpsa::mfma_mb_for(M);
     return (long long)L * MB * 16 * MB * 16 * 4;
   }
-  return (long long)L * M * M * 4 + 256;  // fp32 copy of Omega
+  return (long long)L * M * ((M + 15) / 16 * 16) * 4 + 256;  // fp32 copy of Omega, contraction index padded to 16
 }
 
 long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L) {
@@ -1808,6 +1920,35 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
     return panel_mfma_launch<MODE_QUAD>(MB, Ppk, alpha, nullptr, M, C, L, v, nullptr, 1.f, nullptr, st, W);
   }
   if (C > 0x7fffffffLL) return GPSA_EINVAL;
+  {
+    // the LDS-DMA product (16-byte aligned rows of alpha; zero-padded fp32 copy of Omega in the workspace)
+    static const bool off = [] { const char* e = getenv("GPSA_PROD_BIG"); return e && e[0] == '0'; }();
+    const int Mp = (M + 15) / 16 * 16;
+    const long long need = (long long)L * M * Mp * 4;
+    const long long ctiles = cdiv(C, 128);
+    if (!off && (C & 3) == 0 && C >= 16 && (reinterpret_cast<uintptr_t>(alpha) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(W) & 15) == 0 && need <= workspace_bytes && L <= 65535 && ctiles <= 65535) {
+      float* Pp = (float*)workspace;
+      const long long n = (long long)L * M * Mp;
+      if (omega_dtype == GPSA_F64)
+        pad_k_kernel<double><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const double*)Omega, M, Mp, L, Pp);
+      else if (omega_dtype == GPSA_F32)
+        pad_k_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
+      else
+        return GPSA_EINVAL;
+      GPSA_LAUNCH_CHECK();
+      ProdBigArgs pa{Pp, alpha, W, M, Mp, L, C};
+      prod_big_kernel<<<dim3((unsigned)cdiv(M, 128), (unsigned)L, (unsigned)ctiles), 256, 0, st>>>(pa);
+      GPSA_LAUNCH_CHECK();
+      for (int l0 = 0; l0 < L; l0 += 16384) {
+        const int nb = (L - l0 < 16384) ? L - l0 : 16384;
+        coldot_kernel<float><<<dim3((unsigned)cdiv(C, 64), (unsigned)nb), 256, 0, st>>>(
+            alpha, W + (long long)l0 * M * C, M, C, v + (long long)l0 * C, C);
+        GPSA_LAUNCH_CHECK();
+      }
+      return 0;
+    }
+  }
   const float* Om;
   int rc = operand_as<float>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);
   if (rc) return rc;
