@@ -7,6 +7,7 @@ return structure — with the numerical work done by hand-written HIP kernels (s
 SURVEY.md §8a and flagged ``# quirk N`` below.
 """
 import contextlib
+import weakref
 from collections.abc import Iterable
 
 import numpy as np
@@ -579,7 +580,9 @@ class VariationalGPSA(GPSA):
             check = "deferred"
         elif check == "strict":
             check = True
-        aux = dict(plan=plan, model=self, X=[X_spatial[m].contiguous() for m in mods], eps_G=eps_G, eps_F=eps_F,
+        # (a weak reference: the node must not close a cycle model -> outputs -> node -> model, or its arena would
+        #  wait for the cyclic collector when no backward ever runs)
+        aux = dict(plan=plan, model=weakref.ref(self), X=[X_spatial[m].contiguous() for m in mods], eps_G=eps_G, eps_F=eps_F,
                    G_test=Gt if G_test is not None else None, eps_F_test=eps_Ft,
                    slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
                    want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,

@@ -160,7 +160,7 @@ class StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, aux, *tensors):
-        plan, model = aux["plan"], aux["model"]
+        plan, model = aux["plan"], aux["model"]()
         lib = plan.lib
         dev = tensors[0].device
         nm, S, D = len(plan.mods), plan.S, plan.D
@@ -235,10 +235,12 @@ class StepFn(torch.autograd.Function):
         aux["pending"], aux["mu_z"], aux["flag"] = pending, mu_z, flag
         ctx.aux, ctx.io, ctx.prm = aux, io, prm
         ctx.arena = saved
-        ctx.keep = outs  # F_latent is an input of the backward (dW of the LMC); the rest keeps the pointers alive
-        ctx.save_for_backward(*tensors)
-        ctx.n_in = len(tensors)
         flat = outs["Gm"] + outs["Gs"] + outs["Fl"] + outs["Fo"] + outs["Flt"] + outs["Fot"]
+        # the outputs travel as SAVED tensors (F_latent is an input of the backward - dW of the LMC -, the io struct
+        # points into all of them): as plain attributes they would close a cycle output -> grad_fn -> ctx -> output
+        # and every forward whose backward never runs would wait for the cyclic collector with its arena
+        ctx.save_for_backward(*tensors, *flat)
+        ctx.n_in = len(tensors)
         ctx.layout = [len(outs[k]) for k in ("Gm", "Gs", "Fl", "Fo", "Flt", "Fot")]
         ctx.set_materialize_grads(False)
         if kl is None:
@@ -251,13 +253,13 @@ class StepFn(torch.autograd.Function):
         if aux is None or ctx.arena is None:
             raise RuntimeError("GPSA step: backward through the same forward a second time - its saved arena was "
                                "released after the first backward (run forward again)")
-        plan, model = aux["plan"], aux["model"]
+        plan, model = aux["plan"], aux["model"]()
         if aux.get("deferred") is not None:  # the forward's numerics word: raise before any gradient exists
             pend, aux["deferred"] = aux["deferred"], None
             model._pending_flag = None
             model._raise_on_flags(pend)
         lib = plan.lib
-        tensors = ctx.saved_tensors
+        tensors = ctx.saved_tensors[: ctx.n_in]
         dev = tensors[0].device
         nm = len(plan.mods)
         f32 = torch.float32
@@ -323,7 +325,7 @@ class StepFn(torch.autograd.Function):
         # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
         # would break, steps later
         ctx.arena = None
-        ctx.aux = ctx.io = ctx.prm = ctx.keep = None  # ... and the cycle is cut here for everything else it holds
+        ctx.aux = ctx.io = ctx.prm = None
         return tuple(out)
 
 

@@ -89,6 +89,14 @@ def test_arenas_do_not_pile_up():
             for _ in range(3):
                 model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
             assert torch.cuda.memory_allocated() <= base + (1 << 20)
+        # forwards in training mode whose backward never runs: the node holds the model weakly, so the previous
+        # arena dies with the outputs it belongs to (at most two alive at a time)
+        seen = []
+        for _ in range(5):
+            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
+            del out
+            seen.append(torch.cuda.memory_allocated())
+        assert seen[-1] <= seen[1] + (1 << 20), seen
         used = []
         for _ in range(5):
             out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
