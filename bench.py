@@ -364,7 +364,14 @@ def main():
                                       achieved_tflops=step_flops * (args.steps / dt) / 1e12 / world,
                                       frac=step_flops * (args.steps / dt) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
                                       note="3 x forward flops (SURVEY 8d): data GP 2*C*M^2*(L+1) + 2*C*M*L, "
-                                           "warp GPs 2*n_v*M^2*(1+D); per GPU")
+                                           "warp GPs 2*n_v*M^2*(1+D); per GPU.  An ALGORITHMIC rate (the reference's "
+                                           "step costs that much): this step executes fewer flops - see executed_*")
+            # what the matrix cores actually issue for the three contractions of this step (with kept products the
+            # alpha-gradient re-uses the forward's product: no flops)
+            exec_fl = sum(ks[k]["flops"] * executed_ratio[k] for k in ks if not (kept and k == "quadform_bwd_alpha"))
+            roof["step_level"]["executed_contraction_flops_per_step"] = exec_fl
+            roof["step_level"]["executed_contraction_tflops"] = exec_fl * (args.steps / dt) / 1e12
+            roof["step_level"]["executed_contraction_frac"] = exec_fl * (args.steps / dt) / 1e12 / PEAK_F32_MFMA_TFLOPS
         line = {
             "metric": "training steps/sec (ELBO fwd+bwd), 2-view N=10k M=200, 1/2/4/8 GPU",
             "value": args.steps / dt,
