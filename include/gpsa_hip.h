@@ -316,6 +316,12 @@ int gpsa_kmat_bwd_batched(int kind, const float* Z, long long strideZ, int M, co
 int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
                       const float* var_u, const float* Kbar, double* dZ, double* dX, double* dparams,
                       void* workspace, long long workspace_bytes, void* stream);
+/* ... with the gradient panel in two pieces, Kbar[m,c] + s * d[c] * X2[m,c] (X2 [M,C], d [C] fp32; both NULL: Kbar
+ * alone): the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) formed as it is read */
+int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                           const float* var_u, const float* Kbar, const float* X2, const float* d, double s,
+                           double* dZ, double* dX, double* dparams, void* workspace, long long workspace_bytes,
+                           void* stream);
 /* gpsa_whiten_f64 on an fp32 panel with gpsa_col_axpy fused into its store:
  *   out[m,c] = (Kinv X)[m,c] + s * d[c] * X2[m,c]      (X, X2, out [M,C] fp32; d [C] fp32; fp64 arithmetic)
  * the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) in one pass. */

@@ -56,11 +56,18 @@ struct KmatBatch {
   long long sZ, sX, sK;
   int sP, ragged;  // ragged: use n[]; otherwise every problem has C live columns
   long long n[KM_MAXB];
+  // backward only, optional: the gradient panel is Kbar[m,c] + axs * axd[c] * axX[m,c] (fp32 panel and vector) -
+  // the data GP's dK_uf = gamma + 2 qbar o alpha formed while it is read, in the kernel's arithmetic type
+  const float* axX;
+  const float* axd;
+  float axs;
 };
 static inline KmatBatch kmat_single() {
   KmatBatch kb;
   kb.sZ = kb.sX = kb.sK = 0;
   kb.sP = kb.ragged = 0;
+  kb.axX = kb.axd = nullptr;
+  kb.axs = 0.f;
   for (int i = 0; i < KM_MAXB; ++i) kb.n[i] = 0;
   return kb;
 }
@@ -165,10 +172,12 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long 
       x[d] = (live && d < D) ? (T)X[c * D + d] : T(0);
       dx[d] = T(0);
     }
+    const T axc = (bt.axX != nullptr && live) ? (T)bt.axs * (T)bt.axd[c] : T(0);
     for (int r = 0; r < mc; ++r) {
       T k, cd, pl;
       cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
       T kb = live ? (T)Kbar[(long long)(m0 + r) * C + c] : T(0);
+      if (bt.axX != nullptr && live) kb += axc * (T)bt.axX[(long long)(m0 + r) * C + c];  // uniform branch
       s_ls += kb * pl;
       s_var += kb * k;
       T wgt = kb * cd;
@@ -434,9 +443,24 @@ int gpsa_kmat_bwd_batched(int kind, const float* Z, long long strideZ, int M, co
 int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
                       const float* var_u, const float* Kbar, double* dZ, double* dX, double* dparams,
                       void* workspace, long long workspace_bytes, void* stream) {
+  return gpsa_kmat_bwd_x64_axpy(kind, Z, M, X, C, D, ls_u, var_u, Kbar, nullptr, nullptr, 0.0, dZ, dX, dparams,
+                                workspace, workspace_bytes, stream);
+}
+
+/* the same with the gradient panel given in two pieces: Kbar[m,c] + s * d[c] * X2[m,c]  (X2 [M,C], d [C] fp32; both
+ * NULL: Kbar alone) - the data GP's dK_uf = K^-1 abar + 2 qbar o alpha without a pass that writes it out */
+int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                           const float* var_u, const float* Kbar, const float* X2, const float* d, double s,
+                           double* dZ, double* dX, double* dparams, void* workspace, long long workspace_bytes,
+                           void* stream) {
   if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
+  if ((X2 == nullptr) != (d == nullptr)) return GPSA_EINVAL;
+  gpsa::KmatBatch kb = gpsa::kmat_single();
+  kb.axX = X2;
+  kb.axd = d;
+  kb.axs = (float)s;
   return gpsa::kmat_bwd_launch<float, double, double, float, double>(
-      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, dX, dparams, 0, workspace, workspace_bytes, as_stream(stream));
+      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, dX, dparams, 0, workspace, workspace_bytes, as_stream(stream), 1, kb);
 }
 
 }  // extern "C"

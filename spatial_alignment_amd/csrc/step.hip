@@ -1243,7 +1243,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   // and only dK_uf = gamma + 2 qbar a is needed: the column-scaled update rides in the solve's store
   float* gamma = c.sc.get<float>((long long)Mg * C);
   const bool identity = C >= 4LL * L * Mg;
-  bool fused_axpy = false;
+  bool fused_axpy = false, axpy_in_cov = false;
   {
     const long long wsb = gpsa_whiten_workspace(Mg);
     if (wsb > 0) {
@@ -1315,8 +1315,12 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
         add_inplace_kernel<<<(unsigned)cdiv(mm, 256), 256, 0, c.st>>>(dKuu, sumOm, mm);
         GPSA_LAUNCH_CHECK();
       }
-      if (!fused_axpy)  // dK_uf = gamma + 2 qbar a
+      // dK_uf = gamma + 2 qbar a: formed inside the covariance backward as it reads the panel (no pass that
+      // writes it out) - except for test passes, whose covariance backward is the plain entry point
+      if (!fused_axpy && ps.test)
         GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 2.0, Mg, C, gamma, c.stv()));
+      else if (!fused_axpy)
+        axpy_in_cov = true;
     } else {
       // few columns: W = gamma + qbar a;  dK_uu = -W a^T ADDED in fp64;  dK_uf = W + qbar a
       GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 1.0, Mg, C, gamma, c.stv()));
@@ -1337,8 +1341,9 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       GPSA_RUN(gpsa_kmat_bwd(GPSA_F64, GPSA_F32_ACC64, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D,
                              c.prm.data_ls, c.prm.data_var, gamma, 0, dZ, nullptr, dpar, ws, wsb, c.stv()));
     } else {
-      GPSA_RUN(gpsa_kmat_bwd_x64(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
-                                 c.prm.data_var, gamma, dZ, B.dG64[m], dpar, ws, wsb, c.stv()));
+      GPSA_RUN(gpsa_kmat_bwd_x64_axpy(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
+                                      c.prm.data_var, gamma, axpy_in_cov ? alpha : nullptr, axpy_in_cov ? qbar : nullptr,
+                                      2.0, dZ, B.dG64[m], dpar, ws, wsb, c.stv()));
       B.have_dG[m] = true;
     }
   }

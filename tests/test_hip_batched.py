@@ -106,6 +106,15 @@ def test_kmat_bwd_x64(hip, M, D, C):
     wZ, wX, wp = hip.kmat_bwd("rbf", Z.double(), X64, ls.double(), var.double(), Kbar.double())
     for a, w in ((dZ, wZ), (dX, wX), (dpar, wp)):
         assert (a - w).norm() <= 1e-12 * w.norm()
+    # the gradient panel in two pieces, Kbar + s * d o X2, formed as it is read (in fp64)
+    X2, d = rnd(M, C, seed=6).to(DEV), rnd(C, seed=7).to(DEV)
+    rc = hip.lib.gpsa_kmat_bwd_x64_axpy(0, p(Z), M, p(X64), C, D, p(ls), p(var), p(Kbar), p(X2), p(d), 2.0, p(dZ), p(dX),
+                                        p(dpar), p(ws), wsb, stream())
+    assert rc == 0
+    full = Kbar.double() + 2.0 * d.double()[None, :] * X2.double()
+    wZ, wX, wp = hip.kmat_bwd("rbf", Z.double(), X64, ls.double(), var.double(), full)
+    for a, w in ((dZ, wZ), (dX, wX), (dpar, wp)):
+        assert (a - w).norm() <= 1e-12 * w.norm()
 
 
 @pytest.mark.parametrize("M,Cs,B", [(200, 640, 3), (50, 64, 5), (300, 128, 2)])
