@@ -63,10 +63,19 @@ struct WhitenAxpy {
   float s;
 };
 
-template <int MB, typename TI, typename TO, bool STREAM>
-__global__ void __launch_bounds__(256, (MB >= (STREAM ? 14 : 13)) ? 1 : 2)
+// RS (row split, resident right-hand side only): a workgroup covers 32 columns instead of 64 and each pair of
+// waves shares 16 of them, one wave taking the upper half of the row tiles, the other the lower half (an odd MB
+// makes the halves overlap by one tile: both write it, one counts it in q).  Half the dependent MFMAs per wave:
+// when even the doubled grid leaves every workgroup a CU of its own (the warp GPs of a 1/8 shard: a wave's 676
+// dependent MFMAs are the whole kernel time) the latency drops by a third; the packed inverse is streamed by twice
+// as many workgroups, which is why it is not the rule.
+template <int MB, typename TI, typename TO, bool STREAM, bool RS = false>
+__global__ void __launch_bounds__(256, (MB >= (STREAM ? 14 : 13) && !RS) ? 1 : 2)
 whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, int M, long long C,
                    TO* __restrict__ alpha0, double* __restrict__ q0, long long sX, WhitenAxpy ax) {
+  static_assert(!(RS && STREAM), "row split: resident right-hand side only");
+  constexpr int NRT = RS ? (MB + 1) / 2 : MB;   // row tiles of this wave
+  constexpr int OVER = RS ? 2 * NRT - MB : 0;   // tiles both halves compute
   constexpr int CHUNK = 4 * MB * 64;          // doubles per K chunk (2*MB pieces of 1 KiB)
   // problem blockIdx.y of a batch: its own packed inverse, panels at stride sX, q at stride C
   const long long pb = blockIdx.y;
@@ -82,7 +91,8 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const long long c = blockIdx.x * 64LL + w * 16 + j;
+  const long long c = RS ? blockIdx.x * 32LL + (w & 1) * 16 + j : blockIdx.x * 64LL + w * 16 + j;
+  const int rt0 = (RS && (w >> 1)) ? MB - NRT : 0;  // first row tile of this wave (wave-uniform)
   const bool okc = c < C;
   const TI* xcol = X + (okc ? c : 0);
   // LDS byte address of the ring, taken ONCE from the array's base (one foldable address-space cast)
@@ -112,9 +122,9 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
 #pragma unroll
     for (int kc = 0; kc < MB; ++kc) GPSA_WLOADB(xb[kc], kc, double)
   }
-  f64x4 acc[MB];
+  f64x4 acc[NRT];
 #pragma unroll
-  for (int rt = 0; rt < MB; ++rt) acc[rt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int rt = 0; rt < NRT; ++rt) acc[rt] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
 #pragma unroll
   for (int kc = 0; kc < MB; ++kc) {
@@ -140,8 +150,8 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
     for (int ks = 0; ks < 4; ++ks) {
       const double b = STREAM ? (double)xr[kc & 1][ks] : xb[STREAM ? 0 : kc][ks];
 #pragma unroll
-      for (int rt = 0; rt < MB; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[(ks * MB + rt) * 64], b, acc[rt], 0, 0, 0);
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[(ks * MB + rt0 + rt) * 64], b, acc[rt], 0, 0, 0);
     }
   }
 #undef GPSA_WSTAGE
@@ -151,19 +161,24 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
   double s = 0.0;
   const double axd = (ax.X2 != nullptr && okc) ? (double)ax.s * (double)ax.d[c] : 0.0;
 #pragma unroll
-  for (int rt = 0; rt < MB; ++rt) {
+  for (int rt = 0; rt < NRT; ++rt) {
     double kb[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (STREAM) {
       if (q0 != nullptr) GPSA_WLOADB(kb, rt, double)
+    } else if constexpr (RS) {
+      // the resident slab is indexed by the GLOBAL tile: rt0 is wave-uniform, the select below is a uniform branch
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kb[r] = (rt0 == 0) ? xb[rt][r] : xb[MB - NRT + rt][r];
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) kb[r] = xb[STREAM ? 0 : rt][r];
     }
+    const bool counted = !(RS && rt0 != 0 && rt < OVER);  // the overlapping tile counts once in q
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = rt * 16 + 4 * r + kq;
+      const int row = (rt0 + rt) * 16 + 4 * r + kq;
       double y = acc[rt][r];
-      s += y * kb[r];
+      if (counted) s += y * kb[r];
       if (okc && row < M) {
         if (ax.X2 != nullptr) y += axd * (double)ax.X2[(long long)row * C + c];  // uniform branch
         alpha[(long long)row * C + c] = (TO)y;
@@ -174,7 +189,15 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
   if (q0 != nullptr) {
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (kq == 0 && okc) q[c] = s;
+    if constexpr (RS) {  // the two row halves of a column meet through LDS (the ring is idle by now)
+      __syncthreads();
+      double* qx = &lds[0][0];
+      if ((w >> 1) == 1 && kq == 0) qx[(w & 1) * 16 + j] = s;
+      __syncthreads();
+      if ((w >> 1) == 0 && kq == 0 && okc) q[c] = s + qx[(w & 1) * 16 + j];
+    } else {
+      if (kq == 0 && okc) q[c] = s;
+    }
   }
 }
 
@@ -195,6 +218,25 @@ static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long lon
                          WhitenAxpy ax = WhitenAxpy{nullptr, nullptr, 0.f}) {
   const dim3 grid((unsigned)cdiv(C, 64), (unsigned)batch);
   bool stream = q == nullptr || (long long)grid.x * batch > num_cus();
+  // at most one workgroup per CU and no second pass needed for q: split the rows over wave pairs (RS)
+  static const bool rs_off = [] { const char* e = getenv("GPSA_WHITEN_RS"); return e && e[0] == '0'; }();
+  // (only while the doubled grid still leaves every workgroup a CU of its own: measured at a 1/8 shard, 80
+  //  workgroups 28 -> 19 us, but 391 instead of 196 workgroups 34 -> 44 us)
+  const bool rs = !rs_off && cdiv(C, 32) * batch <= num_cus() && (MB == 13 || MB == 7 || MB == 16 || MB == 4) &&
+                  ax.X2 == nullptr;
+  if (rs) {
+    const dim3 grid2((unsigned)cdiv(C, 32), (unsigned)batch);
+#define GPSA_WRS(V)                                                                                    \
+  case V:                                                                                              \
+    whiten_mfma_kernel<V, TI, TO, false, true><<<grid2, 256, 0, st>>>(Apk, X, M, C, alpha, q, sX, ax); \
+    GPSA_LAUNCH_CHECK();                                                                               \
+    return 0;
+    switch (MB) {
+      GPSA_WRS(4) GPSA_WRS(7) GPSA_WRS(13) GPSA_WRS(16)
+      default: break;
+    }
+#undef GPSA_WRS
+  }
   if (const char* e = getenv("GPSA_WHITEN_STREAM")) stream = atoi(e) != 0;
   if (MB > 16) stream = true;
 #define GPSA_WCASE(V)                                                                     \
