@@ -40,7 +40,7 @@ def rnd(*shape, dtype=torch.float32, scale=1.0):
 
 G = torch.Generator().manual_seed(rng.randrange(1 << 30))
 for it in range(cases):
-    M = rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 50, 100, 127, 199, 200, 208, 209, 255, 256, 257, 300, 385])
+    M = rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 50, 100, 127, 199, 200, 208, 209, 255, 256, 257, 300, 385, 500, 641])
     C = rng.choice([1, 3, 15, 64, 65, 100, 255, 257, 1000, 1249, 1250, 4095, 4096, 4100, 8191, 8200, 16385])
     L = rng.choice([1, 2, 3, 5, 8])
     dt = rng.choice([torch.float32, torch.float64])
@@ -55,6 +55,21 @@ for it in range(cases):
     note("quadform_bwd_alpha", rel(hip.quadform_bwd_alpha(ald, Omd, gd),
                                    FK.quadform_bwd_alpha(al.double(), Om.double(), g.double())), t, ctx)
     note("quadform_bwd_omega", rel(hip.quadform_bwd_omega(ald, gd), FK.quadform_bwd_omega(al.double(), g.double())), t, ctx)
+    if dt == torch.float32:  # the data GP's kept-products pair (both layouts: accumulator order, row-major beyond 256)
+        lib, st = hip.lib, hip._stream(ald)
+        wsb, nb = lib.gpsa_quadform_keep_f32_workspace(M, L), lib.gpsa_quadform_keep_f32_bytes(M, C, L)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+        vk, Wk = torch.empty(L, C, device=DEV), torch.full((nb // 4,), float("nan"), device=DEV)
+        assert lib.gpsa_quadform_fwd_keep_f32(0, ald.data_ptr(), Omd.data_ptr(), M, C, L, vk.data_ptr(), Wk.data_ptr(),
+                                              ws.data_ptr(), wsb, st) == 0
+        note("keep_f32.v", rel(vk, FK.quadform_fwd(al.double(), Om.double())), t, ctx)
+        dc, dm = rnd(M, L), rnd(L, C)
+        dcd, dmd = dc.to(DEV), dm.to(DEV)  # (named: a temporary's pointer dangles)
+        ok = torch.empty(M, C, device=DEV)
+        assert lib.gpsa_quadform_bwd_alpha_kept_f32(Wk.data_ptr(), gd.data_ptr(), M, C, L, dcd.data_ptr(),
+                                                    dmd.data_ptr(), ok.data_ptr(), st) == 0
+        note("keep_f32.dalpha", rel(ok, FK.quadform_bwd_alpha(al.double(), Om.double(), g.double()) + dc.double() @ dm.double()),
+             t, ctx)
     if L <= 3:
         dcT = rnd(M, L, dtype=dt)
         v, W, mean = hip.quadform_fwd_keep(ald, Omd, dcT.to(DEV))
