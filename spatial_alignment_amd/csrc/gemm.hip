@@ -573,6 +573,10 @@ int gpsa_omega_fwd(const float* A, int M, int batch, double jitter, double* Omeg
 int gpsa_omega_fwd2(const float* A0, int n0, double* Omega0, const float* A1, int n1, double* Omega1, int M,
                     double jitter, void* stream) {
   if (M < 1 || n0 < 1 || n1 < 0) return GPSA_EINVAL;
+  {
+    const int rc = gpsa::omega_fwd_dma_launch(A0, n0, Omega0, A1, n1, Omega1, M, jitter, as_stream(stream));
+    if (rc != GPSA_EUNSUPPORTED) return rc;
+  }
   const long long mm = (long long)M * M;
   dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)(n0 + n1));
   gpsa::GemmSeg2<float, float, double> seg{n1 > 0 ? n0 : 0x7fffffff, A1, A1, Omega1};

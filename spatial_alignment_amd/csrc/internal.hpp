@@ -22,4 +22,8 @@ int gemm64_launch(int transA, int transB, int m, int n, long long k, double alph
                   long long sA, const TIB* B, long long ldb, long long sB, double beta, TO* C, long long ldc,
                   long long sC, int batch, int splitk, void* ws, long long ws_bytes, hipStream_t st);
 
+// quadform.hip: Omega = A A^T + jitter I with LDS-DMA staging (GPSA_EUNSUPPORTED: shape / alignment not covered)
+int omega_fwd_dma_launch(const float* A0, int n0, double* O0, const float* A1, int n1, double* O1, int M, double jitter,
+                         hipStream_t st);
+
 }  // namespace gpsa

@@ -715,6 +715,132 @@ __global__ void pad_k_kernel(const TS* __restrict__ src, int M, int Mp, long lon
   dst[idx] = k < M ? (float)src[rowi * M + k] : 0.f;
 }
 
+// Omega[b] = A[b] A[b]^T + jitter I for a batch of small fp32 parameter matrices (M = 200: the 54 variational
+// covariances of a step), fp64 matrix cores.  One workgroup = a 64 x 64 block pair (bi >= bj) of one matrix; both
+// operands are rows of A, contiguous along the contracted index: 16-k chunks of the 64 + 64 rows move to LDS by
+// LDS-DMA as eight 1-KiB pieces in fragment order (a lane's float4 = four consecutive k = the four MFMA steps of
+// the chunk), widened to fp64 as they are read.  The generic product staged the same operands through registers
+// and transposing LDS stores: 44 us for the 54 matrices against 29 us here (a chunk is only 16 MFMAs per wave, so
+// the loop overhead shows; a six-slot ring with five stages in flight was SLOWER, 33 us: not a DMA-latency bound).
+struct OmegaDmaArgs {
+  const float* A0;
+  const float* A1;
+  double* O0;
+  double* O1;
+  int n0, M;
+  double jitter;
+};
+__global__ void __launch_bounds__(256, 4) omega_fwd_dma_kernel(OmegaDmaArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[3][8 * 256];
+  typedef double f64x4_ __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
+  int bi = 0, t = blockIdx.x;
+  while (t > bi) {
+    t -= bi + 1;
+    ++bi;
+  }
+  const int bj = t, M = a.M;
+  int b = blockIdx.z;
+  const float* A = a.A0;
+  double* O = a.O0;
+  if (b >= a.n0) {
+    b -= a.n0;
+    A = a.A1;
+    O = a.O1;
+  }
+  A += (long long)b * M * M;
+  O += (long long)b * M * M;
+  f64x4_ acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) acc[i][k] = (f64x4_){0.0, 0.0, 0.0, 0.0};
+  // pieces 0..3: rows of block bi, 4..7: rows of block bj; wave w moves pieces w and w + 4
+#define GPSA_OM_STAGE(CH, BUF)                                                                \
+  {                                                                                           \
+    int col__ = (CH) * 16 + kq * 4;                                                           \
+    col__ = col__ < M - 4 ? col__ : M - 4;                                                    \
+    _Pragma("unroll") for (int pc = 0; pc < 2; ++pc) {                                        \
+      const int piece = pc * 4 + w;                                                           \
+      int row__ = ((piece < 4) ? bi * 64 + piece * 16 : bj * 64 + (piece - 4) * 16) + j;      \
+      row__ = row__ < M ? row__ : M - 1;                                                      \
+      glds16(A + (long long)row__ * M + col__,                                                \
+             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));               \
+    }                                                                                         \
+  }
+  const int nch = (M + 15) / 16;
+  GPSA_OM_STAGE(0, 0)
+  GPSA_OM_STAGE(nch > 1 ? 1 : 0, 1)
+  GPSA_DMA_WAIT(2);
+  __syncthreads();
+  int buf = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    GPSA_OM_STAGE(ch + 2 < nch ? ch + 2 : nch - 1, buf == 0 ? 2 : buf - 1)
+    const float* base = &lds[buf][lane * 4];
+    float4 av[2], bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      av[i] = *reinterpret_cast<const float4*>(base + (wr * 2 + i) * 256);
+      bv[i] = *reinterpret_cast<const float4*>(base + (4 + wc * 2 + i) * 256);
+    }
+    // the chunk's columns beyond M were clamped onto real ones: they must not count (left operand zeroed)
+    const int kb = ch * 16 + kq * 4;
+    if (kb + 3 >= M) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (kb + 0 >= M) av[i].x = 0.f;
+        if (kb + 1 >= M) av[i].y = 0.f;
+        if (kb + 2 >= M) av[i].z = 0.f;
+        if (kb + 3 >= M) av[i].w = 0.f;
+      }
+    }
+#define GPSA_OM_MMA(F)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                             \
+      acc[i][k] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[i].F, (double)bv[k].F, acc[i][k], 0, 0, 0);
+    GPSA_OM_MMA(x)
+    GPSA_OM_MMA(y)
+    GPSA_OM_MMA(z)
+    GPSA_OM_MMA(w)
+#undef GPSA_OM_MMA
+    GPSA_DMA_WAIT(2);
+    __syncthreads();
+    buf = (buf == 2) ? 0 : buf + 1;
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_OM_STAGE
+  // fp64 C layout: row = kq + 4 r, column = j.  Both halves are written (the product is symmetric bit for bit:
+  // the mirrored entry is the same sum of the same products in the same order)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi * 64 + wr * 32 + i * 16 + kq + 4 * r, col = bj * 64 + wc * 32 + k * 16 + j;
+        if (row < M && col < M) {
+          const double v = acc[i][k][r] + (row == col ? a.jitter : 0.0);
+          O[(long long)row * M + col] = v;
+          if (bi != bj) O[(long long)col * M + row] = v;
+        }
+      }
+}
+
+int omega_fwd_dma_launch(const float* A0, int n0, double* O0, const float* A1, int n1, double* O1, int M, double jitter,
+                         hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("GPSA_OMEGA_DMA"); return e && e[0] == '0'; }();
+  if (off || (M & 3) != 0 || M < 16 || (reinterpret_cast<uintptr_t>(A0) & 15) != 0 ||
+      (n1 > 0 && (reinterpret_cast<uintptr_t>(A1) & 15) != 0) || n0 + n1 > 65535)
+    return GPSA_EUNSUPPORTED;
+  const int nb = (int)cdiv(M, 64);
+  OmegaDmaArgs a{A0, A1, O0, O1, n1 > 0 ? n0 : 0x7fffffff, M, jitter};
+  omega_fwd_dma_kernel<<<dim3((unsigned)(nb * (nb + 1) / 2), 1, (unsigned)(n0 + n1)), 256, 0, st>>>(a);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
 // out[l][i][j] = out[l][j][i] = sum_s part[l][s][max(i,j)][min(i,j)]  (the lower blocks hold every i >= j)
 template <typename TO>
 __global__ void __launch_bounds__(256) gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit,
