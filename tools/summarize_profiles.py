@@ -22,8 +22,8 @@ open(os.path.join(O, f"{tag}_pmc_fetch_write_summary.txt"), "w").write(
 keys = {"panel_mfma_kernel<13, 3, 0, 2>": "panel_mfma_kernel<13,3,QUAD,2> + kept products  (dominant)",
         "kept_wsum_kernel": "kept_wsum_kernel<13,3,4>  (streaming, no MFMA)",
         "gram_mfma_kernel": "gram_mfma_kernel<13,true,2>  (2 outputs per WG)",
-        "whiten_mfma_kernel<13, double, float, true>": "whiten_mfma_kernel<13,double,float,stream> (fp64 MFMA)",
-        "whiten_mfma_kernel<13, float, float, true>": "whiten_mfma_kernel<13,float,float,stream>  (fp64 MFMA)"}
+        "whiten_mfma_kernel<13, double, float, true": "whiten_mfma_kernel<13,double,float,stream> (fp64 MFMA)",
+        "whiten_mfma_kernel<13, float, float, true": "whiten_mfma_kernel<13,float,float,stream>  (fp64 MFMA)"}
 per = collections.defaultdict(dict)
 for r in csv.DictReader(open(os.path.join(P, "busy", "b_counter_collection.csv"))):
     for key in keys:
