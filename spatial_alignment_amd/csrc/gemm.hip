@@ -601,6 +601,10 @@ int gpsa_omega_bwd2(const double* G0, const float* A0, float* dA0, int n0, const
   if (M < 1 || n0 < 1 || n1 < 0) return GPSA_EINVAL;
   const long long mm = (long long)M * M;
   dim3 grid((unsigned)cdiv(M, gpsa::GB_N), (unsigned)cdiv(M, gpsa::GB_M), (unsigned)(n0 + n1));
+  if (symmetric) {
+    const int rc = gpsa::omega_bwd_dma_launch(G0, A0, dA0, n0, G1, A1, dA1, n1, M, as_stream(stream));
+    if (rc != GPSA_EUNSUPPORTED) return rc;
+  }
   gpsa::GemmSeg2<double, float, float> seg{n1 > 0 ? n0 : 0x7fffffff, G1, A1, dA1};
   if (symmetric)
     gpsa::gemm_mfma_kernel<double, false, false, double, float, float, false><<<grid, 256, 0, as_stream(stream)>>>(

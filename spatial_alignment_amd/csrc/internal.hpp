@@ -26,4 +26,8 @@ int gemm64_launch(int transA, int transB, int m, int n, long long k, double alph
 int omega_fwd_dma_launch(const float* A0, int n0, double* O0, const float* A1, int n1, double* O1, int M, double jitter,
                          hipStream_t st);
 
+// quadform.hip: dA = 2 G A for symmetric G with the same staging
+int omega_bwd_dma_launch(const double* G0, const float* A0, float* D0, int n0, const double* G1, const float* A1,
+                         float* D1, int n1, int M, hipStream_t st);
+
 }  // namespace gpsa

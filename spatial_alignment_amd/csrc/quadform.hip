@@ -841,6 +841,131 @@ int omega_fwd_dma_launch(const float* A0, int n0, double* O0, const float* A1, i
   return 0;
 }
 
+// dA[b] = 2 G[b] A[b] (G fp64 symmetric gradient of Omega, A the fp32 parameter, dA fp32): the adjoint of the
+// kernel above for the same batch, same staging.  G's rows are contiguous along the contracted index: a piece is
+// 16 rows x 8 k, a lane's double2 = two consecutive k (component F = one of the two MFMA steps of the piece).
+// A's rows are contiguous along the output index: its piece for a step holds the four rows k of that step with lane
+// j on the columns 4 j .. 4 j + 3, so component G feeds the MFMA tile of the columns {4 j + G} and a lane's four
+// results are one 16-byte store.  One workgroup = 64 x 64 outputs, one wave = 16 rows x 64 columns.
+struct OmegaBwdArgs {
+  const double* G0;
+  const double* G1;
+  const float* A0;
+  const float* A1;
+  float* D0;
+  float* D1;
+  int n0, M;
+};
+__global__ void __launch_bounds__(256, 4) omega_bwd_dma_kernel(OmegaBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[3][12 * 256];
+  typedef double f64x4_ __attribute__((ext_vector_type(4)));
+  typedef double f64x2_ __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int M = a.M, m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  int b = blockIdx.z;
+  const double* Gm = a.G0;
+  const float* A = a.A0;
+  float* D = a.D0;
+  if (b >= a.n0) {
+    b -= a.n0;
+    Gm = a.G1;
+    A = a.A1;
+    D = a.D1;
+  }
+  Gm += (long long)b * M * M;
+  A += (long long)b * M * M;
+  D += (long long)b * M * M;
+  f64x4_ acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f64x4_){0.0, 0.0, 0.0, 0.0};
+  // pieces 0..7: G, row tile p >> 1, k half p & 1;  8..11: A, step s = p - 8 = 2 h + F (rows k0 + 8 h + 2 kq + F)
+#define GPSA_OB_STAGE(CH, BUF)                                                                \
+  {                                                                                           \
+    const int k0__ = (CH) * 16;                                                               \
+    _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                        \
+      const int piece = pc * 4 + w;                                                           \
+      const void* src__;                                                                      \
+      if (piece < 8) {                                                                        \
+        int row__ = m0 + (piece >> 1) * 16 + j;                                               \
+        row__ = row__ < M ? row__ : M - 1;                                                    \
+        int col__ = k0__ + (piece & 1) * 8 + kq * 2;                                          \
+        col__ = col__ < M - 2 ? col__ : M - 2;                                                \
+        src__ = Gm + (long long)row__ * M + col__;                                            \
+      } else {                                                                                \
+        const int s__ = piece - 8;                                                            \
+        int krow__ = k0__ + (s__ >> 1) * 8 + kq * 2 + (s__ & 1);                              \
+        krow__ = krow__ < M ? krow__ : M - 1;                                                 \
+        int col__ = n0 + j * 4;                                                               \
+        col__ = col__ < M - 4 ? col__ : M - 4;                                                \
+        src__ = A + (long long)krow__ * M + col__;                                            \
+      }                                                                                       \
+      glds16(reinterpret_cast<const float*>(src__),                                           \
+             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));               \
+    }                                                                                         \
+  }
+  const int nch = (M + 15) / 16;
+  GPSA_OB_STAGE(0, 0)
+  GPSA_OB_STAGE(nch > 1 ? 1 : 0, 1)
+  GPSA_DMA_WAIT(3);
+  __syncthreads();
+  int buf = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    GPSA_OB_STAGE(ch + 2 < nch ? ch + 2 : nch - 1, buf == 0 ? 2 : buf - 1)
+    const float* base = &lds[buf][lane * 4];
+    f64x2_ g2[2];
+    float4 bv[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      g2[h] = *reinterpret_cast<const f64x2_*>(base + (w * 2 + h) * 256);
+      // columns of G beyond M were clamped onto real ones: they must not count
+      const int kb = ch * 16 + h * 8 + kq * 2;
+      if (kb >= M) g2[h].x = 0.0;
+      if (kb + 1 >= M) g2[h].y = 0.0;
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) bv[s_] = *reinterpret_cast<const float4*>(base + (8 + s_) * 256);
+#define GPSA_OB_MMA(GA, BV)                                                                   \
+  acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(GA, (double)BV.x, acc[0], 0, 0, 0);           \
+  acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(GA, (double)BV.y, acc[1], 0, 0, 0);           \
+  acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(GA, (double)BV.z, acc[2], 0, 0, 0);           \
+  acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(GA, (double)BV.w, acc[3], 0, 0, 0);
+    GPSA_OB_MMA(g2[0].x, bv[0])
+    GPSA_OB_MMA(g2[0].y, bv[1])
+    GPSA_OB_MMA(g2[1].x, bv[2])
+    GPSA_OB_MMA(g2[1].y, bv[3])
+#undef GPSA_OB_MMA
+    GPSA_DMA_WAIT(3);
+    __syncthreads();
+    buf = (buf == 2) ? 0 : buf + 1;
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_OB_STAGE
+  const int col = n0 + j * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + w * 16 + kq + 4 * r;
+    if (row < M && col < M)  // M % 4 == 0: the four columns are in or out together
+      *reinterpret_cast<f32x4*>(D + (long long)row * M + col) =
+          (f32x4){(float)(2.0 * acc[0][r]), (float)(2.0 * acc[1][r]), (float)(2.0 * acc[2][r]), (float)(2.0 * acc[3][r])};
+  }
+}
+
+int omega_bwd_dma_launch(const double* G0, const float* A0, float* D0, int n0, const double* G1, const float* A1,
+                         float* D1, int n1, int M, hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("GPSA_OMEGA_DMA"); return e && e[0] == '0'; }();
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (off || (M & 3) != 0 || M < 16 || !al(G0) || !al(A0) || !al(D0) || (n1 > 0 && (!al(G1) || !al(A1) || !al(D1))) ||
+      n0 + n1 > 65535)
+    return GPSA_EUNSUPPORTED;
+  const unsigned nb = (unsigned)cdiv(M, 64);
+  OmegaBwdArgs a{G0, G1, A0, A1, D0, D1, n1 > 0 ? n0 : 0x7fffffff, M};
+  omega_bwd_dma_kernel<<<dim3(nb, nb, (unsigned)(n0 + n1)), 256, 0, st>>>(a);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
 // out[l][i][j] = out[l][j][i] = sum_s part[l][s][max(i,j)][min(i,j)]  (the lower blocks hold every i >= j)
 template <typename TO>
 __global__ void __launch_bounds__(256) gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit,

@@ -113,7 +113,7 @@ class GradAllReducer:
 
     def _engine_bucket(self):
         """(flat buffer, parameters outside it) when the gradients are views of one step-engine buffer"""
-        from .step_engine import LAST_FLAT
+        from .step_engine import LAST_FLAT, LAST_USED
 
         p0 = self.params[0]
         flat = LAST_FLAT.get(p0.device.index) if p0.is_cuda else None
@@ -127,7 +127,9 @@ class GradAllReducer:
                 inside.append(p)
             else:
                 outside.append(p)
-        used = sum(p.numel() for p in inside)
+        # the views are padded to 256-byte boundaries: the bucket is the whole span (padding included: its content
+        # is reduced too and never read)
+        used = LAST_USED.get(p0.device.index, sum(p.numel() for p in inside))
         if sum(p.numel() for p in outside) > flat.numel() - used:
             return None
         return flat, used, outside

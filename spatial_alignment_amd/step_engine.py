@@ -19,6 +19,7 @@ from .kernels import builtin_kind
 # the flat gradient buffer of the most recent backward per device (its views are the parameters' .grad):
 # parallel.GradAllReducer reduces it in place
 LAST_FLAT = {}
+LAST_USED = {}  # floats of LAST_FLAT the gradient views span (each view starts on a 256-byte boundary)
 
 MAXM = _lib.MAX_MODS
 KINDS = _ops_mod.KINDS
@@ -297,9 +298,14 @@ class StepFn(torch.autograd.Function):
                 og.dkl = gk.data_ptr()
         # ONE flat fp32 buffer for every parameter gradient: the gradients handed to autograd are views of it
         # (a ready-made all-reduce bucket and a single region for the optimiser to stream through)
+        # (every view starts on a 256-byte boundary: the kernels that write whole gradients use 16-byte stores)
         sizes = [t.numel() for t in tensors]
-        flat = torch.empty(sum(sizes) + 64, dtype=f32, device=dev)  # spare room: see parallel.GradAllReducer
-        views = list(flat[: sum(sizes)].split(sizes))
+        offs, used = [], 0
+        for n in sizes:
+            offs.append(used)
+            used += (n + 63) // 64 * 64
+        flat = torch.empty(used + 64, dtype=f32, device=dev)  # spare room: see parallel.GradAllReducer
+        views = [flat[o: o + n] for o, n in zip(offs, sizes)]
         grads = _lib.StepParamGrads()
         (grads.Xtilde, grads.delta_G, grads.Omega_sqt_G, grads.warp_ls, grads.warp_var, grads.Gtilde, grads.data_ls,
          grads.data_var) = (_p(v) for v in views[:8])
@@ -321,6 +327,7 @@ class StepFn(torch.autograd.Function):
         for i, t in enumerate(tensors):
             out.append(views[i].view(t.shape) if ctx.needs_input_grad[1 + i] else None)
         LAST_FLAT[dev.index] = flat
+        LAST_USED[dev.index] = used
         # the arena (gigabytes when the data GPs keep their products) goes back to the allocator NOW: the node sits
         # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
         # would break, steps later
