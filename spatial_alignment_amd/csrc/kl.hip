@@ -92,13 +92,14 @@ mvn_kl_grouped_fwd_kernel(const double* __restrict__ mats, const double* __restr
   if (threadIdx.x == 0) kl[t] = 0.5 * (logdet[p] - logdet[o] + tot - (double)M);
 }
 
-// grid (elements / 256, T + P + 1), one job per blockIdx.y:
-//   y <  T         term t = y:      dOmega[t][e] (+)= 0.5 g_t (K_p^-1 - Omega_t^-1)[e]   (zero for an absent term)
-//   T <= y < T + P prior pg = y - T: S[pg][e] = (sum g_t) K_p[e] - sum g_t (Omega_t[e] + d_t[i] d_t[j]) over its
-//                                    terms ( dK_p = 0.5 K_p^-1 S_p K_p^-1 ), and dD[t] = g_t K_p^-1 d_t
-//   y == T + P     the absent terms' dD rows (zero)
-// (one thread per (term, element) for the T*M*M-sized output: a thread walking all terms of a prior was a
-// chain of 50 dependent loads, 80 us for 57 matrices of 200 x 200; the per-prior sums stay a short loop)
+// grid (elements / 256, P + 1): blockIdx.y = prior group pg (P: the pseudo-group of the absent terms).  A thread owns
+// one element e of the M x M matrices and walks the terms of its group, eight at a time (their index loads are
+// block-uniform, the eight terms' matrix loads are in flight together):
+//   dOmega[t][e] (+)= 0.5 g_t (K_p^-1 - Omega_t^-1)[e]                       (zero for an absent term)
+//   S[pg][e] = (sum g_t) K_p[e] - sum g_t (Omega_t[e] + d_t[i] d_t[j])         ( dK_p = 0.5 K_p^-1 S_p K_p^-1 )
+// and block x == 0 writes dD[t] = g_t K_p^-1 d_t.  (History: one thread walking 50 terms serially was 80 us for
+// 57 matrices of 200 x 200; one block per (term, 256 elements) with a parallel prior lookup 39-53 us - 8500 tiny
+// blocks with two barriers each; this form: one pass over the terms per element, 471 blocks.)
 __global__ void __launch_bounds__(256)
 mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restrict__ inv,
                           const int* __restrict__ om_idx,
@@ -108,36 +109,14 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
                           double* __restrict__ dOmega, double* __restrict__ dD, double* __restrict__ S,
                           int accumulate) {
   const long long mm = (long long)M * M, e = blockIdx.x * 256LL + threadIdx.x;
-  const int y = blockIdx.y;
-  if (y < T) {
-    const int t = y;
-    // prior of term t: the group that lists it (group P = the absent terms).  The listed positions are searched
-    // by the block's threads in parallel (a serial scan was up to T dependent scalar loads in every block)
-    __shared__ int p_sh;
-    if (threadIdx.x == 0) p_sh = -1;
-    __syncthreads();
-    for (int q = threadIdx.x; q < grp_off[P]; q += 256)
-      if (order[q] == t) {
-        int pg = 0;
-        while (q >= grp_off[pg + 1]) ++pg;
-        p_sh = pr_list[pg];
-      }
-    __syncthreads();
-    const int p = p_sh;
-    if (e >= mm) return;
-    double dom = 0.0;
-    if (p >= 0) dom = 0.5 * g[t] * (inv[(long long)p * mm + e] - inv[(long long)om_idx[t] * mm + e]);
-    // accumulate: dOmega already holds the layers' share of the gradient (the step engine's buffer)
-    double* dst = dOmega + (long long)t * mm + e;
-    *dst = accumulate ? *dst + dom : dom;
-    return;
-  }
-  const int pg = y - T;
+  const int pg = blockIdx.y;
   const int t0 = grp_off[pg], t1 = grp_off[pg + 1];
-  if (pg == P) {  // pseudo-group of the absent terms
+  if (pg == P) {  // pseudo-group of the absent terms: zero gradients
     if (blockIdx.x == 0)
       for (int q = t0; q < t1; ++q)
         for (int m = threadIdx.x; m < M; m += 256) dD[(long long)order[q] * M + m] = 0.0;
+    if (!accumulate && e < mm)
+      for (int q = t0; q < t1; ++q) dOmega[(long long)order[q] * mm + e] = 0.0;
     return;
   }
   const int p = pr_list[pg];
@@ -148,20 +127,27 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
     }
   if (e >= mm) return;
   const int i = (int)(e / M), j = (int)(e % M);
-  // eight terms' loads in flight at a time (the term indices are block-uniform); a plain loop over the 50 terms
-  // of the data prior was 25 dependent load latencies, 50 of the kernel's 65 us
+  const double kinv = inv[(long long)p * mm + e];
   double s0 = 0.0, s1 = 0.0, gs = 0.0;
   for (int q = t0; q < t1; q += 8) {
-    double ga[8], om[8], di[8], dj[8];
+    double ga[8], om[8], oi[8], di[8], dj[8], old[8];
+    int tt[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const bool on = q + u < t1;
       const int ta = order[on ? q + u : t0];
+      tt[u] = on ? ta : -1;
       ga[u] = on ? g[ta] : 0.0;
-      om[u] = mats[(long long)om_idx[ta] * mm + e];
+      const long long mo = (long long)om_idx[ta] * mm + e;
+      om[u] = mats[mo];
+      oi[u] = inv[mo];
       di[u] = D[(long long)ta * M + i];
       dj[u] = D[(long long)ta * M + j];
+      old[u] = (accumulate && on) ? dOmega[(long long)ta * mm + e] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (tt[u] >= 0) dOmega[(long long)tt[u] * mm + e] = old[u] + 0.5 * ga[u] * (kinv - oi[u]);
 #pragma unroll
     for (int u = 0; u < 8; u += 2) {
       gs += ga[u] + ga[u + 1];
@@ -191,7 +177,7 @@ int gpsa_mvn_kl_grouped_bwd_acc(const double* mats, const double* inv, const int
                                 const double* KD, const double* g, int M, int T, int P, double* dOmega,
                                 double* dD, double* S, int accumulate, void* stream) {
   if (M < 1 || T < 1 || P < 1) return GPSA_EINVAL;
-  dim3 grid((unsigned)cdiv((long long)M * M, 256), (unsigned)(T + P + 1));
+  dim3 grid((unsigned)cdiv((long long)M * M, 256), (unsigned)(P + 1));
   gpsa::mvn_kl_grouped_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(
       mats, inv, om_idx, pr_list, grp_off, order, D, KD, g, M, T, P, dOmega, dD, S, accumulate);
   GPSA_LAUNCH_CHECK();
