@@ -10,7 +10,10 @@ import torch
 from .models import VariationalGPSA
 
 
-def make_grid_problem(side=100, n_views=2, n_outputs=50, device="cpu", modality="expression"):
+def make_grid_problem(side=100, n_views=2, n_outputs=50, device="cpu", modality="expression", compute_device=None):
+    """``compute_device``: evaluate the random-feature sums there with torch (fp64) instead of numpy on the host -
+    the same construction and the same random streams, values equal to rounding (cos differs by ulps); for the
+    10^5-spot x 1000-output problems, where the host loop takes minutes."""
     lin = np.linspace(0, 10, side)
     x1, x2 = np.meshgrid(lin, lin)
     grid = np.vstack([x1.ravel(), x2.ravel()]).T  # row-major, as generate_twod_data.py:30-35
@@ -18,7 +21,16 @@ def make_grid_problem(side=100, n_views=2, n_outputs=50, device="cpu", modality=
     om = rng.standard_normal((n_outputs, 32, 2))
     a = rng.standard_normal((n_outputs, 32)) / np.sqrt(32.0)
     b = rng.uniform(0, 2 * np.pi, (n_outputs, 32))
-    base = np.einsum("pr,npr->np", a, np.cos(np.einsum("nd,prd->npr", grid, om) + b[None]))
+    # 64 outputs at a time: the [n, p, 32] feature block of 10^5 spots x 1000 outputs would be 26 GB
+    base = np.empty((grid.shape[0], n_outputs))
+    for p0 in range(0, n_outputs, 64):
+        sl = slice(p0, min(p0 + 64, n_outputs))
+        if compute_device is None:
+            base[:, sl] = np.einsum("pr,npr->np", a[sl], np.cos(np.einsum("nd,prd->npr", grid, om[sl]) + b[None, sl]))
+        else:
+            t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(compute_device)
+            ph = torch.einsum("nd,prd->npr", t(grid), t(om[sl])) + t(b[sl])[None]
+            base[:, sl] = torch.einsum("pr,npr->np", t(a[sl]), torch.cos(ph)).cpu().numpy()
     nrng = np.random.default_rng(4321)
     Xs, Ys = [], []
     for v in range(n_views):

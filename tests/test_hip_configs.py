@@ -9,6 +9,8 @@ blocked factorisation, the MFMA / generic Gram and panel paths beyond one LDS ti
 Config 3 runs at FULL size (4 x 10k spots, 500 genes through 10 latent GPs, Matern-1/2 warp) through
 size-independent properties, like test_hip_parity.test_full_size_properties does for config 2.
 """
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -157,3 +159,119 @@ def test_config3_full_size_properties():
             p.add_(h * d)
         fd = float(lp - lm) / (2 * h)
         assert abs(fd - gdir) <= 3e-2 * max(abs(gdir), 1.0), (fd, gdir)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at their STATED size (independent outputs: P = L = 2000 / 1000, S = 1)
+# ---------------------------------------------------------------------------------------------------------
+def _full_size_vs_subset_oracle(side, views, outputs, M, fixed, seed, subset, fd_h):
+    """One training step at full size on the GPU, checked four ways:
+      * every output finite, F_latent IS F_observed (quirk 10), fixed views pass through;
+      * a second step on the same inputs is bitwise equal (loss and every gradient: deterministic reductions);
+      * the fp64 oracle on ALL spots and a SUBSET of the outputs: without LMC the outputs are independent given
+        the warp GP (vgpsa.py:396-432), so G_means / G_samples, the subset's columns of F and the subset's rows of
+        grad Omega_sqt_F / grad delta_F are those of the full problem (the oracle's [S,L,N,M] tensor at all
+        L outputs would be 320 TB / 1.6 PB);
+      * the ELBO moves along its own gradient wrt delta_F as the gradient says (central difference)."""
+    from oracle import gpsa_oracle as orc
+
+    S = 1
+    dd = make_grid_problem(side=side, n_views=views, n_outputs=outputs, device="cpu", compute_device=DEV)
+    model = make_model(dd, m=M, n_latent_gps={MOD: None}, fixed_view_idx=fixed, device="cpu", seed=seed,
+                       kernel_func_warp=gp.rbf_kernel, kernel_func_data=gp.rbf_kernel)
+    _perturb(model, seed + 1)
+    sub = torch.as_tensor(subset)
+    state = {}
+    for k, v in model.state_dict().items():
+        v = v.detach()
+        if k == f"Omega_sqt_F_dict.{MOD}":
+            v = v[sub]
+        elif k == f"delta_F_dict.{MOD}":
+            v = v[:, sub]
+        state[k] = v.clone()
+    for name in ("mean_slopes", "mean_intercepts"):
+        state.setdefault(name, getattr(model, name).detach().clone())
+    model = model.to(DEV)
+    n, N, L = side * side, side * side * views, outputs
+    gen = torch.Generator().manual_seed(seed + 2)
+    fixed_set = set() if fixed is None else {fixed}
+    eps_G = [torch.randn(S, n, 2, generator=gen) for v in range(views) if v not in fixed_set]
+    eps_F = {MOD: torch.randn(S, N, L, generator=gen)}
+    eps_G_d, eps_F_d = [e.to(DEV) for e in eps_G], {MOD: eps_F[MOD].to(DEV)}
+    ddd = {MOD: {"spatial_coords": dd[MOD]["spatial_coords"].to(DEV), "outputs": dd[MOD]["outputs"].to(DEV),
+                 "n_samples_list": dd[MOD]["n_samples_list"]}}
+    view_idx, Ns, _, _ = model.create_view_idx_dict(ddd)
+    Xs = {MOD: ddd[MOD]["spatial_coords"]}
+
+    def loss_at(backward):
+        model.inject_noise(eps_G_d, eps_F_d, None)
+        with contextlib.nullcontext() if backward else torch.no_grad():
+            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=S)
+            loss = model.loss_fn(ddd, out[3])
+        if backward:
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+        return loss.detach(), out
+
+    loss, out = loss_at(True)
+    assert out[2][MOD] is out[3][MOD] and out[3][MOD].shape == (S, N, L)
+    assert torch.isfinite(loss) and all(bool(torch.isfinite(o[MOD]).all()) for o in out)
+    if fixed is not None:
+        X = ddd[MOD]["spatial_coords"]
+        assert torch.equal(out[0][MOD][:n], X[:n]) and torch.equal(out[1][MOD][0, :n], X[:n])
+    name_F, name_d = f"Omega_sqt_F_dict.{MOD}", f"delta_F_dict.{MOD}"
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+    got = {"G_means": out[0][MOD].detach().cpu().numpy(), "G_samples": out[1][MOD].detach().cpu().numpy(),
+           "F_samples": out[3][MOD].detach()[:, :, sub.to(DEV)].cpu().numpy(),
+           "grad/Omega_sqt_F": grads[name_F][sub.to(DEV)].cpu().numpy(),
+           "grad/delta_F": grads[name_d][:, sub.to(DEV)].cpu().numpy()}
+    del out
+    # ---- bitwise repeatability
+    loss2, _ = loss_at(True)
+    assert float(loss2) == float(loss)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, grads[k]), k
+    # ---- the ELBO along its own gradient wrt the variational means of the data GPs
+    p = model.delta_F_dict[MOD]
+    d = grads[name_d] / grads[name_d].norm()
+    gdir = float(grads[name_d].norm())
+    with torch.no_grad():
+        p.add_(fd_h * d)
+        lp, _ = loss_at(False)
+        p.sub_(2 * fd_h * d)
+        lm, _ = loss_at(False)
+        p.add_(fd_h * d)
+    fd = (float(lp) - float(lm)) / (2 * fd_h)
+    print(f"directional derivative wrt delta_F: gradient {gdir:.6g}, central difference {fd:.6g}")
+    assert abs(fd - gdir) <= 2e-2 * abs(gdir), (fd, gdir)
+    # ---- fp64 oracle: all spots, the subset of outputs
+    cfg = dict(modality_names=[MOD], n_views=views, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
+               n_latent_gps={MOD: None}, fixed_view_idx=fixed)
+    ref = orc.evaluate(state, cfg, {MOD: dd[MOD]["spatial_coords"]}, {MOD: dd[MOD]["outputs"][:, sub]},
+                       {MOD: dd[MOD]["n_samples_list"]}, S, eps_G, {MOD: eps_F[MOD][:, :, sub]}, dtype=torch.float64)
+    errs = {
+        "G_means": rel(got["G_means"], ref["G_means"][MOD].numpy()),
+        "G_samples": rel(got["G_samples"], ref["G_samples"][MOD].numpy()),
+        "F_samples": rel(got["F_samples"], ref["F_obs"][MOD].numpy()),
+        "grad/Omega_sqt_F": rel(got["grad/Omega_sqt_F"], ref["grads"][name_F].numpy()),
+        "grad/delta_F": rel(got["grad/delta_F"], ref["grads"][name_d].numpy()),
+    }
+    print("full size vs fp64 oracle on outputs", list(subset), {k: f"{v:.1e}" for k, v in errs.items()})
+    assert errs["G_means"] < 1e-4 and errs["G_samples"] < 1e-4 and errs["F_samples"] < 1e-4, errs
+    assert errs["grad/Omega_sqt_F"] < 5e-4 and errs["grad/delta_F"] < 5e-4, errs
+
+
+def test_config4_full_size():
+    """BASELINE config 4 AS STATED: 8 views x 5041 spots, 2000 genes as 2000 independent outputs, M = 500,
+    fixed_view_idx = 0, S = 1 (8e13 flop of contractions per step)."""
+    _full_size_vs_subset_oracle(side=71, views=8, outputs=2000, M=500, fixed=0, seed=44, subset=(0, 777, 1999),
+                                fd_h=1e-2)
+
+
+def test_config5_full_size():
+    """BASELINE config 5 AS STATED: 2 views x 99 856 spots, 1000 independent outputs, M = 1000, S = 1
+    (1e15 flop of contractions per step)."""
+    _full_size_vs_subset_oracle(side=316, views=2, outputs=1000, M=1000, fixed=None, seed=55, subset=(3, 998),
+                                fd_h=1e-2)

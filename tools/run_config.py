@@ -1,6 +1,8 @@
 """Step time of the other BASELINE.json configurations (or the largest single-GPU cut of them) on one MI355X.
 Diagnostic: these are parity-test configurations, not bench lines.
-usage: python tools/run_config.py c2|c3|c4 [steps]"""
+Names follow BASELINE.json's 1-based numbering: 3, 4cut, 5cut (LMC cuts of rounds 1-2), and 4, 5 = the
+configurations at their STATED size (independent outputs, P = L = 2000 / 1000; S = 1).
+usage: python tools/run_config.py 3|4cut|5cut|4|5 [steps] [warmup]"""
 import os
 import sys
 import time
@@ -15,16 +17,21 @@ ge.build()
 import spatial_alignment_amd as gp  # noqa: E402
 from spatial_alignment_amd.synthetic import make_grid_problem, make_model  # noqa: E402
 
-which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+which = sys.argv[1] if len(sys.argv) > 1 else "3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda:0")
 CFG = {
     # 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2 warp / RBF data
-    "c2": dict(side=100, views=4, outputs=500, M=200, latent=10, fixed=None, warp=gp.matern12_kernel, S=5),
+    "3": dict(side=100, views=4, outputs=500, M=200, latent=10, fixed=None, warp=gp.matern12_kernel, S=5),
     # Visium-scale: 8 views x 5k spots (71 x 71), 2000 genes through 20 latent GPs, M = 500, view 0 fixed
-    "c3": dict(side=71, views=8, outputs=2000, M=500, latent=20, fixed=0, warp=gp.rbf_kernel, S=5),
+    "4cut": dict(side=71, views=8, outputs=2000, M=500, latent=20, fixed=0, warp=gp.rbf_kernel, S=5),
     # Slide-seq-scale cut that fits one GPU step: 2 views x 100k spots (316 x 316), 1000 genes / 10 latent, M = 1000
-    "c4": dict(side=316, views=2, outputs=1000, M=1000, latent=10, fixed=None, warp=gp.rbf_kernel, S=1),
+    "5cut": dict(side=316, views=2, outputs=1000, M=1000, latent=10, fixed=None, warp=gp.rbf_kernel, S=1),
+    # BASELINE config 4 as stated: 8 views x 5041 spots, 2000 genes = 2000 independent outputs, M = 500, view 0 fixed
+    "4": dict(side=71, views=8, outputs=2000, M=500, latent=None, fixed=0, warp=gp.rbf_kernel, S=1),
+    # BASELINE config 5 as stated: 2 views x 99 856 spots, 1000 independent outputs, M = 1000
+    "5": dict(side=316, views=2, outputs=1000, M=1000, latent=None, fixed=None, warp=gp.rbf_kernel, S=1),
 }[which]
 dd_cpu = make_grid_problem(side=CFG["side"], n_views=CFG["views"], n_outputs=CFG["outputs"], device="cpu")
 model = make_model(dd_cpu, m=CFG["M"], n_latent_gps={"expression": CFG["latent"]}, fixed_view_idx=CFG["fixed"],
@@ -49,7 +56,7 @@ def step():
     return loss
 
 
-for _ in range(4):  # allocator growth and first-use code loading settle within the first steps
+for _ in range(warmup):  # allocator growth and first-use code loading settle within the first steps
     l0 = step()
 torch.cuda.synchronize()
 import ctypes  # noqa: E402
@@ -72,7 +79,7 @@ for p in plans:
     n = p.lib.gpsa_step_timing_read(p.handle, buf, steps)
     p.lib.gpsa_step_timing(p.handle, 0)
     if n > 0:
-        C_, L_, M_ = CFG["S"] * CFG["views"] * CFG["side"] ** 2, CFG["latent"], CFG["M"]
+        C_, L_, M_ = CFG["S"] * CFG["views"] * CFG["side"] ** 2, CFG["latent"] or CFG["outputs"], CFG["M"]
         fl = 2.0 * C_ * L_ * M_ * M_
         kept = p.saved_bytes - p.saved_bytes_nokeep  # training keeps the products Omega_l alpha (M <= 256)
         names = ("variance form a^T Omega a" + (" (full product, kept)" if kept else ""),
@@ -83,6 +90,6 @@ for p in plans:
                 print(f"  {name:46s} {ms:8.3f} ms   {kept / ms / 1e6:7.0f} GB/s = {kept / ms / 1e6 / 8000:.2f} of the HBM peak")
             else:
                 print(f"  {name:46s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TF nominal = {fl / ms / 1e9 / 157.3:.2f} of the fp32-MFMA peak")
-print(f"{which}: {CFG['views']} views x {CFG['side'] ** 2} spots, {CFG['outputs']} outputs via {CFG['latent']} latent GPs, "
+print(f"{which}: {CFG['views']} views x {CFG['side'] ** 2} spots, {CFG['outputs']} outputs via {CFG['latent'] or 'no'} latent GPs, "
       f"M={CFG['M']}, S={CFG['S']}: {dt * 1e3:.2f} ms/step, loss {float(l0):.4g} -> {float(loss):.4g}, "
       f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
