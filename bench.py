@@ -1,6 +1,7 @@
 """Headline benchmark: GPSA training steps/sec on the 2-view x 10k-spot, M=200, 50-output grid.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          (starts its own N ranks through torch.distributed.run), or under a launcher:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -141,8 +142,28 @@ def cpu_baseline(args, state, dd_cpu):
     )
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks ourselves (torchrun's module
+    as a CHILD process, before this process has touched the GPU), let rank 0's JSON line through on our stdout and
+    leave with the children's status."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's only working mode on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,7 +178,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 

@@ -387,6 +387,10 @@ typedef struct gpsa_step_desc {
   int want_kl;                              /* factorise the variational covariances and evaluate the KL terms */
   const int* view_fixed;                    /* HOST [V]: 1 = fixed view (vgpsa.py:262-273) */
   const long long* view_rows;               /* HOST [n_mods * V]: rows of view v in modality m, [m * V + v] */
+  long long keep_budget_bytes;              /* HBM a training forward may spend on the data GPs' kept products
+                                               Omega_l alpha (L_m m_g C floats per pass): > 0 that many bytes; < 0
+                                               never keep; 0: GPSA_KEEP_GB (default 48) GiB, and no more than 60 % of
+                                               the device memory free at gpsa_step_create */
 } gpsa_step_desc;
 
 typedef struct gpsa_step_params {           /* device pointers, fp32, the reference's parameter layout */

@@ -74,7 +74,7 @@ class StepDesc(C.Structure):
         ("m_x", _i), ("m_g", _i), ("kind_warp", _i), ("kind_data", _i),
         ("n_latent", _i * MAX_MODS), ("n_out", _i * MAX_MODS), ("has_lmc", _i * MAX_MODS),
         ("n_rows", _ll * MAX_MODS), ("s_test", _i), ("n_test", _ll * MAX_MODS), ("want_kl", _i),
-        ("view_fixed", C.POINTER(_i)), ("view_rows", C.POINTER(_ll)),
+        ("view_fixed", C.POINTER(_i)), ("view_rows", C.POINTER(_ll)), ("keep_budget_bytes", _ll),
     ]
 
 

@@ -715,6 +715,324 @@ __global__ void pad_k_kernel(const TS* __restrict__ src, int M, int Mp, long lon
   dst[idx] = k < M ? (float)src[rowi * M + k] : 0.f;
 }
 
+// P [n][M][M] (TS) -> fp32 [n][M][Mp]: U = diag + 2 strict-upper (zero below the diagonal and for k >= M):
+// a^T P a = a^T U a for symmetric P, and row block m0 of U a contracts k >= m0 only
+template <typename TS>
+__global__ void pad_k_tri_kernel(const TS* __restrict__ src, int M, int Mp, long long n, float* __restrict__ dst) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= n * M * Mp) return;
+  const int k = (int)(idx % Mp);
+  const long long rowi = idx / Mp;
+  const int i = (int)(rowi % M);
+  dst[idx] = (k < M && k >= i) ? (float)(k > i ? 2.0 * (double)src[rowi * M + k] : (double)src[rowi * M + k]) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M > 256 with many outputs (BASELINE configs 4 / 5 at their stated size: L = 2000 / 1000): the quadratic form
+// and its alpha-gradient WITHOUT materialising the products Omega_l alpha (L M C floats: 160 / 800 GB there).
+// Both kernels are prod_big_kernel's 128 x 128 tile with the same LDS-DMA staging in MFMA-fragment order, run as
+// ONE software pipeline over a flattened sequence of tiles so that the accumulators (and the ring) stay live:
+//
+//   big_quad_kernel<TRI, STORE>: one workgroup = (output l, 128 columns), walking the row blocks rb = 0 .. nrb-1.
+//     After the last K chunk of a row block the accumulators hold W[rows of rb][cols]; they are multiplied by alpha
+//     read in the SAME (C-layout) positions and summed into four per-lane column sums; the workgroup closes
+//     v[l, cols] in fixed order (deterministic).  TRI: the operand is U_l = diag + 2 strict-upper(Omega_l) and
+//     row block rb starts at K chunk 8 rb (block-triangular: 10 of 16 / 36 of 64 block products at M = 500 / 1000).
+//     STORE (training with kept products): the full product, each accumulator block also leaving for W[l]
+//     as 16-byte nontemporal stores - prod_big_kernel + the closing column-dot pass in one kernel.
+//   big_accum_kernel: one workgroup = (row block rb, 128 columns), walking l = l0 .. l1-1:
+//     out[rows, cols] = scale * sum_l Omega_l[rows, :] (g[l, cols] o alpha[:, cols]); g scales the B fragments as
+//     they are read, so one accumulator set runs over (l, k).  Workgroups are numbered so that the ones that run
+//     together on an XCD (ids equal mod 8 under the observed round-robin placement; speed only) cover all row blocks
+//     of a few column tiles: an XCD's L2 then streams Omega_l once per l for every column tile it is working on.
+// ------------------------------------------------------------------------------------------------
+struct BigQuadArgs {
+  const float* P;  // [L][M][Mp]  (TRI: U_l, else Omega_l), zero for k >= M
+  const float* X;  // alpha [M][C]
+  float* v;        // [L][C]
+  float* W;        // STORE: [L][M][C]
+  int M, Mp, L;
+  long long C;
+};
+
+// stage K chunk CH of row block RB (rows of P) and of the column tile (rows CH*16.. of X) into ring slot BUF
+#define GPSA_BIG_STAGE(PL, RB, CH, BUF)                                                       \
+  {                                                                                           \
+    const int k0__ = (CH) * 16;                                                               \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) {                                        \
+      const int piece = pc * 4 + w;                                                           \
+      const float* src__;                                                                     \
+      if (piece < 8) {                                                                        \
+        int row__ = (RB) * 128 + piece * 16 + j;                                              \
+        row__ = row__ < M ? row__ : M - 1;                                                    \
+        src__ = (PL) + (long long)row__ * Mp + k0__ + kq * 4;                                 \
+      } else {                                                                                \
+        const int grp__ = (piece - 8) >> 2, F__ = (piece - 8) & 3;                            \
+        int krow__ = k0__ + kq * 4 + F__;                                                     \
+        krow__ = krow__ < M ? krow__ : M - 1;                                                 \
+        long long col__ = c0 + grp__ * 64 + j * 4;                                            \
+        col__ = col__ < C - 4 ? col__ : C - 4;                                                \
+        src__ = a.X + (long long)krow__ * C + col__;                                          \
+      }                                                                                       \
+      glds16(src__, __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));       \
+    }                                                                                         \
+  }
+#define GPSA_BIG_MMA(F, BF)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.x, acc[i][0], 0, 0, 0);      \
+    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.y, acc[i][1], 0, 0, 0);      \
+    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.z, acc[i][2], 0, 0, 0);      \
+    acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.w, acc[i][3], 0, 0, 0);      \
+  }
+
+template <bool TRI, bool STORE>
+__global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
+  const int M = a.M, Mp = a.Mp, l = blockIdx.y;
+  const long long C = a.C;
+  const long long c0 = (long long)blockIdx.x * 128;
+  const float* Pl = a.P + (long long)l * M * Mp;
+  const int nch = Mp / 16, nrb = (M + 127) / 128;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 vs = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // alpha at the accumulators' own (row, column) positions, for the closing sum: K chunk 8 rb + 4 wr + i of row
+  // block rb stages exactly the rows 16 i + 4 kq + F of this wave's 64 as its B fragments (bv[F] = alpha[k0 + 4 kq
+  // + F][the lane's four columns]) - captured as they pass, no second read of alpha
+  float4 aC[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) aC[i][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the lane's four output columns (clamped: columns beyond C are computed on repeated data and never stored)
+  long long colc = c0 + wc * 64 + j * 4;
+  const bool col_ok = colc < C;  // C % 4 == 0: the four columns are in or out together
+  colc = colc < C - 4 ? colc : C - 4;
+  // stage cursor: two chunks ahead of the compute cursor; past the end it keeps re-staging the last chunk
+  int s_rb = 0, s_ch = 0;
+#define GPSA_BQ_ADVANCE()                                \
+  {                                                      \
+    if (s_ch + 1 < nch) {                                \
+      ++s_ch;                                            \
+    } else if (s_rb + 1 < nrb) {                         \
+      ++s_rb;                                            \
+      s_ch = TRI ? s_rb * 8 : 0;                         \
+    }                                                    \
+  }
+  GPSA_BIG_STAGE(Pl, s_rb, s_ch, 0)
+  GPSA_BQ_ADVANCE()
+  GPSA_BIG_STAGE(Pl, s_rb, s_ch, 1)
+  GPSA_BQ_ADVANCE()
+  GPSA_DMA_WAIT(4);
+  __syncthreads();
+  int buf = 0;
+  for (int rb = 0; rb < nrb; ++rb) {
+    for (int ch = TRI ? rb * 8 : 0; ch < nch; ++ch) {
+      GPSA_BIG_STAGE(Pl, s_rb, s_ch, buf == 0 ? 2 : buf - 1)
+      GPSA_BQ_ADVANCE()
+      const float* base = &lds[buf][lane * 4];
+      float4 av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
+        bv[i] = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+      }
+      {
+        const int cc = ch - rb * 8 - wr * 4;  // wave-uniform
+        if (cc == 0) { aC[0][0] = bv[0]; aC[0][1] = bv[1]; aC[0][2] = bv[2]; aC[0][3] = bv[3]; }
+        else if (cc == 1) { aC[1][0] = bv[0]; aC[1][1] = bv[1]; aC[1][2] = bv[2]; aC[1][3] = bv[3]; }
+        else if (cc == 2) { aC[2][0] = bv[0]; aC[2][1] = bv[1]; aC[2][2] = bv[2]; aC[2][3] = bv[3]; }
+        else if (cc == 3) { aC[3][0] = bv[0]; aC[3][1] = bv[1]; aC[3][2] = bv[2]; aC[3][3] = bv[3]; }
+      }
+      GPSA_BIG_MMA(x, bv[0])
+      GPSA_BIG_MMA(y, bv[1])
+      GPSA_BIG_MMA(z, bv[2])
+      GPSA_BIG_MMA(w, bv[3])
+      GPSA_DMA_WAIT(4);
+      __syncthreads();
+      buf = (buf == 2) ? 0 : buf + 1;
+    }
+    // close row block rb: v += sum_rows alpha[row, col] W[row, col]  (accumulator (i, G, r) = row 16 i + 4 kq + r of
+    // the wave's 64, column 4 j + G of its 64)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb * 128 + wr * 64 + i * 16 + kq * 4 + r;
+        const f32x4 o = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        const f32x4 xa = (f32x4){aC[i][r].x, aC[i][r].y, aC[i][r].z, aC[i][r].w};
+        if (row < M) {
+          vs += xa * o;
+          if (STORE) {
+            if (col_ok)
+              __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(a.W + ((long long)l * M + row) * C + colc));
+          }
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_BQ_ADVANCE
+  // column sums: over the four lane quarters (rows), then over the two waves that share the columns
+#pragma unroll
+  for (int G = 0; G < 4; ++G) {
+    vs[G] += __shfl_xor(vs[G], 16);
+    vs[G] += __shfl_xor(vs[G], 32);
+  }
+  __syncthreads();  // every wave has left the ring
+  float* red = &lds[0][0];
+  if (kq == 0) *reinterpret_cast<f32x4*>(red + wr * 128 + wc * 64 + j * 4) = vs;
+  __syncthreads();
+  if (tid < 128 && c0 + tid < C) a.v[(long long)l * C + c0 + tid] = red[tid] + red[128 + tid];
+}
+
+struct BigAccumArgs {
+  const float* P;  // [L][M][Mp] Omega_l, zero for k >= M
+  const float* X;  // alpha [M][C]
+  const float* g;  // [L][C]
+  float* out;      // [nsplit][M][C]
+  int M, Mp, L, nrb, nsplit;
+  long long C, ctiles;
+  float scale;
+};
+
+__global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
+  __shared__ __attribute__((aligned(16))) float sg[3][128];  // g[l, the 128 columns] of each stage's output l
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
+  const int M = a.M, Mp = a.Mp;
+  const long long C = a.C;
+  // workgroup id -> (row block, column tile, split of the outputs): ids equal mod 8 share an XCD
+  const long long id = blockIdx.x, slot = id >> 3, ct8 = (a.ctiles + 7) / 8;
+  const int rb = (int)(slot % a.nrb);
+  const long long t = slot / a.nrb;
+  const long long ct = (t % ct8) * 8 + (id & 7);
+  const int sp = (int)(t / ct8);
+  if (ct >= a.ctiles) return;
+  const long long c0 = ct * 128;
+  const int l0 = (int)((long long)sp * a.L / a.nsplit), l1 = (int)((long long)(sp + 1) * a.L / a.nsplit);
+  const int nch = Mp / 16;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  long long colc = c0 + wc * 64 + j * 4;
+  const bool col_ok = colc < C;
+  colc = colc < C - 4 ? colc : C - 4;
+  int s_l = l0, s_ch = 0;
+#define GPSA_BA_ADVANCE()                                \
+  {                                                      \
+    if (s_ch + 1 < nch) {                                \
+      ++s_ch;                                            \
+    } else if (s_l + 1 < l1) {                           \
+      ++s_l;                                             \
+      s_ch = 0;                                          \
+    }                                                    \
+  }
+  // the stage's g rides along as a fifth operation of every wave (all four write the same 512 bytes; a load the
+  // compiler sees would make it drain the ring - vmcnt(0) - in every iteration): vmcnt(5) = "all but the newest stage"
+  long long gcol = c0 + (lane & 31) * 4;
+  gcol = gcol < C - 4 ? gcol : C - 4;
+#define GPSA_BA_STAGE(BUF)                                                                                  \
+  {                                                                                                         \
+    GPSA_BIG_STAGE(a.P + (long long)s_l * M * Mp, rb, s_ch, BUF)                                            \
+    if (lane < 32) glds16(a.g + (long long)s_l * C + gcol, __builtin_amdgcn_readfirstlane(lds_addr(&sg[BUF][0]))); \
+  }
+  if (l0 < l1) {
+    GPSA_BA_STAGE(0)
+    GPSA_BA_ADVANCE()
+    GPSA_BA_STAGE(1)
+    GPSA_BA_ADVANCE()
+  }
+  GPSA_DMA_WAIT(5);
+  __syncthreads();
+  int buf = 0;
+  for (int l = l0; l < l1; ++l) {
+    for (int ch = 0; ch < nch; ++ch) {
+      GPSA_BA_STAGE(buf == 0 ? 2 : buf - 1)
+      GPSA_BA_ADVANCE()
+      const float* base = &lds[buf][lane * 4];
+      const float4 gl = *reinterpret_cast<const float4*>(&sg[buf][wc * 64 + j * 4]);
+      float4 av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
+        const float4 x = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+        bv[i] = make_float4(x.x * gl.x, x.y * gl.y, x.z * gl.z, x.w * gl.w);
+      }
+      GPSA_BIG_MMA(x, bv[0])
+      GPSA_BIG_MMA(y, bv[1])
+      GPSA_BIG_MMA(z, bv[2])
+      GPSA_BIG_MMA(w, bv[3])
+      GPSA_DMA_WAIT(5);
+      __syncthreads();
+      buf = (buf == 2) ? 0 : buf + 1;
+    }
+  }
+  GPSA_DMA_DRAIN();
+#undef GPSA_BA_STAGE
+#undef GPSA_BA_ADVANCE
+  float* O = a.out + (long long)sp * M * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rb * 128 + wr * 64 + i * 16 + kq * 4 + r;
+      if (row < M && col_ok) {
+        const f32x4 o = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]} * a.scale;
+        *reinterpret_cast<f32x4*>(O + (long long)row * C + colc) = o;
+      }
+    }
+}
+#undef GPSA_BIG_STAGE
+#undef GPSA_BIG_MMA
+
+// out[e] = sum_s part[s][e]  (fixed order), four floats per thread
+__global__ void __launch_bounds__(256) big_accum_reduce_kernel(const float* __restrict__ part, int nsplit, long long n4,
+                                                              float* __restrict__ out) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+  for (int p = 1; p < nsplit; ++p) s += reinterpret_cast<const f32x4*>(part)[(long long)p * n4 + i];
+  reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+// shapes the two kernels cover (everything else stays on the generic tiled product)
+static inline bool big_panel_ok(int M, long long C, int L, const void* alpha) {
+  static const bool off = [] { const char* e = getenv("GPSA_BIG_PANEL"); return e && e[0] == '0'; }();
+  return !off && M > 128 && (C & 3) == 0 && C >= 128 && cdiv(C, 128) * cdiv(M, 128) * 32 < 0x7fffffffLL && L <= 65535 &&
+         (reinterpret_cast<uintptr_t>(alpha) & 15) == 0;
+}
+// splits of the outputs for big_accum_kernel: the fewest (<= 4) that fill the rounds of workgroups (2 per CU) to
+// >= 90 %, else the fullest
+static inline int big_accum_nsplit(int M, long long C, int L) {
+  const long long wgs = cdiv(M, 128) * cdiv(C, 128), slots = 2LL * num_cus();
+  int best = 1;
+  double beff = 0.0;
+  for (int s = 1; s <= 4 && (s == 1 || L / s >= 8); ++s) {
+    const double eff = (double)(wgs * s) / (double)(cdiv(wgs * s, slots) * slots);
+    if (eff > beff) { beff = eff; best = s; }
+    if (eff >= 0.9) break;
+  }
+  return best;
+}
+static inline long long big_accum_ws_bytes(int M, long long C, int L) {
+  const int ns = big_accum_nsplit(M, C, L);
+  return ns > 1 ? (long long)ns * M * C * 4 : 0;
+}
+
 // Omega[b] = A[b] A[b]^T + jitter I for a batch of small fp32 parameter matrices (M = 200: the 54 variational
 // covariances of a step), fp64 matrix cores.  One workgroup = a 64 x 64 block pair (bi >= bj) of one matrix; both
 // operands are rows of A, contiguous along the contracted index: 16-k chunks of the 64 + 64 rows move to LDS by
@@ -2071,6 +2389,32 @@ static int tri_operand(int p_dtype, const void* P, int M, int L, const T** out, 
   *out = dst;
   return 0;
 }
+// dalpha = 2 sum_l Omega_l (g_l o alpha) through big_accum_kernel; GPSA_EUNSUPPORTED: shape / workspace not covered
+static int big_accum_launch(int omega_dtype, const float* alpha, const void* Omega, const float* g, int M, long long C,
+                            int L, float* dalpha, void* workspace, long long workspace_bytes, hipStream_t st) {
+  if (!big_panel_ok(M, C, L, alpha) || (omega_dtype != GPSA_F64 && omega_dtype != GPSA_F32)) return GPSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(dalpha) & 15) != 0 || (reinterpret_cast<uintptr_t>(g) & 15) != 0) return GPSA_EUNSUPPORTED;
+  const int Mp = (M + 15) / 16 * 16, nrb = (int)cdiv(M, 128), ns = big_accum_nsplit(M, C, L);
+  const long long n = (long long)L * M * Mp, pb = (n * 4 + 255) & ~255LL;
+  if (workspace_bytes < pb + big_accum_ws_bytes(M, C, L)) return GPSA_EUNSUPPORTED;
+  float* Pp = (float*)workspace;
+  float* part = ns > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pb) : dalpha;
+  if (omega_dtype == GPSA_F64)
+    pad_k_kernel<double><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const double*)Omega, M, Mp, L, Pp);
+  else
+    pad_k_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
+  GPSA_LAUNCH_CHECK();
+  const long long ctiles = cdiv(C, 128), ct8 = cdiv(ctiles, 8);
+  BigAccumArgs aa{Pp, alpha, g, part, M, Mp, L, nrb, ns, C, ctiles, 2.f};
+  big_accum_kernel<<<(unsigned)(8 * nrb * ct8 * ns), 256, 0, st>>>(aa);  // (3 workgroups per CU: no faster, measured)
+  GPSA_LAUNCH_CHECK();
+  if (ns > 1) {
+    const long long n4 = (long long)M * C / 4;
+    big_accum_reduce_kernel<<<(unsigned)cdiv(n4, 256), 256, 0, st>>>(part, ns, n4, dalpha);
+    GPSA_LAUNCH_CHECK();
+  }
+  return 0;
+}
 }  // namespace gpsa
 
 extern "C" {
@@ -2089,6 +2433,10 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
   long long bo = ((long long)M * C * sz + (long long)gpsa::gram_splitk(C, M) * M * M * sz) * lc;  // bwd_omega
   long long r = generic > bo ? generic : bo;
   r += (long long)L * M * M * sz + 256;  // converted copy of Omega (generic paths, other precision)
+  if (dtype == GPSA_F32 && M > 128) {     // big_quad / big_accum: padded fp32 operand + the splits' partial results
+    const long long big = (long long)L * M * ((M + 15) / 16 * 16) * 4 + gpsa::big_accum_ws_bytes(M, C, L) + 512;
+    if (big > r) r = big;
+  }
   return (r > mfma ? r : mfma) + 256;
 }
 
@@ -2113,6 +2461,23 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
       if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
                                           nullptr, 1.f, nullptr, st);
+    }
+    if (big_panel_ok(M, C, L, alpha) && (omega_dtype == GPSA_F64 || omega_dtype == GPSA_F32)) {
+      // block-triangular LDS-DMA form, closed in the kernel: nothing of size M x C per output is written
+      const int Mp = (M + 15) / 16 * 16;
+      const long long n = (long long)L * M * Mp;
+      if (workspace_bytes >= n * 4) {
+        float* Pp = (float*)workspace;
+        if (omega_dtype == GPSA_F64)
+          pad_k_tri_kernel<double><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const double*)Omega, M, Mp, L, Pp);
+        else
+          pad_k_tri_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
+        GPSA_LAUNCH_CHECK();
+        BigQuadArgs qa{Pp, (const float*)alpha, (float*)v, nullptr, M, Mp, L, C};
+        big_quad_kernel<true, false><<<dim3((unsigned)cdiv(C, 128), (unsigned)L), 256, 0, st>>>(qa);
+        GPSA_LAUNCH_CHECK();
+        return 0;
+      }
     }
     const float* Om;
     int rc = tri_operand<float>(omega_dtype, Omega, M, L, &Om, &workspace, &workspace_bytes, st);
@@ -2188,6 +2553,13 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
       else
         return GPSA_EINVAL;
       GPSA_LAUNCH_CHECK();
+      static const bool old_pb = [] { const char* e = getenv("GPSA_PROD_BIG"); return e && e[0] == '1'; }();
+      if (!old_pb && big_panel_ok(M, C, L, alpha)) {  // product, kept copy and the closing column sums in one kernel
+        BigQuadArgs qa{Pp, alpha, v, W, M, Mp, L, C};
+        big_quad_kernel<false, true><<<dim3((unsigned)ctiles, (unsigned)L), 256, 0, st>>>(qa);
+        GPSA_LAUNCH_CHECK();
+        return 0;
+      }
       ProdBigArgs pa{Pp, alpha, W, M, Mp, L, C};
       prod_big_kernel<<<dim3((unsigned)cdiv(M, 128), (unsigned)L, (unsigned)ctiles), 256, 0, st>>>(pa);
       GPSA_LAUNCH_CHECK();
@@ -2260,6 +2632,14 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
+    // 256 < M <= 512: the register-resident kernel stays ahead of the LDS-DMA one (BASELINE config 4: 319 vs 342 ms);
+    // GPSA_ACCUM_PANEL=0 takes the LDS-DMA kernel there too (tests, A/B)
+    static const bool panel_off = [] { const char* e = getenv("GPSA_ACCUM_PANEL"); return e && e[0] == '0'; }();
+    if (MB > 16 && panel_off && !force_generic()) {
+      const int rc = big_accum_launch(omega_dtype, (const float*)alpha, Omega, (const float*)g, M, C, L, (float*)dalpha,
+                                      workspace, workspace_bytes, st);
+      if (rc != GPSA_EUNSUPPORTED) return rc;
+    }
     if (MB && MB <= MB_MAX_ACCUM && !force_generic()) {
       const long long pk = (long long)L * MB * 16 * MB * 16;
       if (workspace_bytes < (pk + accum_slab_floats(MB)) * 4) return GPSA_EWORKSPACE;
@@ -2268,6 +2648,11 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
       if (rc) return rc;
       return panel_mfma_launch<MODE_ACCUM>(MB, Ppk, (const float*)alpha, (const float*)g, M, C, L,
                                            (float*)dalpha, nullptr, 2.f, Ppk + pk, st);
+    }
+    {
+      const int rc = big_accum_launch(omega_dtype, (const float*)alpha, Omega, (const float*)g, M, C, L, (float*)dalpha,
+                                      workspace, workspace_bytes, st);
+      if (rc != GPSA_EUNSUPPORTED) return rc;
     }
     const float* Om;
     int rc = operand_as<float>(omega_dtype, Omega, (long long)L * M * M, &Om, &workspace, &workspace_bytes, st);

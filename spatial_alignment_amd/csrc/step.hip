@@ -664,6 +664,15 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
   // the part before them); only while they stay within GPSA_KEEP_GB (default 48) GiB in total.
   {
     static const double keep_gb = [] { const char* e = getenv("GPSA_KEEP_GB"); return e ? atof(e) : 48.0; }();
+    double budget = keep_gb * 1073741824.0;
+    if (dsc->keep_budget_bytes > 0) {
+      budget = (double)dsc->keep_budget_bytes;  // the caller has looked at its allocator (step_engine.get_plan)
+    } else if (dsc->keep_budget_bytes < 0) {
+      budget = -1.0;
+    } else if (!host_only) {  // no figure from the caller: never plan beyond what the device has free right now
+      size_t fr = 0, total = 0;
+      if (hipMemGetInfo(&fr, &total) == hipSuccess && 0.6 * (double)fr < budget) budget = 0.6 * (double)fr;
+    }
     long long tot = 0;
     bool ok = true;
     for (auto& q : p->passes) {
@@ -671,7 +680,7 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
       if (b == 0) ok = false;
       tot += b;
     }
-    if (ok && (double)tot <= keep_gb * 1073741824.0)
+    if (ok && (double)tot <= budget)
       for (auto& q : p->passes) q.o_keep = take(gpsa_quadform_keep_f32_bytes(p->Mg, q.C, dsc->n_latent[q.m]));
   }
   p->saved_bytes = o + 256;

@@ -94,6 +94,32 @@ def view_rows(model, view_idx, Ns):
     return tuple(out)
 
 
+def keep_budget_bytes(model, desc, keep_gb=None):
+    """HBM the plan may spend on the data GPs' kept products (gpsa_step_desc.keep_budget_bytes).
+
+    ``model.keep_budget_gb`` (or GPSA_KEEP_GB) when set; otherwise what this process can still get from the device -
+    free memory plus the blocks torch's allocator holds unused - minus the plan's own arenas, minus three more copies
+    of the parameters (their gradient and Adam's two moments may not exist yet), with a tenth of the device left
+    alone: a 288 GB MI355X keeps the 160 GB of BASELINE config 4, a smaller or shared device falls back to recomputing
+    instead of dying in the allocator."""
+    import os
+
+    if keep_gb is None and os.environ.get("GPSA_KEEP_GB"):
+        keep_gb = float(os.environ["GPSA_KEEP_GB"])
+    if keep_gb is not None:
+        return max(1, int(float(keep_gb) * 2**30)) if float(keep_gb) > 0 else -1
+    dev = model.Xtilde.device
+    free, total = torch.cuda.mem_get_info(dev)
+    avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    out = (C.c_longlong * 8)()
+    desc.keep_budget_bytes = -1
+    if _lib.load().gpsa_step_describe(C.byref(desc), out) != 0:
+        return -1
+    params = sum(p.numel() * p.element_size() for p in model.parameters())
+    budget = int(avail - 0.1 * total) - int(out[6]) - int(out[1]) - 3 * params
+    return budget if budget > 0 else -1
+
+
 def get_plan(model, rows, S, test_shapes, want_kl):
     """plan for this model / data shape (cached on the model)"""
     mods = model.modality_names
@@ -106,8 +132,9 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     s_test = test_shapes[0] if test_shapes else 0
     n_test = tuple(test_shapes[1]) if test_shapes else tuple(0 for _ in mods)
     kw, kd = KINDS[builtin_kind(model.kernel_func_warp)], KINDS[builtin_kind(model.kernel_func_data)]
+    keep_gb = getattr(model, "keep_budget_gb", None)
     key = (V, D, len(mods), int(S), int(model.Xtilde.shape[1]), int(model.Gtilde.shape[0]), kw, kd, L, P, lmc, N,
-           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index)
+           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index, keep_gb)
     cache = model.__dict__.setdefault("_step_plans", {})
     plan = cache.get(key)
     if plan is not None:
@@ -121,6 +148,7 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     vf = (C.c_int * V)(*fixed)
     vr = (C.c_longlong * len(rows))(*rows)
     d.view_fixed, d.view_rows = vf, vr
+    d.keep_budget_bytes = keep_budget_bytes(model, d, keep_gb)
     with torch.cuda.device(model.Xtilde.device):
         plan = StepPlan(_lib.load(), key, d, (vf, vr))
     plan.mods, plan.V, plan.D, plan.S, plan.L, plan.P, plan.lmc, plan.N = mods, V, D, int(S), L, P, lmc, N

@@ -289,7 +289,10 @@ def test_chol_flags_indefinite(hip):
 
 QF = [(10, 100, 3), (25, 1000, 5), (50, 333, 2), (100, 500, 4), (200, 2100, 7), (256, 300, 2), (16, 64, 1),
       (300, 130, 2), (200, 50001, 3), (13, 7, 1), (380, 1000, 3), (392, 200, 2), (500, 700, 3), (513, 100, 2),
-      (1000, 1040, 2), (641, 4100, 1)]
+      (1000, 1040, 2), (641, 4100, 1),
+      # M > 256 with more outputs: the LDS-DMA kernels that never write Omega_l alpha (big_quad / big_accum), the
+      # alpha-gradient's split over the outputs, partial row blocks and column tiles
+      (500, 1300, 20), (1000, 3968, 9), (260, 128, 17), (300, 2052, 33)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
