@@ -64,7 +64,16 @@ class HipOps:
         key = (dev, _raw_stream(dev))
         buf = self._scratch.get(key)
         if buf is None or buf.numel() < nbytes:
-            grow = max(int(nbytes), 1 << 20, 0 if buf is None else 2 * buf.numel())
+            # doubling only while that is cheap: the large-M plans ask for tens of GB
+            grow = max(int(nbytes), 1 << 20, 0 if buf is None else min(2 * buf.numel(), int(nbytes) + (256 << 20)))
+            if buf is not None:
+                if torch.cuda.is_current_stream_capturing():
+                    # a block must not go back to the allocator inside a capture (its stream bookkeeping records
+                    # events): the old buffer outlives the capture in this list
+                    self.__dict__.setdefault("_retired", []).append(buf)
+                else:
+                    self._scratch[key] = None  # returned before the larger one is requested
+                del buf
             buf = self._scratch[key] = torch.empty(grow, dtype=torch.uint8, device=like.device)
         return buf
 

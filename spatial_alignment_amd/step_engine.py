@@ -53,6 +53,34 @@ class StepPlan:
             pass
 
 
+# Arenas beyond this size are parked on their plan between a backward and the next forward instead of going back
+# to torch's caching allocator: a 160 GB block (BASELINE config 4's kept products) that other allocations have split
+# in the meantime cannot be had again - the allocator reports it as "reserved but unallocated" and fails.
+ARENA_PARK_BYTES = 1 << 30
+
+
+def _take_arena(plan, nbytes, dev, must=False):
+    parked = plan.__dict__.get("_parked")
+    if parked is not None and parked.device == dev and parked.numel() >= nbytes:
+        if 2 * nbytes < parked.numel():  # a forward without kept products (no backward will hand the arena back):
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)  # leave the large one parked
+        plan._parked = None
+        return parked
+    plan._parked = None  # (too small: let it go before asking for the larger one)
+    del parked
+    try:
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    except torch.OutOfMemoryError:
+        if must:
+            raise
+        return None
+
+
+def _give_arena(plan, arena):
+    if arena is not None and arena.numel() >= ARENA_PARK_BYTES and plan.__dict__.get("_parked") is None:
+        plan._parked = arena
+
+
 def eligible(model, X_spatial, view_idx, G_test):
     """the engine covers: built-in covariance functions, fp32 HIP tensors, views that are consecutive row
     blocks covering each modality (what create_view_idx_dict produces), <= 4 modalities"""
@@ -237,7 +265,11 @@ class StepFn(torch.autograd.Function):
         # backward streams them back; otherwise the cheaper forward and the smaller arena
         keep = any(ctx.needs_input_grad[1:]) and not aux.get("no_keep", False)  # (all False under no_grad)
         io.keep_products = 1 if keep else 0
-        saved = torch.empty(plan.saved_bytes if keep else plan.saved_bytes_nokeep, dtype=torch.uint8, device=dev)
+        saved = _take_arena(plan, plan.saved_bytes if keep else plan.saved_bytes_nokeep, dev)
+        if saved is None:  # the device cannot hold the kept products after all (other tenants, fragmentation)
+            keep = False
+            io.keep_products = 0
+            saved = _take_arena(plan, plan.saved_bytes_nokeep, dev, must=True)
         scratch = o._ws(plan.scratch_bytes, saved)
         stream = _raw_stream(dev.index)
         pending = None
@@ -359,6 +391,7 @@ class StepFn(torch.autograd.Function):
         # the arena (gigabytes when the data GPs keep their products) goes back to the allocator NOW: the node sits
         # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
         # would break, steps later
+        _give_arena(plan, ctx.arena)
         ctx.arena = None
         ctx.aux = ctx.io = ctx.prm = None
         return tuple(out)
