@@ -142,6 +142,37 @@ def cpu_baseline(args, state, dd_cpu):
     )
 
 
+def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
+    """One forward + ELBO of the TRAINED bench model at the full bench size, S = 1, against the fp64 oracle on the
+    same parameters and the same injected draws (the fp32 oracle the timing leg runs is no yardstick here: at
+    M = 200 the fp32 reference is 1e-1 from its own fp64 run on F).  Norm-wise relative errors."""
+    from oracle import gpsa_oracle as orc
+
+    m = "expression"
+    t0 = time.time()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for name in ("mean_slopes", "mean_intercepts"):
+        state.setdefault(name, getattr(model, name).detach().cpu().clone())
+    N, L = dd_cpu[m]["spatial_coords"].shape[0], args.outputs
+    gen = torch.Generator().manual_seed(7)
+    eps_G = [torch.randn(1, n_v, 2, generator=gen) for n_v in dd_cpu[m]["n_samples_list"]]
+    eps_F = {m: torch.randn(1, N, L, generator=gen)}
+    dev = model.Xtilde.device
+    model.inject_noise([e.to(dev) for e in eps_G], {m: eps_F[m].to(dev)}, None)
+    with torch.no_grad():
+        out = model.forward({m: dd[m]["spatial_coords"]}, view_idx=view_idx, Ns=Ns, S=1)
+        loss = model.loss_fn(dd, out[3])
+    cfg = dict(modality_names=[m], n_views=args.views, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
+               n_latent_gps={m: None}, fixed_view_idx=None)
+    ref = orc.evaluate(state, cfg, {m: dd_cpu[m]["spatial_coords"]}, {m: dd_cpu[m]["outputs"]},
+                       {m: dd_cpu[m]["n_samples_list"]}, 1, eps_G, eps_F, want_grads=False, dtype=torch.float64)
+    rel = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / b.double().norm())
+    return dict(S=1, G_means_rel=rel(out[0][m], ref["G_means"][m]), G_samples_rel=rel(out[1][m], ref["G_samples"][m]),
+                F_rel=rel(out[3][m], ref["F_obs"][m]), loss_rel=rel(loss.reshape(1), ref["loss"].reshape(1)),
+                tolerance=1e-4, against="oracle/gpsa_oracle.py in fp64, same trained parameters, same injected draws",
+                seconds=round(time.time() - t0, 1))
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` without a launcher around it: start the N ranks ourselves (torchrun's module
     as a CHILD process, before this process has touched the GPU), let rank 0's JSON line through on our stdout and
@@ -423,6 +454,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, state, dd_full)
+            if emu == 1:
+                try:
+                    line["parity_at_bench_size"] = parity_at_bench_size(args, model, dd_full, dd, view_idx, Ns)
+                except Exception as e:  # the contract line must not die with its extra
+                    line["parity_at_bench_size"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

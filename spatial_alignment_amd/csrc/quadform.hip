@@ -785,9 +785,9 @@ struct BigQuadArgs {
     acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.w, acc[i][3], 0, 0, 0);      \
   }
 
-template <bool TRI, bool STORE>
+template <bool TRI, bool STORE, int NS>
 __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
+  __shared__ __attribute__((aligned(16))) float lds[NS][16 * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
@@ -825,16 +825,17 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
       s_ch = TRI ? s_rb * 8 : 0;                         \
     }                                                    \
   }
-  GPSA_BIG_STAGE(Pl, s_rb, s_ch, 0)
-  GPSA_BQ_ADVANCE()
-  GPSA_BIG_STAGE(Pl, s_rb, s_ch, 1)
-  GPSA_BQ_ADVANCE()
-  GPSA_DMA_WAIT(4);
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) {
+    GPSA_BIG_STAGE(Pl, s_rb, s_ch, s0)
+    GPSA_BQ_ADVANCE()
+  }
+  GPSA_DMA_WAIT(4 * (NS - 2));
   __syncthreads();
   int buf = 0;
   for (int rb = 0; rb < nrb; ++rb) {
     for (int ch = TRI ? rb * 8 : 0; ch < nch; ++ch) {
-      GPSA_BIG_STAGE(Pl, s_rb, s_ch, buf == 0 ? 2 : buf - 1)
+      GPSA_BIG_STAGE(Pl, s_rb, s_ch, buf == 0 ? NS - 1 : buf - 1)
       GPSA_BQ_ADVANCE()
       const float* base = &lds[buf][lane * 4];
       float4 av[4], bv[4];
@@ -854,9 +855,9 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
       GPSA_BIG_MMA(y, bv[1])
       GPSA_BIG_MMA(z, bv[2])
       GPSA_BIG_MMA(w, bv[3])
-      GPSA_DMA_WAIT(4);
+      GPSA_DMA_WAIT(4 * (NS - 2));
       __syncthreads();
-      buf = (buf == 2) ? 0 : buf + 1;
+      buf = (buf == NS - 1) ? 0 : buf + 1;
     }
     // close row block rb: v += sum_rows alpha[row, col] W[row, col]  (accumulator (i, G, r) = row 16 i + 4 kq + r of
     // the wave's 64, column 4 j + G of its 64)
@@ -905,9 +906,10 @@ struct BigAccumArgs {
   float scale;
 };
 
+template <int NS>
 __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
-  __shared__ __attribute__((aligned(16))) float sg[3][128];  // g[l, the 128 columns] of each stage's output l
+  __shared__ __attribute__((aligned(16))) float lds[NS][16 * 256];
+  __shared__ __attribute__((aligned(16))) float sg[NS][128];  // g[l, the 128 columns] of each stage's output l
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
@@ -951,17 +953,18 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
     if (lane < 32) glds16(a.g + (long long)s_l * C + gcol, __builtin_amdgcn_readfirstlane(lds_addr(&sg[BUF][0]))); \
   }
   if (l0 < l1) {
-    GPSA_BA_STAGE(0)
-    GPSA_BA_ADVANCE()
-    GPSA_BA_STAGE(1)
-    GPSA_BA_ADVANCE()
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) {
+      GPSA_BA_STAGE(s0)
+      GPSA_BA_ADVANCE()
+    }
   }
-  GPSA_DMA_WAIT(5);
+  GPSA_DMA_WAIT(5 * (NS - 2));
   __syncthreads();
   int buf = 0;
   for (int l = l0; l < l1; ++l) {
     for (int ch = 0; ch < nch; ++ch) {
-      GPSA_BA_STAGE(buf == 0 ? 2 : buf - 1)
+      GPSA_BA_STAGE(buf == 0 ? NS - 1 : buf - 1)
       GPSA_BA_ADVANCE()
       const float* base = &lds[buf][lane * 4];
       const float4 gl = *reinterpret_cast<const float4*>(&sg[buf][wc * 64 + j * 4]);
@@ -976,9 +979,9 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
       GPSA_BIG_MMA(y, bv[1])
       GPSA_BIG_MMA(z, bv[2])
       GPSA_BIG_MMA(w, bv[3])
-      GPSA_DMA_WAIT(5);
+      GPSA_DMA_WAIT(5 * (NS - 2));
       __syncthreads();
-      buf = (buf == 2) ? 0 : buf + 1;
+      buf = (buf == NS - 1) ? 0 : buf + 1;
     }
   }
   GPSA_DMA_DRAIN();
@@ -2406,7 +2409,8 @@ static int big_accum_launch(int omega_dtype, const float* alpha, const void* Ome
   GPSA_LAUNCH_CHECK();
   const long long ctiles = cdiv(C, 128), ct8 = cdiv(ctiles, 8);
   BigAccumArgs aa{Pp, alpha, g, part, M, Mp, L, nrb, ns, C, ctiles, 2.f};
-  big_accum_kernel<<<(unsigned)(8 * nrb * ct8 * ns), 256, 0, st>>>(aa);  // (3 workgroups per CU: no faster, measured)
+  // (measured, no faster: 3 workgroups per CU; a 4-slot ring with three stages in flight)
+  big_accum_kernel<3><<<(unsigned)(8 * nrb * ct8 * ns), 256, 0, st>>>(aa);
   GPSA_LAUNCH_CHECK();
   if (ns > 1) {
     const long long n4 = (long long)M * C / 4;
@@ -2474,7 +2478,7 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
           pad_k_tri_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
         GPSA_LAUNCH_CHECK();
         BigQuadArgs qa{Pp, (const float*)alpha, (float*)v, nullptr, M, Mp, L, C};
-        big_quad_kernel<true, false><<<dim3((unsigned)cdiv(C, 128), (unsigned)L), 256, 0, st>>>(qa);
+        big_quad_kernel<true, false, 3><<<dim3((unsigned)cdiv(C, 128), (unsigned)L), 256, 0, st>>>(qa);
         GPSA_LAUNCH_CHECK();
         return 0;
       }
@@ -2556,7 +2560,7 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
       static const bool old_pb = [] { const char* e = getenv("GPSA_PROD_BIG"); return e && e[0] == '1'; }();
       if (!old_pb && big_panel_ok(M, C, L, alpha)) {  // product, kept copy and the closing column sums in one kernel
         BigQuadArgs qa{Pp, alpha, v, W, M, Mp, L, C};
-        big_quad_kernel<false, true><<<dim3((unsigned)ctiles, (unsigned)L), 256, 0, st>>>(qa);
+        big_quad_kernel<false, true, 3><<<dim3((unsigned)ctiles, (unsigned)L), 256, 0, st>>>(qa);
         GPSA_LAUNCH_CHECK();
         return 0;
       }

@@ -531,6 +531,14 @@ class VariationalGPSA(GPSA):
             Gt = [G_test[m].to(device=dev, dtype=f32).contiguous() for m in mods]
             test_shapes = (int(Gt[0].shape[0]), tuple(int(g.shape[1]) for g in Gt))
         plan = SE.get_plan(self, rows, S, test_shapes, want_kl=not prediction_mode)
+        # the engine takes raw pointers and trusts the plan's shapes: everything handed over is checked against it
+        for i, m in enumerate(mods):
+            if tuple(X_spatial[m].shape) != (plan.N[i], D):
+                raise ValueError(f"X_spatial[{m!r}] has shape {tuple(X_spatial[m].shape)}, the views' row counts "
+                                 f"give ({plan.N[i]}, {D})")
+            if G_test is not None and (Gt[i].dim() != 3 or tuple(Gt[i].shape) != (plan.s_test, plan.n_test[i], D)):
+                raise ValueError(f"G_test[{m!r}] has shape {tuple(Gt[i].shape)}: every modality needs "
+                                 f"[{plan.s_test} (samples of the first modality), n_test, {D}]")
         # draws: one buffer for the warp GPs of all free, non-empty views (order of vgpsa.py:346-348), one per
         # modality for the data GP; without injected noise or per-purpose generators ALL of them come out of a
         # single launch
@@ -563,11 +571,17 @@ class VariationalGPSA(GPSA):
                 eps_G = self._draw([plan.eps_g_numel], dev, "G")
             for i, m in enumerate(mods):
                 if noise is not None and noise["F"] is not None:
+                    if noise["F"][m].numel() != S * plan.N[i] * plan.L[i]:
+                        raise ValueError(f"injected eps_F[{m!r}] has {noise['F'][m].numel()} values, "
+                                         f"[S, N, L] = {shapes_F[i]} are needed")
                     eps_F.append(noise["F"][m].to(device=dev, dtype=f32).reshape(shapes_F[i]).contiguous())
                 else:
                     eps_F.append(self._draw(shapes_F[i], dev, "F"))
                 if G_test is not None:
                     if noise is not None and noise["F_test"] is not None:
+                        if noise["F_test"][m].numel() != plan.s_test * plan.n_test[i] * plan.L[i]:
+                            raise ValueError(f"injected eps_F_test[{m!r}] has {noise['F_test'][m].numel()} values, "
+                                             f"{shapes_Ft[i]} are needed")
                         eps_Ft.append(noise["F_test"][m].to(device=dev, dtype=f32).reshape(shapes_Ft[i]).contiguous())
                     else:
                         eps_Ft.append(self._draw(shapes_Ft[i], dev, "F"))

@@ -12,12 +12,75 @@ _raw_stream = torch._C._cuda_getCurrentRawStream
 
 class FusedAdam(torch.optim.Optimizer):
     """Adam without weight decay / amsgrad over fp32 HIP parameters; one launch per step (plus the step
-    counter's).  Parameters without a gradient in a step keep their value and their moments (as torch's)."""
+    counter's).  Parameters without a gradient in a step keep their value and their moments (as torch's).
+
+    State layout = ``torch.optim.Adam(capturable=True)``'s: ``state[p] = {"step": fp32 device tensor, "exp_avg",
+    "exp_avg_sq"}``, so ``state_dict()`` / ``load_state_dict()`` round-trip the step count and interchange with
+    torch's Adam.  The parameters of a group that have a gradient in a step share ONE step word (the kernel reads
+    one counter per launch): a parameter that sat a step out is moved to a word of its own, so its count does not
+    advance (torch's behaviour)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # torch.optim.Adam's group keys ride along (at the only values this optimiser implements) so that a saved
+        # state_dict loads into torch's Adam and back
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=True, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self._lib = _lib.load()
-        self._step_dev = {}
+
+    def _step_words(self, ps, dev):
+        """the parameters of this launch grouped by the device word that counts their steps"""
+        groups = {}
+        for p in ps:
+            st = self.state[p]
+            if "step" not in st or not torch.is_tensor(st["step"]) or st["step"].device != dev:
+                old = st.get("step")
+                st["step"] = None  # filled below: new parameters of one launch share one fresh word
+                groups.setdefault(("new", float(old) if old is not None else 0.0), []).append(p)
+            else:
+                groups.setdefault(("ptr", st["step"].data_ptr()), []).append(p)
+        out = []
+        for (kind, val), members in groups.items():
+            if kind == "new":
+                word = torch.full((1,), val, dtype=torch.float32, device=dev)
+                for p in members:
+                    self.state[p]["step"] = word
+            else:
+                word = self.state[members[0]]["step"]
+                sharers = self.__dict__.setdefault("_sharers", {}).get(val, 0)
+                if sharers > len(members):  # some sharers have no gradient this step: these move to their own word
+                    self._sharers[val] = sharers - len(members)
+                    word = word.clone()
+                    for p in members:
+                        self.state[p]["step"] = word
+            self.__dict__.setdefault("_sharers", {})[word.data_ptr()] = len(members)
+            out.append((word, members))
+        return out
+
+    def state_dict(self):
+        """torch's layout: every parameter gets a 0-dim step tensor of its own (the live state shares words)"""
+        sd = super().state_dict()
+        sd["state"] = {k: dict(v) for k, v in sd["state"].items()}
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().reshape(()).clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__["_sharers"] = {}
+        for group in self.param_groups:  # loaded step counts are separate tensors: re-share equal ones per group
+            words = {}
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    v = float(st["step"])
+                    if v not in words:
+                        words[v] = torch.full((1,), v, dtype=torch.float32, device=p.device)
+                    st["step"] = words[v]
+            for w in words.values():
+                self._sharers[w.data_ptr()] = sum(1 for p in group["params"]
+                                                  if self.state.get(p) and self.state[p].get("step") is w)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -29,6 +92,8 @@ class FusedAdam(torch.optim.Optimizer):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
+            if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
+                raise _lib.GpsaHipError("FusedAdam: plain Adam only (no weight decay, amsgrad or maximize)")
             dev = ps[0].device
             if dev.type != "cuda":
                 raise _lib.GpsaHipError("FusedAdam: parameters must live on a HIP device")
@@ -39,19 +104,19 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad
                 gs.append(g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous())
                 st = self.state[p]
-                if not st:
+                if "exp_avg" not in st:
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            key = (gi, dev.index)
-            if key not in self._step_dev:
-                self._step_dev[key] = torch.zeros(1, dtype=torch.float32, device=dev)
-            n = len(ps)
-            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-            numel = (C.c_longlong * n)(*[p.numel() for p in ps])
+            grad_of = {id(p): g for p, g in zip(ps, gs)}
             b1, b2 = group["betas"]
-            rc = self._lib.gpsa_adam_step(n, arr(ps), arr(gs), arr([self.state[p]["exp_avg"] for p in ps]),
-                                          arr([self.state[p]["exp_avg_sq"] for p in ps]), numel, float(group["lr"]),
-                                          float(b1), float(b2), float(group["eps"]),
-                                          self._step_dev[key].data_ptr(), _raw_stream(dev.index))
-            _lib.check(rc, "gpsa_adam_step")
+            for word, members in self._step_words(ps, dev):  # one launch per step word: one in the usual case
+                n = len(members)
+                arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+                numel = (C.c_longlong * n)(*[p.numel() for p in members])
+                rc = self._lib.gpsa_adam_step(n, arr(members), arr([grad_of[id(p)] for p in members]),
+                                              arr([self.state[p]["exp_avg"] for p in members]),
+                                              arr([self.state[p]["exp_avg_sq"] for p in members]), numel,
+                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                              word.data_ptr(), _raw_stream(dev.index))
+                _lib.check(rc, "gpsa_adam_step")
         return loss

@@ -317,8 +317,16 @@ class StepFn(torch.autograd.Function):
         plan, model = aux["plan"], aux["model"]()
         if aux.get("deferred") is not None:  # the forward's numerics word: raise before any gradient exists
             pend, aux["deferred"] = aux["deferred"], None
-            model._pending_flag = None
-            model._raise_on_flags(pend)
+            if model is not None:
+                # only THIS forward's pending check is retired: a later forward whose backward has not run yet
+                # keeps its own (it is raised by that backward, or by the next forward)
+                if model.__dict__.get("_pending_flag") is pend:
+                    model._pending_flag = None
+                model._raise_on_flags(pend)
+            else:  # the model is gone (the node outlived it): the check itself needs no model
+                from .models.vgpsa import VariationalGPSA
+
+                VariationalGPSA._raise_on_flags(pend)
         lib = plan.lib
         tensors = ctx.saved_tensors[: ctx.n_in]
         dev = tensors[0].device

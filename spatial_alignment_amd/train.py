@@ -48,12 +48,13 @@ def fit(model, data_dict, n_epochs, lr=1e-2, S=5, optimizer=None, checker=None, 
     model.train()
     view_idx, Ns, _, _ = model.create_view_idx_dict(data_dict)
     if optimizer is None:
-        if next(model.parameters()).is_cuda:  # torch.optim.Adam's update as one HIP launch (capturable)
-            from .optim import FusedAdam
+        ps = list(model.parameters())
+        if all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+            from .optim import FusedAdam  # torch.optim.Adam's update as one HIP launch (capturable)
 
-            optimizer = FusedAdam(model.parameters(), lr=lr)
-        else:
-            optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+            optimizer = FusedAdam(ps, lr=lr)
+        else:  # CPU, model.double(), ...: what the reference's loop uses
+            optimizer = torch.optim.Adam(ps, lr=lr, capturable=bool(graphed))
     stepper = GraphedTrainStep(model, optimizer, data_dict, view_idx, Ns, S=S) if graphed else None
     trace, pending = [], []
 
@@ -117,6 +118,12 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, **mode):
             self.loss = train_step(model, optimizer, data_dict, view_idx, Ns, S, reducer=reducer, static_grads=True)
             flags = [f.reshape(-1).to(torch.int32) for f in model._cache.flags]
+            # the step engine folds its Cholesky infos and variance flags into ONE device word (check_numerics is
+            # off inside the capture, so nobody else reads it): a non-positive pivot is replaced by 1 and trains on
+            # finite garbage - this word is the only trace of it
+            self.engine_flag = getattr(model._cache, "engine_flag", None)
+            if self.engine_flag is not None:
+                flags.append(self.engine_flag.reshape(-1).to(torch.int32))
             flags.append((~torch.isfinite(self.loss.detach())).reshape(-1).to(torch.int32))
             self.sticky.copy_(torch.maximum(self.sticky, torch.cat(flags).abs().max()))
         # eager forwards after this keep their own numerics check and stream behaviour

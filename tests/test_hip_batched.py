@@ -202,3 +202,41 @@ def test_fused_adam_matches_torch():
         o_got.step()
     for a, b in zip(ref, got):
         assert (b.detach().cpu() - a.detach()).abs().max() <= 2e-6 * max(1.0, float(a.detach().abs().max()))
+
+
+def test_fused_adam_state_dict_and_idle_parameters():
+    """The step count lives in optimizer.state (torch.optim.Adam(capturable=True)'s layout): a resumed optimiser
+    continues the bias correction where it stopped, the state interchanges with torch's Adam, and a parameter
+    without a gradient in a step does not advance (torch's behaviour)."""
+    from spatial_alignment_amd.optim import FusedAdam
+
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(40, 40), (7,), (3, 5)]
+    p0 = [torch.randn(*s, generator=gen) for s in shapes]
+    grads = [[torch.randn(*s, generator=gen) for s in shapes] for _ in range(6)]
+    idle = {(2, 1), (3, 1), (4, 2)}  # (step, parameter) pairs without a gradient
+
+    def run(make_opt, resume_at=None, swap=None):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in p0]
+        opt = make_opt(ps)
+        for it, gs in enumerate(grads):
+            if resume_at == it:  # save, rebuild (possibly as the other implementation), load
+                sd = opt.state_dict()
+                opt = (swap or make_opt)(ps)
+                opt.load_state_dict(sd)
+            for k, (p, g) in enumerate(zip(ps, gs)):
+                p.grad = None if (it, k) in idle else g.clone().to(DEV)
+            opt.step()
+        return [p.detach().cpu() for p in ps], opt
+
+    fused = lambda ps: FusedAdam(ps, lr=1e-2)
+    torch_adam = lambda ps: torch.optim.Adam(ps, lr=1e-2, capturable=True)
+    want, _ = run(torch_adam)
+    for name, got in (("plain", run(fused)[0]), ("resumed", run(fused, resume_at=3)[0]),
+                      ("torch -> fused", run(torch_adam, resume_at=3, swap=fused)[0]),
+                      ("fused -> torch", run(fused, resume_at=3, swap=torch_adam)[0])):
+        for a, b in zip(want, got):
+            assert (a - b).abs().max() <= 2e-6 * max(1.0, float(a.abs().max())), name
+    _, opt = run(fused)
+    steps = [float(opt.state[p]["step"]) for p in opt.param_groups[0]["params"]]
+    assert steps == [6.0, 4.0, 5.0]

@@ -192,3 +192,69 @@ def test_numerics_check_raises_like_the_reference():
     model, dd, Xs, view_idx, Ns = broken()
     model.check_numerics = False
     model.forward(Xs, view_idx, Ns, S=2)
+
+
+def test_graphed_step_folds_the_engine_flag(monkeypatch):
+    """Inside a capture nobody waits for the step engine's numerics word; the sticky word of GraphedTrainStep
+    must fold it in: a non-positive pivot is replaced by 1 and the step trains on finite garbage.  The loss's own
+    non-finite bit is disabled here so that only the engine's word can trip check()."""
+    from spatial_alignment_amd.train import GraphedTrainStep
+
+    g = Golden("c2_three_free_views")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    real = torch.isfinite
+    monkeypatch.setattr(torch, "isfinite", lambda t: torch.ones_like(t, dtype=torch.bool))
+    gs = GraphedTrainStep(model, opt, dd, view_idx, Ns, S=2, warmup=3)
+    monkeypatch.setattr(torch, "isfinite", real)
+    assert gs.engine_flag is not None
+    gs.step()
+    gs.check()  # healthy parameters: nothing to report
+    with torch.no_grad():
+        model.Xtilde[1, 3, 0] = float("nan")  # K_uu of view 1 loses positive definiteness (the graph reads it in place)
+    gs.step()
+    torch.cuda.synchronize()
+    assert int(gs.engine_flag.item()) != 0
+    with pytest.raises(torch.linalg.LinAlgError):
+        gs.check()
+
+
+def test_engine_validates_what_it_hands_to_cxx():
+    """shapes the C++ engine would trust blindly: a modality's G_test with another sample count, coordinates
+    shorter than the views' row counts, injected draws of the wrong size -> ValueError, not an out-of-bounds read"""
+    g = Golden("c5_two_modalities")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+    D = Xs[g.mods[0]].shape[1]
+    Gt = {g.mods[0]: torch.randn(2, 5, D, device=DEV), g.mods[1]: torch.randn(1, 5, D, device=DEV)}
+    with pytest.raises(ValueError):
+        model.forward(Xs, view_idx, Ns, S=2, G_test=Gt)
+    short = dict(Xs)
+    short[g.mods[1]] = Xs[g.mods[1]][:-1]
+    with pytest.raises(ValueError):
+        model.forward(short, view_idx, Ns, S=2)
+    model.inject_noise(None, {m: torch.randn(2, 3, 1) for m in g.mods}, None)
+    with pytest.raises(ValueError):
+        model.forward(Xs, view_idx, Ns, S=2)
+    model._noise = None
+    model.forward(Xs, view_idx, Ns, S=2)  # and the well-formed call still runs
+
+
+def test_deferred_check_belongs_to_its_own_forward():
+    """forward A (healthy), forward B on broken coordinates, backward A: A's backward must not retire B's pending
+    numerics check - the next forward still reports it"""
+    g = Golden("c2_three_free_views")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+    outA = model.forward(Xs, view_idx, Ns, S=2)
+    lossA = model.loss_fn(dd, outA[3])
+    bad = {m: x.clone() for m, x in Xs.items()}
+    bad[g.mods[0]][-1, 0] = float("nan")         # a spot of the last (free) view: its warp variance is not > 0
+    outB = model.forward(bad, view_idx, Ns, S=2)  # (checks A's word on the way in: healthy)
+    lossA.backward()                             # A's own word again: healthy, and B's stays pending
+    with pytest.raises(torch.linalg.LinAlgError):
+        model.forward(Xs, view_idx, Ns, S=2)
+    del outB

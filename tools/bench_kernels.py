@@ -147,3 +147,15 @@ if "gramw" in what:  # the warp layer's Gram shape: L = D = 2 outputs, one view'
         a = torch.randn(200, C, device=dev)
         g = torch.randn(2, C, device=dev)
         print(f"quadform_bwd_omega L=2 C={C}: {timeit(lambda: o.quadform_bwd_omega(a, g, out_dtype=torch.float64), n=20, warm=3):.1f} us", flush=True)
+
+if "big" in what:  # the large-M contraction kernels (BASELINE configs 4 / 5 shapes, fewer outputs)
+    for M, C, L in [(1000, 25600, 64), (500, 40320, 96)]:
+        a = torch.randn(M, C, device=dev)
+        A = torch.randn(L, M, M, device=dev, dtype=torch.float64) / M ** 0.5
+        Om = A @ A.transpose(1, 2)
+        g = torch.randn(L, C, device=dev)
+        fl = 2.0 * C * L * M * M
+        for name, fn in (("quadform_fwd", lambda: o.quadform_fwd(a, Om)), ("quadform_bwd_alpha", lambda: o.quadform_bwd_alpha(a, Om, g)),
+                         ("quadform_bwd_omega", lambda: o.quadform_bwd_omega(a, g))):
+            us = timeit(fn, n=5, warm=2)
+            print(f"{name} M={M} C={C} L={L}: {us / 1e3:.2f} ms  nominal {fl / us / 1e6:.1f} TF", flush=True)
