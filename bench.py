@@ -42,10 +42,25 @@ def parse():
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--static-grads", action="store_true", help="diagnostic: zero_grad(set_to_none=False)")
     ap.add_argument("--overlap", action="store_true", help="diagnostic: per-view side streams in eager mode too")
+    ap.add_argument("--workload", choices=["2", "4", "5"], default="2",
+                    help="BASELINE.json configuration (1-based).  2 = the contract metric's; 4 / 5 = the Visium- / "
+                         "Slide-seq-scale configurations at their stated size (S = 1, independent outputs): "
+                         "diagnostic lines, use with --shard outputs on N > 1")
+    ap.add_argument("--shard", choices=["rows", "outputs"], default="rows",
+                    help="N > 1: rows of every view (default, strong scaling of the contract metric) or the output "
+                         "axis (parallel.shard_outputs: per-output parameters and gradients never leave their rank)")
     ap.add_argument("--emulate-shard", type=int, default=1,
                     help="diagnostic: time rank 0's share of a K-way row sharding on ONE GPU (no all-reduce); "
                          "the line is then NOT the contract metric")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.fixed = None
+    if args.workload == "4":    # 8 views x 5041 spots, 2000 genes, M = 500, fixed_view_idx = 0
+        args.side, args.views, args.outputs, args.M, args.S, args.fixed = 71, 8, 2000, 500, 1, 0
+    elif args.workload == "5":  # 2 views x 99 856 spots, 1000 genes, M = 1000
+        args.side, args.views, args.outputs, args.M, args.S = 316, 2, 1000, 1000, 1
+    if args.workload != "2":
+        args.no_graph = args.no_s1 = args.no_cpu_baseline = True
+    return args
 
 
 class KernelTimer:
@@ -188,7 +203,13 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's only working mode on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
-    return subprocess.run(cmd, env=env).returncode
+    # the children's stdout is relayed line by line: JSON lines to our stdout, anything else (gloo's connection
+    # chatter, launcher notices) to stderr, so that stdout stays "ONE JSON line"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in proc.stdout:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
@@ -224,14 +245,26 @@ def main():
     from spatial_alignment_amd.parallel import GradAllReducer, shard_data_dict
     from spatial_alignment_amd.synthetic import make_grid_problem, make_model
 
-    dd_full = make_grid_problem(side=args.side, n_views=args.views, n_outputs=args.outputs, device="cpu")
-    model = make_model(dd_full, m=args.M, device=dev)  # identical parameters on every rank (seeded)
-    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    from spatial_alignment_amd.parallel import setup_output_sharding, shard_outputs
+
+    dd_full = make_grid_problem(side=args.side, n_views=args.views, n_outputs=args.outputs, device="cpu",
+                                compute_device=dev if args.workload != "2" else None)
     emu = max(1, args.emulate_shard) if world == 1 else 1
-    dd = shard_data_dict(dd_full, rank, world * emu)
+    by_outputs = args.shard == "outputs" and world * emu > 1
+    if by_outputs:  # every row, this rank's slice of the outputs; the model is built on the slice
+        dd = shard_outputs(dd_full, rank, world * emu)
+        model = make_model(dd, m=args.M, device=dev, fixed_view_idx=args.fixed)
+    else:
+        model = make_model(dd_full, m=args.M, device=dev, fixed_view_idx=args.fixed)  # identical on every rank (seeded)
+        dd = shard_data_dict(dd_full, rank, world * emu)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if args.workload == "2" else {}
     dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
               "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
-    model.kl_scale = 1.0 / (world * emu)
+    out_reducer = None
+    if by_outputs:
+        out_reducer = setup_output_sharding(model, rank, world * emu)  # (broadcasts the shared parameters)
+    else:
+        model.kl_scale = 1.0 / (world * emu)
     if args.no_check:
         model.check_numerics = False
     if args.overlap:
@@ -264,7 +297,7 @@ def main():
     from spatial_alignment_amd.train import backward as train_backward
 
     opt = FusedAdam(model.parameters(), lr=1e-2)  # torch.optim.Adam's update as one HIP launch
-    reducer = GradAllReducer(model.parameters())
+    reducer = out_reducer if out_reducer is not None else GradAllReducer(model.parameters())
     timer = KernelTimer(model, args.steps)
     timer.S = args.S
 
@@ -342,7 +375,8 @@ def main():
 
     if rank == 0:
         N = int(sum(dd_full["expression"]["n_samples_list"]))
-        ks = timer.summary(args.M, args.S * int(sum(dd["expression"]["n_samples_list"])), args.outputs)
+        ks = timer.summary(args.M, args.S * int(sum(dd["expression"]["n_samples_list"])),
+                           int(dd["expression"]["outputs"].shape[1]))  # this rank's columns and outputs
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_cfg = (args.S, args.side, args.views, args.outputs, args.M, world) == (5, 100, 2, 50, 200, 1)
@@ -357,29 +391,48 @@ def main():
         MB = -(-args.M // 16)
         tri = (MB * (MB + 1) / 2) / (MB * MB)
         pad_k = args.M / (16.0 * MB)
-        executed_ratio = {
-            "quadform_fwd": tri * (16.0 * MB / args.M) ** 2 * pad_k,
-            "quadform_bwd_alpha": (16.0 * MB / args.M),
-            "quadform_bwd_omega": tri * (16.0 * MB / args.M) ** 2,
-        }
-        kernel_of = {
-            "quadform_fwd": "quad_sym_mfma_kernel (gpsa_quadform_fwd; upper-triangle tiles, all-padding K steps "
-                            "skipped: executes 0.54x of the nominal 2*C*L*M^2 flops)",
-            "quadform_bwd_alpha": "panel_mfma_kernel<MODE_ACCUM> (gpsa_quadform_bwd_alpha)",
-            "quadform_bwd_omega": "gram_mfma_kernel (gpsa_quadform_bwd_omega; lower-triangle tiles: executes "
-                                  "0.58x of the nominal flops)",
-        }
-        # training keeps the data GP's products Omega_l alpha (step engine, io.keep_products): the forward is then
-        # the FULL product (rows and contraction padded to 16 MB), the alpha-gradient one streaming read of them
         kept = any(p.saved_bytes > p.saved_bytes_nokeep for p in timer.plans)
-        keep_bytes = 0
-        if kept:
-            executed_ratio["quadform_fwd"] = (16.0 * MB / args.M) ** 2
-            kernel_of["quadform_fwd"] = ("panel_mfma_kernel<MODE_QUAD> with kept products (gpsa_quadform_fwd_keep_f32: "
-                                         "the full 2*C*L*M^2 product, stored once for the backward)")
-            kernel_of["quadform_bwd_alpha"] = ("kept_wsum_kernel (gpsa_quadform_bwd_alpha_kept_f32: one streaming read "
-                                               "of the kept products; HBM-bound, no matrix-core work)")
-            keep_bytes = sum(p.saved_bytes - p.saved_bytes_nokeep for p in timer.plans)
+        keep_bytes = sum(p.saved_bytes - p.saved_bytes_nokeep for p in timer.plans) if kept else 0
+        if args.M <= 256:
+            executed_ratio = {
+                "quadform_fwd": tri * (16.0 * MB / args.M) ** 2 * pad_k,
+                "quadform_bwd_alpha": (16.0 * MB / args.M),
+                "quadform_bwd_omega": tri * (16.0 * MB / args.M) ** 2,
+            }
+            kernel_of = {
+                "quadform_fwd": "quad_sym_mfma_kernel (gpsa_quadform_fwd; upper-triangle tiles, all-padding K steps "
+                                "skipped: executes 0.54x of the nominal 2*C*L*M^2 flops)",
+                "quadform_bwd_alpha": "panel_mfma_kernel<MODE_ACCUM> (gpsa_quadform_bwd_alpha)",
+                "quadform_bwd_omega": "gram_mfma_kernel (gpsa_quadform_bwd_omega; lower-triangle tiles: executes "
+                                      "0.58x of the nominal flops)",
+            }
+            # training keeps the data GP's products Omega_l alpha (step engine, io.keep_products): the forward is then
+            # the FULL product (rows and contraction padded to 16 MB), the alpha-gradient one streaming read of them
+            if kept:
+                executed_ratio["quadform_fwd"] = (16.0 * MB / args.M) ** 2
+                kernel_of["quadform_fwd"] = ("panel_mfma_kernel<MODE_QUAD> with kept products (gpsa_quadform_fwd_keep_f32: "
+                                             "the full 2*C*L*M^2 product, stored once for the backward)")
+                kernel_of["quadform_bwd_alpha"] = ("kept_wsum_kernel (gpsa_quadform_bwd_alpha_kept_f32: one streaming "
+                                                   "read of the kept products; HBM-bound, no matrix-core work)")
+        else:  # the 128 x 128 LDS-DMA kernels: row blocks of 128, contraction padded to 16
+            Mp, nrb, M2 = 16 * MB, -(-args.M // 128), float(args.M) ** 2
+            executed_ratio = {
+                "quadform_fwd": sum(128 * (Mp - 128 * rb) for rb in range(nrb)) / M2,
+                "quadform_bwd_alpha": (16.0 * MB / args.M) if MB <= 32 else nrb * 128 * Mp / M2,
+                "quadform_bwd_omega": (nrb * (nrb + 1) // 2) * 128 * 128 / M2,
+            }
+            kernel_of = {
+                "quadform_fwd": "big_quad_kernel<TRI> (gpsa_quadform_fwd; block-triangular, form closed in the kernel)",
+                "quadform_bwd_alpha": ("panel_mfma_kernel<MODE_ACCUM>" if MB <= 32 else "big_accum_kernel")
+                                      + " (gpsa_quadform_bwd_alpha)",
+                "quadform_bwd_omega": "gram_big_kernel (gpsa_quadform_bwd_omega; lower-triangle 128 x 128 block pairs)",
+            }
+            if kept:
+                executed_ratio["quadform_fwd"] = nrb * 128 * Mp / M2
+                kernel_of["quadform_fwd"] = ("big_quad_kernel<STORE> with kept products (gpsa_quadform_fwd_keep_f32: the "
+                                             "full product, stored once, form closed in the kernel)")
+                kernel_of["quadform_bwd_alpha"] = ("col_wsum_rows_kernel (gpsa_quadform_bwd_alpha_kept_f32: one streaming "
+                                                   "read of the kept products; HBM-bound)")
         roof = None
         if ks:
             # the dominant kernel = the contraction with the longest launch
@@ -426,7 +479,8 @@ def main():
             roof["step_level"]["executed_contraction_tflops"] = exec_fl * (args.steps / dt) / 1e12
             roof["step_level"]["executed_contraction_frac"] = exec_fl * (args.steps / dt) / 1e12 / PEAK_F32_MFMA_TFLOPS
         line = {
-            "metric": "training steps/sec (ELBO fwd+bwd), 2-view N=10k M=200, 1/2/4/8 GPU",
+            "metric": "training steps/sec (ELBO fwd+bwd), 2-view N=10k M=200, 1/2/4/8 GPU" if args.workload == "2" else
+                      f"training steps/sec (ELBO fwd+bwd), BASELINE config {args.workload} at its stated size (diagnostic)",
             "value": args.steps / dt,
             "unit": "steps/s",
             "n_gpus": world,
@@ -443,7 +497,9 @@ def main():
                             f"{args.outputs} outputs, M_G=M_X={args.M}, RBF warp+data, S={args.S}, "
                             "forward+ELBO+backward+Adam",
                 "n_spots_total": N,
-                "parallelism": f"rows-of-views sharded x{world}, 1 all-reduce/step" if world > 1 else "single GPU",
+                "parallelism": ("single GPU" if world == 1 else
+                                f"outputs sharded x{world}, 1 all-reduce/step of the shared parameters' gradients" if by_outputs
+                                else f"rows-of-views sharded x{world}, 1 all-reduce/step"),
                 "check_numerics_sync": not args.no_check,
                 **({"emulated_shard": f"rank 0 of {emu} (diagnostic, not the contract metric)"} if emu > 1 else {}),
                 "final_loss": final_loss,

@@ -132,7 +132,23 @@ class GradAllReducer:
         used = LAST_USED.get(p0.device.index, sum(p.numel() for p in inside))
         if sum(p.numel() for p in outside) > flat.numel() - used:
             return None
-        return flat, used, outside
+        # The buffer may also hold gradients that are NOT this reducer's (output sharding: the per-output parameters'
+        # gradients, gigabytes at BASELINE config 4, must stay on their rank): reduce only the spans our parameters
+        # occupy.  Views follow each other at 64-float granules, so neighbours merge into one span.
+        es = flat.element_size()
+        spans = sorted(((p.grad.data_ptr() - lo) // es, p.grad.numel()) for p in inside)
+        merged = []
+        for off, n in spans:
+            end = (off + n + 63) // 64 * 64
+            if merged and off <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], end)
+            else:
+                merged.append([off, end])
+        if not merged:
+            return None
+        if len(merged) == 1 and merged[0][0] == 0 and merged[0][1] >= used:
+            return flat, used, outside, None          # everything in the buffer is ours
+        return flat, used, outside, [(a, min(b, used)) for a, b in merged]
 
     def __call__(self):
         if not (dist.is_available() and dist.is_initialized()):
@@ -143,8 +159,19 @@ class GradAllReducer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         bucket = self._engine_bucket()
+        if bucket is not None and bucket[3] is not None:
+            flat, used, outside, spans = bucket
+            for a, b in spans:
+                dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM)
+            if outside:
+                tail = flat[used: used + sum(p.numel() for p in outside)]
+                torch.cat([p.grad.view(-1) for p in outside], out=tail)
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+                torch._foreach_copy_([p.grad.view(-1) for p in outside],
+                                     list(tail.split([p.numel() for p in outside])))
+            return
         if bucket is not None:
-            flat, used, outside = bucket
+            flat, used, outside, _ = bucket
             if outside:
                 tail = flat[used: used + sum(p.numel() for p in outside)]
                 torch.cat([p.grad.view(-1) for p in outside], out=tail)

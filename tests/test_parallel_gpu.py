@@ -26,12 +26,12 @@ def _noise():
     return [torch.randn(3, 400, 2, generator=gen) for _ in range(2)], torch.randn(3, 800, 6, generator=gen)
 
 
-def _grads(model, dd, eG, eF, kl_scale):
+def _grads(model, dd, eG, eF, kl_scale, S=3):
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     model.kl_scale = kl_scale
     model.inject_noise(eG, {"expression": eF})
     model.zero_grad()
-    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=3)
+    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=S)
     loss = model.loss_fn(dd, out[3])
     loss.backward()
     return loss.detach()
@@ -79,6 +79,98 @@ def test_row_sharded_hip_step_equals_full_hip_step():
     assert abs(float(loss1) - loss2) <= 1e-5 * abs(float(loss1))
     for k, p in model.named_parameters():
         a, b = p.grad.detach().cpu().numpy(), g2[k]
+        assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# output (L-axis) sharding: BASELINE configs 4 / 5's scheme (parallel.shard_outputs / setup_output_sharding)
+# ---------------------------------------------------------------------------------------------------------
+def _problem_outputs(dev, rank=None, world=None):
+    """M = 300 (> 256: the large-M kernels of configs 4 / 5), 6 independent outputs; rank's model carries the full
+    model's parameters - shared ones by copy on rank 0 (the others get them by broadcast), its own output slice"""
+    from spatial_alignment_amd.parallel import shard_outputs, shard_rows
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+    dd = make_grid_problem(side=20, n_views=2, n_outputs=6)
+    full = make_model(dd, m=300, seed=0)
+    if rank is None:
+        model, sdd, sl = full, dd, (0, 6)
+    else:
+        sdd = shard_outputs(dd, rank, world)
+        model = make_model(sdd, m=300, seed=100 + rank)  # deliberately different construction RNG per rank
+        sl = shard_rows(6, rank, world)
+        with torch.no_grad():
+            for (n, p), (_, pf) in zip(model.named_parameters(), full.named_parameters()):
+                if n.startswith("Omega_sqt_F_dict."):
+                    p.copy_(pf[sl[0]:sl[1]])
+                elif n.startswith("delta_F_dict."):
+                    p.copy_(pf[:, sl[0]:sl[1]])
+                elif rank == 0:
+                    p.copy_(pf)
+    model = model.to(dev)
+    sdd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
+               "n_samples_list": d["n_samples_list"]} for m, d in sdd.items()}
+    return sdd, model, sl
+
+
+def _worker_outputs(rank, world, port, q):
+    import __graft_entry__ as ge
+    from spatial_alignment_amd.parallel import setup_output_sharding
+
+    ge.build()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    sdd, model, (lo, hi) = _problem_outputs(dev, rank, world)
+    reducer = setup_output_sharding(model, rank, world, seed=5)
+    eG, eF = _noise_outputs()
+    loss = _grads(model, sdd, eG, eF[:, :, lo:hi], 1.0, S=2)
+    reducer()
+    dist.all_reduce(loss)
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, grads)
+    if rank == 0:
+        q.put((float(loss), gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _noise_outputs():
+    gen = torch.Generator().manual_seed(12)
+    return [torch.randn(2, 400, 2, generator=gen) for _ in range(2)], torch.randn(2, 800, 6, generator=gen)
+
+
+def test_output_sharded_hip_step_equals_full_hip_step():
+    """two ranks, each with half of the outputs (their Omega_sqt_F rows / delta_F columns never leave the rank),
+    the shared parameters' gradients all-reduced: per-output gradients concatenate to, shared ones equal, the
+    single-process step on all outputs - through the real HIP path at M > 256"""
+    import __graft_entry__ as ge
+
+    ge.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_outputs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    loss2, per_rank = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    dd, model, _ = _problem_outputs(torch.device("cuda:0"))
+    eG, eF = _noise_outputs()
+    loss1 = _grads(model, dd, eG, eF, 1.0, S=2)
+    assert abs(float(loss1) - loss2) <= 1e-5 * abs(float(loss1)), (float(loss1), loss2)
+    for k, p in model.named_parameters():
+        a = p.grad.detach().cpu().numpy()
+        if k.startswith("Omega_sqt_F_dict."):
+            b = np.concatenate([per_rank[r][k] for r in range(2)], 0)
+        elif k.startswith("delta_F_dict."):
+            b = np.concatenate([per_rank[r][k] for r in range(2)], 1)
+        else:
+            b = per_rank[0][k]
+            assert np.array_equal(per_rank[0][k], per_rank[1][k]), k
         assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
 
 
