@@ -35,6 +35,8 @@ enum { GPSA_EINVAL = -1, GPSA_EWORKSPACE = -2, GPSA_EUNSUPPORTED = -3 };
 /* library / build info */
 int gpsa_version(void);               /* 100*major + minor */
 const char* gpsa_build_arch(void);    /* "gfx950" */
+const char* gpsa_source_hash(void);   /* "GPSA_SOURCE_HASH=<sha256 of csrc/ + this header at build time>": the host
+                                         side refuses a library that was not built from the sources next to it */
 
 /* ---- covariance ("kernel") matrices ---------------------------------------------------------
  * K[m,c] = k(Z[m,:], X[c,:]) (+ jitter on the diagonal m==c, used for K_uu).

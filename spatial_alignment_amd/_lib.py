@@ -16,6 +16,7 @@ _vp, _i, _ll, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_double
 SIGNATURES = {
     "gpsa_version": (_i, []),
     "gpsa_build_arch": (C.c_char_p, []),
+    "gpsa_source_hash": (C.c_char_p, []),
     "gpsa_kmat": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _d, _vp, _vp]),
     "gpsa_kmat_bwd_workspace": (_ll, [_i, _i, _ll, _i]),
     "gpsa_kmat_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
@@ -158,6 +159,36 @@ SIGNATURES.update({
 _lib = None
 
 
+def source_hash():
+    """sha256 over the library's sources (csrc/*.hip, *.hpp, include/gpsa_hip.h: names and contents) - what
+    __graft_entry__.build() stamps into the library; None when the sources are not next to the package"""
+    import glob
+    import hashlib
+
+    csrc = os.path.join(_HERE, "csrc")
+    header = os.path.join(os.path.dirname(_HERE), "include", "gpsa_hip.h")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))
+    if not files or not os.path.exists(header):
+        return None
+    h = hashlib.sha256()
+    for f in files + [header]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def library_hash(path=None):
+    """the stamp inside a built library, read from its bytes (no dlopen), or None"""
+    import re
+
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    m = re.search(rb"GPSA_SOURCE_HASH=([0-9a-f]{64}|unstamped)", open(path, "rb").read())
+    return m.group(1).decode() if m else None
+
+
 class GpsaHipError(RuntimeError):
     pass
 
@@ -177,6 +208,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    want = source_hash()
+    got = lib.gpsa_source_hash().decode().split("=", 1)[1]
+    if want is not None and got != want and os.environ.get("GPSA_ALLOW_STALE_LIB") != "1":
+        raise GpsaHipError(
+            f"{LIB_PATH} was built from other sources (stamp {got[:12]}, sources {want[:12]}): rebuild it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'`"
+        )
     _lib = lib
     return lib
 

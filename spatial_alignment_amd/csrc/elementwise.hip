@@ -614,6 +614,10 @@ int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, c
 }
 
 int gpsa_version(void) { return 100; }
+#ifndef GPSA_SOURCE_HASH
+#define GPSA_SOURCE_HASH "unstamped"
+#endif
+const char* gpsa_source_hash(void) { return "GPSA_SOURCE_HASH=" GPSA_SOURCE_HASH; }
 const char* gpsa_build_arch(void) { return "gfx950"; }
 
 }  // extern "C"

@@ -13,7 +13,8 @@ with an explicit ``torch.Generator`` (the reference draws from numpy's global st
   cos(w_r.x + b_r)``, ``w ~ N(0, 1/ell^2)``, ``b ~ U[0, 2 pi)``, ``a ~ N(0,1)``): O(n R) time and memory, so
   the 100 x 100 and 316 x 316 lattices of BASELINE.json's configurations take milliseconds.
 
-Not on the hot path (no HIP kernel is involved); returns ``(X [n_views * n, D], Y [n_views * n, P],
+On a HIP device the exact draw runs on this package's own kernels (``_exact_draw_hip``: ``gpsa_kmat`` +
+``gpsa_chol_inv*_f64`` + ``gpsa_gemm``); CPU tensors take torch's.  Returns ``(X [n_views * n, D], Y [n_views * n, P],
 n_samples_list, view_idx)`` like the reference, as torch tensors.
 """
 import math
@@ -44,6 +45,29 @@ def rbf_covariance(x, xp, variance=1.0, lengthscale=1.0):
     return variance * torch.exp(-0.5 * d2)
 
 
+def _exact_draw_hip(x64, z, variance, lengthscale, jitter):
+    """f = L z with K + jitter I = L L^T through THIS package's HIP kernels (data/warps.py:55-65 and
+    generate_twod_data.py:49-61 do it with scipy): the covariance from ``gpsa_kmat`` (the fused RBF kernel of the
+    hot path, fp64), the factor's inverse from ``gpsa_chol_inv_f64`` / ``gpsa_chol_inv_blocked_f64``, and
+    L z = K (L^-T z) as two ``gpsa_gemm`` products.  A smooth kernel without jitter is numerically semi-definite
+    (the GP warp asks for jitter 0): the factorisation then flags a non-positive pivot and the draw is retried with
+    a floor of 1e-8 * variance on the diagonal (1e-4 of the prior standard deviation: far below the lattice
+    spacing).  Returns None when even that is flagged (the caller's eigen-decomposition path takes over)."""
+    from . import ops as _ops
+
+    o = _ops.get_ops()
+    dev = x64.device
+    ls_u = torch.full((1,), math.log(float(lengthscale)), dtype=torch.float64, device=dev)
+    var_u = torch.full((1,), math.log(float(variance)), dtype=torch.float64, device=dev)
+    for jit in (float(jitter), max(float(jitter), 1e-8 * float(variance))):
+        K = o.kmat("rbf", x64, x64, ls_u, var_u, jitter=jit, dtype=torch.float64)
+        Linv, _, info = o.chol_inv(K.unsqueeze(0))
+        if int(info.item()) == 0:
+            t = o.gemm(Linv[0], z, transA=True)  # L^-T z
+            return o.gemm(K, t)                 # K L^-T z = L z
+    return None
+
+
 def gp_draws(x, n_draws, variance=1.0, lengthscale=1.0, mean=None, jitter=1e-3, generator=None,
              method="auto", exact_limit=4096, n_features=2048):
     """``n_draws`` independent draws f ~ GP(mean, RBF(variance, lengthscale)) at the rows of ``x`` [n, D].
@@ -58,14 +82,16 @@ def gp_draws(x, n_draws, variance=1.0, lengthscale=1.0, mean=None, jitter=1e-3, 
     f64 = torch.float64
     if method == "exact":
         x64 = x.to(f64)
-        K = rbf_covariance(x64, x64, variance, lengthscale)
-        K.diagonal().add_(jitter)
-        L, info = torch.linalg.cholesky_ex(K)
-        if int(info) != 0:  # smooth kernel, no jitter: numerically semi-definite -> symmetric square root
-            lam, V = torch.linalg.eigh(K)  # (scipy's multivariate_normal.rvs factors through the SVD as well)
-            L = V * lam.clamp_min(0.0).sqrt()
         z = torch.randn(n, n_draws, dtype=f64, device=dev, generator=generator)
-        f = L @ z
+        f = _exact_draw_hip(x64, z, variance, lengthscale, jitter) if x.is_cuda else None
+        if f is None:  # CPU tensors, or a covariance this package's factorisation flags even with the floor jitter
+            K = rbf_covariance(x64, x64, variance, lengthscale)
+            K.diagonal().add_(jitter)
+            L, info = torch.linalg.cholesky_ex(K)
+            if int(info) != 0:  # smooth kernel, no jitter: numerically semi-definite -> symmetric square root
+                lam, V = torch.linalg.eigh(K)  # (scipy's multivariate_normal.rvs factors through the SVD as well)
+                L = V * lam.clamp_min(0.0).sqrt()
+            f = L @ z
     elif method == "rff":
         R = int(n_features)
         w = torch.randn(d, R, dtype=f64, device=dev, generator=generator) / lengthscale

@@ -36,3 +36,11 @@ def test_workspace_queries_are_pure():
     assert lib.gpsa_kmat_bwd_workspace(0, 200, 1000, 2) == (4 * 400 + 25 * 2000 + 4 * 25 * 2) * 4
     assert lib.gpsa_kmat_bwd_workspace(0, 200, 100000, 2) == (391 * 400 + 7 * 200000 + 391 * 7 * 2) * 4
     assert lib.gpsa_quadform_workspace(0, 200, 1000, 50) >= 50 * 208 * 208 * 4
+
+
+def test_library_is_stamped_with_its_sources():
+    """the library carries the sha256 of the sources it was built from; load() refuses another one"""
+    lib = _lib.load()
+    stamp = lib.gpsa_source_hash().decode()
+    assert stamp == "GPSA_SOURCE_HASH=" + _lib.source_hash()
+    assert _lib.library_hash() == _lib.source_hash()

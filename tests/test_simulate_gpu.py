@@ -66,7 +66,31 @@ def test_exact_draw_is_a_factor_of_the_reference_covariance():
         torch.randn = real
     K = (L @ L.t()).cpu().numpy()
     assert np.abs(K - FIX["K_out"]).max() < 1e-10
-    assert float(torch.triu(L, 1).abs().max()) == 0.0  # lower-triangular: a Cholesky factor
+    # lower-triangular: the Cholesky factor (formed as K L^-T by this package's kernels, so the upper triangle is
+    # rounding, not exact zeros)
+    assert float(torch.triu(L, 1).abs().max()) < 1e-9
+
+
+def test_exact_draw_on_the_device_runs_on_this_packages_kernels(monkeypatch):
+    """on a HIP device the exact GP draw is gpsa_kmat + gpsa_chol_inv + gpsa_gemm - torch's
+    distance / factorisation routines are not touched (they raise here), with and without jitter (the GP warp's
+    numerically semi-definite covariance takes the floor jitter)"""
+    def boom(*a, **k):
+        raise AssertionError("torch factorisation / distance routine used on the device path")
+
+    monkeypatch.setattr(torch.linalg, "cholesky_ex", boom)
+    monkeypatch.setattr(torch.linalg, "eigh", boom)
+    monkeypatch.setattr(torch, "cdist", boom)
+    lat = torch.tensor(FIX["lattice"], dtype=f64, device=DEV)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    f = sim.gp_draws(lat, 7, 1.0, 1.0, jitter=1e-3, generator=g, method="exact")
+    assert f.shape == (lat.shape[0], 7) and bool(torch.isfinite(f).all())
+    w = sim.gp_draws(lat, 4, KV, KL, jitter=0.0, generator=g, method="exact")  # the warp's covariance
+    assert bool(torch.isfinite(w).all()) and 0.02 * KV < float(w.var()) < 5 * KV
+    big = sim.lattice_2d(40, device=DEV, dtype=f64)  # 1600 points: the blocked factorisation
+    fb = sim.gp_draws(big, 3, 1.0, 1.0, jitter=1e-3, generator=g, method="exact")
+    assert bool(torch.isfinite(fb).all()) and 0.3 < float(fb.var()) < 2.5
 
 
 def _whitened(resid, K):

@@ -14,6 +14,7 @@ if os.environ.get("GPSA_AB_LIB"):  # A/B a second build of the library inside on
     from spatial_alignment_amd import _lib as _lib_mod  # noqa: E402
 
     _lib_mod.LIB_PATH = os.path.abspath(os.environ["GPSA_AB_LIB"])
+    os.environ["GPSA_ALLOW_STALE_LIB"] = "1"  # (an older build on purpose)
 ge.build()
 from spatial_alignment_amd import ops as ops_mod  # noqa: E402
 
