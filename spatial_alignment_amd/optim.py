@@ -6,6 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import torch_ops  # noqa: F401  (registers torch.ops.gpsa.*)
 
 _raw_stream = torch._C._cuda_getCurrentRawStream
 
@@ -110,13 +111,8 @@ class FusedAdam(torch.optim.Optimizer):
             grad_of = {id(p): g for p, g in zip(ps, gs)}
             b1, b2 = group["betas"]
             for word, members in self._step_words(ps, dev):  # one launch per step word: one in the usual case
-                n = len(members)
-                arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-                numel = (C.c_longlong * n)(*[p.numel() for p in members])
-                rc = self._lib.gpsa_adam_step(n, arr(members), arr([grad_of[id(p)] for p in members]),
-                                              arr([self.state[p]["exp_avg"] for p in members]),
-                                              arr([self.state[p]["exp_avg_sq"] for p in members]), numel,
-                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                              word.data_ptr(), _raw_stream(dev.index))
-                _lib.check(rc, "gpsa_adam_step")
+                torch.ops.gpsa.adam_step(members, [grad_of[id(p)] for p in members],
+                                         [self.state[p]["exp_avg"] for p in members],
+                                         [self.state[p]["exp_avg_sq"] for p in members], word, float(group["lr"]),
+                                         float(b1), float(b2), float(group["eps"]))
         return loss

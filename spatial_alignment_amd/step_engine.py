@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from . import ops as _ops_mod
+from . import torch_ops as TO
 from .kernels import builtin_kind
 
 # the flat gradient buffer of the most recent backward per device (its views are the parameters' .grad):
@@ -271,28 +272,35 @@ class StepFn(torch.autograd.Function):
             io.keep_products = 0
             saved = _take_arena(plan, plan.saved_bytes_nokeep, dev, must=True)
         scratch = o._ws(plan.scratch_bytes, saved)
-        stream = _raw_stream(dev.index)
         pending = None
+        # the C entry point is reached through the dispatcher (torch.ops.gpsa.step_forward, torch_ops.py): the
+        # pointer structs travel as a key, the tensors the call reads and writes as its arguments
+        flat_outs = [t for k in ("Gm", "Gs", "Fl", "Fo", "Flt", "Fot") for t in outs[k]] + [mu_z, flag]
+        if kl is not None:
+            flat_outs.append(kl)
+        ins = [t for t in aux["X"] + list(aux["eps_F"]) + [aux["eps_G"], aux["slopes"], aux["intercepts"]]
+               + list(aux["G_test"] or []) + list(aux["eps_F_test"] or []) if t is not None]
+        call = TO.stash(dict(lib=lib, handle=plan.handle, prm=prm, io=io))
+
+        def run(stages):
+            torch.ops.gpsa.step_forward(list(tensors), ins, flat_outs, saved, scratch, call, stages)
+
         if aux["check"] == "deferred":
             # training: the word is shipped behind an event as below, but nobody waits for it inside forward -
             # the backward of this node does, before it touches a gradient (see StepFn.backward)
-            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 1,
-                                             stream), "gpsa_step_forward")
+            run(1)
             aux["deferred"] = model._post_flag(flag)
-            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 2,
-                                             stream), "gpsa_step_forward")
+            run(2)
         elif aux["check"]:
             # the flag depends on the factorisations and the warp GPs only: ship it to the host behind an event
             # BEFORE the data GPs are queued, so that the check waits for the short part of the forward and the
             # host keeps queueing while the long part runs
-            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 1,
-                                             stream), "gpsa_step_forward")
+            run(1)
             pending = model._post_flag(flag)
-            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 2,
-                                             stream), "gpsa_step_forward")
+            run(2)
         else:
-            _lib.check(lib.gpsa_step_forward(plan.handle, C.byref(prm), C.byref(io), _p(saved), _p(scratch), 3,
-                                             stream), "gpsa_step_forward")
+            run(3)
+        TO.CALLS.pop(call, None)
         aux["pending"], aux["mu_z"], aux["flag"] = pending, mu_z, flag
         ctx.aux, ctx.io, ctx.prm = aux, io, prm
         ctx.arena = saved
@@ -388,9 +396,11 @@ class StepFn(torch.autograd.Function):
                     views[kk].zero_()  # no gradient reached F_obs: the engine leaves dW untouched
                 kk += 1
         scratch = o._ws(plan.scratch_bytes, flat)
-        _lib.check(lib.gpsa_step_backward(plan.handle, C.byref(ctx.prm), C.byref(ctx.io), C.byref(og),
-                                          _p(ctx.arena), _p(scratch), C.byref(grads), _raw_stream(dev.index)),
-                   "gpsa_step_backward")
+        call = TO.stash(dict(lib=lib, handle=plan.handle, prm=ctx.prm, io=ctx.io, og=og, grads=grads))
+        try:
+            torch.ops.gpsa.step_backward(list(tensors), keep, ctx.arena, flat, scratch, call)
+        finally:
+            TO.CALLS.pop(call, None)
         out = [None]
         for i, t in enumerate(tensors):
             out.append(views[i].view(t.shape) if ctx.needs_input_grad[1 + i] else None)
@@ -434,9 +444,8 @@ class ElboLossFn(torch.autograd.Function):
         ll = torch.empty(n, dtype=torch.float64, device=dev)
         ws = o._ws(8 * 4100 * n + 64, loss)
         stream = _raw_stream(dev.index)
-        _lib.check(lib.gpsa_elbo_loss_fwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(klc), 0 if klc is None else klc.numel(),
-                                          float(aux["kl_scale"]), _p(loss), _p(ll), _p(ws), ws.numel(), stream),
-                   "gpsa_elbo_loss_fwd")
+        torch.ops.gpsa.elbo_loss_fwd(Fc, Yc, nz, [int(j) for j in aux["noise_idx"]], klc, float(aux["kl_scale"]), loss,
+                                     ll, ws)
         ctx.aux, ctx.args = aux, (Fc, Yc, nz, Fp, Yp, Np, Sa, Na, Pa)
         ctx.n_kl = 0 if klc is None else klc.numel()
         ctx.noise_meta = (noise.shape, noise.dtype)
@@ -458,8 +467,7 @@ class ElboLossFn(torch.autograd.Function):
         dFp = (C.c_void_p * n)(*[t.data_ptr() for t in dF])
         dNp = (C.c_void_p * n)(*[dnoise.data_ptr() + 4 * j for j in aux["noise_idx"]])
         ws = o._ws(8 * 4100 * n + 64, g)
-        _lib.check(lib.gpsa_elbo_loss_bwd(n, Fp, Yp, Np, Sa, Na, Pa, _p(g), ctx.n_kl, float(aux["kl_scale"]), dFp, dNp,
-                                          _p(dnoise), dnoise.numel(), _p(dkl), _p(ws), ws.numel(), _raw_stream(dev.index)),
-                   "gpsa_elbo_loss_bwd")
+        torch.ops.gpsa.elbo_loss_bwd(Fc, Yc, nz, [int(j) for j in aux["noise_idx"]], g, int(ctx.n_kl),
+                                     float(aux["kl_scale"]), dF, dnoise, dkl, ws)
         shape, dt = ctx.noise_meta
         return (None, dnoise.reshape(shape).to(dt), dkl) + tuple(dF)

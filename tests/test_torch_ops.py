@@ -1,0 +1,145 @@
+"""torch.ops.gpsa.*: the hot path's entry points as dispatcher ops ("PyTorch-ROCm custom ops").
+CPU part: every op family is registered and its fake-tensor function propagates shapes / dtypes without a
+device.  GPU part: the ops run the HIP kernels, their autograd formulas match fp64 torch, and the model's own
+forward / loss / optimiser go through them."""
+import pytest
+import torch
+from torch._subclasses.fake_tensor import FakeTensorMode
+
+import spatial_alignment_amd.torch_ops as TO  # noqa: F401  (registers the ops)
+
+OPS = ["kmat", "kmat_bwd", "chol_inv", "whiten", "quadform", "quadform_bwd_alpha", "quadform_bwd_omega",
+       "gauss_sample_F", "gauss_sample_F_bwd", "mvn_kl", "gauss_loglik_sum", "gauss_loglik_sum_bwd",
+       "step_forward", "step_backward", "elbo_loss_fwd", "elbo_loss_bwd", "adam_step"]
+
+
+def test_every_family_is_registered_with_the_dispatcher():
+    for name in OPS:
+        op = getattr(torch.ops.gpsa, name)
+        assert op.default._schema.name == f"gpsa::{name}"
+    s = str(torch.ops.gpsa.step_forward.default._schema)
+    assert "Tensor(a" in s and "outs" in s  # the mutated arguments are declared as such
+
+
+def test_fake_tensor_shapes_without_a_device():
+    f32, f64 = torch.float32, torch.float64
+    M, C, L, D, S, N, P = 200, 1000, 50, 2, 3, 40, 7
+    with FakeTensorMode():
+        e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device="cuda")
+        o = torch.ops.gpsa
+        K = o.kmat(e(M, D), e(C, D), e(1), e(1), "rbf", 1e-5)
+        assert K.shape == (M, C) and K.dtype == f32 and K.device.type == "cuda"
+        dZ, dX, dpar = o.kmat_bwd(e(M, D), e(C, D), e(1), e(1), e(M, C), "matern32")
+        assert dZ.shape == (M, D) and dX.shape == (C, D) and dpar.shape == (2,)
+        Li, ld, info = o.chol_inv(e(5, M, M, dt=f64))
+        assert Li.shape == (5, M, M) and ld.shape == (5,) and info.dtype == torch.int32
+        al, q = o.whiten(e(M, M, dt=f64), e(M, C, dt=f64))
+        assert al.shape == (M, C) and al.dtype == f32 and q.shape == (C,) and q.dtype == f64
+        v = o.quadform(e(M, C), e(L, M, M, dt=f64))
+        assert v.shape == (L, C) and v.dtype == f32
+        assert o.quadform_bwd_alpha(e(M, C), e(L, M, M), e(L, C)).shape == (M, C)
+        assert o.quadform_bwd_omega(e(M, C), e(L, C)).shape == (L, M, M)
+        F, Sig = o.gauss_sample_F(e(L, C), e(L, C), e(C, dt=f64), e(1), e(C, L))
+        assert F.shape == (C, L) and Sig.shape == (L, C)
+        g, dm, dv = o.gauss_sample_F_bwd(e(C, L), e(C, L), e(L, C), e(1))
+        assert g.shape == (L + 1, C) and dm.shape == (L, C) and dv.shape == (1,)
+        kl, KD = o.mvn_kl(e(M, M, dt=f64), e(1, dt=f64), e(L, M, M, dt=f64), e(L, dt=f64), e(L, M, dt=f64))
+        assert kl.shape == (L,) and KD.shape == (L, M)
+        ll = o.gauss_loglik_sum(e(S, N, P), e(N, P), e(1))
+        assert ll.shape == (1,) and ll.dtype == f64
+        dF, dn = o.gauss_loglik_sum_bwd(e(S, N, P), e(N, P), e(1), e(1, dt=f64))
+        assert dF.shape == (S, N, P) and dn.shape == (1,)
+        # mutating ops trace to nothing but their declared side effects
+        assert o.adam_step([e(4, 4)], [e(4, 4)], [e(4, 4)], [e(4, 4)], e(1), 1e-2, 0.9, 0.999, 1e-8) is None
+
+
+DEV = "cuda:0"
+
+
+def _rnd(*shape, dtype=torch.float32, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g, dtype=torch.float64).to(dtype)
+
+
+@pytest.mark.gpu
+def test_ops_run_the_hip_kernels_and_differentiate():
+    from oracle import gpsa_oracle as orc
+
+    o = torch.ops.gpsa
+    M, C, L, D = 64, 333, 5, 2
+    # (1) covariance: values and gradients vs the oracle's covariance function in fp64
+    Z, X = (_rnd(M, D, dtype=torch.float64, seed=1) * 3).to(DEV), (_rnd(C, D, dtype=torch.float64, seed=2) * 3).to(DEV)
+    ls, var = torch.tensor([0.3], dtype=torch.float64, device=DEV), torch.tensor([-0.2], dtype=torch.float64, device=DEV)
+    ins = [t.clone().requires_grad_(True) for t in (Z, X, ls, var)]
+    K = o.kmat(*ins, "matern32", 0.0)
+    ref_in = [t.detach().cpu().clone().requires_grad_(True) for t in (Z, X, ls, var)]
+    Kr = orc.matern32_kernel(ref_in[0], ref_in[1], ref_in[2], ref_in[3])
+    assert (K.detach().cpu() - Kr.detach()).norm() <= 1e-12 * Kr.norm()
+    w = _rnd(M, C, dtype=torch.float64, seed=3)
+    (K * w.to(DEV)).sum().backward()
+    (Kr * w).sum().backward()
+    for a, b in zip(ins, ref_in):
+        assert (a.grad.cpu() - b.grad).norm() <= 1e-9 * max(float(b.grad.norm()), 1e-12)
+    # (3) quadratic form and both gradients
+    al = _rnd(M, C, seed=4).to(DEV).requires_grad_(True)
+    A = _rnd(L, M, M, dtype=torch.float64, seed=5) / M ** 0.5
+    Om = (A @ A.transpose(1, 2)).to(DEV).requires_grad_(True)
+    v = o.quadform(al, Om)
+    g = _rnd(L, C, seed=6).to(DEV)
+    (v * g).sum().backward()
+    a64, O64 = al.detach().double().cpu().requires_grad_(True), Om.detach().cpu().requires_grad_(True)
+    vr = torch.einsum("mc,lmk,kc->lc", a64, O64, a64)
+    (vr * g.cpu().double()).sum().backward()
+    assert (v.detach().cpu().double() - vr.detach()).norm() <= 3e-6 * vr.norm()
+    assert (al.grad.cpu().double() - a64.grad).norm() <= 3e-6 * a64.grad.norm()
+    assert (Om.grad.cpu() - O64.grad).norm() <= 3e-6 * O64.grad.norm()
+    # (6) likelihood (the variance-as-std quirk 5 included) and its gradients
+    S, N, P = 2, 50, 3
+    F = _rnd(S, N, P, seed=7).to(DEV).requires_grad_(True)
+    Y = _rnd(N, P, seed=8).to(DEV)
+    nz = torch.tensor([-0.4], device=DEV, requires_grad=True)
+    ll = o.gauss_loglik_sum(F, Y, nz)
+    ll.sum().backward()
+    Fr, nr = F.detach().cpu().double().requires_grad_(True), nz.detach().cpu().double().requires_grad_(True)
+    llr = torch.distributions.Normal(Fr, torch.exp(nr) + 1e-5).log_prob(Y.cpu().double()).sum() / S
+    llr.backward()
+    assert abs(float(ll) - float(llr)) <= 1e-6 * abs(float(llr))
+    assert (F.grad.cpu().double() - Fr.grad).norm() <= 1e-5 * Fr.grad.norm()
+    assert abs(float(nz.grad) - float(nr.grad)) <= 1e-5 * abs(float(nr.grad))
+    # schema / fake-tensor consistency as torch checks it
+    torch.library.opcheck(o.kmat.default, (Z, X, ls, var, "rbf", 1e-5), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(o.quadform.default, (al.detach(), Om.detach()), test_utils=("test_schema", "test_faketensor"))
+
+
+@pytest.mark.gpu
+def test_the_model_reaches_the_c_abi_through_the_dispatcher():
+    """forward, loss_fn, backward and the fused optimiser each go through a torch.ops.gpsa.* op: count the calls"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_io import Golden
+    from model_util import build_model
+    from spatial_alignment_amd.optim import FusedAdam
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    seen = {}
+
+    class Count(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = func._schema.name
+            if name.startswith("gpsa::"):
+                seen[name] = seen.get(name, 0) + 1
+            return func(*args, **(kwargs or {}))
+
+    g = Golden("c2_three_free_views")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    with Count():
+        out = model.forward({m: dd[m]["spatial_coords"] for m in g.mods}, view_idx, Ns, S=2)
+        loss = model.loss_fn(dd, out[3])
+        loss.backward()
+        opt.step()
+    assert seen.get("gpsa::step_forward", 0) >= 1 and seen.get("gpsa::elbo_loss_fwd") == 1
+    assert seen.get("gpsa::step_backward") == 1 and seen.get("gpsa::elbo_loss_bwd") == 1
+    assert seen.get("gpsa::adam_step", 0) >= 1
+    assert torch.isfinite(loss)
