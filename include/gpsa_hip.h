@@ -318,6 +318,10 @@ int gpsa_kmat_bwd_batched(int kind, const float* Z, long long strideZ, int M, co
 int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
                       const float* var_u, const float* Kbar, double* dZ, double* dX, double* dparams,
                       void* workspace, long long workspace_bytes, void* stream);
+/* ... with an fp64 gradient panel (the exact inducing-point gradient of the data GP: gpsa_step_desc.exact_inducing_grad) */
+int gpsa_kmat_bwd_x64_f64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                          const float* var_u, const double* Kbar, double* dZ, double* dX, double* dparams,
+                          void* workspace, long long workspace_bytes, void* stream);
 /* ... with the gradient panel in two pieces, Kbar[m,c] + s * d[c] * X2[m,c] (X2 [M,C], d [C] fp32; both NULL: Kbar
  * alone): the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) formed as it is read */
 int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
@@ -393,6 +397,12 @@ typedef struct gpsa_step_desc {
                                                Omega_l alpha (L_m m_g C floats per pass): > 0 that many bytes; < 0
                                                never keep; 0: GPSA_KEEP_GB (default 48) GiB, and no more than 60 % of
                                                the device memory free at gpsa_step_create */
+  int exact_inducing_grad;                  /* 1: the data GP's gradient wrt its inducing points Gtilde from the UNROUNDED
+                                               projection: alpha = K^-1 K_uf kept in fp64 for the backward, gamma =
+                                               K^-1 abar stored in fp64, dK_uu = -(gamma + qbar alpha) alpha^T as one
+                                               C-long fp64 product.  The K_uu and K_uf shares of that gradient cancel to
+                                               1e-4 .. 1e-5 of their size, so fp32 roundings of alpha / gamma are 1e-3 of
+                                               the result at M >= 200.  +8 M C bytes, one M x M x C fp64 product */
 } gpsa_step_desc;
 
 typedef struct gpsa_step_params {           /* device pointers, fp32, the reference's parameter layout */

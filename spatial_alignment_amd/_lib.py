@@ -76,6 +76,7 @@ class StepDesc(C.Structure):
         ("n_latent", _i * MAX_MODS), ("n_out", _i * MAX_MODS), ("has_lmc", _i * MAX_MODS),
         ("n_rows", _ll * MAX_MODS), ("s_test", _i), ("n_test", _ll * MAX_MODS), ("want_kl", _i),
         ("view_fixed", C.POINTER(_i)), ("view_rows", C.POINTER(_ll)), ("keep_budget_bytes", _ll),
+        ("exact_inducing_grad", _i),
     ]
 
 
@@ -121,6 +122,7 @@ SIGNATURES.update({
     "gpsa_kmat_bwd_batched": (_i, [_i, _vp, _ll, _i, _vp, _ll, _ll, _i, _vp, _vp, _i, C.POINTER(_ll), _i, _vp, _ll, _i,
                                    _vp, _ll, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_kmat_bwd_x64_f64": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64_axpy": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _ll,
                                     _vp]),
     "gpsa_whiten_axpy_f32": (_i, [_vp, _vp, _i, _ll, _vp, _vp, _d, _vp, _vp, _ll, _vp]),

@@ -447,6 +447,15 @@ int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long lon
                                 workspace, workspace_bytes, stream);
 }
 
+int gpsa_kmat_bwd_x64_f64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                          const float* var_u, const double* Kbar, double* dZ, double* dX, double* dparams,
+                          void* workspace, long long workspace_bytes, void* stream) {
+  if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
+  return gpsa::kmat_bwd_launch<float, double, double, double, double>(
+      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, dX, dparams, 0, workspace, workspace_bytes, as_stream(stream), 1,
+      gpsa::kmat_single());
+}
+
 /* the same with the gradient panel given in two pieces: Kbar[m,c] + s * d[c] * X2[m,c]  (X2 [M,C], d [C] fp32; both
  * NULL: Kbar alone) - the data GP's dK_uf = K^-1 abar + 2 qbar o alpha without a pass that writes it out */
 int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,

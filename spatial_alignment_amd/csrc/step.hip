@@ -495,6 +495,7 @@ struct Pass {  // one evaluation of the data GP: a modality's own spots, or its 
   long long C = 0;          // columns = S * rows
   long long o_alpha = 0, o_sigma = 0;
   long long o_keep = -1;  // [L][Mg][C] fp32 products Omega_l alpha kept for the backward (-1: not kept)
+  long long o_alpha64 = -1;  // [Mg][C] the projection unrounded (exact_inducing_grad; -1: not kept)
 };
 
 struct Plan {
@@ -655,6 +656,7 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
   for (auto& q : p->passes) {
     q.o_alpha = take((long long)p->Mg * q.C * 4);
     q.o_sigma = take((long long)dsc->n_latent[q.m] * q.C * 4);
+    if (dsc->exact_inducing_grad) q.o_alpha64 = take((long long)p->Mg * q.C * 8);
   }
   p->o_apk_w = take(gpsa_whiten_workspace(p->Mx) * (long long)(p->nf > 0 ? p->nf : 1));
   p->o_apk_d = take(gpsa_whiten_workspace(p->Mg));
@@ -1118,12 +1120,23 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
       GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32_X64, P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D,
                          c.prm.data_ls, c.prm.data_var, 0.0, Kuf, c.stv()));
     const long long wsb = gpsa_whiten_workspace(Mg);
-    if (wsb > 0) {  // the packed inverse stays in the saved arena: later passes and the backward reuse it
+    const bool exact = ps.o_alpha64 >= 0;  // the unrounded projection stays for the backward
+    if (wsb > 0 && !exact) {  // the packed inverse stays in the saved arena: later passes and the backward reuse it
       void* ws = c.sv<char>(P.o_apk_d);
       GPSA_RUN(gpsa_whiten_f64(c.apk_d ? nullptr : Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb, c.stv()));
       c.apk_d = true;
+    } else if (wsb > 0) {
+      void* ws = c.sv<char>(P.o_apk_d);
+      double* a64 = c.sv<double>(ps.o_alpha64);
+      GPSA_RUN(gpsa_whiten_f64(c.apk_d ? nullptr : Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F64, a64, q, ws, wsb, c.stv()));
+      c.apk_d = true;
+      if (!dry) {
+        convert_kernel_step<double, float><<<(unsigned)cdiv((long long)Mg * C, 256), 256, 0, c.st>>>(
+            a64, (long long)Mg * C, alpha);
+        GPSA_LAUNCH_CHECK();
+      }
     } else {  // beyond the projection kernel: alpha (fp64) = K^-1 K_uf, q from it, then rounded
-      double* a64 = c.sc.get<double>((long long)Mg * C);
+      double* a64 = exact ? c.sv<double>(ps.o_alpha64) : c.sc.get<double>((long long)Mg * C);
       GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, Kuf, C, 0, 0.0, a64, C, 0, 1, 1));
       if (!dry) {
         coldot2_kernel<<<dim3((unsigned)cdiv(C, 256), 1), 256, 0, c.st>>>(Kuf, a64, Mg, C, q);
@@ -1248,12 +1261,43 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
                  splitk_for(C, Mg, L)));
   B.have_ddc[m] = true;
+  // exact_inducing_grad: gamma = K^-1 abar STORED in fp64, W = gamma + qbar alpha64, dK_uu = -W alpha64^T as one
+  // C-long fp64 product, dK_uf = W + qbar alpha64 handed to the covariance backward as an fp64 panel
+  const bool exact = ps.o_alpha64 >= 0;
+  double* gamma64 = nullptr;
+  if (exact) {
+    const double* a64 = c.sv<double>(ps.o_alpha64);
+    gamma64 = c.sc.get<double>((long long)Mg * C);
+    double* qbar64 = c.sc.get<double>(C);
+    const long long wsb = gpsa_whiten_workspace(Mg);
+    if (wsb > 0) {
+      GPSA_RUN(gpsa_whiten_f64(nullptr, GPSA_F32, abar, Mg, C, GPSA_F64, gamma64, nullptr, c.sv<char>(P.o_apk_d), wsb,
+                               c.stv()));
+    } else {
+      const long long mk2 = c.sc.mark();
+      double* abar64 = c.sc.get<double>((long long)Mg * C);
+      if (!dry) {
+        convert_kernel_step<float, double><<<(unsigned)cdiv((long long)Mg * C, 256), 256, 0, c.st>>>(
+            abar, (long long)Mg * C, abar64);
+        GPSA_LAUNCH_CHECK();
+      }
+      GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, abar64, C, 0, 0.0, gamma64, C, 0, 1, 1));
+      c.sc.release(mk2);
+    }
+    if (!dry) {
+      convert_kernel_step<float, double><<<(unsigned)cdiv(C, 256), 256, 0, c.st>>>(qbar, C, qbar64);
+      GPSA_LAUNCH_CHECK();
+    }
+    GPSA_RUN(gpsa_col_axpy(GPSA_F64, gamma64, a64, qbar64, 1.0, Mg, C, gamma64, c.stv()));
+    GPSA_CK(gemm64(c, 0, 1, Mg, Mg, C, -1.0, gamma64, C, 0, a64, C, 0, 1.0, dKuu, Mg, 0, 1, splitk_for(C, Mg, Mg)));
+    GPSA_RUN(gpsa_col_axpy(GPSA_F64, gamma64, a64, qbar64, 1.0, Mg, C, gamma64, c.stv()));
+  }
   // gamma = K^-1 abar (fp64 product on the fp32 panel).  With many columns dK_uu comes from the identity below
   // and only dK_uf = gamma + 2 qbar a is needed: the column-scaled update rides in the solve's store
-  float* gamma = c.sc.get<float>((long long)Mg * C);
-  const bool identity = C >= 4LL * L * Mg;
+  float* gamma = exact ? nullptr : c.sc.get<float>((long long)Mg * C);
+  const bool identity = !exact && C >= 4LL * L * Mg;
   bool fused_axpy = false, axpy_in_cov = false;
-  {
+  if (!exact) {
     const long long wsb = gpsa_whiten_workspace(Mg);
     if (wsb > 0) {
       const long long mk2 = c.sc.mark();
@@ -1330,7 +1374,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
         GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 2.0, Mg, C, gamma, c.stv()));
       else if (!fused_axpy)
         axpy_in_cov = true;
-    } else {
+    } else if (!exact) {
       // few columns: W = gamma + qbar a;  dK_uu = -W a^T ADDED in fp64;  dK_uf = W + qbar a
       GPSA_RUN(gpsa_col_axpy(GPSA_F32, gamma, alpha, qbar, 1.0, Mg, C, gamma, c.stv()));
       GPSA_CK((gemmx<float, float, double>(c, 0, 1, Mg, Mg, C, -1.0, gamma, C, 0, alpha, C, 0, 1.0, dKuu, Mg, 0, 1,
@@ -1346,7 +1390,14 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     void* ws = c.sc.get<char>(wsb);
     double* dZ = B.dZ_df + (long long)pass_idx * Mg * D;
     double* dpar = B.dpar_df + (long long)pass_idx * 2;
-    if (ps.test) {
+    if (exact && ps.test) {
+      GPSA_RUN(gpsa_kmat_bwd(GPSA_F64, GPSA_F32_OUT64, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D,
+                             c.prm.data_ls, c.prm.data_var, gamma64, 0, dZ, nullptr, dpar, ws, wsb, c.stv()));
+    } else if (exact) {
+      GPSA_RUN(gpsa_kmat_bwd_x64_f64(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
+                                     c.prm.data_var, gamma64, dZ, B.dG64[m], dpar, ws, wsb, c.stv()));
+      B.have_dG[m] = true;
+    } else if (ps.test) {
       GPSA_RUN(gpsa_kmat_bwd(GPSA_F64, GPSA_F32_ACC64, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D,
                              c.prm.data_ls, c.prm.data_var, gamma, 0, dZ, nullptr, dpar, ws, wsb, c.stv()));
     } else {

@@ -9,6 +9,7 @@ PyTorch remains plumbing: it owns the tensors (parameters, outputs, the two aren
 autograd bookkeeping between the two nodes and the optimiser.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -162,8 +163,14 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     n_test = tuple(test_shapes[1]) if test_shapes else tuple(0 for _ in mods)
     kw, kd = KINDS[builtin_kind(model.kernel_func_warp)], KINDS[builtin_kind(model.kernel_func_data)]
     keep_gb = getattr(model, "keep_budget_gb", None)
+    exact = getattr(model, "exact_inducing_grad", None)
+    if exact is None and os.environ.get("GPSA_EXACT_GRAD") in ("0", "1"):
+        exact = os.environ["GPSA_EXACT_GRAD"] == "1"
+    if exact is None:  # automatic: on where it costs under ~1 % of the step (one M x M x C fp64 product next to 3 L of them)
+        exact = min(L) >= 128
+    exact = int(bool(exact))
     key = (V, D, len(mods), int(S), int(model.Xtilde.shape[1]), int(model.Gtilde.shape[0]), kw, kd, L, P, lmc, N,
-           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index, keep_gb)
+           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index, keep_gb, exact)
     cache = model.__dict__.setdefault("_step_plans", {})
     plan = cache.get(key)
     if plan is not None:
@@ -177,6 +184,7 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     vf = (C.c_int * V)(*fixed)
     vr = (C.c_longlong * len(rows))(*rows)
     d.view_fixed, d.view_rows = vf, vr
+    d.exact_inducing_grad = exact
     d.keep_budget_bytes = keep_budget_bytes(model, d, keep_gb)
     with torch.cuda.device(model.Xtilde.device):
         plan = StepPlan(_lib.load(), key, d, (vf, vr))

@@ -46,6 +46,7 @@ def _step_vs_oracle(side, views, outputs, M, S, fixed, seed, kernel_warp=gp.rbf_
     model = make_model(dd, m=M, n_latent_gps={MOD: None}, fixed_view_idx=fixed, device="cpu", seed=seed,
                        kernel_func_warp=kernel_warp, kernel_func_data=gp.rbf_kernel)
     _perturb(model, seed + 1)
+    model.exact_inducing_grad = True  # (what the configurations' 2000 / 1000 outputs switch on by themselves)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     for name in ("mean_slopes", "mean_intercepts"):
         state.setdefault(name, getattr(model, name).detach().clone())
@@ -97,7 +98,7 @@ def test_config4_shape_eight_views_fixed0_m500_matches_oracle():
     assert errs["G_means"] < 1e-4 and errs["G_samples"] < 1e-4 and errs["F_samples"] < 1e-4
     assert errs["loss"] < 1e-4
     for k, e in gerr.items():
-        assert e < 5e-3, (k, e, gerr)
+        assert e < 5e-4, (k, e, gerr)  # (round 2: 5e-3, for grad/Gtilde's 3e-4 with the rounded projection)
 
 
 def test_config5_shape_two_views_m1000_matches_oracle():
@@ -109,7 +110,7 @@ def test_config5_shape_two_views_m1000_matches_oracle():
     assert errs["G_means"] < 1e-4 and errs["G_samples"] < 1e-4 and errs["F_samples"] < 1e-4
     assert errs["loss"] < 1e-4
     for k, e in gerr.items():
-        assert e < 5e-3, (k, e, gerr)
+        assert e < 5e-4, (k, e, gerr)  # (round 2: 5e-3, for grad/Gtilde's 4e-3 with the rounded projection)
 
 
 def test_config3_full_size_properties():

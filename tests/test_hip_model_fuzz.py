@@ -52,6 +52,7 @@ def test_random_configuration_matches_oracle(seed):
     for name in ("mean_slopes", "mean_intercepts"):
         state.setdefault(name, getattr(model, name).detach().clone())
     model = model.to(DEV)
+    model.exact_inducing_grad = True
     S, L = c["S"], (c["latent"] or c["P"])
     free = [v for v in range(c["V"]) if v != c["fixed"]]
     eps_G = [torch.randn(S, c["ns"][v], c["D"], generator=gen) for v in free]
@@ -70,4 +71,4 @@ def test_random_configuration_matches_oracle(seed):
     assert rel(loss.detach().cpu().numpy(), ref["loss"].numpy()) < 1e-5, c
     for k, p in model.named_parameters():
         if k in ref["grads"] and p.grad is not None and float(ref["grads"][k].norm()) > 0:
-            assert rel(p.grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-3, (k, c)
+            assert rel(p.grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-4, (k, c)
