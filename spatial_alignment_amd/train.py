@@ -34,6 +34,68 @@ def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None, sta
     return loss
 
 
+class Microbatches:
+    """One optimiser step as K forward / ELBO / backward passes over row slices of every view, gradients
+    accumulated: the "minibatched K_NM" of BASELINE.json's Slide-seq-scale configuration.
+
+    Everything N-scaled is independent per spot given the M x M factors, so slice k contributes its spots'
+    likelihood and 1/K of the KL terms (``model.kl_scale``) - summed over k that is the full negative ELBO and its
+    gradient, exactly as for K data-parallel ranks (parallel.shard_data_dict), only one after the other on ONE GPU.
+    What it buys: the data GPs' products Omega_l alpha of a SLICE fit the device (L M C/K floats), so every slice
+    takes the kept-products path - one full product per slice instead of the block-triangular form plus the
+    recomputed alpha-gradient (BASELINE config 5 on one MI355X: 800 GB of products -> 8 slices of 100 GB).  What it
+    costs: the M x M stage (factorisations, KL) runs K times."""
+
+    def __init__(self, model, data_dict, K, quantum=4):
+        """``quantum``: slice sizes are multiples of it (the last slice of a view takes the remainder): the LDS-DMA
+        kernels of the M > 256 data GP want 16-byte aligned rows of the [M, C] panels, i.e. C % 4 == 0"""
+        self.model, self.K = model, int(K)
+        self.slices, self.bounds = [], []  # bounds[k][mod] = [(lo, hi) of slice k within view v]
+        for k in range(self.K):
+            dd = {}
+            self.bounds.append({})
+            for mod, d in data_dict.items():
+                rows, new_ns, off = [], [], 0
+                self.bounds[k][mod] = []
+                for n in (int(x) for x in d["n_samples_list"]):
+                    per = -(-n // self.K)
+                    per = -(-per // quantum) * quantum
+                    lo, hi = min(k * per, n), min((k + 1) * per, n)
+                    self.bounds[k][mod].append((lo, hi))
+                    rows.append(torch.arange(off + lo, off + hi))
+                    new_ns.append(hi - lo)
+                    off += n
+                idx = torch.cat(rows).to(d["spatial_coords"].device)
+                dd[mod] = {"spatial_coords": d["spatial_coords"][idx].contiguous(),
+                           "outputs": d["outputs"][idx].contiguous(), "n_samples_list": new_ns}
+            vi, Ns, _, _ = model.create_view_idx_dict(dd)
+            self.slices.append((dd, vi, Ns))
+
+    def step(self, optimizer, S=5, reducer=None, noise=None):
+        """zero_grad, K accumulating passes, (all-reduce,) optimizer.step(); returns the summed loss (device tensor).
+        ``noise``: per slice ``(eps_G, eps_F)`` for ``model.inject_noise`` (tests / reproducibility)."""
+        model = self.model
+        scale0 = model.kl_scale
+        optimizer.zero_grad(set_to_none=True)
+        total = None
+        try:
+            model.kl_scale = scale0 / self.K
+            for k, (dd, vi, Ns) in enumerate(self.slices):
+                if noise is not None:
+                    model.inject_noise(noise[k][0], noise[k][1], None)
+                out = model.forward({m: d["spatial_coords"] for m, d in dd.items()}, view_idx=vi, Ns=Ns, S=S)
+                loss = model.loss_fn(dd, out[3])
+                backward(loss)  # .grad accumulates across the slices
+                total = loss.detach() if total is None else total + loss.detach()
+                del out, loss
+        finally:
+            model.kl_scale = scale0
+        if reducer is not None:
+            reducer()
+        optimizer.step()
+        return total
+
+
 def fit(model, data_dict, n_epochs, lr=1e-2, S=5, optimizer=None, checker=None, sync_every=10,
         callback=None, graphed=False):
     """The reference's training loop (examples/grid_example.py:59-78 and the convergence test of

@@ -206,3 +206,48 @@ def test_output_sharding_rejects_latent_mixing_and_separates_generators():
     shared = {id(p) for p in shared_parameters(a)}
     local = {n for n, p in a.named_parameters() if id(p) not in shared}
     assert local == {n for n in names if n.startswith(("Omega_sqt_F_dict.", "delta_F_dict."))} and local
+
+
+def test_microbatched_step_accumulates_the_full_gradient():
+    """train.Microbatches: K forward / ELBO / backward passes over row slices of every view, gradients accumulated,
+    equal one pass over all rows (the "minibatched K_NM" of BASELINE config 5) - same draws, sliced"""
+    from fake_ops import FakeOps
+    from spatial_alignment_amd import ops as ops_mod
+    from spatial_alignment_amd.train import Microbatches
+
+    ops_mod.set_ops(FakeOps())
+    try:
+        dd, model = _problem()
+        gen = torch.Generator().manual_seed(3)
+        eG = [torch.randn(2, 64, 2, generator=gen) for _ in range(2)]
+        eF = torch.randn(2, 128, 3, generator=gen)
+        loss1 = _grads(model, dd, eG, {"expression": eF})
+        want = {k: p.grad.clone() for k, p in model.named_parameters()}
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+
+        class Probe(torch.optim.Optimizer):  # records the accumulated gradients at step(), changes nothing
+            def __init__(self, params):
+                super().__init__(params, {})
+                self.seen = None
+
+            def step(self):
+                self.seen = {id(p): p.grad.clone() for g in self.param_groups for p in g["params"] if p.grad is not None}
+
+        K = 3
+        mb = Microbatches(model, dd, K)
+        noise = []
+        for k in range(K):
+            b = mb.bounds[k]["expression"]  # slice k of view v: multiples of 4 rows, the last one the remainder
+            assert all((hi - lo) % 4 == 0 for lo, hi in b) or k == K - 1
+            rows = torch.cat([64 * v + torch.arange(lo, hi) for v, (lo, hi) in enumerate(b)])
+            noise.append(([e[:, lo:hi] for e, (lo, hi) in zip(eG, b)], {"expression": eF[:, rows]}))
+        opt = Probe(model.parameters())
+        total = mb.step(opt, S=2, noise=noise)
+        assert model.kl_scale == 1.0  # restored
+        assert abs(float(total) - float(loss1)) <= 1e-4 * abs(float(loss1))
+        for k, p in model.named_parameters():
+            assert torch.equal(p.detach(), before[k])
+            got = opt.seen[id(p)]
+            assert (got - want[k]).norm() <= 2e-3 * max(float(want[k].norm()), 1e-6), k
+    finally:
+        ops_mod.set_ops(None)

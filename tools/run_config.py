@@ -47,7 +47,16 @@ from spatial_alignment_amd.optim import FusedAdam  # noqa: E402
 opt = FusedAdam(model.parameters(), lr=1e-2)
 
 
+MB = int(os.environ.get("GPSA_MICROBATCHES", "1"))  # K > 1: one step = K accumulating passes over row slices
+if MB > 1:
+    from spatial_alignment_amd.train import Microbatches  # noqa: E402
+
+    mb = Microbatches(model, dd, MB)
+
+
 def step():
+    if MB > 1:
+        return mb.step(opt, S=CFG["S"])
     out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=CFG["S"])
     loss = model.loss_fn(dd, out[3])
     opt.zero_grad(set_to_none=True)
@@ -62,7 +71,7 @@ torch.cuda.synchronize()
 import ctypes  # noqa: E402
 
 plans = [p for p in model.__dict__.get("_step_plans", {}).values() if p.S == CFG["S"]]
-if os.environ.get("GPSA_NOTIMING") == "1":
+if os.environ.get("GPSA_NOTIMING") == "1" or MB > 1:  # (per-contraction rates are per pass: not meaningful over K passes)
     plans = []
 for p in plans:
     p.lib.gpsa_step_timing(p.handle, steps)
@@ -92,4 +101,5 @@ for p in plans:
                 print(f"  {name:46s} {ms:8.3f} ms   {fl / ms / 1e9:7.1f} TF nominal = {fl / ms / 1e9 / 157.3:.2f} of the fp32-MFMA peak")
 print(f"{which}: {CFG['views']} views x {CFG['side'] ** 2} spots, {CFG['outputs']} outputs via {CFG['latent'] or 'no'} latent GPs, "
       f"M={CFG['M']}, S={CFG['S']}: {dt * 1e3:.2f} ms/step, loss {float(l0):.4g} -> {float(loss):.4g}, "
-      f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+      f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB" + (f", {MB} microbatches per step" if MB > 1 else ""),
+      flush=True)
