@@ -266,10 +266,24 @@ gauss_loglik_sum.register_autograd(_ll_backward, setup_context=_ll_setup)
 
 # ---------------------------------------------------------------------------------------------------------
 # the step engine (what the model classes call)
+#
+# These five run once or twice per training step, also on problems whose whole step is under a millisecond, so they
+# are registered through the low-level ``torch.library.Library`` interface (schema string + CUDA kernel + fake
+# function): ~10 us of dispatch per call instead of the ~35 us of a ``custom_op`` object (the reference example's
+# own 2 x 100-spot problem ran 920 -> 720 steps/s with the latter).  Mutated arguments are declared in the schema.
 # ---------------------------------------------------------------------------------------------------------
-@torch.library.custom_op("gpsa::step_forward", mutates_args=("outs", "saved", "scratch"), device_types="cuda")
-def step_forward(params: list[torch.Tensor], ins: list[torch.Tensor], outs: list[torch.Tensor], saved: torch.Tensor,
-                 scratch: torch.Tensor, call: int, stages: int) -> None:
+_ENGINE = torch.library.Library("gpsa", "FRAGMENT")
+
+
+def _engine_op(schema, fn):
+    name = schema.split("(", 1)[0]
+    _ENGINE.define(schema)
+    _ENGINE.impl(name, fn, "CUDA")
+    torch.library.register_fake(f"gpsa::{name}", lambda *a, **k: None, lib=_ENGINE)
+    return fn
+
+
+def _step_forward(params, ins, outs, saved, scratch, call, stages):
     """gpsa_step_forward: warp GPs (stage 1) and data GPs (stage 2) of VariationalGPSA.forward into ``outs``"""
     c = CALLS[call]
     _lib.check(c["lib"].gpsa_step_forward(c["handle"], C.byref(c["prm"]), C.byref(c["io"]), saved.data_ptr(),
@@ -277,14 +291,11 @@ def step_forward(params: list[torch.Tensor], ins: list[torch.Tensor], outs: list
                "gpsa_step_forward")
 
 
-@step_forward.register_fake
-def _(params, ins, outs, saved, scratch, call, stages):
-    return None
+_engine_op("step_forward(Tensor[] params, Tensor[] ins, Tensor(a!)[] outs, Tensor(b!) saved, Tensor(c!) scratch, "
+           "int call, int stages) -> ()", _step_forward)
 
 
-@torch.library.custom_op("gpsa::step_backward", mutates_args=("flat", "scratch"), device_types="cuda")
-def step_backward(params: list[torch.Tensor], grads_out: list[torch.Tensor], saved: torch.Tensor, flat: torch.Tensor,
-                  scratch: torch.Tensor, call: int) -> None:
+def _step_backward(params, grads_out, saved, flat, scratch, call):
     """gpsa_step_backward: every parameter gradient of the step into the flat buffer ``flat``"""
     c = CALLS[call]
     _lib.check(c["lib"].gpsa_step_backward(c["handle"], C.byref(c["prm"]), C.byref(c["io"]), C.byref(c["og"]),
@@ -292,9 +303,8 @@ def step_backward(params: list[torch.Tensor], grads_out: list[torch.Tensor], sav
                                            _raw_stream(saved.device.index)), "gpsa_step_backward")
 
 
-@step_backward.register_fake
-def _(params, grads_out, saved, flat, scratch, call):
-    return None
+_engine_op("step_backward(Tensor[] params, Tensor[] grads_out, Tensor saved, Tensor(a!) flat, Tensor(b!) scratch, "
+           "int call) -> ()", _step_backward)
 
 
 def _ll_arrays(Fs, Ys, noise, noise_idx):
@@ -305,10 +315,7 @@ def _ll_arrays(Fs, Ys, noise, noise_idx):
             (C.c_longlong * n)(*[int(f.shape[1]) for f in Fs]), (C.c_int * n)(*[int(f.shape[2]) for f in Fs]))
 
 
-@torch.library.custom_op("gpsa::elbo_loss_fwd", mutates_args=("loss", "ll", "ws"), device_types="cuda")
-def elbo_loss_fwd(Fs: list[torch.Tensor], Ys: list[torch.Tensor], noise: torch.Tensor, noise_idx: list[int],
-                  kl: torch.Tensor | None, kl_scale: float, loss: torch.Tensor, ll: torch.Tensor,
-                  ws: torch.Tensor) -> None:
+def _elbo_loss_fwd(Fs, Ys, noise, noise_idx, kl, kl_scale, loss, ll, ws):
     """loss = -(sum_i LL_i) + kl_scale * sum(kl): log-likelihood partials, finish and the ELBO glue
     (gpsa_elbo_loss_fwd; contiguous fp32 F / Y / noise, fp64 kl)"""
     n, Fp, Yp, Np, Sa, Na, Pa = _ll_arrays(Fs, Ys, noise, noise_idx)
@@ -318,15 +325,11 @@ def elbo_loss_fwd(Fs: list[torch.Tensor], Ys: list[torch.Tensor], noise: torch.T
                                               _raw_stream(loss.device.index)), "gpsa_elbo_loss_fwd")
 
 
-@elbo_loss_fwd.register_fake
-def _(Fs, Ys, noise, noise_idx, kl, kl_scale, loss, ll, ws):
-    return None
+_engine_op("elbo_loss_fwd(Tensor[] Fs, Tensor[] Ys, Tensor noise, int[] noise_idx, Tensor? kl, float kl_scale, "
+           "Tensor(a!) loss, Tensor(b!) ll, Tensor(c!) ws) -> ()", _elbo_loss_fwd)
 
 
-@torch.library.custom_op("gpsa::elbo_loss_bwd", mutates_args=("dFs", "dnoise", "dkl", "ws"), device_types="cuda")
-def elbo_loss_bwd(Fs: list[torch.Tensor], Ys: list[torch.Tensor], noise: torch.Tensor, noise_idx: list[int],
-                  gloss: torch.Tensor, n_kl: int, kl_scale: float, dFs: list[torch.Tensor], dnoise: torch.Tensor,
-                  dkl: torch.Tensor | None, ws: torch.Tensor) -> None:
+def _elbo_loss_bwd(Fs, Ys, noise, noise_idx, gloss, n_kl, kl_scale, dFs, dnoise, dkl, ws):
     n, Fp, Yp, Np, Sa, Na, Pa = _ll_arrays(Fs, Ys, noise, noise_idx)
     dFp = (C.c_void_p * n)(*[t.data_ptr() for t in dFs])
     dNp = (C.c_void_p * n)(*[dnoise.data_ptr() + 4 * j for j in noise_idx])
@@ -336,16 +339,11 @@ def elbo_loss_bwd(Fs: list[torch.Tensor], Ys: list[torch.Tensor], noise: torch.T
                                               _raw_stream(gloss.device.index)), "gpsa_elbo_loss_bwd")
 
 
-@elbo_loss_bwd.register_fake
-def _(Fs, Ys, noise, noise_idx, gloss, n_kl, kl_scale, dFs, dnoise, dkl, ws):
-    return None
+_engine_op("elbo_loss_bwd(Tensor[] Fs, Tensor[] Ys, Tensor noise, int[] noise_idx, Tensor gloss, int n_kl, "
+           "float kl_scale, Tensor(a!)[] dFs, Tensor(b!) dnoise, Tensor(c!)? dkl, Tensor(d!) ws) -> ()", _elbo_loss_bwd)
 
 
-@torch.library.custom_op("gpsa::adam_step", mutates_args=("params", "exp_avg", "exp_avg_sq", "step"),
-                         device_types="cuda")
-def adam_step(params: list[torch.Tensor], grads: list[torch.Tensor], exp_avg: list[torch.Tensor],
-              exp_avg_sq: list[torch.Tensor], step: torch.Tensor, lr: float, beta1: float, beta2: float,
-              eps: float) -> None:
+def _adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
     """torch.optim.Adam's update over all tensors in one launch, step counter on the device (gpsa_adam_step)"""
     n = len(params)
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
@@ -355,6 +353,5 @@ def adam_step(params: list[torch.Tensor], grads: list[torch.Tensor], exp_avg: li
                                           _raw_stream(step.device.index)), "gpsa_adam_step")
 
 
-@adam_step.register_fake
-def _(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
-    return None
+_engine_op("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, "
+           "Tensor(d!) step, float lr, float beta1, float beta2, float eps) -> ()", _adam_step)
