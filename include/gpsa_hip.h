@@ -452,6 +452,10 @@ typedef struct gpsa_step_io {
                                                    gpsa_step_saved_bytes.  0 (no backward to follow): the cheaper
                                                    forward, gpsa_step_saved_bytes_nokeep suffices, and a backward
                                                    recomputes the products.  Pass the same value to both calls. */
+  int reuse_mm;                             /* in  nonzero: the saved arena still holds the M x M stage (prior and
+                                                   variational covariances, their factorisations and inverses, KL terms)
+                                                   of an earlier gpsa_step_forward on the SAME parameters - skip it.
+                                                   For the slices of one microbatched step (train.Microbatches) */
 } gpsa_step_io;
 
 typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */

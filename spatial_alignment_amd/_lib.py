@@ -103,6 +103,7 @@ class StepIO(C.Structure):
         ("eps_F_test", _vp * MAX_MODS), ("G_means", _vp * MAX_MODS), ("G_samples", _vp * MAX_MODS),
         ("F_latent", _vp * MAX_MODS), ("F_obs", _vp * MAX_MODS), ("F_latent_test", _vp * MAX_MODS),
         ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp), ("keep_products", _i),
+        ("reuse_mm", _i),
     ]
 
 

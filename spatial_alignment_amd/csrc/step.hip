@@ -513,6 +513,7 @@ struct Plan {
   int Loff[MAXMODS], Ltot = 0;
   std::vector<Pass> passes;
   // saved arena
+  long long o_klcache = 0;  // the KL terms of the forward that filled this arena (io.reuse_mm hands them out again)
   long long o_resid = 0, o_Xv = 0, o_alpha_w = 0, o_Wk = 0, o_G64[MAXMODS], o_bad = 0, saved_bytes = 0;
   long long saved_bytes_nokeep = 0;   // arena without the kept products (they sit at its end)
   long long o_apk_w = 0, o_apk_d = 0;  // packed inverses of the projection kernel: forward packs, backward reuses
@@ -645,6 +646,7 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
     G.o_D = take((long long)G.n_omega * G.M * 8);
     G.o_KD = take((long long)G.n_omega * G.M * 8);
   }
+  p->o_klcache = take(((long long)V * D + p->Ltot) * 8);
   p->o_resid = take((long long)V * p->Mx * D * 8);
   p->o_Xv = take((long long)p->nf * p->Cs * D * 4);
   p->o_alpha_w = take((long long)p->nf * p->Mx * p->Cs * 8);
@@ -880,6 +882,12 @@ static int mm_stage_fwd(Ctx& c) {
       GPSA_LAUNCH_CHECK();
     }
   }
+  if (c.io.reuse_mm) {  // same parameters, same arena: everything below is still there
+    if (kl && !dry)
+      GPSA_CK((int)hipMemcpyAsync(c.io.kl, c.sv<double>(P.o_klcache), (size_t)((long long)V * D + P.Ltot) * 8,
+                                  hipMemcpyDeviceToDevice, c.st));
+    return 0;
+  }
   // prior covariances K_uu + 1e-5 I of the free views (batched over runs) and of the data GP
   for (const Run& r : P.runs)
     GPSA_RUN(gpsa_kmat_batched(P.d.kind_warp, c.prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
@@ -972,6 +980,9 @@ static int mm_stage_fwd(Ctx& c) {
                                          c.sv<double>(G.o_D), G.M, G.n_omega, c.io.kl + G.kl_off,
                                          c.sv<double>(G.o_KD), (void*)sst));
     }
+  if (kl && !dry)  // (stream-ordered behind the KL kernels; with the side stream: on it)
+    GPSA_CK((int)hipMemcpyAsync(c.sv<double>(P.o_klcache), c.io.kl, (size_t)((long long)V * D + P.Ltot) * 8,
+                                hipMemcpyDeviceToDevice, sst));
   if (fork) GPSA_CK((int)hipEventRecord(P.sev[2], P.side));
   return 0;
 }

@@ -606,6 +606,7 @@ class VariationalGPSA(GPSA):
                    G_test=Gt if G_test is not None else None, eps_F_test=eps_Ft,
                    slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
                    want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,
+                   mm_epoch=self.__dict__.get("_mm_epoch"),
                    flag_slot=self.__dict__.get("_flag_slot", 0))
         self.__dict__["_flag_slot"] = 1 - aux["flag_slot"]  # two pinned words: consecutive forwards never share one
         outs = SE.StepFn.apply(aux, *SE._param_list(self))
@@ -716,8 +717,8 @@ class VariationalGPSA(GPSA):
             raise AttributeError("loss_fn called before forward (no factorisations cached)")
         V, D = self.n_views, self.n_spatial_dims
         if cache.kl is not None:  # forward ran through the step engine: the KL terms came out of its node
-            kl = cache.kl
-            if self.kl_weight_G != 1.0:  # output-sharded rank: its share of the warp GPs' terms
+            kl = cache.kl if self.kl_scale != 0 else None  # (a slice without a KL share: no KL backward either)
+            if kl is not None and self.kl_weight_G != 1.0:  # output-sharded rank: its share of the warp GPs' terms
                 kl = torch.cat([kl[: V * D] * self.kl_weight_G, kl[V * D:]])
             nn_ = self.noise_variance.numel()
             aux = dict(Y=[data_dict[m]["outputs"] for m in self.modality_names],

@@ -20,6 +20,7 @@ from .kernels import builtin_kind
 
 # the flat gradient buffer of the most recent backward per device (its views are the parameters' .grad):
 # parallel.GradAllReducer reduces it in place
+STATS = {"mm_reused": 0}  # forwards that skipped their M x M stage (io.reuse_mm): tests look at it
 LAST_FLAT = {}
 LAST_USED = {}  # floats of LAST_FLAT the gradient views span (each view starts on a 256-byte boundary)
 
@@ -62,11 +63,15 @@ ARENA_PARK_BYTES = 1 << 30
 
 
 def _take_arena(plan, nbytes, dev, must=False):
+    """-> arena, or None when it cannot be had.  ``plan._took_parked`` says whether it is the plan's own parked block
+    (nobody else has written into it since it was handed back: its contents are the previous forward's)."""
+    plan._took_parked = False
     parked = plan.__dict__.get("_parked")
     if parked is not None and parked.device == dev and parked.numel() >= nbytes:
         if 2 * nbytes < parked.numel():  # a forward without kept products (no backward will hand the arena back):
             return torch.empty(nbytes, dtype=torch.uint8, device=dev)  # leave the large one parked
         plan._parked = None
+        plan._took_parked = True
         return parked
     plan._parked = None  # (too small: let it go before asking for the larger one)
     del parked
@@ -78,8 +83,9 @@ def _take_arena(plan, nbytes, dev, must=False):
         return None
 
 
-def _give_arena(plan, arena):
-    if arena is not None and arena.numel() >= ARENA_PARK_BYTES and plan.__dict__.get("_parked") is None:
+def _give_arena(plan, arena, force=False):
+    """``force``: park whatever its size (the slices of a microbatched step share the arena's M x M stage)"""
+    if arena is not None and (force or arena.numel() >= ARENA_PARK_BYTES) and plan.__dict__.get("_parked") is None:
         plan._parked = arena
 
 
@@ -280,6 +286,13 @@ class StepFn(torch.autograd.Function):
             io.keep_products = 0
             saved = _take_arena(plan, plan.saved_bytes_nokeep, dev, must=True)
         scratch = o._ws(plan.scratch_bytes, saved)
+        # the slices of one microbatched step (train.Microbatches) run on the same parameters: when this forward got
+        # the very arena the previous slice filled, the M x M stage (factorisations, inverses, KL terms) is still in it
+        epoch = aux.get("mm_epoch")
+        token = (saved.data_ptr(), saved.numel(), epoch, tuple(t.data_ptr() for t in tensors))
+        io.reuse_mm = 1 if (epoch is not None and plan._took_parked and plan.__dict__.get("_mm_token") == token) else 0
+        plan._mm_token = token if epoch is not None else None
+        STATS["mm_reused"] += int(io.reuse_mm)
         pending = None
         # the C entry point is reached through the dispatcher (torch.ops.gpsa.step_forward, torch_ops.py): the
         # pointer structs travel as a key, the tensors the call reads and writes as its arguments
@@ -417,7 +430,7 @@ class StepFn(torch.autograd.Function):
         # the arena (gigabytes when the data GPs keep their products) goes back to the allocator NOW: the node sits
         # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
         # would break, steps later
-        _give_arena(plan, ctx.arena)
+        _give_arena(plan, ctx.arena, force=aux.get("mm_epoch") is not None)
         ctx.arena = None
         ctx.aux = ctx.io = ctx.prm = None
         return tuple(out)

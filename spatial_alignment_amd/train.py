@@ -39,12 +39,13 @@ class Microbatches:
     accumulated: the "minibatched K_NM" of BASELINE.json's Slide-seq-scale configuration.
 
     Everything N-scaled is independent per spot given the M x M factors, so slice k contributes its spots'
-    likelihood and 1/K of the KL terms (``model.kl_scale``) - summed over k that is the full negative ELBO and its
-    gradient, exactly as for K data-parallel ranks (parallel.shard_data_dict), only one after the other on ONE GPU.
+    likelihood and the first slice the KL terms - summed over k that is the full negative ELBO and its gradient,
+    the decomposition of K data-parallel ranks (parallel.shard_data_dict), only one after the other on ONE GPU.
     What it buys: the data GPs' products Omega_l alpha of a SLICE fit the device (L M C/K floats), so every slice
     takes the kept-products path - one full product per slice instead of the block-triangular form plus the
     recomputed alpha-gradient (BASELINE config 5 on one MI355X: 800 GB of products -> 8 slices of 100 GB).  What it
-    costs: the M x M stage (factorisations, KL) runs K times."""
+    costs: little - the slices share one M x M stage (the engine reuses the first slice's factorisations from the
+    parked arena, ``gpsa_step_io.reuse_mm``; slices of another shape, e.g. a remainder, redo it)."""
 
     def __init__(self, model, data_dict, K, quantum=4):
         """``quantum``: slice sizes are multiples of it (the last slice of a view takes the remainder): the LDS-DMA
@@ -78,9 +79,13 @@ class Microbatches:
         scale0 = model.kl_scale
         optimizer.zero_grad(set_to_none=True)
         total = None
+        self._stepno = getattr(self, "_stepno", 0) + 1
         try:
-            model.kl_scale = scale0 / self.K
+            # every slice runs on the same parameters: the engine keeps the M x M stage of the first slice (same plan,
+            # same parked arena) for the others; the KL terms are charged once, to the first slice
+            model.__dict__["_mm_epoch"] = (id(self), self._stepno)
             for k, (dd, vi, Ns) in enumerate(self.slices):
+                model.kl_scale = scale0 if k == 0 else 0.0
                 if noise is not None:
                     model.inject_noise(noise[k][0], noise[k][1], None)
                 out = model.forward({m: d["spatial_coords"] for m, d in dd.items()}, view_idx=vi, Ns=Ns, S=S)
@@ -90,6 +95,7 @@ class Microbatches:
                 del out, loss
         finally:
             model.kl_scale = scale0
+            model.__dict__["_mm_epoch"] = None
         if reducer is not None:
             reducer()
         optimizer.step()

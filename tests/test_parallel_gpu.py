@@ -82,6 +82,47 @@ def test_row_sharded_hip_step_equals_full_hip_step():
         assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
 
 
+def test_microbatched_hip_step_equals_full_hip_step():
+    """train.Microbatches through the real engine: 4 accumulating passes over row slices give the single pass's loss
+    and gradients, and slices 2..4 reuse the first slice's M x M stage from the parked arena (gpsa_step_io.reuse_mm)"""
+    import __graft_entry__ as ge
+    from spatial_alignment_amd import step_engine as SE
+    from spatial_alignment_amd.train import Microbatches
+
+    ge.build()
+    dev = torch.device("cuda:0")
+    dd, model = _problem(dev)
+    eG, eF = _noise()
+    loss1 = _grads(model, dd, eG, eF, 1.0)
+    want = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    class Probe(torch.optim.Optimizer):  # records the accumulated gradients at step(), changes nothing
+        def __init__(self, params):
+            super().__init__(params, {})
+            self.seen = None
+
+        def step(self):
+            self.seen = {id(p): p.grad.detach().clone() for g in self.param_groups for p in g["params"] if p.grad is not None}
+
+    K = 4
+    mb = Microbatches(model, dd, K)
+    noise = []
+    for k in range(K):
+        b = mb.bounds[k]["expression"]
+        rows = torch.cat([400 * v + torch.arange(lo, hi) for v, (lo, hi) in enumerate(b)])
+        noise.append(([e[:, lo:hi] for e, (lo, hi) in zip(eG, b)], {"expression": eF[:, rows]}))
+    opt = Probe(model.parameters())
+    for rep in range(2):  # (a second step: a new epoch recomputes the stage once, then reuses it again)
+        before = SE.STATS["mm_reused"]
+        total = mb.step(opt, S=3, noise=noise)
+        assert SE.STATS["mm_reused"] - before == K - 1
+        assert abs(float(total) - float(loss1)) <= 1e-5 * abs(float(loss1)), (float(total), float(loss1))
+        for k, p in model.named_parameters():
+            a, b = want[k], opt.seen[id(p)]
+            assert (a - b).norm() <= 1e-3 * max(float(a.norm()), 1e-6), (k, float((a - b).norm()), float(a.norm()))
+    assert model.kl_scale == 1.0 and model.__dict__.get("_mm_epoch") is None
+
+
 # ---------------------------------------------------------------------------------------------------------
 # output (L-axis) sharding: BASELINE configs 4 / 5's scheme (parallel.shard_outputs / setup_output_sharding)
 # ---------------------------------------------------------------------------------------------------------
