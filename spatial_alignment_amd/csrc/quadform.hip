@@ -2392,6 +2392,37 @@ static int tri_operand(int p_dtype, const void* P, int M, int L, const T** out, 
   *out = dst;
   return 0;
 }
+// [R][C] -> [R][Cp] (zero beyond C) and back: the LDS-DMA kernels of the M > 256 data GP want 16-byte aligned rows of
+// the [M, C] / [L, C] panels, i.e. a column count that is a multiple of 4; any other C (S * N is whatever the data
+// has) runs them on padded copies - two extra panels next to L of them
+__global__ void __launch_bounds__(256) pad_cols_kernel(const float* __restrict__ src, long long R, long long C, long long Cp,
+                                                       float* __restrict__ dst) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= R * Cp) return;
+  const long long r = i / Cp, c = i - r * Cp;
+  dst[i] = c < C ? src[r * C + c] : 0.f;
+}
+__global__ void __launch_bounds__(256) unpad_cols_kernel(const float* __restrict__ src, long long R, long long C, long long Cp,
+                                                         float* __restrict__ dst) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= R * C) return;
+  const long long r = i / C, c = i - r * C;
+  dst[i] = src[r * Cp + c];
+}
+static inline bool big_wants_pad(int M, long long C) {
+  static const bool off = [] { const char* e = getenv("GPSA_BIG_PANEL"); return e && e[0] == '0'; }();
+  return !off && M > 256 && C >= 128 && (C & 3) != 0;
+}
+static inline long long pad4(long long C) { return (C + 3) & ~3LL; }
+// carve ``floats`` (rounded to 64) off the END of a workspace; nullptr when it does not fit
+static inline float* ws_tail(void* ws, long long* bytes, long long floats) {
+  const long long need = ((floats + 63) & ~63LL) * 4;
+  if (*bytes < need) return nullptr;
+  *bytes -= need;
+  *bytes &= ~255LL;
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + *bytes);
+}
+
 // dalpha = 2 sum_l Omega_l (g_l o alpha) through big_accum_kernel; GPSA_EUNSUPPORTED: shape / workspace not covered
 static int big_accum_launch(int omega_dtype, const float* alpha, const void* Omega, const float* g, int M, long long C,
                             int L, float* dalpha, void* workspace, long long workspace_bytes, hipStream_t st) {
@@ -2441,7 +2472,13 @@ long long gpsa_quadform_workspace(int dtype, int M, long long C, int L) {
     const long long big = (long long)L * M * ((M + 15) / 16 * 16) * 4 + gpsa::big_accum_ws_bytes(M, C, L) + 512;
     if (big > r) r = big;
   }
-  return (r > mfma ? r : mfma) + 256;
+  r = (r > mfma ? r : mfma) + 256;
+  if (dtype == GPSA_F32 && gpsa::big_wants_pad(M, C)) {  // padded copies of alpha, g and of the result panel
+    const long long Cp = gpsa::pad4(C);
+    r = gpsa_quadform_workspace(dtype, M, Cp, L) + ((long long)M * Cp + (long long)L * Cp + (long long)(L > M ? L : M) * Cp) * 4 +
+        4096;
+  }
+  return r;
 }
 
 int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void* Omega, int M,
@@ -2465,6 +2502,21 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
       if (!full) return quad_sym_launch(MB, Ppk, (const float*)alpha, M, C, L, (float*)v, st);
       return panel_mfma_launch<MODE_QUAD>(MB, Ppk, (const float*)alpha, nullptr, M, C, L, (float*)v,
                                           nullptr, 1.f, nullptr, st);
+    }
+    if (big_wants_pad(M, C)) {  // unaligned column count: the same kernels on zero-padded copies
+      const long long Cp = pad4(C);
+      long long rest = workspace_bytes;
+      float* ap = ws_tail(workspace, &rest, (long long)M * Cp);
+      float* vp = ap ? ws_tail(workspace, &rest, (long long)L * Cp) : nullptr;
+      if (vp) {
+        pad_cols_kernel<<<(unsigned)cdiv((long long)M * Cp, 256), 256, 0, st>>>((const float*)alpha, M, C, Cp, ap);
+        GPSA_LAUNCH_CHECK();
+        const int rc = gpsa_quadform_fwd(dtype, omega_dtype, ap, Omega, M, Cp, L, vp, workspace, rest, stream);
+        if (rc) return rc;
+        unpad_cols_kernel<<<(unsigned)cdiv((long long)L * C, 256), 256, 0, st>>>(vp, L, C, Cp, (float*)v);
+        GPSA_LAUNCH_CHECK();
+        return 0;
+      }
     }
     if (big_panel_ok(M, C, L, alpha) && (omega_dtype == GPSA_F64 || omega_dtype == GPSA_F32)) {
       // block-triangular LDS-DMA form, closed in the kernel: nothing of size M x C per output is written
@@ -2517,6 +2569,9 @@ long long gpsa_quadform_keep_f32_workspace(int M, int L) {
 
 long long gpsa_quadform_keep_f32_bytes(int M, long long C, int L) {
   if (M < 1 || C < 1 || L < 1) return 0;
+  // (M > 256 with a column count that is not a multiple of 4: the kept buffer's rows would not be 16-byte aligned;
+  //  the caller recomputes instead - 0 = "cannot keep" - through the kernels' padded-copy path)
+  if (!keep_mfma_path(M) && gpsa::big_wants_pad(M, C)) return 0;
   if (keep_mfma_path(M)) {
     const int MB = gpsa::mfma_mb_for(M);
     const long long wgcols = 64LL * gpsa::panel_nct_for(MB);
@@ -2636,6 +2691,23 @@ int gpsa_quadform_bwd_alpha(int dtype, int omega_dtype, const void* alpha, const
   hipStream_t st = as_stream(stream);
   if (dtype == GPSA_F32) {
     const int MB = mfma_mb_for(M);
+    if (big_wants_pad(M, C) && !(MB && MB <= MB_MAX_ACCUM && !force_generic())) {
+      const long long Cp = pad4(C);
+      long long rest = workspace_bytes;
+      float* ap = ws_tail(workspace, &rest, (long long)M * Cp);
+      float* gp = ap ? ws_tail(workspace, &rest, (long long)L * Cp) : nullptr;
+      float* dp = gp ? ws_tail(workspace, &rest, (long long)M * Cp) : nullptr;
+      if (dp) {
+        pad_cols_kernel<<<(unsigned)cdiv((long long)M * Cp, 256), 256, 0, st>>>((const float*)alpha, M, C, Cp, ap);
+        pad_cols_kernel<<<(unsigned)cdiv((long long)L * Cp, 256), 256, 0, st>>>((const float*)g, L, C, Cp, gp);
+        GPSA_LAUNCH_CHECK();
+        const int rc = gpsa_quadform_bwd_alpha(dtype, omega_dtype, ap, Omega, gp, M, Cp, L, dp, workspace, rest, stream);
+        if (rc) return rc;
+        unpad_cols_kernel<<<(unsigned)cdiv((long long)M * C, 256), 256, 0, st>>>(dp, M, C, Cp, (float*)dalpha);
+        GPSA_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     // 256 < M <= 512: the register-resident kernel stays ahead of the LDS-DMA one (BASELINE config 4: 319 vs 342 ms);
     // GPSA_ACCUM_PANEL=0 takes the LDS-DMA kernel there too (tests, A/B)
     static const bool panel_off = [] { const char* e = getenv("GPSA_ACCUM_PANEL"); return e && e[0] == '0'; }();
@@ -2718,6 +2790,18 @@ int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const v
                               (float*)workspace, st);
     }
     if (out_dtype != dtype) return GPSA_EUNSUPPORTED;
+    if (big_wants_pad(M, C)) {  // unaligned column count: the LDS-DMA Gram kernel on zero-padded copies
+      const long long Cp = pad4(C);
+      long long rest = workspace_bytes;
+      float* ap = ws_tail(workspace, &rest, (long long)M * Cp);
+      float* gp = ap ? ws_tail(workspace, &rest, (long long)L * Cp) : nullptr;
+      if (gp) {
+        pad_cols_kernel<<<(unsigned)cdiv((long long)M * Cp, 256), 256, 0, st>>>((const float*)alpha, M, C, Cp, ap);
+        pad_cols_kernel<<<(unsigned)cdiv((long long)L * Cp, 256), 256, 0, st>>>((const float*)g, L, C, Cp, gp);
+        GPSA_LAUNCH_CHECK();
+        return generic_quadform_bwd_omega<float>(ap, gp, M, Cp, L, (float*)dOmega, workspace, rest, st);
+      }
+    }
     return generic_quadform_bwd_omega<float>((const float*)alpha, (const float*)g, M, C, L,
                                              (float*)dOmega, workspace, workspace_bytes, st);
   }

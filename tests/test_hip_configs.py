@@ -113,6 +113,16 @@ def test_config5_shape_two_views_m1000_matches_oracle():
         assert e < 5e-4, (k, e, gerr)  # (round 2: 5e-3, for grad/Gtilde's 4e-3 with the rounded projection)
 
 
+def test_large_m_with_a_column_count_that_is_not_a_multiple_of_4():
+    """M > 256 and S * N = 338: the LDS-DMA kernels want 16-byte aligned panel rows, real data has whatever spot
+    count it has - the step runs them on zero-padded copies (and keeps no products); same bars as the aligned shapes"""
+    errs, gerr, _, _ = _step_vs_oracle(side=13, views=2, outputs=5, M=300, S=1, fixed=None, seed=60)
+    print("M=300, C=338:", {k: f"{v:.1e}" for k, v in errs.items()}, {k: f"{v:.1e}" for k, v in gerr.items()})
+    assert errs["G_means"] < 1e-4 and errs["G_samples"] < 1e-4 and errs["F_samples"] < 1e-4 and errs["loss"] < 1e-4
+    for k, e in gerr.items():
+        assert e < 5e-4, (k, e, gerr)
+
+
 def test_config3_full_size_properties():
     """BASELINE config 3 at full size: 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2
     warp / RBF data, M = 200, S = 5.  Finite outputs of the right shapes, the LMC mixing is exactly
