@@ -328,6 +328,11 @@ int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, lon
                            const float* var_u, const float* Kbar, const float* X2, const float* d, double s,
                            double* dZ, double* dX, double* dparams, void* workspace, long long workspace_bytes,
                            void* stream);
+/* gpsa_whiten_f64 on an fp64 panel with the result stored twice from the same accumulators: unrounded (alpha64) and
+ * rounded to fp32 (alpha32: what the matrix-core contractions read) - the exact inducing-point gradient of the data
+ * GP keeps both (gpsa_step_desc.exact_inducing_grad; autograd of vgpsa.py:177-180, 409) */
+int gpsa_whiten_f64_dual(const double* Kinv, const double* Kuf, int M, long long C, double* alpha64, float* alpha32,
+                         double* q, void* workspace, long long workspace_bytes, void* stream);
 /* gpsa_whiten_f64 on an fp32 panel with gpsa_col_axpy fused into its store:
  *   out[m,c] = (Kinv X)[m,c] + s * d[c] * X2[m,c]      (X, X2, out [M,C] fp32; d [C] fp32; fp64 arithmetic)
  * the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) in one pass. */

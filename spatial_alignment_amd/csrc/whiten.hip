@@ -61,6 +61,7 @@ struct WhitenAxpy {
   const float* X2;
   const float* d;
   float s;
+  float* out32 = nullptr;  // a second, fp32-rounded copy of the result (the exact inducing-point gradient keeps both)
 };
 
 // RS (row split, resident right-hand side only): a workgroup covers 32 columns instead of 64 and each pair of
@@ -182,6 +183,7 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
       if (okc && row < M) {
         if (ax.X2 != nullptr) y += axd * (double)ax.X2[(long long)row * C + c];  // uniform branch
         alpha[(long long)row * C + c] = (TO)y;
+        if (ax.out32 != nullptr) ax.out32[(long long)row * C + c] = (float)y;  // uniform branch
       }
     }
   }
@@ -300,6 +302,27 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
   if (alpha_dtype == GPSA_F32)
     return whiten_launch<float, float>(MB, Apk, (const float*)Kuf, M, C, (float*)alpha, q, st);
   return whiten_launch<float, double>(MB, Apk, (const float*)Kuf, M, C, (double*)alpha, q, st);
+}
+
+/* alpha = Kinv Kuf (fp64 panel) stored TWICE from the same accumulators: unrounded (alpha64) and rounded to fp32
+ * (alpha32, what the matrix-core contractions read); q as gpsa_whiten_f64.  gpsa_step_desc.exact_inducing_grad. */
+int gpsa_whiten_f64_dual(const double* Kinv, const double* Kuf, int M, long long C, double* alpha64, float* alpha32,
+                         double* q, void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || Kuf == nullptr || alpha64 == nullptr || alpha32 == nullptr) return GPSA_EINVAL;
+  const int MB = whiten_mb_for(M);
+  if (MB == 0) return GPSA_EUNSUPPORTED;
+  if (workspace_bytes < gpsa_whiten_workspace(M)) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* Apk = (double*)workspace;
+  const long long tot = (long long)MB * 4 * MB * 64;
+  if (Kinv != nullptr) {
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+    GPSA_LAUNCH_CHECK();
+  }
+  WhitenAxpy ax{nullptr, nullptr, 0.f};
+  ax.out32 = alpha32;
+  return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha64, q, st, 1, 0, ax);
 }
 
 /* gamma = Kinv X (fp32 panel, fp64 arithmetic) with the column-scaled update fused into the store:

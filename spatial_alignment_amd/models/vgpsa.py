@@ -117,7 +117,8 @@ class VariationalGPSA(GPSA):
         self.keep_products = True
         self.keep_budget_gb = None  # HBM for those products: None = what the device can still give (step_engine.py)
         # the data GP's inducing-point gradient from the UNROUNDED projection (gpsa_step_desc.exact_inducing_grad):
-        # True / False, or None = on when its one extra M x M x C fp64 product is under ~1 % of the step (L >= 128).
+        # True / False, or None = on when its one extra M x M x C fp64 product is under ~2 % of the step (L >= 128;
+        # 3.8 % at the 50 outputs of the headline configuration).
         # Off, grad Gtilde carries ~1e-3 relative error at M >= 200 on ill-conditioned K_uu (every other gradient
         # and every output are unaffected): its K_uu and K_uf shares cancel to 1e-4 .. 1e-5 of their size.
         self.exact_inducing_grad = None
