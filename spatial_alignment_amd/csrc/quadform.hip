@@ -361,6 +361,8 @@ struct GramBigArgs {
   float* part;         // [L][nsplit][M][M]   (lower blocks written)
   int M, L, nsplit, nblk;
   long long C, Cpad;
+  int lb;  // > 0: 1-D grid, workgroups that share an XCD (ids equal mod 8) come in runs of ``lb`` outputs of ONE
+           // (block pair, column split): they read the same rows of alpha at about the same time, from that XCD's L2
 };
 __global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
                                 float* __restrict__ gpad);
@@ -376,6 +378,11 @@ struct ProdBigArgs {
 __global__ void prod_big_kernel(ProdBigArgs a);
 template <typename TO>
 __global__ void gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit, TO* __restrict__ out);
+// outputs per run of same-XCD workgroups in the large-M kernels (GPSA_BIG_LB; 0 = the plain 3-D / 2-D grids)
+static inline int big_remap_lb() {
+  static const int v = [] { const char* e = getenv("GPSA_BIG_LB"); return e ? atoi(e) : 16; }();
+  return v;
+}
 static inline bool gram_big_off() {
   static const bool v = [] { const char* e = getenv("GPSA_GRAM_BIG"); return e && e[0] == '0'; }();
   return v;
@@ -402,8 +409,15 @@ int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, i
       float* gpad = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_b);
       pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, gpad);
       GPSA_LAUNCH_CHECK();
-      GramBigArgs a{alpha, gpad, reinterpret_cast<float*>(ws), M, L, (int)ns, nblk, C, Cpad};
-      gram_big_kernel<<<dim3((unsigned)pairs, (unsigned)ns, (unsigned)L), 256, 0, st>>>(a);
+      GramBigArgs a{alpha, gpad, reinterpret_cast<float*>(ws), M, L, (int)ns, nblk, C, Cpad, 0};
+      const int lb = big_remap_lb();
+      const long long combos = (long long)pairs * ns * cdiv(L, lb > 0 ? lb : 1);
+      if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
+        a.lb = lb;
+        gram_big_kernel<<<(unsigned)(8 * lb * cdiv(combos, 8)), 256, 0, st>>>(a);
+      } else {
+        gram_big_kernel<<<dim3((unsigned)pairs, (unsigned)ns, (unsigned)L), 256, 0, st>>>(a);
+      }
       GPSA_LAUNCH_CHECK();
       gram_big_reduce_kernel<float><<<dim3((unsigned)cdiv((long long)M * M, 256), (unsigned)L), 256, 0, st>>>(
           a.part, M, (int)ns, dOmega);
@@ -528,13 +542,30 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
+  // workgroup -> (block pair, column split, output)
+  int t, l, sp;
+  if (a.lb > 0) {
+    const long long id = blockIdx.x, slot = id >> 3;
+    const int npair = a.nblk * (a.nblk + 1) / 2, units = npair * a.nsplit, nlb = (a.L + a.lb - 1) / a.lb;
+    const long long q = (slot / a.lb) * 8 + (id & 7);  // (unit, block of outputs), dealt round-robin to the XCDs
+    if (q >= (long long)units * nlb) return;
+    const int unit = (int)(q % units);
+    l = (int)(q / units) * a.lb + (int)(slot % a.lb);
+    if (l >= a.L) return;
+    t = unit % npair;
+    sp = unit / npair;
+  } else {
+    t = blockIdx.x;
+    l = blockIdx.z;
+    sp = blockIdx.y;
+  }
   // block pair t -> (bi, bj), bj <= bi, row-major over the lower triangle
-  int bi = 0, t = blockIdx.x;
+  int bi = 0;
   while (t > bi) {
     t -= bi + 1;
     ++bi;
   }
-  const int bj = t, l = blockIdx.z, sp = blockIdx.y;
+  const int bj = t;
   const int M = a.M;
   const long long C = a.C;
   const long long nch = (C + 15) / 16;
@@ -753,6 +784,8 @@ struct BigQuadArgs {
   float* W;        // STORE: [L][M][C]
   int M, Mp, L;
   long long C;
+  int lb;  // > 0: 1-D grid; same-XCD workgroups come in runs of ``lb`` outputs of ONE column tile (they share its
+           // alpha tile in that XCD's L2; each U_l / Omega_l is then shared by the few column tiles the XCD works on)
 };
 
 // stage K chunk CH of row block RB (rows of P) and of the column tile (rows CH*16.. of X) into ring slot BUF
@@ -791,9 +824,23 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
-  const int M = a.M, Mp = a.Mp, l = blockIdx.y;
+  const int M = a.M, Mp = a.Mp;
   const long long C = a.C;
-  const long long c0 = (long long)blockIdx.x * 128;
+  int l;
+  long long ctile;
+  if (a.lb > 0) {
+    const long long id = blockIdx.x, slot = id >> 3, ctiles = (C + 127) / 128;
+    const int nlb = (a.L + a.lb - 1) / a.lb;
+    const long long q = (slot / a.lb) * 8 + (id & 7);  // (column tile, block of outputs)
+    if (q >= ctiles * nlb) return;
+    ctile = q % ctiles;
+    l = (int)(q / ctiles) * a.lb + (int)(slot % a.lb);
+    if (l >= a.L) return;
+  } else {
+    l = blockIdx.y;
+    ctile = blockIdx.x;
+  }
+  const long long c0 = ctile * 128;
   const float* Pl = a.P + (long long)l * M * Mp;
   const int nch = Mp / 16, nrb = (M + 127) / 128;
   f32x4 acc[4][4];
@@ -916,12 +963,16 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
   const int M = a.M, Mp = a.Mp;
   const long long C = a.C;
   // workgroup id -> (row block, column tile, split of the outputs): ids equal mod 8 share an XCD
+  // same-XCD workgroups (slot order): row block fastest, then the split of the outputs, then the column tile: the
+  // 64 that run together on an XCD cover all row blocks x all splits of 64 / (nrb nsplit) column tiles - few alpha
+  // tiles (they stay in that XCD's L2 across the outputs), every Omega_l[row block] shared by those column tiles
   const long long id = blockIdx.x, slot = id >> 3, ct8 = (a.ctiles + 7) / 8;
   const int rb = (int)(slot % a.nrb);
   const long long t = slot / a.nrb;
-  const long long ct = (t % ct8) * 8 + (id & 7);
-  const int sp = (int)(t / ct8);
+  const int sp = (int)(t % a.nsplit);
+  const long long ct = (t / a.nsplit) * 8 + (id & 7);
   if (ct >= a.ctiles) return;
+  (void)ct8;
   const long long c0 = ct * 128;
   const int l0 = (int)((long long)sp * a.L / a.nsplit), l1 = (int)((long long)(sp + 1) * a.L / a.nsplit);
   const int nch = Mp / 16;
@@ -1021,6 +1072,8 @@ static inline bool big_panel_ok(int M, long long C, int L, const void* alpha) {
 // splits of the outputs for big_accum_kernel: the fewest (<= 4) that fill the rounds of workgroups (2 per CU) to
 // >= 90 %, else the fullest
 static inline int big_accum_nsplit(int M, long long C, int L) {
+  static const int forced = [] { const char* e = getenv("GPSA_BA_NSPLIT"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return (forced <= L) ? forced : 1;
   const long long wgs = cdiv(M, 128) * cdiv(C, 128), slots = 2LL * num_cus();
   int best = 1;
   double beff = 0.0;
@@ -2529,8 +2582,15 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
         else
           pad_k_tri_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
         GPSA_LAUNCH_CHECK();
-        BigQuadArgs qa{Pp, (const float*)alpha, (float*)v, nullptr, M, Mp, L, C};
-        big_quad_kernel<true, false, 3><<<dim3((unsigned)cdiv(C, 128), (unsigned)L), 256, 0, st>>>(qa);
+        BigQuadArgs qa{Pp, (const float*)alpha, (float*)v, nullptr, M, Mp, L, C, 0};
+        const int lb = big_remap_lb();
+        const long long combos = cdiv(C, 128) * cdiv(L, lb > 0 ? lb : 1);
+        if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
+          qa.lb = lb;
+          big_quad_kernel<true, false, 3><<<(unsigned)(8 * lb * cdiv(combos, 8)), 256, 0, st>>>(qa);
+        } else {
+          big_quad_kernel<true, false, 3><<<dim3((unsigned)cdiv(C, 128), (unsigned)L), 256, 0, st>>>(qa);
+        }
         GPSA_LAUNCH_CHECK();
         return 0;
       }
@@ -2614,8 +2674,15 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
       GPSA_LAUNCH_CHECK();
       static const bool old_pb = [] { const char* e = getenv("GPSA_PROD_BIG"); return e && e[0] == '1'; }();
       if (!old_pb && big_panel_ok(M, C, L, alpha)) {  // product, kept copy and the closing column sums in one kernel
-        BigQuadArgs qa{Pp, alpha, v, W, M, Mp, L, C};
-        big_quad_kernel<false, true, 3><<<dim3((unsigned)ctiles, (unsigned)L), 256, 0, st>>>(qa);
+        BigQuadArgs qa{Pp, alpha, v, W, M, Mp, L, C, 0};
+        const int lb = big_remap_lb();
+        const long long combos = ctiles * cdiv(L, lb > 0 ? lb : 1);
+        if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
+          qa.lb = lb;
+          big_quad_kernel<false, true, 3><<<(unsigned)(8 * lb * cdiv(combos, 8)), 256, 0, st>>>(qa);
+        } else {
+          big_quad_kernel<false, true, 3><<<dim3((unsigned)ctiles, (unsigned)L), 256, 0, st>>>(qa);
+        }
         GPSA_LAUNCH_CHECK();
         return 0;
       }

@@ -150,7 +150,10 @@ if "gramw" in what:  # the warp layer's Gram shape: L = D = 2 outputs, one view'
         print(f"quadform_bwd_omega L=2 C={C}: {timeit(lambda: o.quadform_bwd_omega(a, g, out_dtype=torch.float64), n=20, warm=3):.1f} us", flush=True)
 
 if "big" in what:  # the large-M contraction kernels (BASELINE configs 4 / 5 shapes, fewer outputs)
-    for M, C, L in [(1000, 25600, 64), (500, 40320, 96)]:
+    shapes = [(1000, 25600, 64), (500, 40320, 96)]
+    if "big5" in what:  # alpha (400 MB) beyond the Infinity Cache, as at BASELINE config 5
+        shapes = [(1000, 102400, 48)]
+    for M, C, L in shapes:
         a = torch.randn(M, C, device=dev)
         A = torch.randn(L, M, M, device=dev, dtype=torch.float64) / M ** 0.5
         Om = A @ A.transpose(1, 2)
