@@ -583,19 +583,28 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
   // (they meet g == 0: g is zero-padded to whole chunks).  The chunk's 16 values of g ride along as a fifth
   // operation of every wave (all four write the same 64 bytes): a counted vmcnt(5) then means "everything but the
   // newest stage has landed".
+  // (row pointers are fixed per piece: only the column offset moves with the chunk - recomputing row * C per stage
+  //  was a dozen 64-bit multiply-adds per iteration, issued while the matrix pipe stood still)
+  const float* rowp[4];
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int piece = pc * 4 + w;
+    int row = ((piece < 8) ? bi * 128 + piece * 16 : bj * 128 + (piece - 8) * 16) + j;
+    row = row < M ? row : M - 1;
+    rowp[pc] = a.alpha + (long long)row * C;
+  }
+  const unsigned glds0 = __builtin_amdgcn_readfirstlane(lds_addr(&lds[0][0]));
+  const unsigned gsg0 = __builtin_amdgcn_readfirstlane(lds_addr(&sg[0][0]));
 #define GPSA_GB_STAGE(CH, BUF)                                                                \
   {                                                                                           \
     long long col__ = (long long)(CH) * 16 + kq * 4;                                          \
     col__ = col__ < C - 4 ? col__ : C - 4;                                                    \
-    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) {                                        \
-      const int piece = pc * 4 + w;                                                           \
-      int row__ = ((piece < 8) ? bi * 128 + piece * 16 : bj * 128 + (piece - 8) * 16) + j;    \
-      row__ = row__ < M ? row__ : M - 1;                                                      \
-      glds16(a.alpha + (long long)row__ * C + col__,                                          \
-             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));               \
-    }                                                                                         \
-    if (lane < 4)                                                                             \
-      glds16(gl + (long long)(CH) * 16 + lane * 4, __builtin_amdgcn_readfirstlane(lds_addr(&sg[BUF][0]))); \
+    const unsigned d__ = glds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 1024;       \
+    glds16(rowp[0] + col__, d__);                                                             \
+    glds16(rowp[1] + col__, d__ + 4 * 1024);                                                  \
+    glds16(rowp[2] + col__, d__ + 8 * 1024);                                                  \
+    glds16(rowp[3] + col__, d__ + 12 * 1024);                                                 \
+    if (lane < 4) glds16(gl + (long long)(CH) * 16 + lane * 4, gsg0 + (unsigned)(BUF) * 64);  \
   }
   if (ch0 < ch1) {
     GPSA_GB_STAGE(ch0, 0)
@@ -788,28 +797,6 @@ struct BigQuadArgs {
            // alpha tile in that XCD's L2; each U_l / Omega_l is then shared by the few column tiles the XCD works on)
 };
 
-// stage K chunk CH of row block RB (rows of P) and of the column tile (rows CH*16.. of X) into ring slot BUF
-#define GPSA_BIG_STAGE(PL, RB, CH, BUF)                                                       \
-  {                                                                                           \
-    const int k0__ = (CH) * 16;                                                               \
-    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc) {                                        \
-      const int piece = pc * 4 + w;                                                           \
-      const float* src__;                                                                     \
-      if (piece < 8) {                                                                        \
-        int row__ = (RB) * 128 + piece * 16 + j;                                              \
-        row__ = row__ < M ? row__ : M - 1;                                                    \
-        src__ = (PL) + (long long)row__ * Mp + k0__ + kq * 4;                                 \
-      } else {                                                                                \
-        const int grp__ = (piece - 8) >> 2, F__ = (piece - 8) & 3;                            \
-        int krow__ = k0__ + kq * 4 + F__;                                                     \
-        krow__ = krow__ < M ? krow__ : M - 1;                                                 \
-        long long col__ = c0 + grp__ * 64 + j * 4;                                            \
-        col__ = col__ < C - 4 ? col__ : C - 4;                                                \
-        src__ = a.X + (long long)krow__ * C + col__;                                          \
-      }                                                                                       \
-      glds16(src__, __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));       \
-    }                                                                                         \
-  }
 #define GPSA_BIG_MMA(F, BF)                                                                   \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
     acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, BF.x, acc[i][0], 0, 0, 0);      \
@@ -862,19 +849,60 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
   const bool col_ok = colc < C;  // C % 4 == 0: the four columns are in or out together
   colc = colc < C - 4 ? colc : C - 4;
   // stage cursor: two chunks ahead of the compute cursor; past the end it keeps re-staging the last chunk
+  // ... as pointers advanced by constants (see big_accum_kernel): the wave's two row groups of P (+16 floats per
+  // chunk; a new row block: recomputed, once per ~8-63 chunks) and the X rows k0 + 4 kq + w of the two column groups
+  // (+16 C floats per chunk; a new row block restarts them at its first chunk)
   int s_rb = 0, s_ch = 0;
+  long long xc0 = c0 + j * 4, xc1 = c0 + 64 + j * 4;
+  xc0 = xc0 < C - 4 ? xc0 : C - 4;
+  xc1 = xc1 < C - 4 ? xc1 : C - 4;
+  const float* const xtop0 = a.X + (long long)(kq * 4 + w) * C + xc0;  // chunk 0
+  const float* const xtop1 = a.X + (long long)(kq * 4 + w) * C + xc1;
+  const bool last_oob = (nch - 1) * 16 + kq * 4 + w >= M;  // the last chunk may reach beyond row M - 1 of X
+  const float* const xclamp0 = a.X + (long long)(M - 1) * C + xc0;
+  const float* const xclamp1 = a.X + (long long)(M - 1) * C + xc1;
+  const long long xstep = 16 * C;
+  const float* sx0 = xtop0;
+  const float* sx1 = xtop1;
+  const float *sp0, *sp1;
+#define GPSA_BQ_ROWS()                                                              \
+  {                                                                                 \
+    int r0__ = s_rb * 128 + w * 16 + j, r1__ = s_rb * 128 + (4 + w) * 16 + j;       \
+    r0__ = r0__ < M ? r0__ : M - 1;                                                 \
+    r1__ = r1__ < M ? r1__ : M - 1;                                                 \
+    sp0 = Pl + (long long)r0__ * Mp + s_ch * 16 + kq * 4;                           \
+    sp1 = Pl + (long long)r1__ * Mp + s_ch * 16 + kq * 4;                           \
+  }
+  GPSA_BQ_ROWS()
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&lds[0][0]));
 #define GPSA_BQ_ADVANCE()                                \
   {                                                      \
     if (s_ch + 1 < nch) {                                \
       ++s_ch;                                            \
+      sp0 += 16;                                         \
+      sp1 += 16;                                         \
+      sx0 += xstep;                                      \
+      sx1 += xstep;                                      \
     } else if (s_rb + 1 < nrb) {                         \
       ++s_rb;                                            \
       s_ch = TRI ? s_rb * 8 : 0;                         \
+      GPSA_BQ_ROWS()                                     \
+      sx0 = xtop0 + (long long)s_ch * xstep;             \
+      sx1 = xtop1 + (long long)s_ch * xstep;             \
     }                                                    \
+  }
+#define GPSA_BQ_STAGE(BUF)                                                                    \
+  {                                                                                           \
+    const unsigned d__ = lds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 1024;        \
+    const bool oob__ = last_oob && s_ch == nch - 1;                                           \
+    glds16(sp0, d__);                                                                         \
+    glds16(sp1, d__ + 4 * 1024);                                                              \
+    glds16(oob__ ? xclamp0 : sx0, d__ + 8 * 1024);                                            \
+    glds16(oob__ ? xclamp1 : sx1, d__ + 12 * 1024);                                           \
   }
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) {
-    GPSA_BIG_STAGE(Pl, s_rb, s_ch, s0)
+    GPSA_BQ_STAGE(s0)
     GPSA_BQ_ADVANCE()
   }
   GPSA_DMA_WAIT(4 * (NS - 2));
@@ -882,7 +910,7 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
   int buf = 0;
   for (int rb = 0; rb < nrb; ++rb) {
     for (int ch = TRI ? rb * 8 : 0; ch < nch; ++ch) {
-      GPSA_BIG_STAGE(Pl, s_rb, s_ch, buf == 0 ? NS - 1 : buf - 1)
+      GPSA_BQ_STAGE(buf == 0 ? NS - 1 : buf - 1)
       GPSA_BQ_ADVANCE()
       const float* base = &lds[buf][lane * 4];
       float4 av[4], bv[4];
@@ -929,6 +957,8 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
       for (int k = 0; k < 4; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   GPSA_DMA_DRAIN();
+#undef GPSA_BQ_STAGE
+#undef GPSA_BQ_ROWS
 #undef GPSA_BQ_ADVANCE
   // column sums: over the four lane quarters (rows), then over the two waves that share the columns
 #pragma unroll
@@ -984,24 +1014,63 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
   long long colc = c0 + wc * 64 + j * 4;
   const bool col_ok = colc < C;
   colc = colc < C - 4 ? colc : C - 4;
+  // Stage cursor (two chunks ahead of the compute cursor) as POINTERS advanced by constants: the wave's four pieces
+  // are two row groups of Omega_l[row block] (16 rows each, k contiguous: +16 floats per chunk, +M Mp per output)
+  // and the X rows k0 + 4 kq + w of the two 64-column groups (+16 C floats per chunk, back to the top per output).
+  // Recomputing them from (l, chunk) cost ~60 64-bit multiply-adds per iteration, issued while the matrix pipe of
+  // BOTH resident waves stood still (the two workgroups of a CU run this loop in phase).
   int s_l = l0, s_ch = 0;
-#define GPSA_BA_ADVANCE()                                \
-  {                                                      \
-    if (s_ch + 1 < nch) {                                \
-      ++s_ch;                                            \
-    } else if (s_l + 1 < l1) {                           \
-      ++s_l;                                             \
-      s_ch = 0;                                          \
-    }                                                    \
-  }
+  int prow0 = rb * 128 + w * 16 + j, prow1 = rb * 128 + (4 + w) * 16 + j;
+  prow0 = prow0 < M ? prow0 : M - 1;
+  prow1 = prow1 < M ? prow1 : M - 1;
+  const float* sp0 = a.P + (long long)l0 * M * Mp + (long long)prow0 * Mp + kq * 4;
+  const float* sp1 = a.P + (long long)l0 * M * Mp + (long long)prow1 * Mp + kq * 4;
+  long long xc0 = c0 + j * 4, xc1 = c0 + 64 + j * 4;
+  xc0 = xc0 < C - 4 ? xc0 : C - 4;
+  xc1 = xc1 < C - 4 ? xc1 : C - 4;
+  const float* const xtop0 = a.X + (long long)(kq * 4 + w) * C + xc0;  // chunk 0
+  const float* const xtop1 = a.X + (long long)(kq * 4 + w) * C + xc1;
+  // the last chunk may reach beyond row M - 1 of X (Omega is zero there): those lanes read row M - 1 instead
+  const bool last_oob = (nch - 1) * 16 + kq * 4 + w >= M;
+  const float* const xclamp0 = a.X + (long long)(M - 1) * C + xc0;
+  const float* const xclamp1 = a.X + (long long)(M - 1) * C + xc1;
+  const float* sx0 = xtop0;
+  const float* sx1 = xtop1;
+  const long long xstep = 16 * C, pnext = (long long)M * Mp - (long long)(nch - 1) * 16;
   // the stage's g rides along as a fifth operation of every wave (all four write the same 512 bytes; a load the
   // compiler sees would make it drain the ring - vmcnt(0) - in every iteration): vmcnt(5) = "all but the newest stage"
   long long gcol = c0 + (lane & 31) * 4;
   gcol = gcol < C - 4 ? gcol : C - 4;
-#define GPSA_BA_STAGE(BUF)                                                                                  \
-  {                                                                                                         \
-    GPSA_BIG_STAGE(a.P + (long long)s_l * M * Mp, rb, s_ch, BUF)                                            \
-    if (lane < 32) glds16(a.g + (long long)s_l * C + gcol, __builtin_amdgcn_readfirstlane(lds_addr(&sg[BUF][0]))); \
+  const float* sgp = a.g + (long long)l0 * C + gcol;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&lds[0][0]));
+  const unsigned sg0 = __builtin_amdgcn_readfirstlane(lds_addr(&sg[0][0]));
+#define GPSA_BA_ADVANCE()                                \
+  {                                                      \
+    if (s_ch + 1 < nch) {                                \
+      ++s_ch;                                            \
+      sp0 += 16;                                         \
+      sp1 += 16;                                         \
+      sx0 += xstep;                                      \
+      sx1 += xstep;                                      \
+    } else if (s_l + 1 < l1) {                           \
+      ++s_l;                                             \
+      s_ch = 0;                                          \
+      sp0 += pnext;                                      \
+      sp1 += pnext;                                      \
+      sx0 = xtop0;                                       \
+      sx1 = xtop1;                                       \
+      sgp += C;                                          \
+    }                                                    \
+  }
+#define GPSA_BA_STAGE(BUF)                                                                    \
+  {                                                                                           \
+    const unsigned d__ = lds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 1024;        \
+    const bool oob__ = last_oob && s_ch == nch - 1;                                           \
+    glds16(sp0, d__);                                                                         \
+    glds16(sp1, d__ + 4 * 1024);                                                              \
+    glds16(oob__ ? xclamp0 : sx0, d__ + 8 * 1024);                                            \
+    glds16(oob__ ? xclamp1 : sx1, d__ + 12 * 1024);                                           \
+    if (lane < 32) glds16(sgp, sg0 + (unsigned)(BUF) * 512);                                  \
   }
   if (l0 < l1) {
 #pragma unroll
@@ -1050,7 +1119,6 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
       }
     }
 }
-#undef GPSA_BIG_STAGE
 #undef GPSA_BIG_MMA
 
 // out[e] = sum_s part[s][e]  (fixed order), four floats per thread
