@@ -113,7 +113,7 @@ class VariationalGPSA(GPSA):
         self.use_step_engine = True
         # training forwards keep the data GPs' products Omega_l alpha for the backward (L M C 4 bytes of HBM,
         # one product less per step); False: recompute them in the backward (the memory-lean path, also taken
-        # by itself when M > 256 or the products exceed GPSA_KEEP_GB)
+        # by itself when the products exceed the keep budget below)
         self.keep_products = True
         self.keep_budget_gb = None  # HBM for those products: None = what the device can still give (step_engine.py)
         # the data GP's inducing-point gradient from the UNROUNDED projection (gpsa_step_desc.exact_inducing_grad):
