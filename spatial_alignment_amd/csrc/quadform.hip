@@ -1519,6 +1519,22 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   ord.get(0, stile_, sa_, sb_);
   int sl = sa_;
   bool sdone = false;
+#define GPSA_STAGE_PIECE(BUF, PC)                                                              \
+  {                                                                                            \
+    const float* src__ = Ppk + ((long long)sl * MB + skc) * CHUNK + lane * 4;                  \
+    const int piece = (PC) * 4 + w;                                                            \
+    glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                        \
+           __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                  \
+  }
+#define GPSA_STAGE_ADVANCE()                                                                   \
+  {                                                                                            \
+    if (!sdone) {                                                                              \
+      if (skc + 1 < MB) ++skc;                                                                 \
+      else if (sl < sb_) { skc = 0; ++sl; }                                                    \
+      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl = sa_; skc = 0; } \
+      else sdone = true;                                                                       \
+    }                                                                                          \
+  }
 #define GPSA_STAGE_NEXT(BUF)                                                                   \
   {                                                                                            \
     GPSA_STAGE((long long)sl * MB + skc, BUF)                                                  \
@@ -1605,7 +1621,6 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
       }
 #pragma unroll
       for (int kc = 0; kc < MB; ++kc) {
-        GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
         float bv[NCT][4];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -1621,6 +1636,15 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
         for (int rt = 0; rt < MB; ++rt) {
           const float4 a4 = a_nxt;
           if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
+          // the next-but-one chunk is staged from INSIDE the MFMA stream (its slot was free since the barrier that
+          // ended the previous chunk): the cursor arithmetic and the LDS-DMA issues go into the shadows of the
+          // matrix instructions instead of standing in front of them with the pipe idle (one wave per SIMD here)
+          if (MB >= NPW + 3) {
+            if (rt >= 1 && rt <= NPW) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, rt - 1)
+            if (rt == NPW + 1) GPSA_STAGE_ADVANCE()
+          } else if (rt == 0) {
+            GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
+          }
           __builtin_amdgcn_sched_barrier(0);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -1672,6 +1696,8 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   }
   GPSA_DMA_DRAIN();  // nothing may still be writing this workgroup's LDS when it exits
 #undef GPSA_STAGE
+#undef GPSA_STAGE_PIECE
+#undef GPSA_STAGE_ADVANCE
 #undef GPSA_STAGE_NEXT
 #undef GPSA_FLUSH
 }
@@ -1983,25 +2009,25 @@ __device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS + GR_G], f
       P_[(long long)(P.rr[W][s] * 16 + kq * 4 + r) * MP + P.cc[W][s] * 16 + j] = acc[s][r];
 }
 
-template <int MB, bool ALIGNED, int NL>
-__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2)
-gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C,
-                 int L, int nsplit, float* __restrict__ part) {
+// The body of gram_mfma_kernel for wave W of its workgroup.  The four waves run DIFFERENT tile schedules
+// (gram_wave_chunk<W>), each a straight-line instantiation; with one ``switch (w)`` per chunk inside a common loop
+// the accumulators (2 x 22 tiles = 176 registers) crossed a control-flow join every iteration and the register
+// allocator moved ALL of them between the VGPR and AGPR files there - 178 v_accvgpr_write per chunk of 182 MFMAs,
+// issued with the matrix pipe idle (one wave per SIMD): the kernel sat at 0.76 pipe utilisation.  With the whole
+// loop inside the per-wave instantiation the accumulators have one home.  (Barriers are counted per workgroup,
+// not per program counter: the four waves meet at theirs from four different loops.)
+template <int MB, bool ALIGNED, int NL, int W>
+__device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, const float* __restrict__ g, int M,
+                                              long long C, int L, int nsplit, float* __restrict__ part,
+                                              float* __restrict__ sA_, float* __restrict__ sG_) {
   constexpr int MP = MB * 16;
   constexpr GramPlan<MB> PLAN{};
   constexpr int NS = PLAN.max_cnt();
-  constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;  // 1-KiB pieces (16 rows x 16 cols) per chunk
-  // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
-  // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
-  // conflict-free ds_read_b128 at lane*16 bytes.
-  constexpr int NPW = (NPIECE + 3) / 4;  // LDS-DMA pieces per wave per stage (uniform; + 1 for g)
-  // two slots: the chunk being multiplied and the next one in flight (a chunk is ~12k MFMA cycles per
-  // wave, far longer than the DMA latency, so one stage ahead is enough and the chunks can be big)
-  __shared__ __attribute__((aligned(16))) float sA[2][NPW * 4 * 256];
-  __shared__ __attribute__((aligned(16))) float sG[2][NL * GR_KC];
-
+  constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;
+  constexpr int NPW = (NPIECE + 3) / 4;
+  constexpr int SA_STRIDE = NPW * 4 * 256, SG_STRIDE = NL * GR_KC;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int w = W;
   const int j = lane & 15, kq = lane >> 4;
   const int l0 = blockIdx.x * NL, sp = blockIdx.y;  // outputs l0 .. l0+NL-1 (clamped: a surplus one is not stored)
   const long long nch = (C + GR_KC - 1) / GR_KC;
@@ -2033,12 +2059,12 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
         long long col = cb__ + kb * 16 + kq * 4;                                             \
         col = col < C - 4 ? col : C - 4;                                                     \
         glds16(alpha + (long long)row * C + col,                                             \
-               __builtin_amdgcn_readfirstlane(lds_addr(&sA[BUF][slot * 256])));              \
+               __builtin_amdgcn_readfirstlane(lds_addr(sA_ + (BUF) * SA_STRIDE + slot * 256))); \
       }                                                                                      \
       if (lane < NL * (GR_KC / 4)) {                                                         \
         const int lq__ = min(l0 + lane / (GR_KC / 4), L - 1);                                \
         glds16(g + (long long)lq__ * Cpad + cb__ + (lane % (GR_KC / 4)) * 4,                 \
-               __builtin_amdgcn_readfirstlane(lds_addr(&sG[BUF][0])));                       \
+               __builtin_amdgcn_readfirstlane(lds_addr(sG_ + (BUF) * SG_STRIDE)));           \
       }                                                                                      \
     } else {                                                                                 \
       for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
@@ -2046,10 +2072,10 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
         const int rb = piece / NKB, kb = piece % NKB;                                        \
         const int row = rb * 16 + (ln & 15);                                                 \
         const long long col = cb__ + kb * 16 + (ln >> 4) * 4 + r;                            \
-        sA[BUF][e] = (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;           \
+        sA_[(BUF) * SA_STRIDE + e] = (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f; \
       }                                                                                      \
       if (tid < NL * GR_KC)                                                                  \
-        sG[BUF][tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * Cpad + cb__ + tid % GR_KC]; \
+        sG_[(BUF) * SG_STRIDE + tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * Cpad + cb__ + tid % GR_KC]; \
     }                                                                                        \
   }
 
@@ -2060,13 +2086,8 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   for (long long ch = ch0; ch < ch1; ++ch) {
     // the other slot held chunk ch-1: everyone left it before the barrier that ended that iteration
     if (ch + 1 < ch1) GPSA_GR_STAGE(ch + 1, buf ^ 1)
-    const float* img = &sA[buf][lane * 4];
-    switch (w) {
-      case 0: gram_wave_chunk<MB, NKB, 0, NS, NL>(img, sG[buf], kq, acc); break;
-      case 1: gram_wave_chunk<MB, NKB, 1, NS, NL>(img, sG[buf], kq, acc); break;
-      case 2: gram_wave_chunk<MB, NKB, 2, NS, NL>(img, sG[buf], kq, acc); break;
-      default: gram_wave_chunk<MB, NKB, 3, NS, NL>(img, sG[buf], kq, acc); break;
-    }
+    const float* img = sA_ + buf * SA_STRIDE + lane * 4;
+    gram_wave_chunk<MB, NKB, W, NS, NL>(img, sG_ + buf * SG_STRIDE, kq, acc);
     GPSA_DMA_DRAIN();  // chunk ch+1 (issued a whole chunk of MFMAs ago) has landed
     __syncthreads();
     buf ^= 1;
@@ -2077,19 +2098,32 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   for (int q = 0; q < NL; ++q) {
     if (l0 + q >= L) break;
     float* P = part + ((long long)(l0 + q) * nsplit + sp) * MP * MP;
-    switch (w) {
-      case 0: gram_wave_store<MB, 0, NS>(acc[q], P, j, kq); break;
-      case 1: gram_wave_store<MB, 1, NS>(acc[q], P, j, kq); break;
-      case 2: gram_wave_store<MB, 2, NS>(acc[q], P, j, kq); break;
-      default: gram_wave_store<MB, 3, NS>(acc[q], P, j, kq); break;
-    }
+    gram_wave_store<MB, W, NS>(acc[q], P, j, kq);
   }
 }
 
-// out[l][i][j] = out[l][j][i] = sum_s part[l][s][i][j] for i >= j: the partial slabs hold the lower
-// triangle only, so one thread per lower element (i, j <= i, rounded up to whole rows of the 32-wide
-// column blocks it touches) sums it once - coalesced along j - and writes both mirror positions; the
-// upper-triangle threads of the old one-thread-per-output scheme read the slabs a second time, strided.
+template <int MB, bool ALIGNED, int NL>
+__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2)
+gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C,
+                 int L, int nsplit, float* __restrict__ part) {
+  constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;  // 1-KiB pieces (16 rows x 16 cols) per chunk
+  // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
+  // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
+  // conflict-free ds_read_b128 at lane*16 bytes.
+  constexpr int NPW = (NPIECE + 3) / 4;  // LDS-DMA pieces per wave per stage (uniform; + 1 for g)
+  // two slots: the chunk being multiplied and the next one in flight (a chunk is ~12k MFMA cycles per
+  // wave, far longer than the DMA latency, so one stage ahead is enough and the chunks can be big)
+  __shared__ __attribute__((aligned(16))) float sA[2][NPW * 4 * 256];
+  __shared__ __attribute__((aligned(16))) float sG[2][NL * GR_KC];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  switch (w) {
+    case 0: gram_wave_run<MB, ALIGNED, NL, 0>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    case 1: gram_wave_run<MB, ALIGNED, NL, 1>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    case 2: gram_wave_run<MB, ALIGNED, NL, 2>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    default: gram_wave_run<MB, ALIGNED, NL, 3>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+  }
+}
+
 template <typename TO>
 __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit,
                                    TO* __restrict__ out) {
