@@ -1635,26 +1635,34 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
 #pragma unroll
         for (int rt = 0; rt < MB; ++rt) {
           const float4 a4 = a_nxt;
-          if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
-          // the next-but-one chunk is staged from INSIDE the MFMA stream (its slot was free since the barrier that
-          // ended the previous chunk): the cursor arithmetic and the LDS-DMA issues go into the shadows of the
-          // matrix instructions instead of standing in front of them with the pipe idle (one wave per SIMD here)
-          if (MB >= NPW + 3) {
-            if (rt >= 1 && rt <= NPW) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, rt - 1)
-            if (rt == NPW + 1) GPSA_STAGE_ADVANCE()
-          } else if (rt == 0) {
-            GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
-          }
-          __builtin_amdgcn_sched_barrier(0);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+          // The non-matrix work of a row tile - the next fragment's LDS read, and the staging of the next-but-one
+          // chunk (its slot was free since the barrier that ended the previous chunk: cursor arithmetic and LDS-DMA
+          // issues) - is pinned BETWEEN the K steps of the tile, a few instructions behind each group of NCT MFMAs:
+          // a 16x16x4 fp32 MFMA occupies the pipe for 32 cycles and the wave (alone on its SIMD) can issue ~6 other
+          // instructions in that shadow, but a dozen of them in one clump in front of a tile overrun it and leave
+          // the pipe idle.
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (kc == MB - 1 && r >= RL) continue;  // all-padding K steps (compile time)
+            if (!(kc == MB - 1 && r >= RL)) {  // all-padding K steps are skipped (compile time)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
+              for (int ct = 0; ct < NCT; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[ct][r], acc[rt][ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r == 0) {
+              if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
+            } else if (r == 1) {
+              if (MB >= NPW + 3) {
+                if (rt < NPW) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, rt)
+                if (rt == NPW) GPSA_STAGE_ADVANCE()
+              } else if (rt == 0) {
+                GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
         GPSA_DMA_WAIT(NPW);
         __syncthreads();

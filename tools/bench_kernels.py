@@ -69,6 +69,12 @@ if "panel" in what:
         print(f"quadform_bwd_alpha C={C}: {timeit(lambda: o.quadform_bwd_alpha(X, Om, g), n=10, warm=2):.1f} us", flush=True)
         Os = Om + Om.transpose(1, 2)
         print(f"quadform_fwd C={C}: {timeit(lambda: o.quadform_fwd(X, Os), n=10, warm=2):.1f} us", flush=True)
+if "keep" in what:  # the headline forward: quadratic form with the products kept for the backward
+    for C in (100000,):
+        X = torch.randn(200, C, device=dev)
+        Om = torch.randn(50, 200, 200, device=dev, dtype=torch.float64)
+        Os = Om + Om.transpose(1, 2)
+        print(f"quadform_fwd_keep C={C}: {timeit(lambda: o.quadform_fwd_keep(X, Os), n=10, warm=2):.1f} us", flush=True)
 if "solve" in what:  # gamma = K^-1 abar of the data-layer backward: one fp64-MFMA pass vs two fp32 triangular passes
     for C in (12500, 100000):
         Kinv = spd(1, 200)[0]
