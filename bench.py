@@ -294,7 +294,7 @@ def main():
               flush=True)
         return
     from spatial_alignment_amd.optim import FusedAdam
-    from spatial_alignment_amd.train import backward as train_backward
+    from spatial_alignment_amd.train import train_step
 
     opt = FusedAdam(model.parameters(), lr=1e-2)  # torch.optim.Adam's update as one HIP launch
     reducer = out_reducer if out_reducer is not None else GradAllReducer(model.parameters())
@@ -302,13 +302,9 @@ def main():
     timer.S = args.S
 
     def step():
-        out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=args.S)
-        loss = model.loss_fn(dd, out[3])
-        opt.zero_grad(set_to_none=not args.static_grads)
-        train_backward(loss)  # loss.backward() with the seed gradient kept on the device
-        reducer()
-        opt.step()
-        return loss
+        # the reference loop body (forward, loss_fn, zero_grad, backward, optimiser step) as the package's own helper:
+        # it tells forward which data_dict loss_fn will get, so the engine can fold the likelihood into the data GP's pass
+        return train_step(model, opt, dd, view_idx, Ns, S=args.S, reducer=reducer, static_grads=args.static_grads)
 
     for _ in range(args.warmup):
         step()
@@ -333,12 +329,7 @@ def main():
     s1 = None
     if args.S != 1 and not args.no_s1:
         def step1():
-            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=1)
-            l1 = model.loss_fn(dd, out[3])
-            opt.zero_grad(set_to_none=not args.static_grads)
-            l1.backward()
-            reducer()
-            opt.step()
+            train_step(model, opt, dd, view_idx, Ns, S=1, reducer=reducer, static_grads=args.static_grads)
 
         for _ in range(args.warmup):
             step1()

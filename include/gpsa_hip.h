@@ -152,6 +152,22 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
                                float* v, float* W, void* workspace, long long workspace_bytes, void* stream);
 int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, const float* dcT,
                                      const float* dmeanT, float* dalpha, void* stream);
+/* The data GP's forward, its Gaussian log-likelihood and the backward's abar in ONE pass over the products
+ * Omega_l alpha (training with the engine's own ELBO: replaces gpsa_quadform_fwd_keep_f32 + gpsa_data_sample_fwd +
+ * gpsa_loglik_fwd/_bwd + gpsa_data_sample_bwd + gpsa_quadform_bwd_alpha_kept_f32; reference vgpsa.py:186-204,
+ * 334-351, 532-538 and their autograd adjoints).  Per (l, c), c = s*N + n:
+ *   var = (exp(var_u) - q[c]) + alpha_c^T Omega_l alpha_c + 2e-5;  F = meanT[l,c] + sqrt(var) eps[c,l]
+ *   z = (Y[n,l] - F) / s,  s = exp(noise_u) + 1e-5;   part[] sums z^2  (LL = -z^2/2 - log s - log(2 pi)/2 per element)
+ *   dmeanT[l,c] = dLoss/dF = -(Y - F) / (s^2 S);   g[l,c] = dLoss/dvar = dmeanT * eps / (2 sqrt(var))
+ *   abar[:,c]   = 2 sum_l g[l,c] Omega_l alpha_c                (the mean term's share is NOT included)
+ * all at upstream gradient dLoss = 1 (linear in it).  part: gpsa_quadform_elbo_parts() doubles (unused tail zeroed).
+ * M <= 208 (13 row tiles) only: GPSA_EUNSUPPORTED beyond. */
+int gpsa_quadform_elbo_parts(void);
+long long gpsa_quadform_elbo_f32_workspace(int M, long long C, int L);
+int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                           const float* meanT, const double* q, const float* var_u, const float* eps, const float* Y,
+                           long long N, int S, const float* noise_u, float* g, float* dmeanT, float* abar, double* part,
+                           void* workspace, long long workspace_bytes, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
  * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */
@@ -461,6 +477,16 @@ typedef struct gpsa_step_io {
                                                    variational covariances, their factorisations and inverses, KL terms)
                                                    of an earlier gpsa_step_forward on the SAME parameters - skip it.
                                                    For the slices of one microbatched step (train.Microbatches) */
+  /* Fused ELBO (training through the engine's own loss, Gaussian likelihood on F_latent, no LMC): with fuse_elbo
+   * nonzero and Y[m] / noise_u[m] given, modality m's data GP runs gpsa_quadform_elbo_f32 - its draws are never
+   * materialised (F_latent[m] is not written), ll_part[m] receives the partial sums of z^2 for
+   * gpsa_elbo_loss_fused_fwd / _bwd, and gpsa_step_backward takes the loss's upstream gradient from
+   * gpsa_step_out_grads.gloss instead of dF_latent[m].  Modalities the fused kernel does not cover (LMC, more than
+   * 208 inducing points: gpsa_step_fused(plan, m) == 0) run unfused and must be given F_latent[m] as usual. */
+  int fuse_elbo;
+  const float* Y[GPSA_MAX_MODS];            /* in  [N_m, L_m] observations */
+  const float* noise_u[GPSA_MAX_MODS];      /* in  [1] the likelihood's log "variance" of modality m */
+  double* ll_part[GPSA_MAX_MODS];           /* out [gpsa_quadform_elbo_parts()] */
 } gpsa_step_io;
 
 typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */
@@ -471,6 +497,7 @@ typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar 
   const float* dF_latent_test[GPSA_MAX_MODS];
   const float* dF_obs_test[GPSA_MAX_MODS];
   const double* dkl;                        /* [n_kl] or NULL */
+  const float* gloss;                       /* [1] device scalar: upstream gradient of the loss (io.fuse_elbo) */
 } gpsa_step_out_grads;
 
 void* gpsa_step_create(const gpsa_step_desc* desc);   /* NULL: invalid / unsupported description */
@@ -480,6 +507,7 @@ int gpsa_step_describe(const gpsa_step_desc* desc, long long* out);
 void gpsa_step_destroy(void* plan);
 long long gpsa_step_saved_bytes(const void* plan);
 long long gpsa_step_saved_bytes_nokeep(const void* plan);  /* arena of a forward with io.keep_products == 0 */
+int gpsa_step_fused(const void* plan, int m);         /* 1: modality m's training pass can run the fused ELBO kernel */
 long long gpsa_step_scratch_bytes(const void* plan);
 int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
@@ -514,6 +542,22 @@ int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, c
                        const int* S, const long long* N, const int* P, const float* gloss, int n_kl,
                        double kl_scale, float* const* dF, float* const* dnoise, float* dnoise_all, int n_noise,
                        double* dkl, void* workspace, long long workspace_bytes, void* stream);
+
+/* gpsa_elbo_loss_fwd / _bwd with some likelihood terms fused into the step (gpsa_step_io.fuse_elbo): zpart[i] non-null =
+ * term i's partial sums of z^2 (nparts doubles: gpsa_step_io.ll_part[m]); F[i] / dF[i] are then ignored */
+int gpsa_elbo_loss_fused_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                             const int* S, const long long* N, const int* P, const double* const* zpart, int nparts,
+                             const double* kl, int n_kl, double kl_scale, float* loss, double* ll_out, void* workspace,
+                             long long workspace_bytes, void* stream);
+int gpsa_elbo_loss_fused_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                             const int* S, const long long* N, const int* P, const double* const* zpart, int nparts,
+                             const float* gloss, int n_kl, double kl_scale, float* const* dF, float* const* dnoise,
+                             float* dnoise_all, int n_noise, double* dkl, void* workspace, long long workspace_bytes,
+                             void* stream);
+/* the fused forward's outputs (formed at upstream gradient 1) as the backward wants them: g, dmeanT, abar scaled by the
+ * loss's upstream gradient (untouched when it is 1), g_ext row L = qbar = -sum_l g, dvar_u = exp(var_u) sum g */
+int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
+                         const float* var_u, float* dvar_u, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- fused Adam over a list of tensors (torch.optim.Adam, no weight decay / amsgrad; the optimiser step of
  * the reference loop, examples/grid_example.py:59-78), ONE launch: for every element

@@ -103,7 +103,8 @@ class StepIO(C.Structure):
         ("eps_F_test", _vp * MAX_MODS), ("G_means", _vp * MAX_MODS), ("G_samples", _vp * MAX_MODS),
         ("F_latent", _vp * MAX_MODS), ("F_obs", _vp * MAX_MODS), ("F_latent_test", _vp * MAX_MODS),
         ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp), ("keep_products", _i),
-        ("reuse_mm", _i),
+        ("reuse_mm", _i), ("fuse_elbo", _i), ("Y", _vp * MAX_MODS), ("noise_u", _vp * MAX_MODS),
+        ("ll_part", _vp * MAX_MODS),
     ]
 
 
@@ -111,7 +112,7 @@ class StepOutGrads(C.Structure):
     _fields_ = [
         ("dG_means", _vp * MAX_MODS), ("dG_samples", _vp * MAX_MODS), ("dF_latent", _vp * MAX_MODS),
         ("dF_obs", _vp * MAX_MODS), ("dF_latent_test", _vp * MAX_MODS), ("dF_obs_test", _vp * MAX_MODS),
-        ("dkl", _vp),
+        ("dkl", _vp), ("gloss", _vp),
     ]
 
 
@@ -145,6 +146,10 @@ SIGNATURES.update({
     "gpsa_quadform_fwd_keep_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_keep_f32_bytes": (_ll, [_i, _ll, _i]),
     "gpsa_quadform_bwd_alpha_kept_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp]),
+    "gpsa_quadform_elbo_parts": (_i, []),
+    "gpsa_quadform_elbo_f32_workspace": (_ll, [_i, _ll, _i]),
+    "gpsa_quadform_elbo_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _ll, _vp]),
     "gpsa_step_scratch_bytes": (_ll, [_vp]),
     "gpsa_step_n_kl": (_i, [_vp]),
     "gpsa_step_eps_g_numel": (_ll, [_vp]),
@@ -157,6 +162,12 @@ SIGNATURES.update({
                                 _vp, _vp, _ll, _vp]),
     "gpsa_elbo_loss_bwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _vp, _i, _d, _pp, _pp,
                                 _vp, _i, _vp, _vp, _ll, _vp]),
+    "gpsa_elbo_loss_fused_fwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _pp, _i, _vp, _i,
+                                      _d, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_elbo_loss_fused_bwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _pp, _i, _vp, _i,
+                                      _d, _pp, _pp, _vp, _i, _vp, _vp, _ll, _vp]),
+    "gpsa_elbo_fused_post": (_i, [_vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_step_fused": (_i, [_vp, _i]),
     "gpsa_adam_step": (_i, [_i, _pp, _pp, _pp, _pp, C.POINTER(_ll), _d, _d, _d, _d, _vp, _vp]),
 })
 

@@ -360,7 +360,7 @@ __global__ void loglik_bwd_finish_kernel(const double* __restrict__ part, int n,
                                          float* __restrict__ dnoise_u, const float* __restrict__ gloss = nullptr,
                                          double* __restrict__ dkl = nullptr, int n_kl = 0,
                                          double kl_scale = 0.0, float* __restrict__ zero_base = nullptr,
-                                         int zero_n = 0) {
+                                         int zero_n = 0, double sub = 0.0) {  // sub: part sums z^2, not z^2 - 1
   __shared__ double red[4];
   if (zero_base != nullptr) {  // the whole noise-gradient vector starts at zero (entries no term names stay so)
     for (int t = threadIdx.x; t < zero_n; t += blockDim.x) zero_base[t] = 0.f;
@@ -372,7 +372,7 @@ __global__ void loglik_bwd_finish_kernel(const double* __restrict__ part, int n,
   if (threadIdx.x == 0) {
     const double e = exp((double)noise_u[0]), sc = e + 1e-5;
     const double up = gloss != nullptr ? -(double)gloss[0] : gout[0];
-    dnoise_u[0] = (float)(up * s / sc / (double)S * e);
+    dnoise_u[0] = (float)(up * (s - sub) / sc / (double)S * e);
   }
   if (dkl != nullptr)  // fused ELBO glue: dkl[t] = kl_scale * gloss
     for (int t = threadIdx.x; t < n_kl; t += blockDim.x) dkl[t] = kl_scale * (double)gloss[0];
@@ -383,6 +383,9 @@ __global__ void loglik_bwd_finish_kernel(const double* __restrict__ part, int n,
 struct ElboFinishArgs {
   const double* part[GPSA_MAX_MODS];
   int nb[GPSA_MAX_MODS], S[GPSA_MAX_MODS];
+  // fused terms (gpsa_quadform_elbo_f32): part sums z^2 only; ll = (-0.5 sum z^2 + (-log s - log(2 pi)/2) tot) / S
+  const float* z2_noise[GPSA_MAX_MODS];  // non-null: this term's log "variance"
+  double tot[GPSA_MAX_MODS];
   int n_ll, n_kl;
   const double* kl;
   double kl_scale;
@@ -397,6 +400,10 @@ __global__ void __launch_bounds__(256) elbo_loss_finish_kernel(ElboFinishArgs a)
     for (int k = threadIdx.x; k < a.nb[i]; k += 256) s += a.part[i][k];
     s = block_sum(s, red);
     if (threadIdx.x == 0) {
+      if (a.z2_noise[i] != nullptr) {
+        const double sd = exp((double)a.z2_noise[i][0]) + 1e-5;
+        s = -0.5 * s + (-log(sd) - 0.9189385332046727) * a.tot[i];
+      }
       const double v = s / (double)a.S[i];
       a.ll[i] = v;
       lsum += v;
@@ -406,6 +413,38 @@ __global__ void __launch_bounds__(256) elbo_loss_finish_kernel(ElboFinishArgs a)
   for (int t = threadIdx.x; t < a.n_kl; t += 256) k += a.kl[t];
   k = block_sum(k, red);
   if (threadIdx.x == 0) a.loss[0] = (float)(a.kl_scale * k - lsum);
+}
+
+// ---- fused ELBO (gpsa_quadform_elbo_f32) -> the backward's conventions ------------------------------------------
+// per column: qbar[c] = -gl sum_l g[l,c]; part[block] = gl sum g (for d var);  with an upstream gradient gl != 1
+// g and dmeanT are scaled in place (they were formed at gl = 1)
+__global__ void __launch_bounds__(256)
+elbo_post_kernel(float* __restrict__ g, float* __restrict__ dmeanT, long long C, int L, const float* __restrict__ gloss,
+                 float* __restrict__ qbar, double* __restrict__ part) {
+  __shared__ double red[4];
+  const float gl = gloss[0];
+  const long long c = blockIdx.x * 256LL + threadIdx.x;
+  float s = 0.f;
+  if (c < C) {
+    for (int l = 0; l < L; ++l) {
+      const long long o = (long long)l * C + c;
+      const float v = g[o] * gl;
+      s += v;
+      if (gl != 1.f) {
+        g[o] = v;
+        dmeanT[o] *= gl;
+      }
+    }
+    qbar[c] = -s;
+  }
+  const double t = block_sum((double)s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256) scale_unless_one_kernel(float* __restrict__ x, long long n,
+                                                               const float* __restrict__ gloss) {
+  const float gl = gloss[0];
+  if (gl == 1.f) return;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= gl;
 }
 
 static inline int loglik_blocks(long long tot) {
@@ -584,6 +623,8 @@ int gpsa_elbo_loss_fwd(int n_ll, const float* const* F, const float* const* Y, c
     a.part[i] = part;
     a.nb[i] = nb;
     a.S[i] = S[i];
+    a.z2_noise[i] = nullptr;
+    a.tot[i] = (double)tot;
   }
   gpsa::elbo_loss_finish_kernel<<<1, 256, 0, st>>>(a);
   GPSA_LAUNCH_CHECK();
@@ -605,6 +646,93 @@ int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, c
     double* part = reinterpret_cast<double*>(workspace) + 4100LL * i;
     gpsa::loglik_bwd_kernel<<<nb, 256, 0, st>>>(F[i], Y[i], noise_u[i], nullptr, S[i], tot, NP, dF[i], part, gloss);
     // the first term's finishing launch also writes dkl
+    gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(part, nb, noise_u[i], nullptr, S[i], dnoise[i], gloss,
+                                                      i == 0 ? dkl : nullptr, n_kl, kl_scale,
+                                                      i == 0 ? dnoise_all : nullptr, n_noise);
+  }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+/* the fused forward's outputs (formed at upstream gradient 1) as the backward wants them: g, dmeanT, abar scaled by the
+ * loss's upstream gradient (nothing is touched when that is 1), qbar = -sum_l g, dvar_u = exp(var_u) sum g.
+ * g_ext: [L+1][C], row L receives qbar.  abar: [M][C].  workspace: 8 * ceil(C/256) bytes */
+int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
+                         const float* var_u, float* dvar_u, void* workspace, long long workspace_bytes, void* stream) {
+  if (M < 1 || C < 1 || L < 1 || !g_ext || !dmeanT || !abar || !gloss || !var_u || !dvar_u) return GPSA_EINVAL;
+  const long long nb = cdiv(C, 256);
+  if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* part = (double*)workspace;
+  gpsa::elbo_post_kernel<<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part);
+  gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
+  gpsa::scale_unless_one_kernel<<<2048, 256, 0, st>>>(abar, (long long)M * C, gloss);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+/* gpsa_elbo_loss_fwd / _bwd with some likelihood terms FUSED into the step (gpsa_step_io.fuse_elbo): zpart[i] non-null
+ * = term i's partial sums of z^2 (nparts doubles, gpsa_step_io.ll_part); F[i] / dF[i] are then ignored. */
+int gpsa_elbo_loss_fused_fwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                             const int* S, const long long* N, const int* P, const double* const* zpart, int nparts,
+                             const double* kl, int n_kl, double kl_scale, float* loss, double* ll_out, void* workspace,
+                             long long workspace_bytes, void* stream) {
+  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !loss || !ll_out || !zpart)
+    return GPSA_EINVAL;
+  if (workspace_bytes < 8LL * 4100 * n_ll) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  gpsa::ElboFinishArgs a;
+  a.n_ll = n_ll;
+  a.n_kl = kl ? n_kl : 0;
+  a.kl = kl;
+  a.kl_scale = kl_scale;
+  a.ll = ll_out;
+  a.loss = loss;
+  for (int i = 0; i < n_ll; ++i) {
+    if (S[i] < 1 || N[i] < 1 || P[i] < 1) return GPSA_EINVAL;
+    const long long NP = N[i] * P[i], tot = NP * S[i];
+    a.S[i] = S[i];
+    a.z2_noise[i] = nullptr;
+    a.tot[i] = (double)tot;
+    if (zpart[i] != nullptr) {
+      if (nparts < 1) return GPSA_EINVAL;
+      a.part[i] = zpart[i];
+      a.nb[i] = nparts;
+      a.z2_noise[i] = noise_u[i];
+      continue;
+    }
+    const int nb = gpsa::loglik_blocks(tot);
+    double* part = reinterpret_cast<double*>(workspace) + 4100LL * i;
+    gpsa::loglik_fwd_kernel<<<nb, 256, 0, st>>>(F[i], Y[i], noise_u[i], tot, NP, part);
+    a.part[i] = part;
+    a.nb[i] = nb;
+  }
+  gpsa::elbo_loss_finish_kernel<<<1, 256, 0, st>>>(a);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+int gpsa_elbo_loss_fused_bwd(int n_ll, const float* const* F, const float* const* Y, const float* const* noise_u,
+                             const int* S, const long long* N, const int* P, const double* const* zpart, int nparts,
+                             const float* gloss, int n_kl, double kl_scale, float* const* dF, float* const* dnoise,
+                             float* dnoise_all, int n_noise, double* dkl, void* workspace, long long workspace_bytes,
+                             void* stream) {
+  if (n_ll < 1 || n_ll > GPSA_MAX_MODS || !F || !Y || !noise_u || !S || !N || !P || !gloss || !dF || !dnoise || !zpart)
+    return GPSA_EINVAL;
+  if (workspace_bytes < 8LL * 4100 * n_ll) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  for (int i = 0; i < n_ll; ++i) {
+    if (S[i] < 1 || N[i] < 1 || P[i] < 1) return GPSA_EINVAL;
+    const long long NP = N[i] * P[i], tot = NP * S[i];
+    if (zpart[i] != nullptr) {
+      gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(zpart[i], nparts, noise_u[i], nullptr, S[i], dnoise[i], gloss,
+                                                        i == 0 ? dkl : nullptr, n_kl, kl_scale,
+                                                        i == 0 ? dnoise_all : nullptr, n_noise, (double)tot);
+      continue;
+    }
+    const int nb = gpsa::loglik_blocks(tot);
+    double* part = reinterpret_cast<double*>(workspace) + 4100LL * i;
+    gpsa::loglik_bwd_kernel<<<nb, 256, 0, st>>>(F[i], Y[i], noise_u[i], nullptr, S[i], tot, NP, dF[i], part, gloss);
     gpsa::loglik_bwd_finish_kernel<<<1, 256, 0, st>>>(part, nb, noise_u[i], nullptr, S[i], dnoise[i], gloss,
                                                       i == 0 ? dkl : nullptr, n_kl, kl_scale,
                                                       i == 0 ? dnoise_all : nullptr, n_noise);

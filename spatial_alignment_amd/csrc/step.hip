@@ -512,6 +512,10 @@ struct Pass {  // one evaluation of the data GP: a modality's own spots, or its 
   long long o_alpha = 0, o_sigma = 0;
   long long o_keep = -1;  // [L][Mg][C] fp32 products Omega_l alpha kept for the backward (-1: not kept)
   long long o_alpha64 = -1;  // [Mg][C] the projection unrounded (exact_inducing_grad; -1: not kept)
+  // fused ELBO (gpsa_quadform_elbo_f32): g_ext [L+1][C], dmeanT [L][C], abar [Mg][C] live from the forward to the
+  // backward (-1: this pass cannot run fused: a test pass, LMC, more than 13 row tiles)
+  long long o_fuse = -1;
+  bool fused(const gpsa_step_io& io) const { return io.fuse_elbo != 0 && o_fuse >= 0 && io.Y[m] != nullptr; }
 };
 
 struct Plan {
@@ -675,6 +679,9 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
     q.o_alpha = take((long long)p->Mg * q.C * 4);
     q.o_sigma = take((long long)dsc->n_latent[q.m] * q.C * 4);
     if (dsc->exact_inducing_grad) q.o_alpha64 = take((long long)p->Mg * q.C * 8);
+    const int Lq = dsc->n_latent[q.m];
+    if (!q.test && !dsc->has_lmc[q.m] && gpsa_quadform_elbo_f32_workspace(p->Mg, q.C, Lq) > 0)
+      q.o_fuse = take((2LL * Lq + 1 + p->Mg) * q.C * 4);
   }
   p->o_apk_w = take(gpsa_whiten_workspace(p->Mx) * (long long)(p->nf > 0 ? p->nf : 1));
   p->o_apk_d = take(gpsa_whiten_workspace(p->Mg));
@@ -1174,6 +1181,23 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
   float* v = c.sc.get<float>((long long)L * C);
   // mean[l,c] = sum_m delta_F[m,l] alpha[m,c]   (mu_z = 0 for the data GP)
   GPSA_CK(gemm32(c, 1, 0, L, (int)C, Mg, 1.0, c.prm.delta_F[m], L, 0, alpha, C, 0, 0.0, meanT, C, 0, 1, 1));
+  if (ps.fused(c.io)) {
+    // variance, draw, likelihood and the backward's abar in one pass over the products: F and Sigma are never written
+    if (c.io.noise_u[m] == nullptr || c.io.ll_part[m] == nullptr) return GPSA_EINVAL;
+    float* g_ext = c.sv<float>(ps.o_fuse);
+    float* dmeanT = g_ext + (long long)(L + 1) * C;
+    float* abar = dmeanT + (long long)L * C;
+    const long long wsb = gpsa_quadform_elbo_f32_workspace(Mg, C, L);
+    void* ws = c.sc.get<char>(wsb);
+    const bool timed = !dry && &ps == &P.passes[0];
+    if (timed) P.tick(0, 0, true, c.st);
+    GPSA_RUN(gpsa_quadform_elbo_f32(GPSA_F64, alpha, Om, Mg, C, L, meanT, q, c.prm.data_var, eps, c.io.Y[m],
+                                    (long long)(C / P.S), P.S, c.io.noise_u[m], g_ext, dmeanT, abar, c.io.ll_part[m], ws, wsb,
+                                    c.stv()));
+    if (timed) { P.tick(0, 1, true, c.st); ++P.tfwd; }
+    c.sc.release(mk);
+    return 0;
+  }
   {
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
     void* ws = c.sc.get<char>(wsb);
@@ -1220,7 +1244,7 @@ struct BwdBufs {          // fp64 pieces of the parameter gradients (scratch, al
 };
 
 static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_in, const float* dFo_in,
-                         BwdBufs& B, const gpsa_step_param_grads& out, bool first_for_mod) {
+                         BwdBufs& B, const gpsa_step_param_grads& out, bool first_for_mod, const float* gloss) {
   Plan& P = c.P;
   const bool dry = c.dry;
   const int m = ps.m, Mg = P.Mg, D = P.D, L = P.d.n_latent[m], Pm = P.d.n_out[m];
@@ -1251,18 +1275,27 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   } else if (dFl == nullptr) {
     dFl = dFo_in;
   }
-  float* g_ext = c.sc.get<float>((long long)(L + 1) * C);
-  float* dmeanT = c.sc.get<float>((long long)L * C);
+  const bool fusedp = ps.fused(c.io);
+  float* g_ext = fusedp ? c.sv<float>(ps.o_fuse) : c.sc.get<float>((long long)(L + 1) * C);
+  float* dmeanT = fusedp ? g_ext + (long long)(L + 1) * C : c.sc.get<float>((long long)L * C);
   float* qbar = g_ext + (long long)L * C;
-  {
+  if (!fusedp) {
     const long long wsb = 8 * (C / 32 + 2);
     void* ws = c.sc.get<char>(wsb);
     GPSA_RUN(gpsa_data_sample_bwd(dFl, eps, Sigma, c.prm.data_var, C, L, g_ext, dmeanT, qbar,
                                   B.dvar_ds + pass_idx, ws, wsb, c.stv()));
   }
   // abar = delta_F dmean + 2 sum_l g_l Omega_l alpha
-  float* abar = c.sc.get<float>((long long)Mg * C);
-  {
+  float* abar = fusedp ? dmeanT + (long long)L * C : c.sc.get<float>((long long)Mg * C);
+  if (fusedp) {
+    // the forward left g, dmean and 2 sum_l g_l Omega_l alpha (at upstream gradient 1) in the saved arena
+    if (gloss == nullptr) return GPSA_EINVAL;
+    const long long wsb = 8 * (C / 256 + 2);
+    void* ws = c.sc.get<char>(wsb);
+    GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, B.dvar_ds + pass_idx, ws, wsb,
+                                  c.stv()));
+    GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
+  } else {
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
     const long long mk2 = c.sc.mark();
     void* ws = c.sc.get<char>(wsb);
@@ -1592,10 +1625,10 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
     const Pass& ps = P.passes[pi];
     const float* dFl = ps.test ? og.dF_latent_test[ps.m] : og.dF_latent[ps.m];
     const float* dFo = ps.test ? og.dF_obs_test[ps.m] : og.dF_obs[ps.m];
-    if (dFl == nullptr && dFo == nullptr) continue;  // no gradient reached this pass's draws
+    if (dFl == nullptr && dFo == nullptr && !ps.fused(io)) continue;  // no gradient reached this pass's draws
     // pi selects this pass's slot of the per-pass pieces; the first pass of a modality writes its shared
     // pieces (dOmega rows, d delta_F, dW), later ones add to them
-    GPSA_CK(data_pass_bwd(c, ps, pi, dFl, dFo, B, out, !seen[ps.m]));
+    GPSA_CK(data_pass_bwd(c, ps, pi, dFl, dFo, B, out, !seen[ps.m], og.gloss));
     seen[ps.m] = true;
   }
   // ---- warp GPs
@@ -1753,6 +1786,17 @@ static gpsa::Plan* plan_with_sizes(const gpsa_step_desc* desc, bool host_only) {
   if (step_forward(*p, prm, io, nullptr, a, nullptr, 3) != 0) { free_plan(p); return nullptr; }
   a.off = 0;
   if (step_backward(*p, prm, io, og, nullptr, a, pg, nullptr) != 0) { free_plan(p); return nullptr; }
+  // ... and the fused-ELBO variant of the same step (its kernel's workspace holds the partial-tile slabs)
+  io.fuse_elbo = 1;
+  og.gloss = &dummy;
+  for (int m = 0; m < p->nm; ++m) {
+    io.Y[m] = io.noise_u[m] = &dummy;
+    io.ll_part[m] = const_cast<double*>(&dummyd);
+  }
+  a.off = 0;
+  if (step_forward(*p, prm, io, nullptr, a, nullptr, 3) != 0) { free_plan(p); return nullptr; }
+  a.off = 0;
+  if (step_backward(*p, prm, io, og, nullptr, a, pg, nullptr) != 0) { free_plan(p); return nullptr; }
   p->scratch_bytes = a.high + 4096;
   return p;
 }
@@ -1761,6 +1805,12 @@ void gpsa_step_destroy(void* plan) { gpsa::free_plan(reinterpret_cast<gpsa::Plan
 long long gpsa_step_saved_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->saved_bytes : -1; }
 long long gpsa_step_saved_bytes_nokeep(const void* plan) {
   return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->saved_bytes_nokeep : -1;
+}
+int gpsa_step_fused(const void* plan, int m) {
+  if (!plan) return 0;
+  for (const gpsa::Pass& q : reinterpret_cast<const gpsa::Plan*>(plan)->passes)
+    if (q.m == m && !q.test) return q.o_fuse >= 0 ? 1 : 0;
+  return 0;
 }
 long long gpsa_step_scratch_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->scratch_bytes : -1; }
 int gpsa_step_n_kl(const void* plan) {

@@ -11,6 +11,8 @@ import weakref
 from collections.abc import Iterable
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -46,6 +48,7 @@ class _StepCache:
         self.kl = None  # step engine: the per-term KL vector (a differentiable output of the forward node)
         self.batch = self.free = None  # (matrices, inverses, logdets) of the whole factorisation batch
         self.Om_fwd = self.Om_kl = None  # per-view row groups of Omega_G
+        self.fuse = None  # step engine, fused ELBO: the record forward and loss_fn share (step_engine.StepFn)
 
 
 class VariationalGPSA(GPSA):
@@ -115,6 +118,11 @@ class VariationalGPSA(GPSA):
         # one product less per step); False: recompute them in the backward (the memory-lean path, also taken
         # by itself when the products exceed the keep budget below)
         self.keep_products = True
+        # train.train_step / fit / GraphedTrainStep / Microbatches tell forward which data_dict loss_fn will see: the
+        # Gaussian likelihood and its gradient then ride in the data GP's own pass over the products Omega_l alpha
+        # (gpsa_quadform_elbo_f32) - nothing is kept, nothing streamed back.  False (or GPSA_FUSE_ELBO=0): the separate
+        # kernels, as a hand-written forward / loss_fn loop always gets
+        self.fuse_elbo = os.environ.get("GPSA_FUSE_ELBO", "1") != "0"
         self.keep_budget_gb = None  # HBM for those products: None = what the device can still give (step_engine.py)
         # the data GP's inducing-point gradient from the UNROUNDED projection (gpsa_step_desc.exact_inducing_grad):
         # True / False, or None = on when its one extra M x M x C fp64 product is under ~2 % of the step (L >= 128;
@@ -283,7 +291,11 @@ class VariationalGPSA(GPSA):
         return torch.empty(shape, dtype=torch.float32, device=device).normal_(generator=gen)
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, X_spatial, view_idx, Ns, S=1, prediction_mode=False, G_test=None):
+    def forward(self, X_spatial, view_idx, Ns, S=1, prediction_mode=False, G_test=None, _fuse_loss=None):
+        """``_fuse_loss`` (the training helpers of train.py, not part of the reference's interface): the data_dict the
+        NEXT call, loss_fn(data_dict, F_samples), will be given.  The step engine then folds the Gaussian likelihood
+        and its gradient into the data GP's pass (gpsa_quadform_elbo_f32): the draws are not materialised, and the
+        returned F_samples are handles only loss_fn understands."""
         if prediction_mode:
             self.eval()
         dev = self.Xtilde.device
@@ -294,7 +306,7 @@ class VariationalGPSA(GPSA):
         if self.use_step_engine and dev.type == "cuda" and SE.eligible(self, X_spatial, view_idx, G_test):
             rows = SE.view_rows(self, view_idx, Ns)
             if rows is not None:
-                return self._forward_engine(X_spatial, rows, S, G_test, noise, prediction_mode)
+                return self._forward_engine(X_spatial, rows, S, G_test, noise, prediction_mode, _fuse_loss)
         cache = _StepCache()
 
         # per-view slices of the parameters, unbound once (one autograd node per parameter instead of
@@ -527,7 +539,31 @@ class VariationalGPSA(GPSA):
             )
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
-    def _forward_engine(self, X_spatial, rows, S, G_test, noise, prediction_mode):
+    def _fuse_setup(self, plan, data_dict, S, G_test, prediction_mode):
+        """-> the ``fuse`` record of a fused-ELBO forward, or None when this step cannot (or should not) fuse"""
+        if data_dict is None or not self.fuse_elbo or prediction_mode or G_test is not None:
+            return None
+        if not torch.is_grad_enabled() or not any(p.requires_grad for p in SE._param_list(self)):
+            return None
+        mods = self.modality_names
+        f32 = torch.float32
+        Ys, flags = [], []
+        for i, m in enumerate(mods):
+            Y = data_dict[m]["outputs"]
+            ok = (isinstance(Y, torch.Tensor) and Y.is_cuda and Y.dtype == f32 and Y.is_contiguous()
+                  and tuple(Y.shape) == (plan.N[i], plan.L[i]) and not plan.lmc[i]
+                  and bool(plan.lib.gpsa_step_fused(plan.handle, i)))
+            Ys.append(Y if ok else None)
+            flags.append(ok)
+        nz = self.noise_variance
+        if not any(flags) or nz.dtype != f32 or not nz.is_contiguous():
+            return None
+        nn_ = nz.numel()
+        return dict(mods=flags, Y=Ys, noise=nz.detach(),
+                    noise_ptr=[nz.data_ptr() + 4 * (nn_ - self.n_modalities + i) for i in range(len(mods))],  # quirk 5
+                    shapes=[(int(S), plan.N[i], plan.L[i]) for i in range(len(mods))], gloss=None)
+
+    def _forward_engine(self, X_spatial, rows, S, G_test, noise, prediction_mode, fuse_loss=None):
         """forward through the C++ step engine: one autograd node, one host call each way"""
         dev = self.Xtilde.device
         mods = self.modality_names
@@ -608,7 +644,8 @@ class VariationalGPSA(GPSA):
                    slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
                    want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,
                    mm_epoch=self.__dict__.get("_mm_epoch"),
-                   flag_slot=self.__dict__.get("_flag_slot", 0))
+                   flag_slot=self.__dict__.get("_flag_slot", 0),
+                   fuse=self._fuse_setup(plan, fuse_loss, S, G_test, prediction_mode))
         self.__dict__["_flag_slot"] = 1 - aux["flag_slot"]  # two pinned words: consecutive forwards never share one
         outs = SE.StepFn.apply(aux, *SE._param_list(self))
         nm = len(mods)
@@ -626,6 +663,9 @@ class VariationalGPSA(GPSA):
         cache = _StepCache()
         cache.kl = outs[k] if not prediction_mode else None
         cache.mu_z, cache.engine_flag = aux["mu_z"], aux["flag"]
+        cache.fuse = aux["fuse"]
+        if cache.fuse is not None:
+            cache.fuse["handles"] = [Fl[i] for i in range(nm)]
         G_means = {m: Gm[i] for i, m in enumerate(mods)}
         G_samples = {m: Gs[i] for i, m in enumerate(mods)}
         self.F_latent_samples = {m: Fl[i] for i, m in enumerate(mods)}
@@ -725,6 +765,15 @@ class VariationalGPSA(GPSA):
             aux = dict(Y=[data_dict[m]["outputs"] for m in self.modality_names],
                        noise_idx=[nn_ - self.n_modalities + i for i in range(self.n_modalities)],  # quirk 5
                        kl_scale=self.kl_scale)
+            fuse = getattr(cache, "fuse", None)
+            if fuse is not None:
+                # forward(_fuse_loss=...) folded the likelihood into the step: this must be the call it was told about
+                for i, m in enumerate(self.modality_names):
+                    if fuse["mods"][i] and (F_samples[m] is not fuse["handles"][i]
+                                            or data_dict[m]["outputs"].data_ptr() != fuse["Y"][i].data_ptr()):
+                        raise ValueError("loss_fn after forward(_fuse_loss=data_dict): call it with that data_dict and "
+                                         "the F_samples forward returned")
+                aux["fuse"] = fuse
             loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *[F_samples[m] for m in self.modality_names])
             return loss.to(self.Xtilde.dtype)
         f64 = torch.float64

@@ -226,6 +226,9 @@ def _fill_params(st, tensors, model, plan):
     return st
 
 
+_PLACEHOLDER = {}
+
+
 class StepFn(torch.autograd.Function):
     """(parameters) -> G_means[m].., G_samples[m].., F_latent[m].., F_obs[m] (LMC).., test draws.., kl [T].
     ``aux``: everything that is not differentiated (plan, coordinates, draws, stream policy)."""
@@ -246,13 +249,26 @@ class StepFn(torch.autograd.Function):
         io = _lib.StepIO()
         empty = lambda *sh: torch.empty(*sh, dtype=f32, device=dev)
         outs = {"Gm": [], "Gs": [], "Fl": [], "Fo": [], "Flt": [], "Fot": []}
+        # fused ELBO (aux["fuse"], set up by VariationalGPSA.forward for the training helpers): modality i's draws are
+        # never materialised - its "F_latent" output is the vector of partial sums the likelihood finishes from
+        fuse = aux.get("fuse")
+        fused = fuse["mods"] if fuse is not None else [False] * nm
+        if fuse is not None:
+            io.fuse_elbo = 1
+            nparts = int(lib.gpsa_quadform_elbo_parts())
         for i, m in enumerate(plan.mods):
             N, L, P = plan.N[i], plan.L[i], plan.P[i]
             io.X[i] = _p(aux["X"][i])
             io.eps_F[i] = _p(aux["eps_F"][i])
-            Gm, Gs, Fl = empty(N, D), empty(S, N, D), empty(S, N, L)
+            Gm, Gs = empty(N, D), empty(S, N, D)
+            if fused[i]:
+                Fl = torch.empty(nparts, dtype=torch.float64, device=dev)
+                io.Y[i], io.noise_u[i], io.ll_part[i] = _p(fuse["Y"][i]), fuse["noise_ptr"][i], _p(Fl)
+            else:
+                Fl = empty(S, N, L)
+                io.F_latent[i] = _p(Fl)
             outs["Gm"].append(Gm); outs["Gs"].append(Gs); outs["Fl"].append(Fl)
-            io.G_means[i], io.G_samples[i], io.F_latent[i] = _p(Gm), _p(Gs), _p(Fl)
+            io.G_means[i], io.G_samples[i] = _p(Gm), _p(Gs)
             if plan.lmc[i]:
                 Fo = empty(S, N, P)
                 outs["Fo"].append(Fo)
@@ -279,6 +295,8 @@ class StepFn(torch.autograd.Function):
         # training (a backward will follow): the data GPs keep their products Omega_l alpha in the arena and the
         # backward streams them back; otherwise the cheaper forward and the smaller arena
         keep = any(ctx.needs_input_grad[1:]) and not aux.get("no_keep", False)  # (all False under no_grad)
+        if fuse is not None and all(fused):  # nothing left that would stream kept products back
+            keep = False
         io.keep_products = 1 if keep else 0
         saved = _take_arena(plan, plan.saved_bytes if keep else plan.saved_bytes_nokeep, dev)
         if saved is None:  # the device cannot hold the kept products after all (other tenants, fragmentation)
@@ -300,7 +318,8 @@ class StepFn(torch.autograd.Function):
         if kl is not None:
             flat_outs.append(kl)
         ins = [t for t in aux["X"] + list(aux["eps_F"]) + [aux["eps_G"], aux["slopes"], aux["intercepts"]]
-               + list(aux["G_test"] or []) + list(aux["eps_F_test"] or []) if t is not None]
+               + list(aux["G_test"] or []) + list(aux["eps_F_test"] or [])
+               + (list(fuse["Y"]) + [fuse["noise"]] if fuse is not None else []) if t is not None]
         call = TO.stash(dict(lib=lib, handle=plan.handle, prm=prm, io=io))
 
         def run(stages):
@@ -379,8 +398,19 @@ class StepFn(torch.autograd.Function):
             og.dG_means[i] = grad_ptr(gouts[k]); k += 1
         for i in range(nGs):
             og.dG_samples[i] = grad_ptr(gouts[k]); k += 1
+        fuse = aux.get("fuse")
         for i in range(nFl):
-            og.dF_latent[i] = grad_ptr(gouts[k]); k += 1
+            if fuse is not None and fuse["mods"][i]:
+                # the gradient that arrives for the partial sums is a placeholder: the loss's upstream gradient itself
+                # was left by ElboLossFn.backward (a device scalar)
+                if fuse.get("gloss") is None:
+                    raise RuntimeError("GPSA fused ELBO: the step's backward ran without the loss's (the partial sums "
+                                       "of a fused forward are only meaningful to loss_fn)")
+                keep.append(fuse["gloss"])
+                og.gloss = fuse["gloss"].data_ptr()
+            else:
+                og.dF_latent[i] = grad_ptr(gouts[k])
+            k += 1
         for j in range(nFo):
             og.dF_obs[lmc_idx[j]] = grad_ptr(gouts[k]); k += 1
         for i in range(nFlt):
@@ -442,6 +472,8 @@ class ElboLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, aux, noise, kl, *Fs):
+        if aux.get("fuse") is not None:
+            return ElboLossFn._forward_fused(ctx, aux, noise, kl, *Fs)
         lib = _lib.load()
         o = _ops_mod.get_ops()
         n = len(Fs)
@@ -473,7 +505,69 @@ class ElboLossFn(torch.autograd.Function):
         return loss.reshape(())
 
     @staticmethod
+    def _forward_fused(ctx, aux, noise, kl, *Fs):
+        """some terms arrive as the step's partial sums of z^2 (StepFn with aux["fuse"]) instead of draws"""
+        o = _ops_mod.get_ops()
+        fuse = aux["fuse"]
+        fused = [bool(z) for z in fuse["mods"]]
+        n = len(Fs)
+        dev = Fs[0].device
+        Fc = [f.detach() if (z or (f.dtype == torch.float32 and f.is_contiguous())) else f.detach().float().contiguous()
+              for f, z in zip(Fs, fused)]
+        Yc = [y if (y.dtype == torch.float32 and y.is_contiguous()) else y.float().contiguous() for y in aux["Y"]]
+        nz = noise.detach()
+        nz = nz if (nz.dtype == torch.float32 and nz.is_contiguous()) else nz.float().contiguous()
+        shapes = []
+        for i in range(n):
+            shapes += list(fuse["shapes"][i]) if fused[i] else [int(d) for d in Fc[i].shape]
+        klc = None
+        if kl is not None:
+            klc = kl.detach()
+            klc = klc if (klc.dtype == torch.float64 and klc.is_contiguous()) else klc.double().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ll = torch.empty(n, dtype=torch.float64, device=dev)
+        ws = o._ws(8 * 4100 * n + 64, loss)
+        idx = [int(j) for j in aux["noise_idx"]]
+        torch.ops.gpsa.elbo_loss_fused_fwd(Fc, Yc, nz, idx, shapes, [int(z) for z in fused], klc, float(aux["kl_scale"]),
+                                           loss, ll, ws)
+        ctx.aux, ctx.args = aux, (Fc, Yc, nz, idx, shapes, fused)
+        ctx.n_kl = 0 if klc is None else klc.numel()
+        ctx.noise_meta = (noise.shape, noise.dtype)
+        return loss.reshape(())
+
+    @staticmethod
+    def _backward_fused(ctx, gloss):
+        o = _ops_mod.get_ops()
+        aux = ctx.aux
+        fuse = aux["fuse"]
+        Fc, Yc, nz, idx, shapes, fused = ctx.args
+        dev = Fc[0].device
+        g = gloss.detach().reshape(1)
+        g = g if g.dtype == torch.float32 else g.float()
+        fuse["gloss"] = g  # StepFn.backward hands it to the engine (gpsa_step_out_grads.gloss)
+        dF = []
+        for f, z in zip(Fc, fused):
+            if z:  # a gradient of the right shape and type so that autograd walks on to the step's node; never read
+                key = (dev, f.numel())
+                d = _PLACEHOLDER.get(key)
+                if d is None:
+                    d = _PLACEHOLDER[key] = torch.zeros(1, dtype=torch.float64, device=dev).expand(f.numel())
+                dF.append(d)
+            else:
+                dF.append(torch.empty_like(f))
+        dnoise = torch.empty(nz.numel(), dtype=torch.float32, device=dev)
+        dkl = torch.empty(ctx.n_kl, dtype=torch.float64, device=dev) if ctx.n_kl else None
+        ws = o._ws(8 * 4100 * len(Fc) + 64, g)
+        real = [d if not z else g for d, z in zip(dF, fused)]  # (mutable-argument list: no expanded tensors in it)
+        torch.ops.gpsa.elbo_loss_fused_bwd(Fc, Yc, nz, idx, shapes, [int(z) for z in fused], g, int(ctx.n_kl),
+                                           float(aux["kl_scale"]), real, dnoise, dkl, ws)
+        shape, dt = ctx.noise_meta
+        return (None, dnoise.reshape(shape).to(dt), dkl) + tuple(dF)
+
+    @staticmethod
     def backward(ctx, gloss):
+        if ctx.aux.get("fuse") is not None:
+            return ElboLossFn._backward_fused(ctx, gloss)
         lib = _lib.load()
         o = _ops_mod.get_ops()
         aux = ctx.aux

@@ -343,6 +343,47 @@ _engine_op("elbo_loss_bwd(Tensor[] Fs, Tensor[] Ys, Tensor noise, int[] noise_id
            "float kl_scale, Tensor(a!)[] dFs, Tensor(b!) dnoise, Tensor(c!)? dkl, Tensor(d!) ws) -> ()", _elbo_loss_bwd)
 
 
+def _ll_arrays_fused(Fs, Ys, noise, noise_idx, shapes, fused):
+    """as _ll_arrays with explicit [S, N, P] per term; a fused term's "F" is its partial-sum vector (gpsa_step_io.ll_part)"""
+    n = len(Fs)
+    arr = lambda vals: (C.c_void_p * n)(*vals)
+    nparts = max([int(f.numel()) for f, z in zip(Fs, fused) if z] or [0])
+    return (n, arr([0 if z else f.data_ptr() for f, z in zip(Fs, fused)]), arr([y.data_ptr() for y in Ys]),
+            arr([noise.data_ptr() + 4 * j for j in noise_idx]), (C.c_int * n)(*[int(shapes[3 * i]) for i in range(n)]),
+            (C.c_longlong * n)(*[int(shapes[3 * i + 1]) for i in range(n)]),
+            (C.c_int * n)(*[int(shapes[3 * i + 2]) for i in range(n)]),
+            arr([f.data_ptr() if z else 0 for f, z in zip(Fs, fused)]), nparts)
+
+
+def _elbo_loss_fused_fwd(Fs, Ys, noise, noise_idx, shapes, fused, kl, kl_scale, loss, ll, ws):
+    """gpsa_elbo_loss_fused_fwd: the loss with some likelihood terms already reduced to partial sums by the step"""
+    n, Fp, Yp, Np, Sa, Na, Pa, Zp, nparts = _ll_arrays_fused(Fs, Ys, noise, noise_idx, shapes, fused)
+    _lib.check(_lib.load().gpsa_elbo_loss_fused_fwd(n, Fp, Yp, Np, Sa, Na, Pa, Zp, nparts,
+                                                    0 if kl is None else kl.data_ptr(), 0 if kl is None else kl.numel(),
+                                                    float(kl_scale), loss.data_ptr(), ll.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), _raw_stream(loss.device.index)),
+               "gpsa_elbo_loss_fused_fwd")
+
+
+_engine_op("elbo_loss_fused_fwd(Tensor[] Fs, Tensor[] Ys, Tensor noise, int[] noise_idx, int[] shapes, int[] fused, "
+           "Tensor? kl, float kl_scale, Tensor(a!) loss, Tensor(b!) ll, Tensor(c!) ws) -> ()", _elbo_loss_fused_fwd)
+
+
+def _elbo_loss_fused_bwd(Fs, Ys, noise, noise_idx, shapes, fused, gloss, n_kl, kl_scale, dFs, dnoise, dkl, ws):
+    n, Fp, Yp, Np, Sa, Na, Pa, Zp, nparts = _ll_arrays_fused(Fs, Ys, noise, noise_idx, shapes, fused)
+    dFp = (C.c_void_p * n)(*[0 if z else t.data_ptr() for t, z in zip(dFs, fused)])
+    dNp = (C.c_void_p * n)(*[dnoise.data_ptr() + 4 * j for j in noise_idx])
+    _lib.check(_lib.load().gpsa_elbo_loss_fused_bwd(n, Fp, Yp, Np, Sa, Na, Pa, Zp, nparts, gloss.data_ptr(), int(n_kl),
+                                                    float(kl_scale), dFp, dNp, dnoise.data_ptr(), dnoise.numel(),
+                                                    0 if dkl is None else dkl.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    _raw_stream(gloss.device.index)), "gpsa_elbo_loss_fused_bwd")
+
+
+_engine_op("elbo_loss_fused_bwd(Tensor[] Fs, Tensor[] Ys, Tensor noise, int[] noise_idx, int[] shapes, int[] fused, "
+           "Tensor gloss, int n_kl, float kl_scale, Tensor(a!)[] dFs, Tensor(b!) dnoise, Tensor(c!)? dkl, "
+           "Tensor(d!) ws) -> ()", _elbo_loss_fused_bwd)
+
+
 def _adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
     """torch.optim.Adam's update over all tensors in one launch, step counter on the device (gpsa_adam_step)"""
     n = len(params)

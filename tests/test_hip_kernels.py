@@ -198,6 +198,42 @@ def test_quadform_keep_f32(hip, M, C, L):
         assert nb == L * M * C * 4
 
 
+@pytest.mark.parametrize("M,N,S,L", [(200, 700, 3, 50), (64, 333, 1, 7), (16, 70, 2, 5), (100, 5000, 2, 9),
+                                     (208, 129, 5, 3), (30, 64, 1, 1), (200, 20000, 2, 4)])
+def test_quadform_elbo(hip, M, N, S, L):
+    """variance + draw + Gaussian likelihood + abar in one pass over the products (gpsa_quadform_elbo_f32) against
+    the formulas of the separate kernels (elementwise.hip) evaluated in fp64"""
+    C = S * N
+    al = rnd(M, C, seed=1) / M ** 0.5
+    A = rnd(L, M, M, seed=2, dtype=torch.float64) / M ** 0.5
+    Om = A @ A.transpose(1, 2) + 1e-5 * torch.eye(M, dtype=torch.float64)
+    meanT = rnd(L, C, seed=3)
+    var_u, noise_u = torch.tensor([0.3]), torch.tensor([-0.7])
+    q = (rnd(C, seed=4, dtype=torch.float64).abs() * 0.2).clamp(max=1.0)
+    eps, Y = rnd(S, N, L, seed=5), rnd(N, L, seed=6)
+    g, dm, abar, z2 = hip.quadform_elbo(al.to(DEV), Om.to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV), eps.to(DEV),
+                                        Y.to(DEV), noise_u.to(DEV))
+    ad = al.double()
+    W = torch.einsum("lmk,kc->lmc", Om, ad)
+    v = (W * ad[None]).sum(1)                                           # [L, C]
+    var = (var_u.double().exp() - q)[None] + v + 2e-5
+    e = eps.double().reshape(C, L).t()                                  # [L, C]
+    F = meanT.double() + var.sqrt() * e
+    sN = noise_u.double().exp() + 1e-5
+    r = Y.double().t().repeat(1, S) - F                                 # column c = s*N + n  ->  Y[n]
+    dF = -r / (sN * sN * S)
+    gw = dF * e * 0.5 / var.sqrt()
+    close(dm, dF, 3e-6)
+    close(g, gw, 3e-6)
+    close(abar, 2.0 * torch.einsum("lc,lmc->mc", gw, W), 5e-6)
+    close(z2.reshape(1), ((r / sN) ** 2).sum().reshape(1), 1e-6)
+    if M > 208:
+        return
+    with pytest.raises(Exception):
+        hip.quadform_elbo(rnd(240, C).to(DEV), rnd(L, 240, 240).to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV),
+                          eps.to(DEV), Y.to(DEV), noise_u.to(DEV))
+
+
 @pytest.mark.parametrize("M,n0,n1", [(5, 3, 2), (200, 4, 50), (72, 1, 1)])
 def test_omega_two_segments(hip, M, n0, n1):
     """gpsa_omega_fwd2 / _bwd2: two parameter tensors in one launch == the two single-segment calls, bit for bit"""

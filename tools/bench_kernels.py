@@ -75,6 +75,17 @@ if "keep" in what:  # the headline forward: quadratic form with the products kep
         Om = torch.randn(50, 200, 200, device=dev, dtype=torch.float64)
         Os = Om + Om.transpose(1, 2)
         print(f"quadform_fwd_keep C={C}: {timeit(lambda: o.quadform_fwd_keep(X, Os), n=10, warm=2):.1f} us", flush=True)
+if "elbo" in what:  # variance + draw + likelihood + abar in one pass over the products (vs keep-forward + kept_wsum)
+    for N, S in ((20000, 5), (20000, 1)):
+        C = N * S
+        X = torch.randn(200, C, device=dev) / 14
+        A = torch.randn(50, 200, 200, device=dev, dtype=torch.float64) / 14
+        Om = A @ A.transpose(1, 2)
+        meanT = torch.randn(50, C, device=dev)
+        q = torch.rand(C, device=dev, dtype=torch.float64) * 0.2
+        vu, nu = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        eps, Y = torch.randn(S, N, 50, device=dev), torch.randn(N, 50, device=dev)
+        print(f"quadform_elbo C={C}: {timeit(lambda: o.quadform_elbo(X, Om, meanT, q, vu, eps, Y, nu), n=10, warm=2):.1f} us", flush=True)
 if "solve" in what:  # gamma = K^-1 abar of the data-layer backward: one fp64-MFMA pass vs two fp32 triangular passes
     for C in (12500, 100000):
         Kinv = spd(1, 200)[0]
