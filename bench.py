@@ -424,6 +424,17 @@ def main():
                                              "full product, stored once, form closed in the kernel)")
                 kernel_of["quadform_bwd_alpha"] = ("col_wsum_rows_kernel (gpsa_quadform_bwd_alpha_kept_f32: one streaming "
                                                    "read of the kept products; HBM-bound)")
+        fused = bool(getattr(model.__dict__.get("_cache"), "fuse", None))
+        if fused and args.M <= 208:
+            # the training helpers fold the likelihood into the data GP's pass (gpsa_quadform_elbo_f32): the full
+            # product, closed and weighted into the alpha-gradient in the accumulators - nothing kept, nothing re-read
+            executed_ratio["quadform_fwd"] = (16.0 * MB / args.M) ** 2
+            kernel_of["quadform_fwd"] = ("panel_elbo_kernel (gpsa_quadform_elbo_f32: the full 2*C*L*M^2 product, with the "
+                                         "variance, draw, Gaussian likelihood, its gradient and abar = 2 sum_l g_l Omega_l "
+                                         "alpha formed from the accumulators)")
+            kernel_of["quadform_bwd_alpha"] = ("what is left of the alpha-gradient: elbo_post_kernel (column sums of g) + "
+                                               "the mean term's [M,L] x [L,C] product; no pass over the products")
+            kept = False
         roof = None
         if ks:
             # the dominant kernel = the contraction with the longest launch
@@ -465,7 +476,12 @@ def main():
                                            "step costs that much): this step executes fewer flops - see executed_*")
             # what the matrix cores actually issue for the three contractions of this step (with kept products the
             # alpha-gradient re-uses the forward's product: no flops)
-            exec_fl = sum(ks[k]["flops"] * executed_ratio[k] for k in ks if not (kept and k == "quadform_bwd_alpha"))
+            exec_fl = sum(ks[k]["flops"] * executed_ratio[k] for k in ks
+                          if not ((kept or fused) and k == "quadform_bwd_alpha"))
+            if fused and "quadform_bwd_alpha" in roof["other_kernels"]:
+                o = roof["other_kernels"]["quadform_bwd_alpha"]
+                roof["other_kernels"]["quadform_bwd_alpha"] = dict(kernel=o["kernel"], avg_ms=o["avg_ms"])
+            roof["fused_elbo"] = fused
             roof["step_level"]["executed_contraction_flops_per_step"] = exec_fl
             roof["step_level"]["executed_contraction_tflops"] = exec_fl * (args.steps / dt) / 1e12
             roof["step_level"]["executed_contraction_frac"] = exec_fl * (args.steps / dt) / 1e12 / PEAK_F32_MFMA_TFLOPS

@@ -1292,9 +1292,12 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     if (gloss == nullptr) return GPSA_EINVAL;
     const long long wsb = 8 * (C / 256 + 2);
     void* ws = c.sc.get<char>(wsb);
+    const bool timed = !dry && &ps == &P.passes[0];
+    if (timed) P.tick(1, 0, false, c.st);  // (slot 1: what is left of the alpha-gradient - the mean term's share)
     GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, B.dvar_ds + pass_idx, ws, wsb,
                                   c.stv()));
     GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
+    if (timed) P.tick(1, 1, false, c.st);
   } else {
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
     const long long mk2 = c.sc.mark();
