@@ -36,7 +36,7 @@ def main():
         out["kernels"][k[:120]] = {"launches": len(fetch[k]), "fetch_bytes": fb, "write_bytes": wb}
         bl = out.setdefault("hbm_bytes_per_launch", {})
         pm = re.search(r"panel_mfma_kernel<\d+, \d+, (\d+)", k)  # third argument: 0 QUAD, 1 ACCUM, 2 STORE
-        if "quad_sym_mfma_kernel" in k or (pm and pm.group(1) == "0"):
+        if "quad_sym_mfma_kernel" in k or "panel_elbo_kernel" in k or (pm and pm.group(1) == "0"):
             bl["quadform_fwd"] = fb + wb
         elif (pm and pm.group(1) == "1") or "kept_wsum_kernel" in k:
             bl["quadform_bwd_alpha"] = fb + wb

@@ -19,7 +19,8 @@ open(os.path.join(O, f"{tag}_pmc_fetch_write_summary.txt"), "w").write(
     "--no-cpu-baseline --no-graph --no-s1\n(profiles/pmc_summarize.py: KiB -> bytes, FETCH doubled per "
     "MI355X_MICROARCH.md; per-launch averages, top 12 by fetch)\n\n" + fw)
 
-keys = {"panel_mfma_kernel<13, 3, 0, 2>": "panel_mfma_kernel<13,3,QUAD,2> + kept products  (dominant)",
+keys = {"panel_elbo_kernel<13, 2, 2>": "panel_elbo_kernel<13,2,2>: product + likelihood + abar  (dominant)",
+        "panel_mfma_kernel<13, 3, 0, 2>": "panel_mfma_kernel<13,3,QUAD,2> + kept products  (unfused step)",
         "kept_wsum_kernel": "kept_wsum_kernel<13,3,4>  (streaming, no MFMA)",
         "gram_mfma_kernel": "gram_mfma_kernel<13,true,2>  (2 outputs per WG)",
         "whiten_mfma_kernel<13, double, float, true": "whiten_mfma_kernel<13,double,float,stream> (fp64 MFMA)",
