@@ -482,6 +482,11 @@ def main():
                 o = roof["other_kernels"]["quadform_bwd_alpha"]
                 roof["other_kernels"]["quadform_bwd_alpha"] = dict(kernel=o["kernel"], avg_ms=o["avg_ms"])
             roof["fused_elbo"] = fused
+            if fused:
+                roof["note"] = ("this launch also carries the Gaussian likelihood and the alpha-gradient - the work of "
+                                "panel_mfma_kernel<QUAD> (3.25-3.31 ms, frac 0.77 / executed 0.84), kept_wsum_kernel "
+                                "(0.68-0.81 ms, 4.2 GB read) and four elementwise kernels (0.08 ms) of the unfused step "
+                                "(GPSA_FUSE_ELBO=0): frac counts the product's 2*C*L*M^2 flops alone")
             roof["step_level"]["executed_contraction_flops_per_step"] = exec_fl
             roof["step_level"]["executed_contraction_tflops"] = exec_fl * (args.steps / dt) / 1e12
             roof["step_level"]["executed_contraction_frac"] = exec_fl * (args.steps / dt) / 1e12 / PEAK_F32_MFMA_TFLOPS
