@@ -426,11 +426,21 @@ elbo_post_kernel(float* __restrict__ g, float* __restrict__ dmeanT, long long C,
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   float s = 0.f;
   if (c < C) {
-    for (int l = 0; l < L; ++l) {
-      const long long o = (long long)l * C + c;
-      const float v = g[o] * gl;
-      s += v;
-      if (gl != 1.f) {
+    if (gl == 1.f) {  // (uniform) the usual case: a pure column sum, ten loads in flight per thread
+      int l = 0;
+      for (; l + 10 <= L; l += 10) {
+        float v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = g[(long long)(l + u) * C + c];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) s += v[u];
+      }
+      for (; l < L; ++l) s += g[(long long)l * C + c];
+    } else {
+      for (int l = 0; l < L; ++l) {
+        const long long o = (long long)l * C + c;
+        const float v = g[o] * gl;
+        s += v;
         g[o] = v;
         dmeanT[o] *= gl;
       }
