@@ -199,7 +199,8 @@ def test_quadform_keep_f32(hip, M, C, L):
 
 
 @pytest.mark.parametrize("M,N,S,L", [(200, 700, 3, 50), (64, 333, 1, 7), (16, 70, 2, 5), (100, 5000, 2, 9),
-                                     (208, 129, 5, 3), (30, 64, 1, 1), (200, 20000, 2, 4)])
+                                     (208, 129, 5, 3), (30, 64, 1, 1), (200, 20000, 2, 4), (5, 1, 1, 2), (200, 3, 2, 1),
+                                     (1, 17, 1, 3)])
 def test_quadform_elbo(hip, M, N, S, L):
     """variance + draw + Gaussian likelihood + abar in one pass over the products (gpsa_quadform_elbo_f32) against
     the formulas of the separate kernels (elementwise.hip) evaluated in fp64"""
