@@ -26,18 +26,20 @@ def _noise():
     return [torch.randn(3, 400, 2, generator=gen) for _ in range(2)], torch.randn(3, 800, 6, generator=gen)
 
 
-def _grads(model, dd, eG, eF, kl_scale, S=3):
+def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False):
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     model.kl_scale = kl_scale
     model.inject_noise(eG, {"expression": eF})
     model.zero_grad()
-    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=S)
+    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=S,
+                        _fuse_loss=dd if fuse else None)  # fuse: the step the training helpers run (fused ELBO)
+    assert (model._cache.fuse is not None) == fuse
     loss = model.loss_fn(dd, out[3])
     loss.backward()
     return loss.detach()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, fuse=False):
     import __graft_entry__ as ge
     from spatial_alignment_amd.parallel import GradAllReducer, shard_data_dict, shard_rows
 
@@ -50,7 +52,7 @@ def _worker(rank, world, port, q):
     sdd = shard_data_dict(dd, rank, world)
     lo, hi = shard_rows(400, rank, world)
     rows = torch.cat([torch.arange(lo, hi), 400 + torch.arange(lo, hi)])
-    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0 / world)
+    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0 / world, fuse=fuse)
     GradAllReducer(model.parameters())()
     dist.all_reduce(loss)
     if rank == 0:
@@ -59,14 +61,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_row_sharded_hip_step_equals_full_hip_step():
+@pytest.mark.parametrize("fuse", [False, True])
+def test_row_sharded_hip_step_equals_full_hip_step(fuse):
+    """two ranks' row shards + one all-reduce against the single-process step (the full step always through the
+    separate kernels: ``fuse`` also pins the fused ELBO step to them across processes)"""
     import __graft_entry__ as ge
 
     ge.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + (7 if fuse else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fuse)) for r in range(2)]
     for p in procs:
         p.start()
     loss2, g2 = q.get(timeout=600)
