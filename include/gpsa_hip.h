@@ -161,13 +161,15 @@ int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long
  *   dmeanT[l,c] = dLoss/dF = -(Y - F) / (s^2 S);   g[l,c] = dLoss/dvar = dmeanT * eps / (2 sqrt(var))
  *   abar[:,c]   = 2 sum_l g[l,c] Omega_l alpha_c                (the mean term's share is NOT included)
  * all at upstream gradient dLoss = 1 (linear in it).  part: gpsa_quadform_elbo_parts() doubles (unused tail zeroed).
+ * FT (optional, NULL = not wanted): [L][C], the draws themselves, F[s][n][l] at FT[l][s N + n] - for a caller that
+ * looks at them afterwards; nothing on the path reads them.
  * M <= 208 (13 row tiles) only: GPSA_EUNSUPPORTED beyond. */
 int gpsa_quadform_elbo_parts(void);
 long long gpsa_quadform_elbo_f32_workspace(int M, long long C, int L);
 int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
                            const float* meanT, const double* q, const float* var_u, const float* eps, const float* Y,
                            long long N, int S, const float* noise_u, float* g, float* dmeanT, float* abar, double* part,
-                           void* workspace, long long workspace_bytes, void* stream);
+                           float* FT, void* workspace, long long workspace_bytes, void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
  * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */
@@ -478,8 +480,8 @@ typedef struct gpsa_step_io {
                                                    of an earlier gpsa_step_forward on the SAME parameters - skip it.
                                                    For the slices of one microbatched step (train.Microbatches) */
   /* Fused ELBO (training through the engine's own loss, Gaussian likelihood on F_latent, no LMC): with fuse_elbo
-   * nonzero and Y[m] / noise_u[m] given, modality m's data GP runs gpsa_quadform_elbo_f32 - its draws are never
-   * materialised (F_latent[m] is not written), ll_part[m] receives the partial sums of z^2 for
+   * nonzero and Y[m] / noise_u[m] given, modality m's data GP runs gpsa_quadform_elbo_f32 - F_latent[m] is not
+   * written (the draws leave only through the optional F_fused_T[m]), ll_part[m] receives the partial sums of z^2 for
    * gpsa_elbo_loss_fused_fwd / _bwd, and gpsa_step_backward takes the loss's upstream gradient from
    * gpsa_step_out_grads.gloss instead of dF_latent[m].  Modalities the fused kernel does not cover (LMC, more than
    * 208 inducing points: gpsa_step_fused(plan, m) == 0) run unfused and must be given F_latent[m] as usual. */
@@ -487,6 +489,8 @@ typedef struct gpsa_step_io {
   const float* Y[GPSA_MAX_MODS];            /* in  [N_m, L_m] observations */
   const float* noise_u[GPSA_MAX_MODS];      /* in  [1] the likelihood's log "variance" of modality m */
   double* ll_part[GPSA_MAX_MODS];           /* out [gpsa_quadform_elbo_parts()] */
+  float* F_fused_T[GPSA_MAX_MODS];          /* out, optional: [L_m][S N_m] the draws of a fused modality, F[s][n][l] at
+                                                   [l][s N_m + n] (gpsa_quadform_elbo_f32's FT) */
 } gpsa_step_io;
 
 typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */
@@ -513,7 +517,13 @@ int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
 /* stages: bit 0 = the M x M factorisations, the KL terms and the warp GPs (everything ``flag`` depends on),
  * bit 1 = the data GPs.  3 = the whole forward; a caller that wants to look at ``flag`` while the data GPs
- * run enqueues the two stages with two calls and its flag copy in between. */
+ * run enqueues the two stages with two calls and its flag copy in between.
+ * bits 8 .. 8 + GPSA_MAX_MODS - 1 (with bit 1): run the data GP of these modalities' training rows only (0: every
+ * pass), on the ``saved`` arena stage 1 filled.  This is how the reference's two calls map onto the fused ELBO:
+ * forward() enqueues stage 1 (+ the modalities that cannot fuse), loss_fn(), which is where the observations arrive
+ * (vgpsa.py:491, 532-538), sets io.Y[m] and enqueues modality m's pass.  A caller that wants modality m's draws after
+ * all passes Y[m] = NULL and F_latent[m] instead (the unfused kernels; the same io then goes to gpsa_step_backward).
+ * bit 2: such a pass is an extra (re-)run, not one of the step's launches gpsa_step_timing records. */
 int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_step_io* io, void* saved,
                       void* scratch, int stages, void* stream);
 /* diagnostic (bench.py's roofline figures): HIP events around the three contraction launches (the variance

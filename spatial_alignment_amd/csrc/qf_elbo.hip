@@ -1,0 +1,292 @@
+// panel_elbo_kernel: the data GP's forward, its Gaussian likelihood and the backward's abar in one pass over the
+// products Omega_l alpha (the dominant kernel of the training step).
+#include "qf_common.hpp"
+
+namespace gpsa {
+
+// ------------------------------------------------------------------------------------------------
+// The data GP's forward, its Gaussian likelihood and the backward's  abar = 2 sum_l g_l Omega_l alpha  in ONE
+// pass over the products  W_l = Omega_l alpha  (vgpsa.py:186-204 variance, :334-351 draw, :532-538 likelihood).
+// The gradient of the ELBO wrt the draw's variance,
+//     g[l,c] = dLoss/dF[c,l] * eps[c,l] / (2 sqrt(var[l,c])),   dLoss/dF = -(Y - F) / (s^2 S)   (loss = ... - LL),
+// is elementwise in (l, c) once v[l,c] = alpha_c . W_l[:,c] is known: the workgroup that has just closed output l
+// of a column tile holds W_l for those columns in its accumulators, so g_l W_l joins a second accumulator set there
+// and the products never leave the chip - no 4 GB kept copy written by the forward and streamed back by the
+// backward (0.7-0.8 ms per step at the headline size).  Everything is formed at upstream gradient 1: the
+// backward scales by the loss's actual upstream gradient (linear).
+// Same schedule as panel_mfma_kernel<QUAD> (persistent balanced items, LDS-DMA ring, register-resident alpha
+// slab); the second accumulator set leaves like ACCUM's (plain store, or slabs for a column tile whose outputs
+// are split between workgroups).  The per-(l, column) inputs mean / eps / Y reach the closing through LDS-DMA
+// too (4-byte gathers issued under the output's first chunk): a compiler-visible load there would make hipcc wait
+// for vmcnt(0), i.e. for the two ring stages in flight.
+
+template <int MB, int NCT, int RL>
+__global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a) {
+  constexpr int MP = MB * 16;
+  constexpr int WGCOLS = 64 * NCT;
+  constexpr int CHUNK = MP * 16;
+  constexpr int NPW = (MB + 3) / 4;
+  constexpr int BUFF = NPW * 4 * 256;
+  constexpr int NGATHER = (3 * NCT * 16 + 63) / 64;  // 4-byte LDS-DMA operations per wave and output
+  __shared__ __attribute__((aligned(16))) float lds[3][BUFF];
+  __shared__ __attribute__((aligned(16))) float sgat[4][NGATHER * 64];  // [wave][(ct*3 + kind)*16 + j]: mean, eps, Y
+  __shared__ double red[4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const float* __restrict__ Ppk = a.Ppk;
+  const float* __restrict__ X = a.X;
+  const int M = a.M, L = a.L;
+  const long long C = a.C;
+
+  const long long ntiles = (C + WGCOLS - 1) / WGCOLS;
+  const long long T = ntiles * L;
+  const long long it0 = (long long)blockIdx.x * T / gridDim.x;
+  const long long it1 = (long long)(blockIdx.x + 1) * T / gridDim.x;
+  if (blockIdx.x == 0)
+    for (int i = (int)gridDim.x + tid; i < a.nparts; i += 256) a.part[i] = 0.0;
+  if (it0 >= it1) {
+    if (tid == 0) a.part[blockIdx.x] = 0.0;
+    return;
+  }
+
+  float xb[NCT][MB][4];
+  float xl[NCT][4];
+  f32x4 acc[MB][NCT], ab[MB][NCT];
+#define GPSA_STAGE(Q, BUF)                                                                     \
+  {                                                                                            \
+    const float* src__ = Ppk + (long long)(Q) * CHUNK + lane * 4;                              \
+    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
+      const int piece = pc * 4 + w;                                                            \
+      glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                      \
+             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                \
+    }                                                                                          \
+  }
+  const TileOrder ord(it0, it1, L);
+  long long sstep = 0, stile_;
+  int sa_, sb_, skc = 0;
+  ord.get(0, stile_, sa_, sb_);
+  int sl = sa_;
+  bool sdone = false;
+#define GPSA_STAGE_PIECE(BUF, PC)                                                              \
+  {                                                                                            \
+    const float* src__ = Ppk + ((long long)sl * MB + skc) * CHUNK + lane * 4;                  \
+    const int piece = (PC) * 4 + w;                                                            \
+    glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                        \
+           __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                  \
+  }
+#define GPSA_STAGE_ADVANCE()                                                                   \
+  {                                                                                            \
+    if (!sdone) {                                                                              \
+      if (skc + 1 < MB) ++skc;                                                                 \
+      else if (sl < sb_) { skc = 0; ++sl; }                                                    \
+      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl = sa_; skc = 0; } \
+      else sdone = true;                                                                       \
+    }                                                                                          \
+  }
+#define GPSA_STAGE_NEXT(BUF)                                                                   \
+  {                                                                                            \
+    GPSA_STAGE((long long)sl * MB + skc, BUF)                                                  \
+    GPSA_STAGE_ADVANCE()                                                                       \
+  }
+
+  // likelihood constants (elementwise.hip: loglik_*_kernel)
+  const double sN = exp((double)a.noise_u[0]) + 1e-5;
+  const float inv = (float)(1.0 / sN);
+  const float coef = (float)(-1.0 / (sN * sN * (double)a.S));  // dLoss/dF = coef (Y - F) at upstream gradient 1
+  const double var0 = exp((double)a.var_u[0]);
+  double z2 = 0.0;
+
+  int buf = 0;
+  GPSA_STAGE_NEXT(0)
+  GPSA_STAGE_NEXT(1)
+  GPSA_DMA_WAIT(NPW);
+  __syncthreads();
+
+  for (long long step = 0; step < ord.n; ++step) {
+    long long tile;
+    int l_lo, l_hi;
+    ord.get(step, tile, l_lo, l_hi);
+    const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
+    float resid[NCT];
+    bool okc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const long long c = cw + ct * 16 + j;
+      okc[ct] = c < C;
+      // sigma^2 - q formed in fp64 before rounding (data_sample_fwd_kernel)
+      resid[ct] = okc[ct] ? (float)(var0 - a.q[c]) : 1.f;
+#pragma unroll
+      for (int t = 0; t < MB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = t * 16 + kq * 4 + r;
+          xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
+      if (RL < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (MB - 1) * 16 + r * 4 + kq;
+          xl[ct][r] = (r < RL && c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
+      }
+    }
+    // gather addresses of this lane for output l_lo: operation o moves element (o*64 + lane) of the wave's
+    // [(ct*3 + kind)*16 + j] table; kind 0: mean[l][c] (next output: + C), 1: eps[c][l] (+ 1), 2: Y[c % N][l] (+ 1)
+    const float* gp[NGATHER];
+    long long gstep[NGATHER];
+#pragma unroll
+    for (int o = 0; o < NGATHER; ++o) {
+      int e = o * 64 + lane;
+      if (e >= 3 * NCT * 16) e = 0;  // surplus lanes re-load element 0 (never read)
+      const int ct = e / 48, kind = (e % 48) / 16, jj = e % 16;
+      long long c = cw + ct * 16 + jj;
+      c = c < C ? c : C - 1;
+      gp[o] = kind == 0 ? a.meanT + (long long)l_lo * C + c
+                        : (kind == 1 ? a.eps + c * L + l_lo : a.Y + (c % a.N) * L + l_lo);
+      gstep[o] = kind == 0 ? C : 1;
+    }
+#pragma unroll
+    for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm("v_accvgpr_write_b32 %0, 0" : "=a"(ab[rt][ct][r]));
+      }
+
+    for (int l = l_lo; l <= l_hi; ++l) {
+#pragma unroll
+      for (int kc = 0; kc < MB; ++kc) {
+        float bv[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[ct][r] = (RL < 4 && kc == MB - 1) ? xl[ct][r] : xb[ct][kc][r];
+        const float* base = &lds[buf][lane * 4];
+        float4 a_nxt = *reinterpret_cast<const float4*>(base);
+        if (kc == 0) {
+          // this output's mean / eps / Y: BEFORE the chunk's ring stage is issued, so that the counted wait at the
+          // end of the chunk (all but the newest NPW operations) covers them
+#pragma unroll
+          for (int o = 0; o < NGATHER; ++o) {
+            unsigned keep__;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep__)
+                : "v"(gp[o]), "s"(__builtin_amdgcn_readfirstlane(lds_addr(&sgat[w][o * 64])))
+                : "memory");
+            gp[o] += gstep[o];
+          }
+        }
+#pragma unroll
+        for (int rt = 0; rt < MB; ++rt) {
+          const float4 a4 = a_nxt;
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (!(kc == MB - 1 && r >= RL)) {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    av[r], bv[ct][r], (kc == 0 && r == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[rt][ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r == 0) {
+              if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
+            } else if (r == 1) {
+              if (MB >= NPW + 3) {
+                if (rt < NPW) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, rt)
+                if (rt == NPW) GPSA_STAGE_ADVANCE()
+              } else if (rt == 0) {
+                GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        GPSA_DMA_WAIT(NPW);
+        __syncthreads();
+        buf = (buf == 2) ? 0 : buf + 1;
+      }
+      // closing of output l: v, the draw, its likelihood term and gradient, and g_l W_l into the second set
+      float z2l = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        float s = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += acc[rt][ct][r] * xb[ct][rt][r];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = sgat[w][(ct * 3 + 0) * 16 + j];
+        const float e = sgat[w][(ct * 3 + 1) * 16 + j];
+        const float y = sgat[w][(ct * 3 + 2) * 16 + j];
+        const float var = resid[ct] + s + 2e-5f;  // TWO_JITTER (elementwise.hip)
+        const float sd = sqrtf(var);
+        const float Fd = mean + sd * e;  // the draw (data_sample_fwd_kernel's expression)
+        const float rres = y - Fd;
+        const float dF = coef * rres;
+        const float gv = okc[ct] ? dF * e * 0.5f / sd : 0.f;
+        if (okc[ct] && kq == 0) {
+          const long long o = (long long)l * C + cw + ct * 16 + j;
+          a.g[o] = gv;
+          a.dmeanT[o] = dF;
+          if (a.FT != nullptr) a.FT[o] = Fd;  // (uniform)
+          const float z = rres * inv;
+          z2l += z * z;
+        }
+        // g_l W_l joins the second accumulator set, which lives in the AGPR file like the first (every access through
+        // an "a"-constrained operand): left to itself the allocator homes it in VGPRs - the VALU cannot address AGPRs -
+        // and evicts the alpha slab to AGPRs instead, 150 register copies in front of the MFMAs of every output.
+#pragma unroll
+        for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t;
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(ab[rt][ct][r]));
+            t = fmaf(gv, acc[rt][ct][r], t);
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(ab[rt][ct][r]) : "v"(t));
+          }
+      }
+      z2 += (double)z2l;
+    }
+    // the column tile's abar: straight to the output when this workgroup covered all its outputs, else a slab
+    {
+      const bool pl = (l_lo == 0) && (l_hi == L - 1);
+      const int which = (tile == ord.tile0) ? 0 : 1;
+      float* dst = pl ? a.abar : a.slab + ((long long)blockIdx.x * 2 + which) * MP * WGCOLS;
+      const long long rs = pl ? C : (long long)WGCOLS;
+      const int mlim = pl ? M : MP;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const long long c = cw + ct * 16 + j;
+        const long long col = pl ? c : (long long)(w * (16 * NCT) + ct * 16 + j);
+        const bool ok = pl ? (c < C) : true;
+#pragma unroll
+        for (int rt = 0; rt < MB; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + kq * 4 + r;
+            float t;
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(ab[rt][ct][r]));
+            if (ok && row < mlim) dst[(long long)row * rs + col] = 2.f * t;
+          }
+      }
+    }
+  }
+  GPSA_DMA_DRAIN();
+  z2 = block_sum(z2, red);
+  if (tid == 0) a.part[blockIdx.x] = z2;
+#undef GPSA_STAGE
+#undef GPSA_STAGE_PIECE
+#undef GPSA_STAGE_ADVANCE
+#undef GPSA_STAGE_NEXT
+}
+
+GPSA_ELBO_SHAPES(GPSA_ELBO_DEFINE)
+
+}  // namespace gpsa

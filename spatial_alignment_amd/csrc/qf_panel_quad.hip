@@ -1,0 +1,6 @@
+// panel_mfma_kernel<MODE_QUAD>: explicit instantiations (see qf_panel_kernel.hpp)
+#include "qf_panel_kernel.hpp"
+
+namespace gpsa {
+GPSA_PANEL_SHAPES(GPSA_PANEL_DEFINE, MODE_QUAD)
+}  // namespace gpsa

@@ -822,6 +822,7 @@ struct Ctx {
   hipStream_t st;
   bool dry;
   bool apk_d = false;  // the data GP's packed inverse has been written in this call
+  bool quiet = false;  // a materialising re-run of a pass: not one of the step's timed launches
   void* stv() const { return (void*)st; }
   template <typename T> T* sv(long long off) const { return reinterpret_cast<T*>(saved + off); }
   double* mats(const Group& G, int pos) const { return sv<double>(G.o_mats) + (long long)pos * G.M * G.M; }
@@ -1189,11 +1190,11 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
     float* abar = dmeanT + (long long)L * C;
     const long long wsb = gpsa_quadform_elbo_f32_workspace(Mg, C, L);
     void* ws = c.sc.get<char>(wsb);
-    const bool timed = !dry && &ps == &P.passes[0];
+    const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(0, 0, true, c.st);
     GPSA_RUN(gpsa_quadform_elbo_f32(GPSA_F64, alpha, Om, Mg, C, L, meanT, q, c.prm.data_var, eps, c.io.Y[m],
-                                    (long long)(C / P.S), P.S, c.io.noise_u[m], g_ext, dmeanT, abar, c.io.ll_part[m], ws, wsb,
-                                    c.stv()));
+                                    (long long)(C / P.S), P.S, c.io.noise_u[m], g_ext, dmeanT, abar, c.io.ll_part[m],
+                                    c.io.F_fused_T[m], ws, wsb, c.stv()));
     if (timed) { P.tick(0, 1, true, c.st); ++P.tfwd; }
     c.sc.release(mk);
     return 0;
@@ -1201,7 +1202,7 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
   {
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
     void* ws = c.sc.get<char>(wsb);
-    const bool timed = !dry && &ps == &P.passes[0];
+    const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(0, 0, true, c.st);
     if (c.io.keep_products && ps.o_keep >= 0)  // training: the full product, kept for the backward
       GPSA_RUN(gpsa_quadform_fwd_keep_f32(GPSA_F64, alpha, Om, Mg, C, L, v, c.sv<float>(ps.o_keep), ws, wsb, c.stv()));
@@ -1223,8 +1224,17 @@ static int step_forward(Plan& P, const gpsa_step_params& prm, const gpsa_step_io
     GPSA_CK(mm_stage_fwd(c));
     GPSA_CK(warp_stage_fwd(c));
   }
-  if (stages & 2)
-    for (const Pass& ps : P.passes) GPSA_CK(data_pass_fwd(c, ps));
+  if (stages & 2) {
+    // bits 8..: only the training passes of these modalities (0: every pass): a training forward leaves the
+    // modalities whose likelihood can ride in the data GP's pass for loss_fn, which knows the observations; bit 2:
+    // a re-run that materialises such a modality's draws after the fact (not one of the step's timed launches)
+    const int mask = (stages >> 8) & ((1 << MAXMODS) - 1);
+    c.quiet = (stages & 4) != 0;
+    for (const Pass& ps : P.passes) {
+      if (mask != 0 && (ps.test || ((mask >> ps.m) & 1) == 0)) continue;
+      GPSA_CK(data_pass_fwd(c, ps));
+    }
+  }
   return 0;
 }
 
@@ -1292,7 +1302,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     if (gloss == nullptr) return GPSA_EINVAL;
     const long long wsb = 8 * (C / 256 + 2);
     void* ws = c.sc.get<char>(wsb);
-    const bool timed = !dry && &ps == &P.passes[0];
+    const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(1, 0, false, c.st);  // (slot 1: what is left of the alpha-gradient - the mean term's share)
     GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, B.dvar_ds + pass_idx, ws, wsb,
                                   c.stv()));
@@ -1302,7 +1312,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
     const long long mk2 = c.sc.mark();
     void* ws = c.sc.get<char>(wsb);
-    const bool timed = !dry && &ps == &P.passes[0];
+    const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(1, 0, false, c.st);
     const bool kept = c.io.keep_products && ps.o_keep >= 0;
     if (kept)  // one streaming pass over the products the forward kept, the mean term's share in the same pass
@@ -1394,7 +1404,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
     void* ws = c.sc.get<char>(wsb);
     double* dst = first_for_mod ? dOm : c.sc.get<double>((long long)L * mm);
-    const bool timed = !dry && &ps == &P.passes[0];
+    const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(2, 0, false, c.st);
     int rc = dry ? 0 : gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F64, alpha, g_ext, Mg, C, L, dst, ws, wsb, c.stv());
     if (rc == GPSA_EUNSUPPORTED) {  // generic path stores in the compute type: convert

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .. import engine as E
 from .. import step_engine as SE
+from ..lazy import LazyDraws
 from ..kernels import builtin_kind, rbf_kernel
 from .gpsa import GPSA
 
@@ -118,10 +119,12 @@ class VariationalGPSA(GPSA):
         # one product less per step); False: recompute them in the backward (the memory-lean path, also taken
         # by itself when the products exceed the keep budget below)
         self.keep_products = True
-        # train.train_step / fit / GraphedTrainStep / Microbatches tell forward which data_dict loss_fn will see: the
-        # Gaussian likelihood and its gradient then ride in the data GP's own pass over the products Omega_l alpha
-        # (gpsa_quadform_elbo_f32) - nothing is kept, nothing streamed back.  False (or GPSA_FUSE_ELBO=0): the separate
-        # kernels, as a hand-written forward / loss_fn loop always gets
+        # A training forward leaves the data GP of every modality the fused kernel covers (Gaussian likelihood on
+        # F_latent, no LMC, M <= 208) to loss_fn, which is where the observations arrive (vgpsa.py:532-538): variance,
+        # draw, likelihood, its gradient and the backward's alpha-gradient then ride in ONE pass over the products
+        # Omega_l alpha (gpsa_quadform_elbo_f32) - nothing is kept, nothing streamed back.  F_samples come back as lazy
+        # handles (lazy.LazyDraws) that loss_fn understands and that turn into real draws when anything else touches
+        # them.  False (or GPSA_FUSE_ELBO=0): always the separate kernels
         self.fuse_elbo = os.environ.get("GPSA_FUSE_ELBO", "1") != "0"
         self.keep_budget_gb = None  # HBM for those products: None = what the device can still give (step_engine.py)
         # the data GP's inducing-point gradient from the UNROUNDED projection (gpsa_step_desc.exact_inducing_grad):
@@ -291,11 +294,7 @@ class VariationalGPSA(GPSA):
         return torch.empty(shape, dtype=torch.float32, device=device).normal_(generator=gen)
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, X_spatial, view_idx, Ns, S=1, prediction_mode=False, G_test=None, _fuse_loss=None):
-        """``_fuse_loss`` (the training helpers of train.py, not part of the reference's interface): the data_dict the
-        NEXT call, loss_fn(data_dict, F_samples), will be given.  The step engine then folds the Gaussian likelihood
-        and its gradient into the data GP's pass (gpsa_quadform_elbo_f32): the draws are not materialised, and the
-        returned F_samples are handles only loss_fn understands."""
+    def forward(self, X_spatial, view_idx, Ns, S=1, prediction_mode=False, G_test=None):
         if prediction_mode:
             self.eval()
         dev = self.Xtilde.device
@@ -306,7 +305,7 @@ class VariationalGPSA(GPSA):
         if self.use_step_engine and dev.type == "cuda" and SE.eligible(self, X_spatial, view_idx, G_test):
             rows = SE.view_rows(self, view_idx, Ns)
             if rows is not None:
-                return self._forward_engine(X_spatial, rows, S, G_test, noise, prediction_mode, _fuse_loss)
+                return self._forward_engine(X_spatial, rows, S, G_test, noise, prediction_mode)
         cache = _StepCache()
 
         # per-view slices of the parameters, unbound once (one autograd node per parameter instead of
@@ -539,31 +538,27 @@ class VariationalGPSA(GPSA):
             )
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
-    def _fuse_setup(self, plan, data_dict, S, G_test, prediction_mode):
-        """-> the ``fuse`` record of a fused-ELBO forward, or None when this step cannot (or should not) fuse"""
-        if data_dict is None or not self.fuse_elbo or prediction_mode or G_test is not None:
+    def _fuse_setup(self, plan, S, G_test, prediction_mode):
+        """-> the ``fuse`` record of a training forward that leaves its fusable data GPs to loss_fn, or None"""
+        if not self.fuse_elbo or prediction_mode or G_test is not None:
             return None
         if not torch.is_grad_enabled() or not any(p.requires_grad for p in SE._param_list(self)):
             return None
         mods = self.modality_names
-        f32 = torch.float32
-        Ys, flags = [], []
-        for i, m in enumerate(mods):
-            Y = data_dict[m]["outputs"]
-            ok = (isinstance(Y, torch.Tensor) and Y.is_cuda and Y.dtype == f32 and Y.is_contiguous()
-                  and tuple(Y.shape) == (plan.N[i], plan.L[i]) and not plan.lmc[i]
-                  and bool(plan.lib.gpsa_step_fused(plan.handle, i)))
-            Ys.append(Y if ok else None)
-            flags.append(ok)
+        flags = [not plan.lmc[i] and bool(plan.lib.gpsa_step_fused(plan.handle, i)) for i in range(len(mods))]
         nz = self.noise_variance
-        if not any(flags) or nz.dtype != f32 or not nz.is_contiguous():
+        if not any(flags) or nz.dtype != torch.float32 or not nz.is_contiguous():
             return None
         nn_ = nz.numel()
-        return dict(mods=flags, Y=Ys, noise=nz.detach(),
+        return dict(mods=flags, Y=[None] * len(mods), noise=nz.detach(),
                     noise_ptr=[nz.data_ptr() + 4 * (nn_ - self.n_modalities + i) for i in range(len(mods))],  # quirk 5
-                    shapes=[(int(S), plan.N[i], plan.L[i]) for i in range(len(mods))], gloss=None)
+                    shapes=[(int(S), plan.N[i], plan.L[i]) for i in range(len(mods))], gloss=None,
+                    # per modality: "lazy" (handle untouched) -> "fused" (loss_fn ran the fused pass) or "real"
+                    # (materialised first: an unfused modality from then on); see lazy.py
+                    state=["lazy" if z else None for z in flags], dF=[None] * len(mods), F_real=[None] * len(mods),
+                    live=None, parts=None, FT=[None] * len(mods))
 
-    def _forward_engine(self, X_spatial, rows, S, G_test, noise, prediction_mode, fuse_loss=None):
+    def _forward_engine(self, X_spatial, rows, S, G_test, noise, prediction_mode):
         """forward through the C++ step engine: one autograd node, one host call each way"""
         dev = self.Xtilde.device
         mods = self.modality_names
@@ -645,7 +640,7 @@ class VariationalGPSA(GPSA):
                    want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,
                    mm_epoch=self.__dict__.get("_mm_epoch"),
                    flag_slot=self.__dict__.get("_flag_slot", 0),
-                   fuse=self._fuse_setup(plan, fuse_loss, S, G_test, prediction_mode))
+                   fuse=self._fuse_setup(plan, S, G_test, prediction_mode))
         self.__dict__["_flag_slot"] = 1 - aux["flag_slot"]  # two pinned words: consecutive forwards never share one
         outs = SE.StepFn.apply(aux, *SE._param_list(self))
         nm = len(mods)
@@ -665,7 +660,14 @@ class VariationalGPSA(GPSA):
         cache.mu_z, cache.engine_flag = aux["mu_z"], aux["flag"]
         cache.fuse = aux["fuse"]
         if cache.fuse is not None:
-            cache.fuse["handles"] = [Fl[i] for i in range(nm)]
+            # a fused modality's "F_latent" output is the vector of partial sums its likelihood finishes from: what the
+            # caller gets is a handle with the draws' shape that loss_fn recognises and that materialises on any other use
+            Fl = list(Fl)
+            for i in range(nm):
+                if cache.fuse["mods"][i]:
+                    h = LazyDraws(cache.fuse, i, (S, plan.N[i], plan.L[i]), dev)
+                    h._parts = Fl[i]
+                    Fl[i] = h
         G_means = {m: Gm[i] for i, m in enumerate(mods)}
         G_samples = {m: Gs[i] for i, m in enumerate(mods)}
         self.F_latent_samples = {m: Fl[i] for i, m in enumerate(mods)}
@@ -766,15 +768,34 @@ class VariationalGPSA(GPSA):
                        noise_idx=[nn_ - self.n_modalities + i for i in range(self.n_modalities)],  # quirk 5
                        kl_scale=self.kl_scale)
             fuse = getattr(cache, "fuse", None)
-            if fuse is not None:
-                # forward(_fuse_loss=...) folded the likelihood into the step: this must be the call it was told about
-                for i, m in enumerate(self.modality_names):
-                    if fuse["mods"][i] and (F_samples[m] is not fuse["handles"][i]
-                                            or data_dict[m]["outputs"].data_ptr() != fuse["Y"][i].data_ptr()):
-                        raise ValueError("loss_fn after forward(_fuse_loss=data_dict): call it with that data_dict and "
-                                         "the F_samples forward returned")
-                aux["fuse"] = fuse
-            loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *[F_samples[m] for m in self.modality_names])
+            Fs, eff, run_i, run_Y = [], [], [], []
+            for i, m in enumerate(self.modality_names):
+                F = F_samples[m]
+                take = False
+                if isinstance(F, LazyDraws):
+                    # forward left this modality's data GP to us: run it with the likelihood folded in when the handle is
+                    # that forward's own, untouched, and the observations are what the fused kernel reads (fp32, on the
+                    # device, [N, L]); anything else gets the draws themselves (the handle materialises)
+                    Y = data_dict[m]["outputs"]
+                    mine = fuse is not None and F._rec is fuse
+                    fresh = mine and fuse["state"][i] == "lazy"
+                    take = mine and fuse["state"][i] == "fused" and torch.is_tensor(Y) and Y is fuse["Y"][i]
+                    if fresh and (torch.is_tensor(Y) and Y.is_cuda and Y.device == F.device and Y.dtype == torch.float32
+                                  and Y.is_contiguous() and tuple(Y.shape) == (fuse["shapes"][i][1], fuse["shapes"][i][2])):
+                        take = True
+                        fuse["state"][i] = "fused"
+                        run_i.append(i)
+                        run_Y.append(Y)
+                    F = F._parts if take else F.materialize()
+                Fs.append(F)
+                eff.append(take)
+            if run_i:
+                from ..lazy import run_fused
+
+                run_fused(fuse, run_i, run_Y)
+            if any(eff):
+                aux["fuse"], aux["fuse_mods"] = fuse, eff
+            loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *Fs)
             return loss.to(self.Xtilde.dtype)
         f64 = torch.float64
         kl = None

@@ -271,11 +271,11 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_fwd_keep")
         return (v, W) if dcT is None else (v, W, meanT)
 
-    def quadform_elbo(self, alpha, Omega, meanT, q, var_u, eps, Y, noise_u):
+    def quadform_elbo(self, alpha, Omega, meanT, q, var_u, eps, Y, noise_u, want_draws=False):
         """The data GP's variance, draw, Gaussian likelihood and the backward's abar in one pass over the products
         Omega_l alpha (gpsa_quadform_elbo_f32; alpha fp32 [M,C], Omega [L,M,M], meanT [L,C], q fp64 [C], eps [S,N,L] or
         [C,L], Y [N,L]).  Returns (g [L,C], dmeanT [L,C], abar [M,C], z2 = sum ((Y - F)/s)^2 as an fp64 0-dim tensor), all at
-        upstream gradient 1 of loss = -LL."""
+        upstream gradient 1 of loss = -LL; with ``want_draws`` also the draws, transposed: FT [L,C]."""
         alpha, Omega = self._c(alpha), self._c(Omega)
         M, Cn = alpha.shape
         L = Omega.shape[0]
@@ -292,11 +292,12 @@ class HipOps:
         if wsb <= 0:
             raise _lib.GpsaHipError("gpsa_quadform_elbo_f32: more than 13 row tiles (M > 208)")
         ws = self._ws(wsb, alpha)
+        FT = torch.empty(L, Cn, dtype=torch.float32, device=dev) if want_draws else None
         rc = self.lib.gpsa_quadform_elbo_f32(_dt(Omega), _p(alpha), _p(Omega), M, Cn, L, _p(meanT), _p(q), _p(var_u),
-                                             _p(eps), _p(Y), N, S, _p(noise_u), _p(g), _p(dm), _p(abar), _p(part), _p(ws),
-                                             ws.numel(), self._stream(alpha))
+                                             _p(eps), _p(Y), N, S, _p(noise_u), _p(g), _p(dm), _p(abar), _p(part),
+                                             _p(FT), _p(ws), ws.numel(), self._stream(alpha))
         _lib.check(rc, "gpsa_quadform_elbo_f32")
-        return g, dm, abar, part.sum()
+        return (g, dm, abar, part.sum(), FT) if want_draws else (g, dm, abar, part.sum())
 
     def quadform_bwd_alpha_kept(self, W, g, dcT=None, dmeanT=None):
         """2 sum_l g_l o W_l  (+ dcT dmeanT, the mean term's share of the alpha-gradient, in the same pass)"""

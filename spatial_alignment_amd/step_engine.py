@@ -229,6 +229,16 @@ def _fill_params(st, tensors, model, plan):
 _PLACEHOLDER = {}
 
 
+def placeholder_grad(dev, n):
+    """a gradient of the right shape and type for a fused modality's partial sums, so that autograd walks on to the
+    step's node; never read (the real upstream gradients travel through the ``fuse`` record)"""
+    key = (dev, n)
+    d = _PLACEHOLDER.get(key)
+    if d is None:
+        d = _PLACEHOLDER[key] = torch.zeros(1, dtype=torch.float64, device=dev).expand(n)
+    return d
+
+
 class StepFn(torch.autograd.Function):
     """(parameters) -> G_means[m].., G_samples[m].., F_latent[m].., F_obs[m] (LMC).., test draws.., kl [T].
     ``aux``: everything that is not differentiated (plan, coordinates, draws, stream policy)."""
@@ -249,8 +259,9 @@ class StepFn(torch.autograd.Function):
         io = _lib.StepIO()
         empty = lambda *sh: torch.empty(*sh, dtype=f32, device=dev)
         outs = {"Gm": [], "Gs": [], "Fl": [], "Fo": [], "Flt": [], "Fot": []}
-        # fused ELBO (aux["fuse"], set up by VariationalGPSA.forward for the training helpers): modality i's draws are
-        # never materialised - its "F_latent" output is the vector of partial sums the likelihood finishes from
+        # fused ELBO (aux["fuse"], set up by VariationalGPSA.forward in training): modality i's data GP is left for
+        # loss_fn, which knows the observations (lazy.run_fused) - its "F_latent" output is the vector of partial sums
+        # the likelihood finishes from, the draws are never materialised
         fuse = aux.get("fuse")
         fused = fuse["mods"] if fuse is not None else [False] * nm
         if fuse is not None:
@@ -263,7 +274,11 @@ class StepFn(torch.autograd.Function):
             Gm, Gs = empty(N, D), empty(S, N, D)
             if fused[i]:
                 Fl = torch.empty(nparts, dtype=torch.float64, device=dev)
-                io.Y[i], io.noise_u[i], io.ll_part[i] = _p(fuse["Y"][i]), fuse["noise_ptr"][i], _p(Fl)
+                io.noise_u[i], io.ll_part[i] = fuse["noise_ptr"][i], _p(Fl)  # (io.Y[i]: set by loss_fn)
+                # the draws themselves leave the fused pass too, transposed ([L, S N]: 20 MB at the headline size, two
+                # more 64-byte stores per output and wave): what the handle shows to anyone who looks after loss_fn
+                fuse["FT"][i] = torch.empty(L, S * N, dtype=f32, device=dev)
+                io.F_fused_T[i] = _p(fuse["FT"][i])
             else:
                 Fl = empty(S, N, L)
                 io.F_latent[i] = _p(Fl)
@@ -319,28 +334,41 @@ class StepFn(torch.autograd.Function):
             flat_outs.append(kl)
         ins = [t for t in aux["X"] + list(aux["eps_F"]) + [aux["eps_G"], aux["slopes"], aux["intercepts"]]
                + list(aux["G_test"] or []) + list(aux["eps_F_test"] or [])
-               + (list(fuse["Y"]) + [fuse["noise"]] if fuse is not None else []) if t is not None]
+               if t is not None]
         call = TO.stash(dict(lib=lib, handle=plan.handle, prm=prm, io=io))
+        # stage 2 of THIS call: every data GP, or - with fused modalities - only the ones that cannot fuse
+        rest = sum(1 << (8 + i) for i in range(nm) if not fused[i]) if fuse is not None else 0
 
         def run(stages):
-            torch.ops.gpsa.step_forward(list(tensors), ins, flat_outs, saved, scratch, call, stages)
+            if fuse is not None and (stages & 2):
+                stages = (stages & 1) | ((2 | rest) if rest else 0)
+            if stages:
+                torch.ops.gpsa.step_forward(list(tensors), ins, flat_outs, saved, scratch, call, stages)
 
-        if aux["check"] == "deferred":
-            # training: the word is shipped behind an event as below, but nobody waits for it inside forward -
-            # the backward of this node does, before it touches a gradient (see StepFn.backward)
-            run(1)
-            aux["deferred"] = model._post_flag(flag)
-            run(2)
-        elif aux["check"]:
-            # the flag depends on the factorisations and the warp GPs only: ship it to the host behind an event
-            # BEFORE the data GPs are queued, so that the check waits for the short part of the forward and the
-            # host keeps queueing while the long part runs
-            run(1)
-            pending = model._post_flag(flag)
-            run(2)
-        else:
-            run(3)
-        TO.CALLS.pop(call, None)
+        try:
+            if aux["check"] == "deferred":
+                # training: the word is shipped behind an event as below, but nobody waits for it inside forward -
+                # the backward of this node does, before it touches a gradient (see StepFn.backward)
+                run(1)
+                aux["deferred"] = model._post_flag(flag)
+                run(2)
+            elif aux["check"]:
+                # the flag depends on the factorisations and the warp GPs only: ship it to the host behind an event
+                # BEFORE the data GPs are queued, so that the check waits for the short part of the forward and the
+                # host keeps queueing while the long part runs
+                run(1)
+                pending = model._post_flag(flag)
+                run(2)
+            else:
+                run(3)
+        finally:
+            TO.CALLS.pop(call, None)
+        if fuse is not None:
+            # what lazy.materialize_values needs to run a fused modality's data GP again with the separate kernels
+            # (no reference to ``aux`` itself: aux -> fuse -> live -> aux would keep the arena until the cyclic collector)
+            fuse["live"] = dict(plan=plan, io=io, prm=prm, saved=saved, tensors=tensors,
+                                ins=[t for t in aux["X"] + list(aux["eps_F"]) + [aux["eps_G"]] if t is not None])
+            fuse["parts"] = [outs["Fl"][i] if fused[i] else None for i in range(nm)]
         aux["pending"], aux["mu_z"], aux["flag"] = pending, mu_z, flag
         ctx.aux, ctx.io, ctx.prm = aux, io, prm
         ctx.arena = saved
@@ -399,15 +427,22 @@ class StepFn(torch.autograd.Function):
         for i in range(nGs):
             og.dG_samples[i] = grad_ptr(gouts[k]); k += 1
         fuse = aux.get("fuse")
+        io = ctx.io
         for i in range(nFl):
             if fuse is not None and fuse["mods"][i]:
-                # the gradient that arrives for the partial sums is a placeholder: the loss's upstream gradient itself
-                # was left by ElboLossFn.backward (a device scalar)
-                if fuse.get("gloss") is None:
-                    raise RuntimeError("GPSA fused ELBO: the step's backward ran without the loss's (the partial sums "
-                                       "of a fused forward are only meaningful to loss_fn)")
-                keep.append(fuse["gloss"])
-                og.gloss = fuse["gloss"].data_ptr()
+                # the gradient that arrives for the partial sums is a placeholder; what the modality's draws were used
+                # for decides (lazy.py): "fused" - loss_fn took the fused likelihood: the loss's upstream gradient was
+                # left by ElboLossFn.backward (a device scalar);  "real" - the draws were materialised before loss_fn
+                # saw them: an unfused modality, its draws' gradient was left by MaterializeFn.backward;  "lazy" -
+                # nobody touched them: no gradient reaches this modality's data GP
+                state = fuse["state"][i]
+                if state == "fused" and fuse.get("gloss") is not None:
+                    keep.append(fuse["gloss"])
+                    og.gloss = fuse["gloss"].data_ptr()
+                elif state == "real":
+                    og.dF_latent[i] = grad_ptr(fuse["dF"][i])
+                else:
+                    io.Y[i] = None  # (the engine then sees an unfused pass without a gradient and skips it)
             else:
                 og.dF_latent[i] = grad_ptr(gouts[k])
             k += 1
@@ -462,6 +497,9 @@ class StepFn(torch.autograd.Function):
         # would break, steps later
         _give_arena(plan, ctx.arena, force=aux.get("mm_epoch") is not None)
         ctx.arena = None
+        if fuse is not None:  # the arena is gone: so is the chance to materialise this forward's draws
+            fuse["live"] = fuse["parts"] = None
+            fuse["gloss"] = None
         ctx.aux = ctx.io = ctx.prm = None
         return tuple(out)
 
@@ -509,7 +547,7 @@ class ElboLossFn(torch.autograd.Function):
         """some terms arrive as the step's partial sums of z^2 (StepFn with aux["fuse"]) instead of draws"""
         o = _ops_mod.get_ops()
         fuse = aux["fuse"]
-        fused = [bool(z) for z in fuse["mods"]]
+        fused = [bool(z) for z in aux["fuse_mods"]]  # the modalities whose term comes as partial sums in THIS call
         n = len(Fs)
         dev = Fs[0].device
         Fc = [f.detach() if (z or (f.dtype == torch.float32 and f.is_contiguous())) else f.detach().float().contiguous()
@@ -544,17 +582,9 @@ class ElboLossFn(torch.autograd.Function):
         dev = Fc[0].device
         g = gloss.detach().reshape(1)
         g = g if g.dtype == torch.float32 else g.float()
-        fuse["gloss"] = g  # StepFn.backward hands it to the engine (gpsa_step_out_grads.gloss)
-        dF = []
-        for f, z in zip(Fc, fused):
-            if z:  # a gradient of the right shape and type so that autograd walks on to the step's node; never read
-                key = (dev, f.numel())
-                d = _PLACEHOLDER.get(key)
-                if d is None:
-                    d = _PLACEHOLDER[key] = torch.zeros(1, dtype=torch.float64, device=dev).expand(f.numel())
-                dF.append(d)
-            else:
-                dF.append(torch.empty_like(f))
+        # StepFn.backward hands it to the engine (gpsa_step_out_grads.gloss); loss_fn called twice on one forward: summed
+        fuse["gloss"] = g if fuse.get("gloss") is None else fuse["gloss"] + g
+        dF = [placeholder_grad(dev, f.numel()) if z else torch.empty_like(f) for f, z in zip(Fc, fused)]
         dnoise = torch.empty(nz.numel(), dtype=torch.float32, device=dev)
         dkl = torch.empty(ctx.n_kl, dtype=torch.float64, device=dev) if ctx.n_kl else None
         ws = o._ws(8 * 4100 * len(Fc) + 64, g)

@@ -24,7 +24,7 @@ def train_step(model, optimizer, data_dict, view_idx, Ns, S=5, reducer=None, sta
     ``static_grads``: keep the .grad buffers (zeroed, accumulated into) instead of letting autograd hand
     over fresh ones: needed under graph capture, ~one extra launch per parameter otherwise."""
     Xs = {m: d["spatial_coords"] for m, d in data_dict.items()}
-    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=S, _fuse_loss=data_dict)
+    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=S)
     loss = model.loss_fn(data_dict, out[3])
     optimizer.zero_grad(set_to_none=not static_grads)
     backward(loss)
@@ -88,8 +88,7 @@ class Microbatches:
                 model.kl_scale = scale0 if k == 0 else 0.0
                 if noise is not None:
                     model.inject_noise(noise[k][0], noise[k][1], None)
-                out = model.forward({m: d["spatial_coords"] for m, d in dd.items()}, view_idx=vi, Ns=Ns, S=S,
-                                    _fuse_loss=dd)
+                out = model.forward({m: d["spatial_coords"] for m, d in dd.items()}, view_idx=vi, Ns=Ns, S=S)
                 loss = model.loss_fn(dd, out[3])
                 backward(loss)  # .grad accumulates across the slices
                 total = loss.detach() if total is None else total + loss.detach()

@@ -1,6 +1,8 @@
-"""The fused ELBO step (forward(_fuse_loss=data_dict): variance, draw, Gaussian likelihood, its gradient and the
-backward's abar inside the data GP's one pass over the products, gpsa_quadform_elbo_f32) against the separate kernels
-and against the reference's fp64 run: same loss, same parameter gradients."""
+"""The fused ELBO step - what the reference's own loop, forward(...) then loss_fn(data_dict, F_samples)
+(examples/grid_example.py:62-78), runs here: forward stops in front of the data GPs and hands out lazy handles, loss_fn
+runs them with variance, draw, Gaussian likelihood, its gradient and the backward's abar inside one pass over the products
+(gpsa_quadform_elbo_f32) - against the separate kernels and against the reference's fp64 run: same loss, same parameter
+gradients; and the handles (lazy.LazyDraws) behave as the tensors they stand for whatever the caller does with them."""
 import numpy as np
 import pytest
 import torch
@@ -13,20 +15,29 @@ DEV = "cuda:0"
 
 
 def run(model, dd, g, fuse, gscale=None):
+    """the reference's loop body, written as the reference writes it"""
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+    model.fuse_elbo = fuse
     model.inject_noise(g.eps_G, g.eps_F, None)
     model.zero_grad()
-    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S, _fuse_loss=dd if fuse else None)
-    loss = model.loss_fn(dd, out[3])
+    G_means, G_samples, F_latent_samples, F_samples = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)
+    loss = model.loss_fn(dd, F_samples)
     (loss if gscale is None else loss * gscale).backward()
     res = {"loss": loss.detach().cpu().numpy()}
     for k, p in model.named_parameters():
         res[f"grad/{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy()
-    return res, model._cache.fuse
+    return res, model._cache.fuse, F_samples
 
 
 TRAIN = [c for c in CASES if Golden(c).G_test is None]
+
+
+def fusable(name):
+    g = Golden(name)
+    model, dd = build_model(g, device=DEV)
+    _, rec, _ = run(model, dd, g, True)
+    return rec is not None
 
 
 @pytest.mark.parametrize("name", TRAIN)
@@ -35,13 +46,13 @@ def test_fused_matches_separate_kernels(name):
     res = {}
     for fuse in (True, False):
         model, dd = build_model(g, device=DEV)
-        res[fuse], rec = run(model, dd, g, fuse)
+        res[fuse], rec, _ = run(model, dd, g, fuse)
         if fuse:
             lmc = any(model.n_latent_gps[m] is not None for m in g.mods)
             if rec is None:  # nothing fusable in this case: say why
                 assert lmc or model.Gtilde.shape[0] > 208, "an eligible case ran unfused"
                 pytest.skip("no modality of this case can run fused (LMC / more than 13 row tiles)")
-            assert any(rec["mods"])
+            assert "fused" in rec["state"]
         else:
             assert rec is None
     big = bool(g.cfg.get("summary_only"))
@@ -62,12 +73,16 @@ def test_fused_matches_separate_kernels(name):
 def test_fused_matches_reference_fp64(name):
     g = Golden(name)
     model, dd = build_model(g, device=DEV)
-    res, rec = run(model, dd, g, True)
+    res, rec, F = run(model, dd, g, True)
     if rec is None:
         pytest.skip("not fusable")
     big = bool(g.cfg.get("summary_only"))
+    # the draws the handles show after the step (written by the fused pass itself) are the reference's too
+    for m in g.mods:
+        res[f"F_obs/{m}"] = F[m].detach().cpu().numpy()
     bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4 if not big else 3e-3)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert any(k.startswith("F_obs/") for k in errs)
     assert not bad, bad
 
 
@@ -77,29 +92,147 @@ def test_fused_upstream_gradient_scales_everything():
     out = {}
     for fuse in (True, False):
         model, dd = build_model(g, device=DEV)
-        out[fuse], _ = run(model, dd, g, fuse, gscale=0.37)
+        out[fuse], _, _ = run(model, dd, g, fuse, gscale=0.37)
     for k, want in out[False].items():
         if np.linalg.norm(want.astype(np.float64)) == 0:
             continue
         assert rel(out[True][k], want) <= 3e-5, k
 
 
-def test_fused_handles_are_only_for_loss_fn():
+def _setup(fuse=True):
     g = Golden(TRAIN[0])
     model, dd = build_model(g, device=DEV)
+    model.fuse_elbo = fuse
+    # the unfused yardstick without kept products: then it runs the very kernels a materialising handle runs
+    # (symmetric form in the forward, recomputed products in the backward) and the comparison can be bit for bit
+    model.keep_products = False
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
-    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S, _fuse_loss=dd)
+    model.inject_noise(g.eps_G, g.eps_F, None)
+    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)
+    return g, model, dd, out
+
+
+def _grads(model):
+    return {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+
+
+def _same_grads(model, ref, tol=1e-6, scale=1.0, need_all=True):
+    for (k, a), (_, b) in zip(_grads(model).items(), _grads(ref).items()):
+        if need_all:
+            assert (a is None) == (b is None), k
+        if b is None or float(b.norm()) == 0:
+            continue
+        assert a is not None, k
+        err = float((a.double() - scale * b.double()).norm() / (scale * b.double()).norm())
+        assert err <= tol, (k, err)
+
+
+def test_reference_loop_gets_lazy_handles_that_quack_like_the_draws():
+    from spatial_alignment_amd.lazy import LazyDraws
+
+    g, model, dd, out = _setup()
+    rec = model._cache.fuse
+    if rec is None:
+        pytest.skip("not fusable")
+    m = g.mods[0]
+    F = out[3][m]
+    assert isinstance(F, LazyDraws) and isinstance(F, torch.Tensor) and torch.is_tensor(F)
+    assert out[2][m] is F and model.F_latent_samples[m] is F and model.F_observed_samples[m] is F   # quirk 10
+    N, P = dd[m]["outputs"].shape
+    assert tuple(F.shape) == (g.S, N, P) and F.size(1) == N and F.dim() == 3 and F.numel() == g.S * N * P
+    assert F.dtype == torch.float32 and F.device == dd[m]["outputs"].device and F.is_cuda and F.requires_grad
+    assert rec["state"] == ["lazy"] and not F.is_materialized      # none of that computed anything
+    loss = model.loss_fn(dd, out[3])
+    assert rec["state"] == ["fused"]
+    loss.backward()
+    assert all(p.grad is not None for k, p in model.named_parameters() if not k.startswith("noise"))
+
+
+def test_touching_the_handle_before_loss_fn_gives_the_unfused_step():
+    g, model, dd, out = _setup()
     if model._cache.fuse is None:
         pytest.skip("not fusable")
-    other = {m: dict(d, outputs=d["outputs"].clone()) for m, d in dd.items()}
-    with pytest.raises(ValueError):
-        model.loss_fn(other, out[3])
-    # the step's backward without the loss's: refused, not silently wrong
-    model2, dd2 = build_model(g, device=DEV)
-    out2 = model2.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S, _fuse_loss=dd2)
+    _, ref_model, ref_dd, ref_out = _setup(fuse=False)
+    m = g.mods[0]
+    # any use materialises: here an operator and an index
+    mean0 = out[3][m].mean(0)
+    assert model._cache.fuse["state"] == ["real"] and out[3][m].is_materialized
+    assert torch.equal(mean0, ref_out[3][m].mean(0))                 # the same kernels on the same state: bit for bit
+    assert torch.equal(out[3][m][0, :5], ref_out[3][m][0, :5])
+    loss = model.loss_fn(dd, out[3])
+    ref_loss = ref_model.loss_fn(ref_dd, ref_out[3])
+    assert torch.equal(loss, ref_loss)
+    loss.backward()
+    ref_loss.backward()
+    _same_grads(model, ref_model)
+
+
+def test_a_loss_of_the_callers_own_on_the_draws_is_differentiated():
+    g, model, dd, out = _setup()
+    if model._cache.fuse is None:
+        pytest.skip("not fusable")
+    _, ref_model, ref_dd, ref_out = _setup(fuse=False)
+    m = g.mods[0]
+    (out[3][m] ** 2).mean().backward()
+    (ref_out[3][m] ** 2).mean().backward()
+    _same_grads(model, ref_model)
+
+
+def test_the_handle_shows_the_draws_after_the_step():
+    """experiments/expression/visium/visium_component_analysis.py plots its training draws after optimizer.step()"""
+    g, model, dd, out = _setup()
+    if model._cache.fuse is None:
+        pytest.skip("not fusable")
+    _, ref_model, ref_dd, ref_out = _setup(fuse=False)
+    m = g.mods[0]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    loss = model.loss_fn(dd, out[3])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    F = out[2][m].mean(0).detach().cpu().numpy()                     # as the script does
+    want = ref_out[2][m].mean(0).detach().cpu().numpy()
+    assert F.shape == want.shape and rel(F, want) <= 1e-6
+    full = out[3][m].detach()
+    assert tuple(full.shape) == tuple(ref_out[3][m].shape) and rel(full.cpu().numpy(), ref_out[3][m].detach().cpu().numpy()) <= 1e-6
+    # the likelihood's gradient went the fused way: a gradient through the shown draws is refused, not dropped
     with pytest.raises(RuntimeError):
-        out2[3][g.mods[0]].sum().backward()
-    # a hand-written loop (no _fuse_loss) gets real draws
-    out3 = model2.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)
-    assert out3[3][g.mods[0]].dim() == 3 and model2._cache.fuse is None
+        out[3][m].sum().backward()
+
+
+def test_other_observations_in_loss_fn_fall_back_to_the_draws():
+    g, model, dd, out = _setup()
+    if model._cache.fuse is None:
+        pytest.skip("not fusable")
+    _, ref_model, ref_dd, ref_out = _setup(fuse=False)
+    # observations the fused kernel cannot read (fp64 here): loss_fn materialises the draws and takes the separate kernels
+    other = {m: dict(d, outputs=d["outputs"].double()) for m, d in dd.items()}
+    loss = model.loss_fn(other, out[3])
+    assert model._cache.fuse["state"] == ["real"]
+    ref_loss = ref_model.loss_fn({m: dict(d, outputs=d["outputs"].double()) for m, d in ref_dd.items()}, ref_out[3])
+    assert torch.equal(loss, ref_loss)
+    loss.backward()
+
+
+def test_a_backward_that_never_saw_loss_fn_skips_the_data_gp():
+    g, model, dd, out = _setup()
+    if model._cache.fuse is None:
+        pytest.skip("not fusable")
+    _, ref_model, _, ref_out = _setup(fuse=False)
+    m = g.mods[0]
+    out[1][m].square().sum().backward()      # G_samples only
+    ref_out[1][m].square().sum().backward()
+    _same_grads(model, ref_model, need_all=False)
+
+
+def test_loss_fn_twice_on_one_forward():
+    g, model, dd, out = _setup()
+    if model._cache.fuse is None:
+        pytest.skip("not fusable")
+    _, one, dd1, out1 = _setup()
+    l1, l2 = model.loss_fn(dd, out[3]), model.loss_fn(dd, out[3])
+    assert torch.equal(l1, l2)
+    (l1 + l2).backward()
+    one.loss_fn(dd1, out1[3]).backward()
+    _same_grads(model, one, tol=1e-6, scale=2.0, need_all=False)

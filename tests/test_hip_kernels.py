@@ -200,7 +200,9 @@ def test_quadform_keep_f32(hip, M, C, L):
 
 @pytest.mark.parametrize("M,N,S,L", [(200, 700, 3, 50), (64, 333, 1, 7), (16, 70, 2, 5), (100, 5000, 2, 9),
                                      (208, 129, 5, 3), (30, 64, 1, 1), (200, 20000, 2, 4), (5, 1, 1, 2), (200, 3, 2, 1),
-                                     (1, 17, 1, 3)])
+                                     (1, 17, 1, 3),
+                                     (200, 20000, 5, 50)])  # the headline step's exact launch (column tiles split over
+                                                            # workgroups, partial tiles leaving through the slabs)
 def test_quadform_elbo(hip, M, N, S, L):
     """variance + draw + Gaussian likelihood + abar in one pass over the products (gpsa_quadform_elbo_f32) against
     the formulas of the separate kernels (elementwise.hip) evaluated in fp64"""
@@ -212,11 +214,18 @@ def test_quadform_elbo(hip, M, N, S, L):
     var_u, noise_u = torch.tensor([0.3]), torch.tensor([-0.7])
     q = (rnd(C, seed=4, dtype=torch.float64).abs() * 0.2).clamp(max=1.0)
     eps, Y = rnd(S, N, L, seed=5), rnd(N, L, seed=6)
-    g, dm, abar, z2 = hip.quadform_elbo(al.to(DEV), Om.to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV), eps.to(DEV),
-                                        Y.to(DEV), noise_u.to(DEV))
-    ad = al.double()
-    W = torch.einsum("lmk,kc->lmc", Om, ad)
-    v = (W * ad[None]).sum(1)                                           # [L, C]
+    g, dm, abar, z2, FT = hip.quadform_elbo(al.to(DEV), Om.to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV),
+                                            eps.to(DEV), Y.to(DEV), noise_u.to(DEV), want_draws=True)
+    big = L * M * C > 2e8  # the fp64 restatement of the headline size: on the device, output by output
+    rd = DEV if big else "cpu"
+    ad, Om = al.double().to(rd), Om.to(rd)
+    meanT, eps, Y, q, var_u, noise_u = (t.to(rd) for t in (meanT, eps, Y, q, var_u, noise_u))
+    if big:
+        W = None
+        v = torch.stack([((Om[l] @ ad) * ad).sum(0) for l in range(L)])
+    else:
+        W = torch.einsum("lmk,kc->lmc", Om, ad)
+        v = (W * ad[None]).sum(1)                                       # [L, C]
     var = (var_u.double().exp() - q)[None] + v + 2e-5
     e = eps.double().reshape(C, L).t()                                  # [L, C]
     F = meanT.double() + var.sqrt() * e
@@ -226,8 +235,14 @@ def test_quadform_elbo(hip, M, N, S, L):
     gw = dF * e * 0.5 / var.sqrt()
     close(dm, dF, 3e-6)
     close(g, gw, 3e-6)
-    close(abar, 2.0 * torch.einsum("lc,lmc->mc", gw, W), 5e-6)
+    close(FT, F, 1e-6)
+    want_abar = 2.0 * torch.einsum("lc,lmc->mc", gw, W) if W is not None else \
+        2.0 * sum(Om[l] @ (ad * gw[l][None]) for l in range(L))
+    close(abar, want_abar, 5e-6)
     close(z2.reshape(1), ((r / sN) ** 2).sum().reshape(1), 1e-6)
+    g2 = hip.quadform_elbo(al.to(DEV), Om.to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV), eps.to(DEV), Y.to(DEV),
+                           noise_u.to(DEV))  # without the draws: the same numbers, bit for bit
+    assert torch.equal(g2[0], g) and torch.equal(g2[2], abar)
     if M > 208:
         return
     with pytest.raises(Exception):

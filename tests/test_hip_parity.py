@@ -96,6 +96,7 @@ def test_large_and_mixed_inducing_counts_match_oracle(M, mG):
     for name in ("mean_slopes", "mean_intercepts"):  # non-persistent buffers the oracle needs
         state.setdefault(name, getattr(model, name).detach().clone())
     model = model.to(DEV)
+    model.exact_inducing_grad = True
     S, n, L = 2, 400, 6
     gen = torch.Generator().manual_seed(9)
     eps_G = [torch.randn(S, n, 2, generator=gen) for _ in range(2)]
@@ -114,9 +115,12 @@ def test_large_and_mixed_inducing_counts_match_oracle(M, mG):
     assert rel(out[0][m].detach().cpu().numpy(), ref["G_means"][m].numpy()) < 1e-5
     assert rel(out[3][m].detach().cpu().numpy(), ref["F_obs"][m].numpy()) < 1e-4
     assert rel(loss.detach().cpu().numpy(), ref["loss"].numpy()) < 1e-5
-    grads = dict(model.named_parameters())
-    for k in ("Xtilde", "delta_G_list", f"Omega_sqt_F_dict.{m}", "data_kernel_lengthscale"):
-        assert rel(grads[k].grad.cpu().numpy(), ref["grads"][k].numpy()) < 2e-3, k
+    # every gradient (round 3 looked at four of them at 2e-3), with the exact inducing-point gradient on
+    gerr = {k: rel(p.grad.cpu().numpy(), ref["grads"][k].numpy()) for k, p in model.named_parameters()
+            if k in ref["grads"] and float(ref["grads"][k].norm()) > 0}
+    print(f"M = {M}, m_G = {mG}:", {k: f"{v:.1e}" for k, v in gerr.items()})
+    for k, e in gerr.items():
+        assert e < 5e-4, (k, e)
 
 
 def test_training_reduces_loss_and_is_deterministic():
@@ -334,10 +338,13 @@ def test_config3_shape_lmc_matern_multiview():
         assert abs(fd - gdir) <= 5e-2 * max(abs(gdir), 1.0), (fd, gdir)
 
 
-def test_config2_full_size_matches_fp64_oracle():
+@pytest.mark.parametrize("fused", [True, False])
+def test_config2_full_size_matches_fp64_oracle(fused):
     """The headline configuration at FULL size (2 views x 10 000 spots, 50 outputs, M = 200; S = 1 so that the
     oracle's materialised [S,L,N,M] tensor is 1.6 GB in fp64) against the fp64 oracle, vgpsa.py:212-540 end to
-    end: every output and the ELBO within 1e-4 norm-wise, every gradient reported and held to the M = 200 bar."""
+    end: every output and the ELBO within 1e-4 norm-wise, and every gradient within 1e-4 too (exact inducing-point
+    gradient on: DESIGN.md section 2) - through the fused ELBO step (panel_elbo_kernel, what the reference's loop and
+    bench.py run: column tiles split over workgroups, partial tiles through the slabs) AND the separate kernels."""
     import spatial_alignment_amd as gp
     from oracle import gpsa_oracle as orc
     from spatial_alignment_amd.synthetic import make_grid_problem, make_model
@@ -357,6 +364,8 @@ def test_config2_full_size_matches_fp64_oracle():
     for name in ("mean_slopes", "mean_intercepts"):
         state.setdefault(name, getattr(model, name).detach().clone())
     model = model.to(DEV)
+    model.fuse_elbo = fused
+    model.exact_inducing_grad = True
     n, N = side * side, side * side * views
     eps_G = [torch.randn(S, n, 2, generator=gen) for _ in range(views)]
     eps_F = {MOD: torch.randn(S, N, L, generator=gen)}
@@ -367,6 +376,7 @@ def test_config2_full_size_matches_fp64_oracle():
     out = model.forward({MOD: ddd[MOD]["spatial_coords"]}, view_idx=view_idx, Ns=Ns, S=S)
     loss = model.loss_fn(ddd, out[3])
     loss.backward()
+    assert (model._cache.fuse is not None and model._cache.fuse["state"] == ["fused"]) == fused
     cfg = dict(modality_names=[MOD], n_views=views, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
                n_latent_gps={MOD: None}, fixed_view_idx=None)
     ref = orc.evaluate(state, cfg, {MOD: dd[MOD]["spatial_coords"]}, {MOD: dd[MOD]["outputs"]},
@@ -381,4 +391,4 @@ def test_config2_full_size_matches_fp64_oracle():
     print("   gradients:", {k: f"{v:.1e}" for k, v in gerr.items()})
     assert all(v < 1e-4 for v in errs.values()), errs
     for k, e in gerr.items():
-        assert e < 3e-3, (k, e)
+        assert e < 1e-4, (k, e)

@@ -31,10 +31,11 @@ def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False):
     model.kl_scale = kl_scale
     model.inject_noise(eG, {"expression": eF})
     model.zero_grad()
-    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=S,
-                        _fuse_loss=dd if fuse else None)  # fuse: the step the training helpers run (fused ELBO)
+    model.fuse_elbo = fuse  # True: what the reference's loop gets (the likelihood folded into the data GP's pass)
+    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=S)
     assert (model._cache.fuse is not None) == fuse
     loss = model.loss_fn(dd, out[3])
+    assert not fuse or model._cache.fuse["state"] == ["fused"]
     loss.backward()
     return loss.detach()
 
