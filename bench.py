@@ -39,13 +39,19 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="disable the per-forward numerics sync")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay timing")
     ap.add_argument("--no-s1", action="store_true", help="skip the secondary S = 1 timing")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of --steps steps each (barrier + synchronize around every block); value = steps / "
+                         "median block, min / max reported")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the config1 / config3 extra keys (BASELINE configs 1 and 3 on this GPU)")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--static-grads", action="store_true", help="diagnostic: zero_grad(set_to_none=False)")
     ap.add_argument("--overlap", action="store_true", help="diagnostic: per-view side streams in eager mode too")
-    ap.add_argument("--workload", choices=["2", "4", "5"], default="2",
-                    help="BASELINE.json configuration (1-based).  2 = the contract metric's; 4 / 5 = the Visium- / "
-                         "Slide-seq-scale configurations at their stated size (S = 1, independent outputs): "
-                         "diagnostic lines, use with --shard outputs on N > 1")
+    ap.add_argument("--workload", choices=["1", "2", "3", "4", "5"], default="2",
+                    help="BASELINE.json configuration (1-based).  2 = the contract metric's; 1 = the reference example's "
+                         "size (2 x 100 spots, 30 outputs, M = 25, view 0 fixed), 3 = 4 views x 10k spots, 500 outputs "
+                         "through 10 latent GPs, Matern-1/2 warp; 4 / 5 = the Visium- / Slide-seq-scale configurations at "
+                         "their stated size (S = 1, independent outputs).  All but 2: diagnostic lines")
     ap.add_argument("--shard", choices=["rows", "outputs"], default="rows",
                     help="N > 1: rows of every view (default, strong scaling of the contract metric) or the output "
                          "axis (parallel.shard_outputs: per-output parameters and gradients never leave their rank)")
@@ -53,13 +59,19 @@ def parse():
                     help="diagnostic: time rank 0's share of a K-way row sharding on ONE GPU (no all-reduce); "
                          "the line is then NOT the contract metric")
     args = ap.parse_args()
-    args.fixed = None
+    args.fixed, args.latent, args.warp = None, None, "rbf"
+    if args.workload == "1":    # examples/grid_example.py: 2 views x 100 spots, 30 outputs, M = 25, fixed_view_idx = 0
+        args.side, args.views, args.outputs, args.M, args.fixed = 10, 2, 30, 25, 0
+    elif args.workload == "3":  # 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2 warp, M = 200
+        args.side, args.views, args.outputs, args.M, args.latent, args.warp = 100, 4, 500, 200, 10, "matern12"
     if args.workload == "4":    # 8 views x 5041 spots, 2000 genes, M = 500, fixed_view_idx = 0
         args.side, args.views, args.outputs, args.M, args.S, args.fixed = 71, 8, 2000, 500, 1, 0
     elif args.workload == "5":  # 2 views x 99 856 spots, 1000 genes, M = 1000
         args.side, args.views, args.outputs, args.M, args.S = 316, 2, 1000, 1000, 1
     if args.workload != "2":
-        args.no_graph = args.no_s1 = args.no_cpu_baseline = True
+        args.no_s1 = args.no_extras = True
+        args.no_cpu_baseline = args.workload != "1"  # (config 1 is BASELINE's "CPU reference" configuration)
+        args.no_graph = args.workload != "1"
     return args
 
 
@@ -121,7 +133,7 @@ def cpu_baseline(args, state, dd_cpu):
     need = 6.0 * args.S * L * N * args.M * 4 / 2**30  # ~22 GB at the headline config
     S_run = args.S if avail > need * 1.3 else 1
     cfg = dict(modality_names=[m], n_views=args.views, n_spatial_dims=2, kernel_warp="rbf",
-               kernel_data="rbf", n_latent_gps={m: None}, fixed_view_idx=None)
+               kernel_data="rbf", n_latent_gps={m: None}, fixed_view_idx=args.fixed)
     gen = torch.Generator().manual_seed(1)
     n_v = N // args.views
     ns = {m: dd_cpu[m]["n_samples_list"]}
@@ -129,8 +141,10 @@ def cpu_baseline(args, state, dd_cpu):
     params = {k: torch.nn.Parameter(v.clone()) for k, v in state.items() if k.startswith(orc.TRAINABLE_PREFIXES)}
     opt = torch.optim.Adam(list(params.values()), lr=1e-2)
     times, loss = [], None
-    for it in range(4):  # 1 warm-up + 3 timed
-        eps_G = [torch.randn(S_run, n_v, 2, generator=gen) for _ in range(args.views)]
+    n_free = args.views - (0 if args.fixed is None else 1)
+    n_timed = 3 if N * L > 1e5 else 20  # (the reference example's size: milliseconds per step)
+    for it in range(1 + n_timed):  # 1 warm-up + the timed ones
+        eps_G = [torch.randn(S_run, n_v, 2, generator=gen) for _ in range(n_free)]
         eps_F = {m: torch.randn(S_run, N, L, generator=gen)}
         st = dict(state)
         st.update({k: p.detach() for k, p in params.items()})
@@ -150,17 +164,19 @@ def cpu_baseline(args, state, dd_cpu):
     return dict(
         value=1.0 / (med * scale), unit="steps/s (forward+ELBO+backward+Adam)",
         cores=torch.get_num_threads(), nproc=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
-        sample=f"oracle steps at the full config with S={S_run}: 1 warm-up, then median of 3 timed "
-               f"({', '.join(f'{t:.1f}' for t in times)} s)"
+        sample=f"oracle steps at the full config with S={S_run}: 1 warm-up, then median of {n_timed} timed "
+               f"({', '.join(f'{t:.3g}' for t in times[:5])}{' ...' if len(times) > 5 else ''} s)"
                + (f", time scaled x{scale:.0f} to S={args.S}" if scale != 1 else "")
                + f"; anomaly mode off, host RAM avail {avail:.0f} GB",
     )
 
 
 def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
-    """One forward + ELBO of the TRAINED bench model at the full bench size, S = 1, against the fp64 oracle on the
-    same parameters and the same injected draws (the fp32 oracle the timing leg runs is no yardstick here: at
-    M = 200 the fp32 reference is 1e-1 from its own fp64 run on F).  Norm-wise relative errors."""
+    """ONE TRAINING STEP of the TRAINED bench model at the full bench size, S = 1 - the reference's two calls, i.e. the
+    fused ELBO step the timed loop runs (panel_elbo_kernel: column tiles split over workgroups, partial tiles through the
+    slabs), then backward - against the fp64 oracle on the same parameters and the same injected draws: outputs, ELBO
+    and every parameter gradient (the fp32 oracle the timing leg runs is no yardstick here: at M = 200 the fp32
+    reference is 1e-1 from its own fp64 run on F).  Norm-wise relative errors."""
     from oracle import gpsa_oracle as orc
 
     m = "expression"
@@ -174,18 +190,63 @@ def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
     eps_F = {m: torch.randn(1, N, L, generator=gen)}
     dev = model.Xtilde.device
     model.inject_noise([e.to(dev) for e in eps_G], {m: eps_F[m].to(dev)}, None)
-    with torch.no_grad():
+    model.zero_grad(set_to_none=True)
+    exact0, model.exact_inducing_grad = model.exact_inducing_grad, True  # (gradient yardstick: DESIGN.md section 2)
+    try:
         out = model.forward({m: dd[m]["spatial_coords"]}, view_idx=view_idx, Ns=Ns, S=1)
         loss = model.loss_fn(dd, out[3])
+        loss.backward()
+    finally:
+        model.exact_inducing_grad = exact0
+    fuse = getattr(model._cache, "fuse", None)
     cfg = dict(modality_names=[m], n_views=args.views, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
                n_latent_gps={m: None}, fixed_view_idx=None)
     ref = orc.evaluate(state, cfg, {m: dd_cpu[m]["spatial_coords"]}, {m: dd_cpu[m]["outputs"]},
-                       {m: dd_cpu[m]["n_samples_list"]}, 1, eps_G, eps_F, want_grads=False, dtype=torch.float64)
+                       {m: dd_cpu[m]["n_samples_list"]}, 1, eps_G, eps_F, want_grads=True, dtype=torch.float64)
     rel = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / b.double().norm())
-    return dict(S=1, G_means_rel=rel(out[0][m], ref["G_means"][m]), G_samples_rel=rel(out[1][m], ref["G_samples"][m]),
+    gerr = {k: rel(p.grad, ref["grads"][k]) for k, p in model.named_parameters()
+            if p.grad is not None and k in ref["grads"] and float(ref["grads"][k].norm()) > 0}
+    model.zero_grad(set_to_none=True)
+    return dict(S=1, step="forward + loss_fn + backward, " + ("fused ELBO (panel_elbo_kernel)" if fuse is not None and
+                "fused" in fuse["state"] else "separate kernels"),
+                G_means_rel=rel(out[0][m], ref["G_means"][m]), G_samples_rel=rel(out[1][m], ref["G_samples"][m]),
                 F_rel=rel(out[3][m], ref["F_obs"][m]), loss_rel=rel(loss.reshape(1), ref["loss"].reshape(1)),
+                grad_rel_max=max(gerr.values()), grad_rel_worst=max(gerr, key=gerr.get),
+                grad_rel={k: float(f"{v:.2e}") for k, v in gerr.items()},
                 tolerance=1e-4, against="oracle/gpsa_oracle.py in fp64, same trained parameters, same injected draws",
                 seconds=round(time.time() - t0, 1))
+
+
+def extra_workload(which, args):
+    """the JSON line of ``bench.py --workload which`` (a child process: nothing it does can take the contract line down),
+    cut to what the default line carries for it"""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", which, "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--blocks", "3"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+        last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if not last:
+            return dict(error=f"rc={r.returncode}", stderr=r.stderr[-300:])
+        d = json.loads(last[-1])
+    except Exception as e:
+        return dict(error=f"{type(e).__name__}: {e}"[:300])
+    out = dict(workload=d["config"]["workload"], eager_steps_per_s=d["value"], ms_per_step=d["ms_per_step"],
+               ms_per_step_min_max=[d["timing"]["ms_per_step_min"], d["timing"]["ms_per_step_max"]])
+    if d.get("graph_replay"):
+        out["graph_replay_steps_per_s"] = d["graph_replay"].get("value")
+    if d.get("cpu_baseline"):
+        cb = d["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+        out["gpu_over_cpu"] = d["value"] / cb["value"]
+    roof = d.get("roofline")
+    if roof:
+        out["contractions"] = {"forward": dict(kernel=roof["kernel"].split(" (")[0], avg_ms=roof["avg_launch_ms"],
+                                               frac=roof["frac"], executed_frac=roof["executed_frac"]),
+                               **{k: {kk: v.get(kk) for kk in ("kernel", "avg_ms", "frac", "nominal_frac") if kk in v}
+                                  for k, v in roof.get("other_kernels", {}).items()}}
+    return out
 
 
 def launch_ranks(args):
@@ -251,13 +312,20 @@ def main():
                                 compute_device=dev if args.workload != "2" else None)
     emu = max(1, args.emulate_shard) if world == 1 else 1
     by_outputs = args.shard == "outputs" and world * emu > 1
+    import spatial_alignment_amd as gp
+
+    mkw = dict(m=args.M, device=dev, fixed_view_idx=args.fixed)
+    if args.latent is not None:
+        mkw["n_latent_gps"] = {"expression": args.latent}
+    if args.warp == "matern12":
+        mkw["kernel_func_warp"] = gp.matern12_kernel
     if by_outputs:  # every row, this rank's slice of the outputs; the model is built on the slice
         dd = shard_outputs(dd_full, rank, world * emu)
-        model = make_model(dd, m=args.M, device=dev, fixed_view_idx=args.fixed)
+        model = make_model(dd, **mkw)
     else:
-        model = make_model(dd_full, m=args.M, device=dev, fixed_view_idx=args.fixed)  # identical on every rank (seeded)
+        model = make_model(dd_full, **mkw)  # identical on every rank (seeded)
         dd = shard_data_dict(dd_full, rank, world * emu)
-    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if args.workload == "2" else {}
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if args.workload in ("1", "2") else {}
     dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
               "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
     out_reducer = None
@@ -298,55 +366,68 @@ def main():
 
     opt = FusedAdam(model.parameters(), lr=1e-2)  # torch.optim.Adam's update as one HIP launch
     reducer = out_reducer if out_reducer is not None else GradAllReducer(model.parameters())
-    timer = KernelTimer(model, args.steps)
+    timer = KernelTimer(model, args.steps * max(1, args.blocks))
     timer.S = args.S
 
-    def step():
-        # the reference loop body (forward, loss_fn, zero_grad, backward, optimiser step) as the package's own helper:
-        # it tells forward which data_dict loss_fn will get, so the engine can fold the likelihood into the data GP's pass
-        return train_step(model, opt, dd, view_idx, Ns, S=args.S, reducer=reducer, static_grads=args.static_grads)
+    def reference_step(S):
+        # examples/grid_example.py:62-78, line for line: forward, loss_fn, zero_grad, backward, optimiser step
+        # (+ the all-reduce of the gradient on N > 1).  Nothing here is this package's helper and nothing tells
+        # forward what loss_fn will get: forward leaves the data GP to loss_fn, which runs it with the likelihood
+        # folded in (panel_elbo_kernel)
+        G_means, G_samples, F_latent_samples, F_samples = model.forward(X_spatial=Xs, view_idx=view_idx, Ns=Ns, S=S)
+        loss = model.loss_fn(dd, F_samples)
+        opt.zero_grad()
+        loss.backward()
+        reducer()
+        opt.step()
+        return loss
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timer.start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    def helper_step(S):  # the same loop body as the package's helper (seed gradient kept on the device)
+        return train_step(model, opt, dd, view_idx, Ns, S=S, reducer=reducer, static_grads=args.static_grads)
+
+    def time_blocks(step, S, blocks, before=None):
+        """``blocks`` x (barrier + synchronize, --steps steps, synchronize + barrier), MAX over ranks per block"""
+        for _ in range(args.warmup):
+            step(S)
+        out, loss = [], None
+        for b in range(blocks):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            if before is not None and b == 0:
+                before()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step(S)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out.append(float(t.item()))
+        return out, loss
+
+    def summary(ts):
+        srt = sorted(ts)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        return dict(value=args.steps / med, unit="steps/s", ms_per_step=1e3 * med / args.steps, blocks=len(ts),
+                    steps_per_block=args.steps, ms_per_step_min=1e3 * srt[0] / args.steps,
+                    ms_per_step_max=1e3 * srt[-1] / args.steps,
+                    ms_per_step_blocks=[round(1e3 * t / args.steps, 4) for t in ts])
+
+    nblk = max(1, args.blocks)
+    times, loss = time_blocks(reference_step, args.S, nblk, before=timer.start)
+    head = summary(times)
+    dt = args.steps / head["value"]  # the median block
     final_loss = float(loss.item())
+    # the package's own helper around the same two calls (what round 3's line timed): same kernels, one launch less
+    helper = summary(time_blocks(helper_step, args.S, min(nblk, 3))[0]) if args.workload == "2" else None
 
     # secondary (SURVEY.md §8d): the same step at S = 1, the reference's forward default; same protocol
     s1 = None
     if args.S != 1 and not args.no_s1:
-        def step1():
-            train_step(model, opt, dd, view_idx, Ns, S=1, reducer=reducer, static_grads=args.static_grads)
-
-        for _ in range(args.warmup):
-            step1()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step1()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        s1 = dict(S=1, value=args.steps / float(tt.item()), unit="steps/s",
-                  ms_per_step=1e3 * float(tt.item()) / args.steps)
+        s1 = dict(S=1, **summary(time_blocks(reference_step, 1, min(nblk, 3))[0]))
 
     graph_info = None
     if world == 1 and not args.no_graph and not args.graph_only:
@@ -355,8 +436,9 @@ def main():
         import subprocess
 
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps),
-               "--S", str(args.S), "--side", str(args.side), "--views", str(args.views),
-               "--outputs", str(args.outputs), "--M", str(args.M), "--emulate-shard", str(emu)]
+               "--S", str(args.S), "--emulate-shard", str(emu)] + (
+                   ["--workload", args.workload] if args.workload != "2" else
+                   ["--side", str(args.side), "--views", str(args.views), "--outputs", str(args.outputs), "--M", str(args.M)])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -366,8 +448,8 @@ def main():
 
     if rank == 0:
         N = int(sum(dd_full["expression"]["n_samples_list"]))
-        ks = timer.summary(args.M, args.S * int(sum(dd["expression"]["n_samples_list"])),
-                           int(dd["expression"]["outputs"].shape[1]))  # this rank's columns and outputs
+        ks = timer.summary(args.M, args.S * int(sum(dd["expression"]["n_samples_list"])),  # this rank's columns and
+                           int(args.latent or dd["expression"]["outputs"].shape[1]))       # (latent) outputs
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_cfg = (args.S, args.side, args.views, args.outputs, args.M, world) == (5, 100, 2, 50, 200, 1)
@@ -464,16 +546,16 @@ def main():
                 roof["other_kernels"]["quadform_bwd_alpha"] = dict(
                     kernel=o["kernel"], avg_ms=o["avg_ms"], bound="hbm", bytes_per_launch=keep_bytes,
                     achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0)
-            # step level: algorithmic flops of a whole step / step time / peak
-            Mq, Cq, Lq = args.M, args.S * N, args.outputs
+            # step level: what the matrix cores execute per step, against the peak (the SURVEY 8d formula counts three
+            # full products per step where this step executes one full product and a triangular Gram: its rate
+            # exceeded the peak in round 3's record and said nothing - it is given as a flop count only)
+            Mq, Cq, Lq = args.M, args.S * N, (args.latent or args.outputs)
             step_flops = 3.0 * (2.0 * Cq * Mq * Mq * (Lq + 1) + 2.0 * Cq * Mq * Lq
                                 + sum(2.0 * n_v * Mq * Mq * 3 for n_v in dd_full["expression"]["n_samples_list"]))
-            roof["step_level"] = dict(algorithmic_flops_per_step=step_flops,
-                                      achieved_tflops=step_flops * (args.steps / dt) / 1e12 / world,
-                                      frac=step_flops * (args.steps / dt) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
-                                      note="3 x forward flops (SURVEY 8d): data GP 2*C*M^2*(L+1) + 2*C*M*L, "
-                                           "warp GPs 2*n_v*M^2*(1+D); per GPU.  An ALGORITHMIC rate (the reference's "
-                                           "step costs that much): this step executes fewer flops - see executed_*")
+            roof["step_level"] = dict(reference_algorithm_flops_per_step=step_flops,
+                                      note="reference_algorithm_flops_per_step: 3 x forward flops of the reference's "
+                                           "step (SURVEY 8d), for scale only; executed_*: the contraction flops this "
+                                           "step's kernels issue / median step time / peak, per GPU")
             # what the matrix cores actually issue for the three contractions of this step (with kept products the
             # alpha-gradient re-uses the forward's product: no flops)
             exec_fl = sum(ks[k]["flops"] * executed_ratio[k] for k in ks
@@ -499,6 +581,15 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "timing": {"protocol": f"{head['blocks']} blocks of {args.steps} steps, barrier + synchronize around each, max "
+                                   "over ranks per block; value / ms_per_step = the MEDIAN block",
+                       **{k: head[k] for k in ("blocks", "ms_per_step_min", "ms_per_step_max", "ms_per_step_blocks")}},
+            # the timed loop IS the reference's two-call loop (examples/grid_example.py:62-78 verbatim, bench.py
+            # reference_step); "helper_loop": the same step through train.train_step (what round 3's line timed)
+            "reference_loop": {"is_the_headline": True, "value": head["value"], "ms_per_step": head["ms_per_step"],
+                               "calls": "model.forward(X_spatial=, view_idx=, Ns=, S=); model.loss_fn(data_dict, F_samples); "
+                                        "optimizer.zero_grad(); loss.backward(); optimizer.step()"},
+            "helper_loop": helper,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -506,8 +597,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic 2D grid, {args.views} views x {args.side * args.side} spots, "
-                            f"{args.outputs} outputs, M_G=M_X={args.M}, RBF warp+data, S={args.S}, "
-                            "forward+ELBO+backward+Adam",
+                            f"{args.outputs} outputs" + (f" through {args.latent} latent GPs" if args.latent else "")
+                            + f", M_G=M_X={args.M}, " + ("Matern-1/2 warp / RBF data" if args.warp == "matern12" else
+                                                        "RBF warp+data")
+                            + (f", fixed_view_idx={args.fixed}" if args.fixed is not None else "")
+                            + f", S={args.S}, forward+ELBO+backward+Adam",
                 "n_spots_total": N,
                 "parallelism": ("single GPU" if world == 1 else
                                 f"outputs sharded x{world}, 1 all-reduce/step of the shared parameters' gradients" if by_outputs
@@ -520,15 +614,21 @@ def main():
             "secondary_S1": s1,
             "graph_replay": graph_info,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
+            if world > 1:  # (the launcher hands each rank 1/N of the host threads: take what a 1-GPU run uses)
+                torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
             line["cpu_baseline"] = cpu_baseline(args, state, dd_full)
-            if emu == 1:
+            if emu == 1 and world == 1 and args.workload == "2":
                 try:
                     line["parity_at_bench_size"] = parity_at_bench_size(args, model, dd_full, dd, view_idx, Ns)
                 except Exception as e:  # the contract line must not die with its extra
                     line["parity_at_bench_size"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         else:
             line["cpu_baseline"] = None
+        if world == 1 and emu == 1 and not args.no_extras:
+            # BASELINE configs 1 and 3 on this GPU, each as a child process running this file with --workload
+            line["config1"] = extra_workload("1", args)
+            line["config3"] = extra_workload("3", args)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

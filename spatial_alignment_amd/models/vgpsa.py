@@ -209,6 +209,16 @@ class VariationalGPSA(GPSA):
             return False
         return (v in f) if isinstance(f, Iterable) else (f == v)
 
+    def release_arenas(self):
+        """Hand back the arenas the step engine keeps parked between training steps (a GiB and more each: the kept
+        products of a large configuration).  ``eval()`` and ``prediction_mode`` do it by themselves."""
+        SE.release_arenas(self)
+
+    def train(self, mode=True):
+        if not mode:
+            SE.release_arenas(self)
+        return super().train(mode)
+
     def inject_noise(self, eps_G=None, eps_F=None, eps_F_test=None):
         """Use the given standard-normal draws in the NEXT forward instead of drawing them.
 

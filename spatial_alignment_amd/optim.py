@@ -30,31 +30,38 @@ class FusedAdam(torch.optim.Optimizer):
         self._lib = _lib.load()
 
     def _step_words(self, ps, dev):
-        """the parameters of this launch grouped by the device word that counts their steps"""
+        """the parameters of this launch grouped by the device word that counts their steps.
+        ``self._sharers``: id(word) -> [word, parameters sharing it]; the entry holds the word, so neither its id nor
+        its address can be taken by another tensor while it is counted (round 3 keyed this by data_ptr and never
+        removed entries: a freed word's address, reused, looked shared and was cloned at every step)."""
+        share = self.__dict__.setdefault("_sharers", {})
         groups = {}
         for p in ps:
-            st = self.state[p]
-            if "step" not in st or not torch.is_tensor(st["step"]) or st["step"].device != dev:
-                old = st.get("step")
-                st["step"] = None  # filled below: new parameters of one launch share one fresh word
-                groups.setdefault(("new", float(old) if old is not None else 0.0), []).append(p)
-            else:
-                groups.setdefault(("ptr", st["step"].data_ptr()), []).append(p)
+            w = self.state[p].get("step")
+            if torch.is_tensor(w) and id(w) in share and w.device == dev:
+                groups.setdefault(("word", id(w)), []).append(p)
+            elif torch.is_tensor(w) and w.is_cuda:  # a device count nobody registered (foreign state): no host sync
+                groups.setdefault(("tensor", id(w)), []).append(p)
+            else:  # no count yet, a Python number or a CPU tensor
+                groups.setdefault(("value", float(w) if w is not None else 0.0), []).append(p)
         out = []
         for (kind, val), members in groups.items():
-            if kind == "new":
-                word = torch.full((1,), val, dtype=torch.float32, device=dev)
-                for p in members:
-                    self.state[p]["step"] = word
-            else:
-                word = self.state[members[0]]["step"]
-                sharers = self.__dict__.setdefault("_sharers", {}).get(val, 0)
-                if sharers > len(members):  # some sharers have no gradient this step: these move to their own word
-                    self._sharers[val] = sharers - len(members)
+            if kind == "word":
+                word, n = share[val]
+                if n > len(members):  # some sharers have no gradient this step: these move to a word of their own
+                    share[val][1] = n - len(members)
                     word = word.clone()
+                    share[id(word)] = [word, len(members)]
                     for p in members:
                         self.state[p]["step"] = word
-            self.__dict__.setdefault("_sharers", {})[word.data_ptr()] = len(members)
+            else:
+                if kind == "tensor":
+                    word = self.state[members[0]]["step"].detach().to(device=dev, dtype=torch.float32).reshape(1).clone()
+                else:
+                    word = torch.full((1,), val, dtype=torch.float32, device=dev)
+                share[id(word)] = [word, len(members)]
+                for p in members:
+                    self.state[p]["step"] = word
             out.append((word, members))
         return out
 
@@ -80,8 +87,8 @@ class FusedAdam(torch.optim.Optimizer):
                         words[v] = torch.full((1,), v, dtype=torch.float32, device=p.device)
                     st["step"] = words[v]
             for w in words.values():
-                self._sharers[w.data_ptr()] = sum(1 for p in group["params"]
-                                                  if self.state.get(p) and self.state[p].get("step") is w)
+                self._sharers[id(w)] = [w, sum(1 for p in group["params"]
+                                               if self.state.get(p) and self.state[p].get("step") is w)]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -62,22 +62,41 @@ class StepPlan:
 ARENA_PARK_BYTES = 1 << 30
 
 
-def _take_arena(plan, nbytes, dev, must=False):
+def _take_arena(plan, nbytes, dev, must=False, siblings=None):
     """-> arena, or None when it cannot be had.  ``plan._took_parked`` says whether it is the plan's own parked block
-    (nobody else has written into it since it was handed back: its contents are the previous forward's)."""
+    (nobody else has written into it since it was handed back: its contents are the previous forward's).
+    ``siblings``: the model's other plans - their parked blocks are let go before an allocation is given up."""
     plan._took_parked = False
     parked = plan.__dict__.get("_parked")
-    if parked is not None and parked.device == dev and parked.numel() >= nbytes:
+    # Under stream capture the arena's address is baked into the graph: it must come from the graph's private pool, not
+    # be an eagerly allocated block that an eager forward between two replays could take from the plan and free
+    # (ADVICE r3: later replays would then write into memory other tensors own)
+    capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if parked is not None and not capturing and parked.device == dev and parked.numel() >= nbytes:
         if 2 * nbytes < parked.numel():  # a forward without kept products (no backward will hand the arena back):
             return torch.empty(nbytes, dtype=torch.uint8, device=dev)  # leave the large one parked
         plan._parked = None
         plan._took_parked = True
         return parked
-    plan._parked = None  # (too small: let it go before asking for the larger one)
+    if not capturing:
+        plan._parked = None  # (too small: let it go before asking for the larger one)
     del parked
     try:
         return torch.empty(nbytes, dtype=torch.uint8, device=dev)
     except torch.OutOfMemoryError:
+        # memory may sit idle on a sibling plan of the same model (the S = 1 leg, prediction_mode, a remainder
+        # microbatch shape): let every parked block go and ask once more
+        freed = False
+        for other in (siblings or ()):
+            if other.__dict__.get("_parked") is not None and not capturing:
+                other._parked = None
+                freed = True
+        if freed:
+            torch.cuda.empty_cache()
+            try:
+                return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            except torch.OutOfMemoryError:
+                pass
         if must:
             raise
         return None
@@ -85,8 +104,16 @@ def _take_arena(plan, nbytes, dev, must=False):
 
 def _give_arena(plan, arena, force=False):
     """``force``: park whatever its size (the slices of a microbatched step share the arena's M x M stage)"""
-    if arena is not None and (force or arena.numel() >= ARENA_PARK_BYTES) and plan.__dict__.get("_parked") is None:
+    if arena is None or (arena.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return  # (a captured step's arena belongs to the graph's pool)
+    if (force or arena.numel() >= ARENA_PARK_BYTES) and plan.__dict__.get("_parked") is None:
         plan._parked = arena
+
+
+def release_arenas(model):
+    """let go of every arena parked on the model's plans (VariationalGPSA.release_arenas; eval() calls it)"""
+    for plan in model.__dict__.get("_step_plans", {}).values():
+        plan.__dict__["_parked"] = None
 
 
 def eligible(model, X_spatial, view_idx, G_test):
@@ -313,11 +340,12 @@ class StepFn(torch.autograd.Function):
         if fuse is not None and all(fused):  # nothing left that would stream kept products back
             keep = False
         io.keep_products = 1 if keep else 0
-        saved = _take_arena(plan, plan.saved_bytes if keep else plan.saved_bytes_nokeep, dev)
+        sib = [q for q in model.__dict__.get("_step_plans", {}).values() if q is not plan]
+        saved = _take_arena(plan, plan.saved_bytes if keep else plan.saved_bytes_nokeep, dev, siblings=sib)
         if saved is None:  # the device cannot hold the kept products after all (other tenants, fragmentation)
             keep = False
             io.keep_products = 0
-            saved = _take_arena(plan, plan.saved_bytes_nokeep, dev, must=True)
+            saved = _take_arena(plan, plan.saved_bytes_nokeep, dev, must=True, siblings=sib)
         scratch = o._ws(plan.scratch_bytes, saved)
         # the slices of one microbatched step (train.Microbatches) run on the same parameters: when this forward got
         # the very arena the previous slice filled, the M x M stage (factorisations, inverses, KL terms) is still in it

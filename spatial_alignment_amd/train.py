@@ -51,6 +51,14 @@ class Microbatches:
         """``quantum``: slice sizes are multiples of it (the last slice of a view takes the remainder): the LDS-DMA
         kernels of the M > 256 data GP want 16-byte aligned rows of the [M, C] panels, i.e. C % 4 == 0"""
         self.model, self.K = model, int(K)
+        if self.K < 1:
+            raise ValueError(f"Microbatches: K = {K} slices")
+        # every slice must hold rows: with sizes rounded up to ``quantum``, slice k of a view starts at k * per
+        biggest = max(int(n) for d in data_dict.values() for n in d["n_samples_list"])
+        per_max = -(-(-(-biggest // self.K)) // quantum) * quantum
+        if (self.K - 1) * per_max >= biggest:
+            raise ValueError(f"Microbatches: K = {self.K} slices of multiples of {quantum} rows leave the last slice(s) "
+                             f"empty in every view (largest view: {biggest} rows); use K <= {max(1, -(-biggest // quantum))}")
         self.slices, self.bounds = [], []  # bounds[k][mod] = [(lo, hi) of slice k within view v]
         for k in range(self.K):
             dd = {}

@@ -231,6 +231,52 @@ def test_graphed_step_equals_eager_step():
         assert (a - b).norm() <= 1e-5 * max(a.norm().item(), 1e-6), k
 
 
+def test_eager_forward_between_graph_replays_leaves_the_graph_intact(monkeypatch):
+    """with arenas parked on the plan, a captured step must not bake a parked (eagerly allocated)
+    block into the graph - an eager forward between two replays takes that block from the plan, frees it, and later
+    replays would write into memory other tensors own.  Every arena is parked here (threshold 1 byte)."""
+    from spatial_alignment_amd import step_engine as SE
+    from spatial_alignment_amd.optim import FusedAdam
+    from spatial_alignment_amd.train import GraphedTrainStep
+
+    monkeypatch.setattr(SE, "ARENA_PARK_BYTES", 1)
+    g = Golden("c2_three_free_views")
+    finals = []
+    for interleave in (False, True):
+        model, dd = build_model(g, device=DEV)
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+        eps_G = [e.to(DEV) for e in g.eps_G]
+        eps_F = {m: e.to(DEV) for m, e in g.eps_F.items()}
+        orig = model.forward
+
+        def fwd(*a, _orig=orig, _m=model, **k):  # same injected noise on every call
+            _m.inject_noise(eps_G, eps_F)
+            return _orig(*a, **k)
+
+        model.forward = fwd
+        gs = GraphedTrainStep(model, FusedAdam(model.parameters(), lr=1e-2), dd, view_idx, Ns, S=g.S, warmup=2)
+        gs.step()
+        if interleave:
+            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)  # train mode, no backward: its arena is dropped
+            del out
+            model._cache = None
+            import gc
+
+            gc.collect()
+            junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(16)]  # trample what was freed
+            torch.cuda.synchronize()
+            del junk
+        for _ in range(3):
+            loss = gs.step()
+        gs.check()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 @pytest.mark.parametrize("name", ["c2_three_free_views", "c5_two_modalities"])
 def test_adam_trajectory_matches_cpu_host_logic(name):
     """six Adam steps with the same injected noise: the HIP path and the CPU restatement of the ops
