@@ -1,6 +1,9 @@
 // Shared pieces of the quadratic-form translation units (quadform.hip: generic kernels, launchers and the C ABI;
 // qf_panel_*.hip, qf_elbo.hip, qf_sym.hip, qf_gram.hip, qf_big.hip: one kernel family each, explicitly instantiated
 // there and declared ``extern template`` here - a launch from another unit calls the host stub its own unit defines).
+// The declarations CARRY the launch bounds: an instantiation takes its attributes from the first declaration, and
+// without them here every kernel was built for 1024 threads - 128 registers, the accumulators in scratch, 4.7x slower
+// (tests/test_cabi.py::test_kernel_resources now reads the code objects' metadata).
 #pragma once
 #include <stdlib.h>
 
@@ -112,7 +115,7 @@ struct GramBigArgs {
 };
 __global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
                                 float* __restrict__ gpad);
-__global__ void gram_big_kernel(GramBigArgs a);
+__global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a);
 // W[l] = P[l] X for large M (see prod_big_kernel)
 struct ProdBigArgs {
   const float* P;  // [L][M][Mp], zero for k >= M (Mp = a multiple of 16)
@@ -121,9 +124,9 @@ struct ProdBigArgs {
   int M, Mp, L;
   long long C;
 };
-__global__ void prod_big_kernel(ProdBigArgs a);
+__global__ void __launch_bounds__(256, 2) prod_big_kernel(ProdBigArgs a);
 template <typename TO>
-__global__ void gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit, TO* __restrict__ out);
+__global__ void __launch_bounds__(256) gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit, TO* __restrict__ out);
 // outputs per run of same-XCD workgroups in the large-M kernels (GPSA_BIG_LB; 0 = the plain 3-D / 2-D grids)
 static inline int big_remap_lb() {
   static const int v = [] { const char* e = getenv("GPSA_BIG_LB"); return e ? atoi(e) : 16; }();
@@ -155,7 +158,7 @@ struct BigAccumArgs {
   float scale;
 };
 
-__global__ void big_accum_reduce_kernel(const float* __restrict__ part, int nsplit, long long n4, float* __restrict__ out);
+__global__ void __launch_bounds__(256) big_accum_reduce_kernel(const float* __restrict__ part, int nsplit, long long n4, float* __restrict__ out);
 // shapes the two kernels cover (everything else stays on the generic tiled product)
 static inline bool big_panel_ok(int M, long long C, int L, const void* alpha) {
   static const bool off = [] { const char* e = getenv("GPSA_BIG_PANEL"); return e && e[0] == '0'; }();
@@ -187,9 +190,9 @@ __global__ void pad_k_kernel(const TS* __restrict__ src, int M, int Mp, long lon
 template <typename TS>
 __global__ void pad_k_tri_kernel(const TS* __restrict__ src, int M, int Mp, long long n, float* __restrict__ dst);
 template <bool TRI, bool STORE, int NS>
-__global__ void big_quad_kernel(BigQuadArgs a);
+__global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a);
 template <int NS>
-__global__ void big_accum_kernel(BigAccumArgs a);
+__global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a);
 extern template __global__ void pad_k_kernel<float>(const float* __restrict__, int, int, long long, float* __restrict__);
 extern template __global__ void pad_k_kernel<double>(const double* __restrict__, int, int, long long, float* __restrict__);
 extern template __global__ void pad_k_tri_kernel<float>(const float* __restrict__, int, int, long long, float* __restrict__);
@@ -201,7 +204,7 @@ extern template __global__ void gram_big_reduce_kernel<float>(const float* __res
 
 // ---- register-resident panel kernels (M <= 512): qf_panel_quad.hip / qf_panel_accum.hip / qf_panel_store.hip
 template <int MB, int NCT, int MODE, int RL>
-__global__ void panel_mfma_kernel(const float* __restrict__ Ppk, const float* __restrict__ X, const float* __restrict__ g, int M, long long C, int L, float* __restrict__ out, float* __restrict__ colsq, float out_scale, float* __restrict__ slab, float* __restrict__ keep);
+__global__ void __launch_bounds__(256, (MB * NCT >= 24) ? 1 : 2) panel_mfma_kernel(const float* __restrict__ Ppk, const float* __restrict__ X, const float* __restrict__ g, int M, long long C, int L, float* __restrict__ out, float* __restrict__ colsq, float out_scale, float* __restrict__ slab, float* __restrict__ keep);
 #define GPSA_PANEL_SIG (const float* __restrict__ Ppk, const float* __restrict__ X, const float* __restrict__ g, int M, long long C, int L, float* __restrict__ out, float* __restrict__ colsq, float out_scale, float* __restrict__ slab, float* __restrict__ keep)
 #define GPSA_PANEL_SHAPES(X, MODE) X(2, 4, MODE) X(4, 4, MODE) X(7, 4, MODE) X(13, 3, MODE) X(16, 2, MODE)
 #define GPSA_PANEL_SHAPES_BIG(X, MODE) X(24, 1, MODE) X(32, 1, MODE)  // accumulate only; one unit per instantiation:
@@ -242,7 +245,7 @@ struct ElboArgs {
 };
 
 template <int MB, int NCT, int RL>
-__global__ void panel_elbo_kernel(ElboArgs a);
+__global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a);
 #define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2)
 #define GPSA_ELBO_EXTERN(MB, NCT)                                          \
   extern template __global__ void panel_elbo_kernel<MB, NCT, 2>(ElboArgs); \
@@ -254,7 +257,7 @@ GPSA_ELBO_SHAPES(GPSA_ELBO_EXTERN)
 
 // ---- symmetric quadratic form: qf_sym.hip
 template <int MB, int NCT, int RL>
-__global__ void quad_sym_mfma_kernel(const float* __restrict__ Ppk, const float* __restrict__ X, int M, long long C, int L, float* __restrict__ out);
+__global__ void __launch_bounds__(256, (MB * NCT >= 24) ? 1 : 2) quad_sym_mfma_kernel(const float* __restrict__ Ppk, const float* __restrict__ X, int M, long long C, int L, float* __restrict__ out);
 #define GPSA_SYM_SIG (const float* __restrict__ Ppk, const float* __restrict__ X, int M, long long C, int L, float* __restrict__ out)
 #define GPSA_SYM_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 3) X(16, 2) X(24, 1)
 #define GPSA_SYM_EXTERN(MB, NCT)                                                 \
@@ -268,7 +271,7 @@ GPSA_SYM_SHAPES(GPSA_SYM_EXTERN)
 // ---- Gram sums (M <= 256): qf_gram.hip
 constexpr int GR_KC = 64;  // columns per staged chunk (four 16-deep MFMA K blocks)
 template <int MB, bool ALIGNED, int NL>
-__global__ void gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C, int L, int nsplit, float* __restrict__ part);
+__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2) gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C, int L, int nsplit, float* __restrict__ part);
 #define GPSA_GRAM_SIG (const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C, int L, int nsplit, float* __restrict__ part)
 #define GPSA_GRAM_SHAPES(X) X(2, 2) X(4, 2) X(7, 2) X(13, 2) X(2, 1) X(4, 1) X(7, 1) X(13, 1) X(16, 1)
 #define GPSA_GRAM_EXTERN(MB, NL)                                                \

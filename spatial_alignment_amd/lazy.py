@@ -70,6 +70,15 @@ class LazyDraws(torch.Tensor):
         with _DISABLE():
             return func(*tree_map(swap, args), **tree_map(swap, kwargs))
 
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # (wrapper subclasses must have one.  Everything that goes through the Python API is answered by
+        #  __torch_function__ above; what still arrives here - an ATen call made below it - gets the draws too)
+        from torch.utils._pytree import tree_map
+
+        swap = lambda x: x.materialize() if isinstance(x, LazyDraws) else x
+        return func(*tree_map(swap, args), **tree_map(swap, kwargs or {}))
+
     @property
     def is_materialized(self):
         return self._real is not None
@@ -167,9 +176,11 @@ class _ValuesOnlyFn(torch.autograd.Function):
             "model.fuse_elbo = False")
 
 
-def run_fused(rec, idx, Ys):
+def run_fused(rec, idx, Ys, parts):
     """loss_fn's half of the step: the data GP of the modalities ``idx`` with their likelihood folded in, on the
-    observations ``Ys`` (gpsa_step_forward, stage 2 restricted to these modalities; forward left them out)"""
+    observations ``Ys`` (gpsa_step_forward, stage 2 restricted to these modalities; forward left them out).
+    ``parts``: their partial-sum outputs (held by the handles, not by ``rec``: rec -> outputs -> node -> rec would be
+    a cycle that keeps the arena of a forward without a backward until the cyclic collector runs)"""
     live = rec.get("live")
     if live is None:
         raise RuntimeError("GPSA: loss_fn on the F_samples of a forward whose backward has already run")
@@ -181,7 +192,7 @@ def run_fused(rec, idx, Ys):
         mask |= 1 << (8 + i)
     o = _ops_mod.get_ops()
     scratch = o._ws(plan.scratch_bytes, saved)
-    outs = [rec["parts"][i] for i in idx]
+    outs = [p.detach() for p in parts]
     call = TO.stash(dict(lib=plan.lib, handle=plan.handle, prm=prm, io=io))
     try:
         torch.ops.gpsa.step_forward(list(tensors), ins + list(Ys) + [rec["noise"]], outs, saved, scratch, call, 2 | mask)

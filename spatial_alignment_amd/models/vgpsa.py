@@ -566,7 +566,7 @@ class VariationalGPSA(GPSA):
                     # per modality: "lazy" (handle untouched) -> "fused" (loss_fn ran the fused pass) or "real"
                     # (materialised first: an unfused modality from then on); see lazy.py
                     state=["lazy" if z else None for z in flags], dF=[None] * len(mods), F_real=[None] * len(mods),
-                    live=None, parts=None, FT=[None] * len(mods))
+                    live=None, FT=[None] * len(mods))
 
     def _forward_engine(self, X_spatial, rows, S, G_test, noise, prediction_mode):
         """forward through the C++ step engine: one autograd node, one host call each way"""
@@ -778,7 +778,7 @@ class VariationalGPSA(GPSA):
                        noise_idx=[nn_ - self.n_modalities + i for i in range(self.n_modalities)],  # quirk 5
                        kl_scale=self.kl_scale)
             fuse = getattr(cache, "fuse", None)
-            Fs, eff, run_i, run_Y = [], [], [], []
+            Fs, eff, run_i, run_Y, run_parts = [], [], [], [], []
             for i, m in enumerate(self.modality_names):
                 F = F_samples[m]
                 take = False
@@ -796,13 +796,14 @@ class VariationalGPSA(GPSA):
                         fuse["state"][i] = "fused"
                         run_i.append(i)
                         run_Y.append(Y)
+                        run_parts.append(F._parts)
                     F = F._parts if take else F.materialize()
                 Fs.append(F)
                 eff.append(take)
             if run_i:
                 from ..lazy import run_fused
 
-                run_fused(fuse, run_i, run_Y)
+                run_fused(fuse, run_i, run_Y, run_parts)
             if any(eff):
                 aux["fuse"], aux["fuse_mods"] = fuse, eff
             loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *Fs)

@@ -396,7 +396,6 @@ class StepFn(torch.autograd.Function):
             # (no reference to ``aux`` itself: aux -> fuse -> live -> aux would keep the arena until the cyclic collector)
             fuse["live"] = dict(plan=plan, io=io, prm=prm, saved=saved, tensors=tensors,
                                 ins=[t for t in aux["X"] + list(aux["eps_F"]) + [aux["eps_G"]] if t is not None])
-            fuse["parts"] = [outs["Fl"][i] if fused[i] else None for i in range(nm)]
         aux["pending"], aux["mu_z"], aux["flag"] = pending, mu_z, flag
         ctx.aux, ctx.io, ctx.prm = aux, io, prm
         ctx.arena = saved
@@ -526,7 +525,7 @@ class StepFn(torch.autograd.Function):
         _give_arena(plan, ctx.arena, force=aux.get("mm_epoch") is not None)
         ctx.arena = None
         if fuse is not None:  # the arena is gone: so is the chance to materialise this forward's draws
-            fuse["live"] = fuse["parts"] = None
+            fuse["live"] = None
             fuse["gloss"] = None
         ctx.aux = ctx.io = ctx.prm = None
         return tuple(out)

@@ -44,3 +44,37 @@ def test_library_is_stamped_with_its_sources():
     stamp = lib.gpsa_source_hash().decode()
     assert stamp == "GPSA_SOURCE_HASH=" + _lib.source_hash()
     assert _lib.library_hash() == _lib.source_hash()
+
+
+def test_kernel_resources():
+    """what the register allocator did, read from the code objects inside the built library (tools/kernel_meta.py; no
+    GPU needed).  Round 4 found the hard way that an ``extern template`` declaration without __launch_bounds__ builds
+    every instantiation for 1024 threads: 128 registers, the accumulators in scratch, kernels 4.7x slower - and
+    numerically fine, so no parity test notices."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from kernel_meta import demangle, library_kernels
+
+    from spatial_alignment_amd import _lib
+
+    ks = library_kernels(_lib.LIB_PATH)
+    names = demangle([k["name"] for k in ks])
+    by = dict(zip(names, ks))
+    assert len(by) > 150
+    families = ("panel_mfma_kernel<", "panel_elbo_kernel<", "quad_sym_mfma_kernel<", "gram_mfma_kernel<", "big_quad_kernel<",
+                "big_accum_kernel<", "gram_big_kernel(", "prod_big_kernel(", "whiten_mfma_kernel<", "omega_fwd_dma_kernel(",
+                "omega_bwd_dma_kernel(")
+    seen = {f: 0 for f in families}
+    for nm, k in by.items():
+        for f in families:
+            if f in nm:
+                seen[f] += 1
+                assert k["max_wg"] == 256, (nm, k)  # the launch bounds reached the instantiation
+    assert all(seen.values()), seen
+    # the headline step's three contraction kernels own the whole register file (one wave per SIMD) and spill next to
+    # nothing: accumulators in scratch would show as kilobytes here
+    for nm, k in by.items():
+        if "panel_elbo_kernel<13, 2, 2>" in nm or "gram_mfma_kernel<13, true, 2>" in nm or "panel_mfma_kernel<13, 3, 0, 2>" in nm:
+            assert k["vgpr"] + 0 >= 400 and k["scratch"] <= 512, (nm, k)

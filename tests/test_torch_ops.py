@@ -139,7 +139,9 @@ def test_the_model_reaches_the_c_abi_through_the_dispatcher():
         loss = model.loss_fn(dd, out[3])
         loss.backward()
         opt.step()
-    assert seen.get("gpsa::step_forward", 0) >= 1 and seen.get("gpsa::elbo_loss_fwd") == 1
-    assert seen.get("gpsa::step_backward") == 1 and seen.get("gpsa::elbo_loss_bwd") == 1
+    # (the reference's two calls: forward enqueues stage 1, loss_fn the data GP with the likelihood folded in)
+    assert seen.get("gpsa::step_forward", 0) == 2 and seen.get("gpsa::elbo_loss_fused_fwd") == 1
+    assert seen.get("gpsa::step_backward") == 1 and seen.get("gpsa::elbo_loss_fused_bwd") == 1
+    assert "gpsa::elbo_loss_fwd" not in seen
     assert seen.get("gpsa::adam_step", 0) >= 1
     assert torch.isfinite(loss)
