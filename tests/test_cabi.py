@@ -77,4 +77,4 @@ def test_kernel_resources():
     # nothing: accumulators in scratch would show as kilobytes here
     for nm, k in by.items():
         if "panel_elbo_kernel<13, 2, 2>" in nm or "gram_mfma_kernel<13, true, 2>" in nm or "panel_mfma_kernel<13, 3, 0, 2>" in nm:
-            assert k["vgpr"] + 0 >= 400 and k["scratch"] <= 512, (nm, k)
+            assert k["vgpr"] > 256 and k["scratch"] <= 512, (nm, k)  # (more than 256: one wave per SIMD, by design)
