@@ -14,6 +14,7 @@ namespace gpsa {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
 
@@ -44,6 +45,28 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base)
       : "memory");
+}
+// The same with the LDS target given as  m0 + IMM  (IMM: the instruction's immediate offset, which the hardware adds
+// to the LDS address AND to the global address - the caller passes  source - IMM bytes).  Writing m0 is what makes an
+// LDS-DMA issue expensive next to a busy matrix pipe: measured (tools/microbench/panel_shape2.hip, the fused kernel's
+// loop, fraction of the fp32-MFMA peak) 0.926 with m0 set once, 0.912 with ONE write per ring stage and the stage's
+// pieces reached through IMM, 0.878 with a write per piece (round 3's glds16 above, which also saved and restored
+// m0: two writes per piece); the m0 set-up alone, without any load, 0.907.  So a wave's pieces of a stage sit within
+// 4 KiB of each other (immediate offsets reach +-4 KiB) and m0 is written once per stage.  Nothing the compiler emits
+// for these kernels uses m0 (no dynamic register indexing: -Werror=pass-failed; no GWS / sendmsg), and the clobber
+// tells it where it changes.
+__device__ __forceinline__ void dma_set_m0(unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_base) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void glds16_m0(const float* gsrc_minus_imm) {
+  static_assert(IMM >= 0 && IMM < 4096, "immediate offset of a global instruction");
+  asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gsrc_minus_imm), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void glds4_m0(const float* gsrc_minus_imm) {
+  static_assert(IMM >= 0 && IMM < 4096, "immediate offset of a global instruction");
+  asm volatile("global_load_lds_dword %0, off offset:%1" ::"v"(gsrc_minus_imm), "n"(IMM) : "memory");
 }
 #define GPSA_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // wait until at most N of this wave's vector-memory operations are outstanding (N = the LDS-DMA
@@ -246,7 +269,7 @@ struct ElboArgs {
 
 template <int MB, int NCT, int RL>
 __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a);
-#define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2)
+#define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2) X(13, 1)
 #define GPSA_ELBO_EXTERN(MB, NCT)                                          \
   extern template __global__ void panel_elbo_kernel<MB, NCT, 2>(ElboArgs); \
   extern template __global__ void panel_elbo_kernel<MB, NCT, 4>(ElboArgs);

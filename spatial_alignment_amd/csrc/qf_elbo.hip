@@ -54,42 +54,51 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
   float xb[NCT][MB][4];
   float xl[NCT][4];
   f32x4 acc[MB][NCT], ab[MB][NCT];
-#define GPSA_STAGE(Q, BUF)                                                                     \
-  {                                                                                            \
-    const float* src__ = Ppk + (long long)(Q) * CHUNK + lane * 4;                              \
-    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
-      const int piece = pc * 4 + w;                                                            \
-      glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                      \
-             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                \
-    }                                                                                          \
-  }
+  // LDS layout of a ring slot: wave-major - wave w's pieces (w, w + 4, ...) are the NPW consecutive KiB at w * NPW, so
+  // that one m0 write per stage covers them through the instruction's immediate offset (qf_common.hpp: glds16_m0);
+  // row tile rt's fragment (piece rt) sits at KiB (rt & 3) * NPW + (rt >> 2)
+#define GPSA_POS(P_) (((P_) & 3) * NPW + ((P_) >> 2))
   const TileOrder ord(it0, it1, L);
+  // The stage cursor: the chunks of a step (a column tile's outputs a .. b) are consecutive in the packed operand, so
+  // the cursor is a pointer that advances by one chunk and a count of the chunks left in the step; the next step's
+  // start is looked up (TileOrder::get: branches, 64-bit compares) only when the count runs out - a few times per
+  // workgroup.  (Round 3 re-derived (step, l, kc) -> address with that branchy code at every chunk: ~75 scalar
+  // instructions and three taken branches between two MFMAs, 13 times per output.)
   long long sstep = 0, stile_;
-  int sa_, sb_, skc = 0;
+  int sa_, sb_;
   ord.get(0, stile_, sa_, sb_);
-  int sl = sa_;
-  bool sdone = false;
+  const float* sp = Ppk + (long long)sa_ * MB * CHUNK + lane * 4;  // this lane's 16 bytes of piece 0 of the chunk
+  int srem = (sb_ - sa_ + 1) * MB;                                  // chunks of the step not staged yet
+  // piece PC (compile time) of the stage cursor's chunk -> slot BUF; m0 is written with the first piece of a stage
 #define GPSA_STAGE_PIECE(BUF, PC)                                                              \
   {                                                                                            \
-    const float* src__ = Ppk + ((long long)sl * MB + skc) * CHUNK + lane * 4;                  \
-    const int piece = (PC) * 4 + w;                                                            \
-    glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                        \
-           __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                  \
+    constexpr int pc__ = (PC);                                                                 \
+    if (pc__ == 0) dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][w * NPW * 256]))); \
+    const int piece = pc__ * 4 + w;                                                            \
+    glds16_m0<pc__ * 1024>(sp + ((piece < MB ? piece : MB - 1) - pc__) * 256);                 \
   }
 #define GPSA_STAGE_ADVANCE()                                                                   \
   {                                                                                            \
-    if (!sdone) {                                                                              \
-      if (skc + 1 < MB) ++skc;                                                                 \
-      else if (sl < sb_) { skc = 0; ++sl; }                                                    \
-      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl = sa_; skc = 0; } \
-      else sdone = true;                                                                       \
+    if (--srem > 0) {                                                                          \
+      sp += CHUNK;                                                                             \
+    } else if (sstep + 1 < ord.n) {                                                            \
+      ++sstep;                                                                                 \
+      ord.get(sstep, stile_, sa_, sb_);                                                        \
+      sp = Ppk + (long long)sa_ * MB * CHUNK + lane * 4;                                       \
+      srem = (sb_ - sa_ + 1) * MB;                                                             \
+    } else {                                                                                   \
+      srem = 0x7fffffff; /* nothing left: the surplus stages re-read the last chunk */         \
     }                                                                                          \
   }
 #define GPSA_STAGE_NEXT(BUF)                                                                   \
   {                                                                                            \
-    GPSA_STAGE((long long)sl * MB + skc, BUF)                                                  \
+    GPSA_STAGE_PIECE(BUF, 0)                                                                   \
+    if (NPW > 1) GPSA_STAGE_PIECE(BUF, (NPW > 1 ? 1 : 0))                                      \
+    if (NPW > 2) GPSA_STAGE_PIECE(BUF, (NPW > 2 ? 2 : 0))                                      \
+    if (NPW > 3) GPSA_STAGE_PIECE(BUF, (NPW > 3 ? 3 : 0))                                      \
     GPSA_STAGE_ADVANCE()                                                                       \
   }
+  static_assert(NPW <= 4, "a wave's pieces of a stage must lie within the 4 KiB an immediate offset reaches");
 
   // likelihood constants (elementwise.hip: loglik_*_kernel)
   const double sN = exp((double)a.noise_u[0]) + 1e-5;
@@ -103,6 +112,11 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
   GPSA_STAGE_NEXT(1)
   GPSA_DMA_WAIT(NPW);
   __syncthreads();
+  // The fragment of row tile 0 of the NEXT chunk is read during the last row tile of the current one: the chunk's
+  // wait + barrier sit in FRONT of that last row tile (every wave has then issued - and, by its lgkmcnt wait,
+  // received - all its reads of the current slot, and the next slot's pieces, issued two chunks ago, have landed),
+  // so no chunk starts with an LDS round trip in the open (13 of them per output before)
+  float4 a_nxt = *reinterpret_cast<const float4*>(&lds[0][lane * 4 + GPSA_POS(0) * 256]);
 
   for (long long step = 0; step < ord.n; ++step) {
     long long tile;
@@ -165,25 +179,32 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) bv[ct][r] = (RL < 4 && kc == MB - 1) ? xl[ct][r] : xb[ct][kc][r];
         const float* base = &lds[buf][lane * 4];
-        float4 a_nxt = *reinterpret_cast<const float4*>(base);
+        const float* nbase = &lds[buf == 2 ? 0 : buf + 1][lane * 4];
         if (kc == 0) {
           // this output's mean / eps / Y: BEFORE the chunk's ring stage is issued, so that the counted wait at the
           // end of the chunk (all but the newest NPW operations) covers them
-#pragma unroll
-          for (int o = 0; o < NGATHER; ++o) {
-            unsigned keep__;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep__)
-                : "v"(gp[o]), "s"(__builtin_amdgcn_readfirstlane(lds_addr(&sgat[w][o * 64])))
-                : "memory");
-            gp[o] += gstep[o];
+          dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(&sgat[w][0])));
+          glds4_m0<0>(gp[0]);
+          gp[0] += gstep[0];
+          if (NGATHER > 1) {
+            glds4_m0<256>(gp[NGATHER > 1 ? 1 : 0] - 64);
+            gp[NGATHER > 1 ? 1 : 0] += gstep[NGATHER > 1 ? 1 : 0];
           }
+          if (NGATHER > 2) {
+            glds4_m0<512>(gp[NGATHER > 2 ? 2 : 0] - 128);
+            gp[NGATHER > 2 ? 2 : 0] += gstep[NGATHER > 2 ? 2 : 0];
+          }
+          static_assert(NGATHER <= 3, "gather operations per wave and output");
         }
 #pragma unroll
         for (int rt = 0; rt < MB; ++rt) {
           const float4 a4 = a_nxt;
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+          if (rt == MB - 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's last read of the current slot is in
+            GPSA_DMA_WAIT(NPW);
+            __syncthreads();
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -195,10 +216,14 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
             }
             __builtin_amdgcn_sched_barrier(0);
             if (r == 0) {
-              if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
+              a_nxt = *reinterpret_cast<const float4*>((rt + 1 < MB ? base + GPSA_POS(rt + 1 < MB ? rt + 1 : 0) * 256
+                                                                    : nbase + GPSA_POS(0) * 256));
             } else if (r == 1) {
               if (MB >= NPW + 3) {
-                if (rt < NPW) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, rt)
+                if (rt == 0) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, 0)
+                if (rt == 1 && NPW > 1) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, (NPW > 1 ? 1 : 0))
+                if (rt == 2 && NPW > 2) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, (NPW > 2 ? 2 : 0))
+                if (rt == 3 && NPW > 3) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, (NPW > 3 ? 3 : 0))
                 if (rt == NPW) GPSA_STAGE_ADVANCE()
               } else if (rt == 0) {
                 GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
@@ -207,19 +232,20 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        GPSA_DMA_WAIT(NPW);
-        __syncthreads();
         buf = (buf == 2) ? 0 : buf + 1;
       }
       // closing of output l: v, the draw, its likelihood term and gradient, and g_l W_l into the second set
       float z2l = 0.f;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
-        float s = 0.f;
+        f32x2 s2a = (f32x2){0.f, 0.f}, s2b = (f32x2){0.f, 0.f};  // packed FMAs (VGPR x VGPR), two independent chains
 #pragma unroll
-        for (int rt = 0; rt < MB; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s += acc[rt][ct][r] * xb[ct][rt][r];
+        for (int rt = 0; rt < MB; ++rt) {
+          const f32x2 x01 = (f32x2){xb[ct][rt][0], xb[ct][rt][1]}, x23 = (f32x2){xb[ct][rt][2], xb[ct][rt][3]};
+          s2a = __builtin_elementwise_fma(acc[rt][ct].xy, x01, s2a);
+          s2b = __builtin_elementwise_fma(acc[rt][ct].zw, x23, s2b);
+        }
+        float s = (s2a.x + s2a.y) + (s2b.x + s2b.y);
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         const float mean = sgat[w][(ct * 3 + 0) * 16 + j];
@@ -239,9 +265,14 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
           const float z = rres * inv;
           z2l += z * z;
         }
-        // g_l W_l joins the second accumulator set, which lives in the AGPR file like the first (every access through
-        // an "a"-constrained operand): left to itself the allocator homes it in VGPRs - the VALU cannot address AGPRs -
-        // and evicts the alpha slab to AGPRs instead, 150 register copies in front of the MFMAs of every output.
+        // Register files (round 4): this unit is built with -amdgpu-mfma-vgpr-form (__graft_entry__.build), so the FIRST
+        // accumulator set (the product being formed) and the alpha slab live in arch VGPRs - the dot product above
+        // needs no register-file crossing - and the SECOND set lives in the AGPR file, every access through an
+        // "a"-constrained operand (left to itself the allocator would home it in VGPRs and evict the alpha slab).
+        // Measured, kernel + pack + slab reduce at the headline size: both sets in AGPRs (round 3) 3468 us, this 3381;
+        // tried and not kept: alpha slab in AGPRs as the MFMAs' B operand (full rate: tools/microbench/mfma_operand.hip)
+        // with both sets in VGPRs and a packed-FMA update - 60 % fewer closing instructions, 3423 us (3343 against
+        // 3330 with the stage cursor below: v_pk_fma_f32 buys nothing here and the allocator spills 900 bytes).
 #pragma unroll
         for (int rt = 0; rt < MB; ++rt)
 #pragma unroll
@@ -281,7 +312,7 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
   GPSA_DMA_DRAIN();
   z2 = block_sum(z2, red);
   if (tid == 0) a.part[blockIdx.x] = z2;
-#undef GPSA_STAGE
+#undef GPSA_POS
 #undef GPSA_STAGE_PIECE
 #undef GPSA_STAGE_ADVANCE
 #undef GPSA_STAGE_NEXT

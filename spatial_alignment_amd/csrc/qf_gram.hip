@@ -62,15 +62,23 @@ constexpr int GR_G = 4;
 // NL outputs l per workgroup share every staged byte and every fragment read (their row fragments differ
 // only by the g row they are scaled with): the non-MFMA instructions of a chunk are amortised over NL x
 // the MFMAs.
-template <int MB, int NKB, int W, int NS, int NL>
+// ``stage(kb, gp)``: the caller's LDS-DMA issues for the NEXT chunk, one per group of the first groups of every K
+// block, pinned between the groups' MFMAs (in one clump in front of the chunk they cost 8 % of the kernel: 14 issues
+// with the matrix pipe idle, 156 times per workgroup; without any staging the kernel ran 1750 instead of 1900 us)
+template <int MB, int NKB, int W, int NS, int NL, typename STG>
 __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
                                                 const float* __restrict__ gvec, int kq,
-                                                f32x4 (&acc)[NL][NS + GR_G]) {
+                                                f32x4 (&acc)[NL][NS + GR_G], STG&& stage) {
   constexpr GramPlan<MB> P{};
   constexpr int N = P.cnt[W];
   constexpr int NGRP = (((NS + GR_G - 1) / GR_G) + 1) & ~1;
+  // LDS image of a chunk, wave-major (round 4): K block kb of all row tiles is staged by wave kb and sits in NPW
+  // consecutive KiB at kb * NPW, so that the staging wave reaches its pieces through immediate offsets from a few m0
+  // values (qf_common.hpp: glds16_m0) - piece (tile_row, kb) is KiB kb * NPW + tile_row
+  constexpr int NPW_ = (MB * NKB + 3) / 4;
+  static_assert(NKB == 4, "one K block per staging wave");
   auto frag = [&](int kb, int tile_row) {
-    return *reinterpret_cast<const float4*>(img + kb * 256 + tile_row * (NKB * 256));
+    return *reinterpret_cast<const float4*>(img + kb * (NPW_ * 256) + tile_row * 256);
   };
   // slot s of the wave's schedule: tile (rr, cc), or a repeat of the last tile into scratch
   auto tile_of = [](int s) { return s < N ? s : N - 1; };
@@ -107,6 +115,8 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
           gn[q] = *reinterpret_cast<const float4*>(gvec + q * GR_KC + (kb + 1) * 16 + kq * 4);
         GPSA_GR_FETCH(nxt, kb + 1, 0)
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (gp < 5) stage(kb, gp);
       __builtin_amdgcn_sched_barrier(0);
       float4 a[NL][GR_G];
       int sl[GR_G];
@@ -191,21 +201,24 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
   {                                                                                          \
     const long long cb__ = (long long)(CH) * GR_KC;                                          \
     if (ALIGNED) {                                                                           \
+      /* wave w stages K block w of every row tile: piece pc = row tile pc -> KiB w * NPW + pc; m0 once per 4 pieces */ \
+      long long col = cb__ + w * 16 + kq * 4;                                                \
+      col = col < C - 4 ? col : C - 4;                                                       \
       _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                   \
-        const int slot = pc * 4 + w;                                                         \
-        const int piece = slot < NPIECE ? slot : 0;                                          \
-        const int rb = piece / NKB, kb = piece % NKB;                                        \
-        int row = rb * 16 + j;                                                               \
+        if ((pc & 3) == 0)                                                                   \
+          dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sA_ + (BUF) * SA_STRIDE + (w * NPW + pc) * 256))); \
+        int row = (pc < MB ? pc : 0) * 16 + j;                                               \
         row = row < M ? row : M - 1;                                                         \
-        long long col = cb__ + kb * 16 + kq * 4;                                             \
-        col = col < C - 4 ? col : C - 4;                                                     \
-        glds16(alpha + (long long)row * C + col,                                             \
-               __builtin_amdgcn_readfirstlane(lds_addr(sA_ + (BUF) * SA_STRIDE + slot * 256))); \
+        const float* gp__ = alpha + (long long)row * C + col;                                \
+        if ((pc & 3) == 0) glds16_m0<0>(gp__);                                               \
+        if ((pc & 3) == 1) glds16_m0<1024>(gp__ - 256);                                      \
+        if ((pc & 3) == 2) glds16_m0<2048>(gp__ - 512);                                      \
+        if ((pc & 3) == 3) glds16_m0<3072>(gp__ - 768);                                      \
       }                                                                                      \
       if (lane < NL * (GR_KC / 4)) {                                                         \
         const int lq__ = min(l0 + lane / (GR_KC / 4), L - 1);                                \
-        glds16(g + (long long)lq__ * Cpad + cb__ + (lane % (GR_KC / 4)) * 4,                 \
-               __builtin_amdgcn_readfirstlane(lds_addr(sG_ + (BUF) * SG_STRIDE)));           \
+        dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sG_ + (BUF) * SG_STRIDE)));       \
+        glds16_m0<0>(g + (long long)lq__ * Cpad + cb__ + (lane % (GR_KC / 4)) * 4);          \
       }                                                                                      \
     } else {                                                                                 \
       for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
@@ -213,7 +226,8 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
         const int rb = piece / NKB, kb = piece % NKB;                                        \
         const int row = rb * 16 + (ln & 15);                                                 \
         const long long col = cb__ + kb * 16 + (ln >> 4) * 4 + r;                            \
-        sA_[(BUF) * SA_STRIDE + e] = (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f; \
+        sA_[(BUF) * SA_STRIDE + (kb * NPW + rb) * 256 + (e & 255)] =                         \
+            (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;                    \
       }                                                                                      \
       if (tid < NL * GR_KC)                                                                  \
         sG_[(BUF) * SG_STRIDE + tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * Cpad + cb__ + tid % GR_KC]; \
@@ -226,9 +240,39 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
   int buf = 0;
   for (long long ch = ch0; ch < ch1; ++ch) {
     // the other slot held chunk ch-1: everyone left it before the barrier that ended that iteration
-    if (ch + 1 < ch1) GPSA_GR_STAGE(ch + 1, buf ^ 1)
+    const bool more = ch + 1 < ch1;
+    constexpr int NGRP_ = (((NS + GR_G - 1) / GR_G) + 1) & ~1;
+    constexpr bool SPREAD = ALIGNED && NGRP_ >= 5;  // (the g piece rides in group 4 of K block 0)
+    if (more && !SPREAD) GPSA_GR_STAGE(ch + 1, buf ^ 1)
     const float* img = sA_ + buf * SA_STRIDE + lane * 4;
-    gram_wave_chunk<MB, NKB, W, NS, NL>(img, sG_ + buf * SG_STRIDE, kq, acc);
+    // next chunk's pieces of this wave (K block w of row tiles 0 .. MB-1 -> KiB w * NPW + row tile), four per K block
+    // of the current chunk: m0 with the first of the four, the others through the immediate offset
+    long long ncol = (ch + 1) * GR_KC + w * 16 + kq * 4;
+    ncol = ncol < C - 4 ? ncol : C - 4;
+    const float* nsrc = alpha + ncol;
+    float* nimg = sA_ + (buf ^ 1) * SA_STRIDE + w * NPW * 256;
+    auto stage = [&](int kb, int gp) {
+      if (!SPREAD || !more) return;
+      if (gp < 4) {
+        const int pc = kb * 4 + gp;
+        if (pc < NPW) {  // (uniform)
+          if (gp == 0) dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(nimg + kb * 4 * 256)));
+          int row = pc * 16 + j;
+          row = row < M ? row : M - 1;
+          const float* gp__ = nsrc + (long long)row * C;
+          if (gp == 0) glds16_m0<0>(gp__);
+          if (gp == 1) glds16_m0<1024>(gp__ - 256);
+          if (gp == 2) glds16_m0<2048>(gp__ - 512);
+          if (gp == 3) glds16_m0<3072>(gp__ - 768);
+        }
+      } else if (kb == 0 && lane < NL * (GR_KC / 4)) {
+        const int lq = min(l0 + lane / (GR_KC / 4), L - 1);
+        dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sG_ + (buf ^ 1) * SG_STRIDE)));
+        glds16_m0<0>(g + (long long)lq * Cpad + (ch + 1) * GR_KC + (lane % (GR_KC / 4)) * 4);
+      }
+    };
+    static_assert(NPW <= 16, "four pieces per K block of the chunk being multiplied");
+    gram_wave_chunk<MB, NKB, W, NS, NL>(img, sG_ + buf * SG_STRIDE, kq, acc, stage);
     GPSA_DMA_DRAIN();  // chunk ch+1 (issued a whole chunk of MFMAs ago) has landed
     __syncthreads();
     buf ^= 1;

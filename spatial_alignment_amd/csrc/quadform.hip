@@ -1117,7 +1117,12 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
 }
 
 /* ---- forward + likelihood + abar in one pass (panel_elbo_kernel) ------------------------------------------ */
-static inline int elbo_nct_for(int MB) { return MB == 13 ? 2 : 4; }
+// MB = 13: one wave per SIMD with 32 columns (NCT = 2), or - GPSA_ELBO_NCT=1 - two workgroups per CU with 16 columns per
+// wave and half the register file each (the other wave's MFMAs fill the matrix pipe during a wave's closing and ring issues)
+static inline int elbo_nct_for(int MB) {
+  static const int nct13 = [] { const char* e = getenv("GPSA_ELBO_NCT"); return (e && e[0] == '1') ? 1 : 2; }();
+  return MB == 13 ? nct13 : 4;
+}
 static inline bool elbo_path(int M) {
   const int MB = gpsa::mfma_mb_for(M);
   return MB && MB <= 13 && !gpsa::force_generic();
@@ -1153,7 +1158,7 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
   ElboArgs a{Ppk, alpha, M, C, L, meanT, q, var_u, eps, Y, noise_u, N, S, g, dmeanT, FT, abar, slab, part, gmax};
   long long grid = 0;
 #define GPSA_ELBO_CASE(MBV, NCTV)                                                                       \
-  case MBV: {                                                                                           \
+  case MBV * 8 + NCTV: {                                                                                        \
     const long long ntiles = cdiv(C, 64 * NCTV), T = ntiles * L;                                        \
     grid = (long long)num_cus() * ((MBV * NCTV >= 14) ? 1 : 2);                                         \
     if (grid > T) grid = T;                                                                             \
@@ -1164,11 +1169,12 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
     dim3 rg((unsigned)ntiles, ntiles >= 512 ? 8 : (ntiles >= 128 ? 16 : 32));                           \
     panel_slab_reduce_kernel<<<rg, 256, 0, st>>>(slab, M, MBV * 16, 64 * NCTV, C, L, ntiles, (int)grid, abar); \
   } break;
-  switch (MB) {
+  switch (MB * 8 + elbo_nct_for(MB)) {
     GPSA_ELBO_CASE(2, 4)
     GPSA_ELBO_CASE(4, 4)
     GPSA_ELBO_CASE(7, 4)
     GPSA_ELBO_CASE(13, 2)
+    GPSA_ELBO_CASE(13, 1)
     default:
       return GPSA_EUNSUPPORTED;
   }
