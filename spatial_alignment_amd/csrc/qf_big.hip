@@ -5,6 +5,9 @@
 
 namespace gpsa {
 
+// KiB of piece P_ (0 .. 15) inside a ring slot of the 128 x 128 kernels: wave-major, see gram_big_kernel's stage
+#define GPSA_BIG_POS(P_) ((((P_) & 3) << 2) + ((P_) >> 2))
+
 __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
   __shared__ __attribute__((aligned(16))) float sg[3][16];
@@ -68,12 +71,18 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
   {                                                                                           \
     long long col__ = (long long)(CH) * 16 + kq * 4;                                          \
     col__ = col__ < C - 4 ? col__ : C - 4;                                                    \
-    const unsigned d__ = glds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 1024;       \
-    glds16(rowp[0] + col__, d__);                                                             \
-    glds16(rowp[1] + col__, d__ + 4 * 1024);                                                  \
-    glds16(rowp[2] + col__, d__ + 8 * 1024);                                                  \
-    glds16(rowp[3] + col__, d__ + 12 * 1024);                                                 \
-    if (lane < 4) glds16(gl + (long long)(CH) * 16 + lane * 4, gsg0 + (unsigned)(BUF) * 64);  \
+    /* wave-major ring slot (round 4): the wave's four pieces w, 4+w, 8+w, 12+w are the four consecutive KiB at   \
+       4 w - ONE m0 write per stage, the pieces through the immediate offset (qf_common.hpp: glds16_m0; an m0 write \
+       next to a busy matrix pipe costs ~40 cycles, and glds16 did two per piece) */                              \
+    dma_set_m0(glds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 4096);                \
+    glds16_m0<0>(rowp[0] + col__);                                                            \
+    glds16_m0<1024>(rowp[1] + col__ - 256);                                                   \
+    glds16_m0<2048>(rowp[2] + col__ - 512);                                                   \
+    glds16_m0<3072>(rowp[3] + col__ - 768);                                                   \
+    if (lane < 4) {                                                                           \
+      dma_set_m0(gsg0 + (unsigned)(BUF) * 64);                                                \
+      glds16_m0<0>(gl + (long long)(CH) * 16 + lane * 4);                                     \
+    }                                                                                         \
   }
   if (ch0 < ch1) {
     GPSA_GB_STAGE(ch0, 0)
@@ -90,9 +99,9 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
     float4 av[4], bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 x = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
+      const float4 x = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(wr * 4 + i) * 256);
       av[i] = make_float4(x.x * gk.x, x.y * gk.y, x.z * gk.z, x.w * gk.w);
-      bv[i] = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+      bv[i] = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(8 + wc * 4 + i) * 256);
     }
 #define GPSA_GB_MMA(F)                                                                        \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(256, 2) prod_big_kernel(ProdBigArgs a) {
     float4 av[4], bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
+      av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);  // (piece-major slot: this kernel's own stage)
       bv[i] = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
     }
     // step F: A = av[rt].F ; B tile G = bv[F].G
@@ -352,12 +361,12 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
   }
 #define GPSA_BQ_STAGE(BUF)                                                                    \
   {                                                                                           \
-    const unsigned d__ = lds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 1024;        \
     const bool oob__ = last_oob && s_ch == nch - 1;                                           \
-    glds16(sp0, d__);                                                                         \
-    glds16(sp1, d__ + 4 * 1024);                                                              \
-    glds16(oob__ ? xclamp0 : sx0, d__ + 8 * 1024);                                            \
-    glds16(oob__ ? xclamp1 : sx1, d__ + 12 * 1024);                                           \
+    dma_set_m0(lds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 4096); /* wave-major slot: gram_big_kernel */ \
+    glds16_m0<0>(sp0);                                                                        \
+    glds16_m0<1024>(sp1 - 256);                                                               \
+    glds16_m0<2048>((oob__ ? xclamp0 : sx0) - 512);                                           \
+    glds16_m0<3072>((oob__ ? xclamp1 : sx1) - 768);                                           \
   }
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) {
@@ -375,8 +384,8 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
       float4 av[4], bv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
-        bv[i] = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+        av[i] = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(wr * 4 + i) * 256);
+        bv[i] = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(8 + wc * 4 + i) * 256);
       }
       {
         const int cc = ch - rb * 8 - wr * 4;  // wave-uniform
@@ -514,13 +523,16 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
   }
 #define GPSA_BA_STAGE(BUF)                                                                    \
   {                                                                                           \
-    const unsigned d__ = lds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 1024;        \
     const bool oob__ = last_oob && s_ch == nch - 1;                                           \
-    glds16(sp0, d__);                                                                         \
-    glds16(sp1, d__ + 4 * 1024);                                                              \
-    glds16(oob__ ? xclamp0 : sx0, d__ + 8 * 1024);                                            \
-    glds16(oob__ ? xclamp1 : sx1, d__ + 12 * 1024);                                           \
-    if (lane < 32) glds16(sgp, sg0 + (unsigned)(BUF) * 512);                                  \
+    dma_set_m0(lds0 + (unsigned)(BUF) * (16 * 256 * 4) + (unsigned)w * 4096); /* wave-major slot: gram_big_kernel */ \
+    glds16_m0<0>(sp0);                                                                        \
+    glds16_m0<1024>(sp1 - 256);                                                               \
+    glds16_m0<2048>((oob__ ? xclamp0 : sx0) - 512);                                           \
+    glds16_m0<3072>((oob__ ? xclamp1 : sx1) - 768);                                           \
+    if (lane < 32) {                                                                          \
+      dma_set_m0(sg0 + (unsigned)(BUF) * 512);                                                \
+      glds16_m0<0>(sgp);                                                                      \
+    }                                                                                         \
   }
   if (l0 < l1) {
 #pragma unroll
@@ -541,8 +553,8 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
       float4 av[4], bv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        av[i] = *reinterpret_cast<const float4*>(base + (wr * 4 + i) * 256);
-        const float4 x = *reinterpret_cast<const float4*>(base + (8 + wc * 4 + i) * 256);
+        av[i] = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(wr * 4 + i) * 256);
+        const float4 x = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(8 + wc * 4 + i) * 256);
         bv[i] = make_float4(x.x * gl.x, x.y * gl.y, x.z * gl.z, x.w * gl.w);
       }
       GPSA_BIG_MMA(x, bv[0])
