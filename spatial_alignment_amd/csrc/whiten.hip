@@ -19,13 +19,17 @@ namespace gpsa {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr64_t;
 
-__device__ __forceinline__ void glds16_f64(const double* gsrc, unsigned lds_base) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_base)
-      : "memory");
+// LDS-DMA of 16 bytes per lane to  m0 + IMM + 16 lane  (IMM also added to the global address: the caller passes
+// source - IMM bytes).  m0 is written once per group of up to four 1-KiB pieces: an s_mov to m0 next to a busy matrix
+// pipe costs the wave ~40 cycles (tools/microbench/panel_shape2.hip), and round 3's helper saved, set and restored it
+// around every piece - 14 writes per wave and K chunk here, against 52 fp64 MFMAs.
+__device__ __forceinline__ void dma64_set_m0(unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_base) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void glds16_f64_m0(const double* gsrc_minus_imm) {
+  static_assert(IMM >= 0 && IMM < 4096, "immediate offset of a global instruction");
+  asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gsrc_minus_imm), "n"(IMM) : "memory");
 }
 
 // Kinv [M][M] row-major -> Apk[kc][ks][rt][lane] = Kinv[16 rt + (lane&15)][16 kc + 4 ks + (lane>>4)]
@@ -99,15 +103,37 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
   // LDS byte address of the ring, taken ONCE from the array's base (one foldable address-space cast)
   const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr64_t)(&lds[0][0]);
 
+  // ring slot, wave-major: wave w's pieces w, w + 4, ... are the NPW consecutive KiB at w * NPW (one m0 value reaches
+  // four of them through the immediate offset); element e = (ks * MB + rt) * 64 + lane of a chunk sits at
+  //   GPSA_WPOS(e >> 7) * 128 + (e & 127)
+#define GPSA_WPOS(P_) (((P_) & 3) * NPW + ((P_) >> 2))
+#define GPSA_WELEM(KS, RT) (GPSA_WPOS(((KS) * MB + (RT)) >> 1) * 128 + ((((KS) * MB + (RT)) & 1) << 6))
+  // piece PC (compile time) of chunk Q -> slot BUF
+#define GPSA_WSTAGE_PIECE(Q, BUF, PC)                                                          \
+  {                                                                                            \
+    constexpr int pc__ = (PC);                                                                 \
+    if ((pc__ & 3) == 0)                                                                       \
+      dma64_set_m0(__builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((BUF) * BUFD + (w * NPW + pc__) * 128) * 8))); \
+    const int piece = pc__ * 4 + w;                                                            \
+    glds16_f64_m0<(pc__ & 3) * 1024>(Apk + (long long)(Q) * CHUNK + lane * 2 +                 \
+                                     ((piece < NPIECE ? piece : NPIECE - 1) - (pc__ & 3)) * 128); \
+  }
 #define GPSA_WSTAGE(Q, BUF)                                                                    \
   {                                                                                            \
-    const double* src__ = Apk + (long long)(Q) * CHUNK + lane * 2;                             \
-    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
-      const int piece = pc * 4 + w;                                                            \
-      glds16_f64(src__ + (piece < NPIECE ? piece : NPIECE - 1) * 128,                          \
-                 __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((BUF) * BUFD + piece * 128) * 8))); \
-    }                                                                                          \
+    GPSA_WSTAGE_PIECE(Q, BUF, 0)                                                               \
+    if (NPW > 1) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 1 ? 1 : 0))                                  \
+    if (NPW > 2) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 2 ? 2 : 0))                                  \
+    if (NPW > 3) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 3 ? 3 : 0))                                  \
+    if (NPW > 4) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 4 ? 4 : 0))                                  \
+    if (NPW > 5) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 5 ? 5 : 0))                                  \
+    if (NPW > 6) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 6 ? 6 : 0))                                  \
+    if (NPW > 7) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 7 ? 7 : 0))                                  \
+    if (NPW > 8) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 8 ? 8 : 0))                                  \
+    if (NPW > 9) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 9 ? 9 : 0))                                  \
+    if (NPW > 10) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 10 ? 10 : 0))                               \
+    if (NPW > 11) GPSA_WSTAGE_PIECE(Q, BUF, (NPW > 11 ? 11 : 0))                               \
   }
+  static_assert(NPW <= 12, "pieces per wave and stage");
 #define GPSA_WLOADB(DST, KC, T)                                                                \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                           \
     const int row = 16 * (KC) + 4 * ks + kq;                                                   \
@@ -143,19 +169,43 @@ whiten_mfma_kernel(const double* __restrict__ Apk0, const TI* __restrict__ X0, i
     }
     __syncthreads();
     if (kc + 1 < MB) {
-      GPSA_WSTAGE(kc + 1, (kc + 1) & 1)
       if constexpr (STREAM) GPSA_WLOADB(xr[(kc + 1) & 1], kc + 1, TI)
     }
     const double* base = &lds[kc & 1][lane];
+    constexpr int PPK = (NPW + 3) / 4;  // the next stage's pieces are issued PPK at a time between the four K steps
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (kc + 1 < MB) {
+#pragma unroll
+        for (int u = 0; u < PPK; ++u) {
+          if (ks * PPK + u < NPW) {
+            switch (ks * PPK + u) {  // (compile time after unrolling: the immediate offset must be a constant)
+              case 0: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 0) break;
+              case 1: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 1) break;
+              case 2: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 2) break;
+              case 3: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 3) break;
+              case 4: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 4) break;
+              case 5: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 5) break;
+              case 6: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 6) break;
+              case 7: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 7) break;
+              case 8: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 8) break;
+              case 9: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 9) break;
+              case 10: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 10) break;
+              default: GPSA_WSTAGE_PIECE(kc + 1, (kc + 1) & 1, 11) break;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const double b = STREAM ? (double)xr[kc & 1][ks] : xb[STREAM ? 0 : kc][ks];
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[(ks * MB + rt0 + rt) * 64], b, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[GPSA_WELEM(ks, rt0 + rt)], b, acc[rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #undef GPSA_WSTAGE
+#undef GPSA_WSTAGE_PIECE
 
   // the accumulator row of register r is the row the lane held as B operand (4 r + kq within the
   // tile), so q = k^T alpha closes lane-locally
