@@ -564,6 +564,17 @@ int gpsa_elbo_loss_fused_bwd(int n_ll, const float* const* F, const float* const
                              const float* gloss, int n_kl, double kl_scale, float* const* dF, float* const* dnoise,
                              float* dnoise_all, int n_noise, double* dkl, void* workspace, long long workspace_bytes,
                              void* stream);
+/* ---- LMC likelihood without F_obs (round 4; replaces, for an LMC modality in training, the product
+ * F_obs = F_latent W of vgpsa.py:428-432, the Gaussian likelihood over [S, N, P] of vgpsa.py:532-538 and autograd's
+ * dF_latent = dF_obs W^T, dW = F_latent^T dF_obs): one pass that forms, at upstream gradient 1 of loss = -LL,
+ *   zpart[]  block partials of sum ((Y[n,p] - F_obs[s,n,p]) / s)^2  (nparts doubles, tail zeroed: the ``zpart`` of
+ *            gpsa_elbo_loss_fused_fwd / _bwd, which finish LL and the noise gradient from it),
+ *   dF [S N, L] = dLoss/dF_latent,   dW [L, P] = dLoss/dW,        with s = exp(noise_u) + 1e-5, dF_obs = -(Y - F_obs)/(s^2 S).
+ * F [S N, L] (F_latent, sample-major as the API tensor), W [L, P], Y [N, P].  L <= 32 (GPSA_EUNSUPPORTED beyond). */
+long long gpsa_lmc_loglik_workspace(long long C, int L, int P, int nparts);
+int gpsa_lmc_loglik_fused_f32(const float* F, const float* W, const float* Y, const float* noise_u, int S, long long N,
+                              int L, int P, double* zpart, int nparts, float* dF, float* dW, void* workspace,
+                              long long workspace_bytes, void* stream);
 /* the fused forward's outputs (formed at upstream gradient 1) as the backward wants them: g, dmeanT, abar scaled by the
  * loss's upstream gradient (untouched when it is 1), g_ext row L = qbar = -sum_l g, dvar_u = exp(var_u) sum g */
 int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,

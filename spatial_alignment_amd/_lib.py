@@ -146,6 +146,8 @@ SIGNATURES.update({
     "gpsa_quadform_fwd_keep_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_keep_f32_bytes": (_ll, [_i, _ll, _i]),
     "gpsa_quadform_bwd_alpha_kept_f32": (_i, [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp]),
+    "gpsa_lmc_loglik_workspace": (_ll, [_ll, _i, _i, _i]),
+    "gpsa_lmc_loglik_fused_f32": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_elbo_parts": (_i, []),
     "gpsa_quadform_elbo_f32_workspace": (_ll, [_i, _ll, _i]),
     "gpsa_quadform_elbo_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp,

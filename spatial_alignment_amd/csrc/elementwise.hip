@@ -492,6 +492,130 @@ elbo_bwd_kernel(const float* __restrict__ gloss, int n_ll, int n_kl, double kl_s
 
 }  // namespace gpsa
 
+/* ---- LMC likelihood without F_obs (vgpsa.py:428-432, 532-538; round 4) ---------------------------------------------
+ * An LMC modality's observed draws are  F_obs[s,n,:] = F_latent[s,n,:] W  ([S,N,L] x [L,P]); the reference
+ * materialises them ([S,N,P]: 400 MB at BASELINE config 3) and the likelihood, its gradient dF_obs and the two LMC
+ * gradient products each stream that size again.  Here ONE pass per tile of 16 columns forms, for every (column c, p):
+ *     fobs = F[c,:] . W[:,p];   r = Y[c mod N, p] - fobs;   z^2 += (r / s)^2;   dfo = -r / (s^2 S)
+ *     dW[l,p] += F[c,l] dfo          (a thread owns its p: register accumulators over all the block's columns)
+ *     dF[c,l]  = sum_p dfo W[l,p]    (the tile's dfo through LDS, one thread per (c, l))
+ * - nothing of size [S,N,P] exists.  Everything at upstream gradient 1 (the caller scales; linear).
+ * zpart: nparts doubles (the block partials of sum z^2, tail zeroed) for gpsa_elbo_loss_fused_fwd / _bwd. */
+namespace gpsa {
+constexpr int LMC_TC = 16, LMC_PC = 512, LMC_PS = LMC_PC + 4;  // columns per tile, p per chunk, LDS row stride
+// (rows stay 16-byte aligned for the ds_read_b128 of the dF pass; 516 = 4 mod 32: lanes on rows l, l + 8 share banks)
+
+template <int LB>
+__global__ void __launch_bounds__(256)
+lmc_loglik_kernel(const float* __restrict__ F, const float* __restrict__ W, const float* __restrict__ Y,
+                  const float* __restrict__ noise_u, int S, long long N, int L, int P, long long C,
+                  double* __restrict__ zpart, int nparts, float* __restrict__ dF, float* __restrict__ dWpart) {
+  extern __shared__ __attribute__((aligned(16))) float lmc_smem[];
+  float* sF = lmc_smem;                    // [16][LB]
+  float* sW = sF + LMC_TC * LB;            // [LB][513]
+  float* sD = sW + LB * LMC_PS;            // [16][513]
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const double sN = exp((double)noise_u[0]) + 1e-5;  // "variance" used as std
+  const float inv = (float)(1.0 / sN);
+  const float coef = (float)(-1.0 / (sN * sN * (double)S));
+  const long long ntiles = (C + LMC_TC - 1) / LMC_TC;
+  double z2 = 0.0;
+  for (int p0 = 0; p0 < P; p0 += LMC_PC) {
+    float w[2][LB], dw[2][LB];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int p = p0 + tid + 256 * k;
+#pragma unroll
+      for (int l = 0; l < LB; ++l) {
+        w[k][l] = (p < P && l < L) ? W[(long long)l * P + p] : 0.f;
+        dw[k][l] = 0.f;
+        sW[l * LMC_PS + tid + 256 * k] = w[k][l];
+      }
+    }
+    __syncthreads();
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const long long c0 = t * LMC_TC;
+      for (int e = tid; e < LMC_TC * LB; e += 256) {
+        const int cc = e / LB, l = e - cc * LB;
+        const long long c = c0 + cc;
+        sF[e] = (c < C && l < L) ? F[c * L + l] : 0.f;
+      }
+      __syncthreads();
+      float z2l = 0.f;
+#pragma unroll 4
+      for (int cc = 0; cc < LMC_TC; ++cc) {
+        const long long c = c0 + cc;
+        const bool okc = c < C;
+        const float* yrow = Y + (okc ? (c % N) : 0) * P;
+        float f[LB];
+#pragma unroll
+        for (int l = 0; l < LB; ++l) f[l] = sF[cc * LB + l];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int p = p0 + tid + 256 * k;
+          float fobs = 0.f;
+#pragma unroll
+          for (int l = 0; l < LB; ++l) fobs = fmaf(f[l], w[k][l], fobs);
+          const bool ok = okc && p < P;
+          const float r = ok ? yrow[p] - fobs : 0.f;
+          const float z = r * inv;
+          z2l = fmaf(z, z, z2l);
+          const float dfo = coef * r;
+          sD[cc * LMC_PS + tid + 256 * k] = dfo;
+#pragma unroll
+          for (int l = 0; l < LB; ++l) dw[k][l] = fmaf(f[l], dfo, dw[k][l]);
+        }
+      }
+      z2 += (double)z2l;
+      __syncthreads();
+      for (int e = tid; e < LMC_TC * LB; e += 256) {
+        const int cc = e / LB, l = e - cc * LB;
+        const float* dr = sD + cc * LMC_PS;
+        const float* wr = sW + l * LMC_PS;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+        for (int p = 0; p < LMC_PC; p += 4) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dr + p), w4 = *reinterpret_cast<const float4*>(wr + p);
+          s0 = fmaf(d4.x, w4.x, s0);
+          s1 = fmaf(d4.y, w4.y, s1);
+          s2 = fmaf(d4.z, w4.z, s2);
+          s3 = fmaf(d4.w, w4.w, s3);
+        }
+        const long long c = c0 + cc;
+        if (c < C && l < L) {
+          const long long o = c * L + l;
+          const float sum = (s0 + s1) + (s2 + s3);
+          dF[o] = p0 == 0 ? sum : dF[o] + sum;  // (this block owns the column in every chunk of p)
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int p = p0 + tid + 256 * k;
+      if (p < P)
+#pragma unroll
+        for (int l = 0; l < LB; ++l)
+          if (l < L) dWpart[((long long)blockIdx.x * L + l) * P + p] = dw[k][l];
+    }
+    __syncthreads();
+  }
+  z2 = block_sum(z2, red);
+  if (tid == 0) zpart[blockIdx.x] = z2;
+  if (blockIdx.x == 0)
+    for (int i = (int)gridDim.x + tid; i < nparts; i += 256) zpart[i] = 0.0;
+}
+
+static inline int lmc_blocks(long long C, int nparts) {
+  long long g = (C + LMC_TC - 1) / LMC_TC;
+  const long long cap = 2LL * num_cus();
+  if (g > cap) g = cap;
+  if (g > nparts) g = nparts;
+  return (int)(g < 1 ? 1 : g);
+}
+}  // namespace gpsa
+
 extern "C" {
 
 int gpsa_data_sample_fwd(const float* meanT, const float* v, const double* q, const float* var_u,
@@ -747,6 +871,52 @@ int gpsa_elbo_loss_fused_bwd(int n_ll, const float* const* F, const float* const
                                                       i == 0 ? dkl : nullptr, n_kl, kl_scale,
                                                       i == 0 ? dnoise_all : nullptr, n_noise);
   }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+long long gpsa_lmc_loglik_workspace(long long C, int L, int P, int nparts) {
+  if (C < 1 || L < 1 || P < 1 || nparts < 1) return 0;
+  return (long long)gpsa::lmc_blocks(C, nparts) * L * P * 4 + 256;
+}
+
+int gpsa_lmc_loglik_fused_f32(const float* F, const float* W, const float* Y, const float* noise_u, int S, long long N,
+                              int L, int P, double* zpart, int nparts, float* dF, float* dW, void* workspace,
+                              long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (!F || !W || !Y || !noise_u || !zpart || !dF || !dW || S < 1 || N < 1 || L < 1 || P < 1 || nparts < 1)
+    return GPSA_EINVAL;
+  if (L > 32) return GPSA_EUNSUPPORTED;
+  const long long C = (long long)S * N;
+  if (workspace_bytes < gpsa_lmc_loglik_workspace(C, L, P, nparts)) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int G = lmc_blocks(C, nparts);
+  float* part = (float*)workspace;
+#define GPSA_LMC_CASE(LBV)                                                                                 \
+  {                                                                                                        \
+    const size_t sm = (size_t)(LMC_TC * LBV + LBV * LMC_PS + LMC_TC * LMC_PS) * 4;                         \
+    if (sm > 65536) {                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void*)lmc_loglik_kernel<LBV>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);             \
+      if (e != hipSuccess) return (int)e;                                                                  \
+    }                                                                                                      \
+    lmc_loglik_kernel<LBV><<<G, 256, sm, st>>>(F, W, Y, noise_u, S, N, L, P, C, zpart, nparts, dF, part);  \
+  }
+  switch ((L + 3) / 4) {  // register arrays of L rounded up to a multiple of 4
+    case 1: GPSA_LMC_CASE(4) break;
+    case 2: GPSA_LMC_CASE(8) break;
+    case 3: GPSA_LMC_CASE(12) break;
+    case 4: GPSA_LMC_CASE(16) break;
+    case 5: GPSA_LMC_CASE(20) break;
+    case 6: GPSA_LMC_CASE(24) break;
+    case 7: GPSA_LMC_CASE(28) break;
+    default: GPSA_LMC_CASE(32) break;
+  }
+#undef GPSA_LMC_CASE
+  GPSA_LAUNCH_CHECK();
+  // dW[l,p] = sum over the blocks' partials, in block order (deterministic)
+  const long long n = (long long)L * P;
+  reduce_rows_kernel<float, float><<<(unsigned)cdiv(n, 64), 256, 0, st>>>(part, G, n, n, dW, 1.0);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

@@ -45,15 +45,8 @@ def _meta_functions():
 _META = None
 
 
-class LazyDraws(torch.Tensor):
-    """``F_latent_samples[m]`` / ``F_observed_samples[m]`` of a fused training forward (see the module docstring)."""
-
-    @staticmethod
-    def __new__(cls, rec, i, shape, device):
-        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device,
-                                                requires_grad=True)
-        t._rec, t._i, t._real, t._parts, t._peek = rec, i, None, None, None
-        return t
+class _Lazy(torch.Tensor):
+    """a tensor that is computed the first time anything but its metadata is asked of it (subclasses: materialize())"""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -66,18 +59,57 @@ class LazyDraws(torch.Tensor):
                 return func(*args, **kwargs)
         from torch.utils._pytree import tree_map
 
-        swap = lambda x: x.materialize() if isinstance(x, LazyDraws) else x
+        swap = lambda x: x.materialize() if isinstance(x, _Lazy) else x
         with _DISABLE():
             return func(*tree_map(swap, args), **tree_map(swap, kwargs))
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
         # (wrapper subclasses must have one.  Everything that goes through the Python API is answered by
-        #  __torch_function__ above; what still arrives here - an ATen call made below it - gets the draws too)
+        #  __torch_function__ above; what still arrives here - an ATen call made below it - gets the values too)
         from torch.utils._pytree import tree_map
 
-        swap = lambda x: x.materialize() if isinstance(x, LazyDraws) else x
+        swap = lambda x: x.materialize() if isinstance(x, _Lazy) else x
         return func(*tree_map(swap, args), **tree_map(swap, kwargs or {}))
+
+
+class LazyProduct(_Lazy):
+    """``F_observed_samples[m]`` of an LMC modality in training: F_latent[m] @ W[m]  ([S, N, L] x [L, P]), formed when
+    somebody asks for it (an ordinary differentiable product then).  ``loss_fn`` does not: it runs the likelihood, its
+    gradient and the two LMC gradient products in one pass over (F_latent, W, Y) without the [S, N, P] tensor
+    (gpsa_lmc_loglik_fused_f32) - 400 MB each way at BASELINE config 3."""
+
+    @staticmethod
+    def __new__(cls, thunk, shape, device, F_latent, W):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device,
+                                                requires_grad=True)
+        t._thunk, t._real, t._peek, t._lmc = thunk, None, None, (F_latent, W)
+        return t
+
+    @property
+    def is_materialized(self):
+        return self._real is not None
+
+    def materialize(self):
+        if self._real is not None:
+            return self._real
+        if torch.is_grad_enabled():
+            self._real = self._thunk()
+            return self._real
+        if self._peek is None:
+            self._peek = self._thunk()
+        return self._peek
+
+
+class LazyDraws(_Lazy):
+    """``F_latent_samples[m]`` / ``F_observed_samples[m]`` of a fused training forward (see the module docstring)."""
+
+    @staticmethod
+    def __new__(cls, rec, i, shape, device):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device,
+                                                requires_grad=True)
+        t._rec, t._i, t._real, t._parts, t._peek = rec, i, None, None, None
+        return t
 
     @property
     def is_materialized(self):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import engine as E
 from .. import step_engine as SE
-from ..lazy import LazyDraws
+from ..lazy import LazyDraws, LazyProduct
 from ..kernels import builtin_kind, rbf_kernel
 from .gpsa import GPSA
 
@@ -548,6 +548,15 @@ class VariationalGPSA(GPSA):
             )
         return G_means, G_samples, self.F_latent_samples, self.F_observed_samples
 
+    def _lazy_obs(self, plan, G_test, prediction_mode):
+        """per modality: True = an LMC modality whose F_obs = F_latent W is left to whoever asks for it (training;
+        loss_fn runs gpsa_lmc_loglik_fused_f32 on (F_latent, W, Y) instead of forming it)"""
+        training = (self.fuse_elbo and not prediction_mode and G_test is None and torch.is_grad_enabled()
+                    and any(p.requires_grad for p in SE._param_list(self)))
+        return [bool(training and plan.lmc[i] and plan.L[i] <= 32 and self.W_dict[m].dtype == torch.float32
+                     and self.W_dict[m].is_contiguous())
+                for i, m in enumerate(self.modality_names)]
+
     def _fuse_setup(self, plan, S, G_test, prediction_mode):
         """-> the ``fuse`` record of a training forward that leaves its fusable data GPs to loss_fn, or None"""
         if not self.fuse_elbo or prediction_mode or G_test is not None:
@@ -650,7 +659,8 @@ class VariationalGPSA(GPSA):
                    want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,
                    mm_epoch=self.__dict__.get("_mm_epoch"),
                    flag_slot=self.__dict__.get("_flag_slot", 0),
-                   fuse=self._fuse_setup(plan, S, G_test, prediction_mode))
+                   fuse=self._fuse_setup(plan, S, G_test, prediction_mode),
+                   lazy_obs=self._lazy_obs(plan, G_test, prediction_mode))
         self.__dict__["_flag_slot"] = 1 - aux["flag_slot"]  # two pinned words: consecutive forwards never share one
         outs = SE.StepFn.apply(aux, *SE._param_list(self))
         nm = len(mods)
@@ -678,6 +688,13 @@ class VariationalGPSA(GPSA):
                     h = LazyDraws(cache.fuse, i, (S, plan.N[i], plan.L[i]), dev)
                     h._parts = Fl[i]
                     Fl[i] = h
+        if any(aux["lazy_obs"]):
+            Fo = list(Fo)
+            for i, m in enumerate(mods):
+                if aux["lazy_obs"][i]:
+                    Wm, Fli = self.W_dict[m], Fl[i]
+                    Fo[lmc.index(i)] = LazyProduct(lambda Fli=Fli, Wm=Wm: E.MatmulFn.apply(Fli, Wm),
+                                                   (S, plan.N[i], plan.P[i]), dev, Fli, Wm)
         G_means = {m: Gm[i] for i, m in enumerate(mods)}
         G_samples = {m: Gs[i] for i, m in enumerate(mods)}
         self.F_latent_samples = {m: Fl[i] for i, m in enumerate(mods)}
@@ -779,10 +796,27 @@ class VariationalGPSA(GPSA):
                        kl_scale=self.kl_scale)
             fuse = getattr(cache, "fuse", None)
             Fs, eff, run_i, run_Y, run_parts = [], [], [], [], []
+            lmc_terms, Ws, shapes = {}, [], [None] * self.n_modalities
             for i, m in enumerate(self.modality_names):
                 F = F_samples[m]
                 take = False
-                if isinstance(F, LazyDraws):
+                if isinstance(F, LazyProduct):
+                    # an LMC modality whose F_obs = F_latent W nobody has asked for: the likelihood, dF_latent and dW come
+                    # out of one pass over (F_latent, W, Y) (gpsa_lmc_loglik_fused_f32) when the observations are what
+                    # that kernel reads; otherwise the product is formed and the separate kernels run
+                    Y = data_dict[m]["outputs"]
+                    Fl_, W_ = F._lmc
+                    if (not F.is_materialized and torch.is_tensor(Y) and Y.is_cuda and Y.device == F.device
+                            and Y.dtype == torch.float32 and Y.is_contiguous()
+                            and tuple(Y.shape) == (int(F.shape[1]), int(F.shape[2])) and W_ is self.W_dict[m]):
+                        take = True
+                        lmc_terms[i] = len(Ws)
+                        Ws.append(W_)
+                        shapes[i] = tuple(int(d) for d in F.shape)
+                        F = Fl_
+                    else:
+                        F = F.materialize()
+                elif isinstance(F, LazyDraws):
                     # forward left this modality's data GP to us: run it with the likelihood folded in when the handle is
                     # that forward's own, untouched, and the observations are what the fused kernel reads (fp32, on the
                     # device, [N, L]); anything else gets the draws themselves (the handle materialises)
@@ -805,8 +839,11 @@ class VariationalGPSA(GPSA):
 
                 run_fused(fuse, run_i, run_Y, run_parts)
             if any(eff):
-                aux["fuse"], aux["fuse_mods"] = fuse, eff
-            loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *Fs)
+                for i in range(self.n_modalities):
+                    if eff[i] and shapes[i] is None:
+                        shapes[i] = tuple(fuse["shapes"][i])
+                aux["fuse"], aux["fuse_mods"], aux["lmc"], aux["term_shapes"] = fuse, eff, lmc_terms, shapes
+            loss = SE.ElboLossFn.apply(aux, self.noise_variance, kl, *Fs, *Ws)
             return loss.to(self.Xtilde.dtype)
         f64 = torch.float64
         kl = None

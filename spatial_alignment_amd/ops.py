@@ -299,6 +299,24 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_elbo_f32")
         return (g, dm, abar, part.sum(), FT) if want_draws else (g, dm, abar, part.sum())
 
+    def lmc_loglik_fused(self, F, W, Y, noise_u):
+        """gpsa_lmc_loglik_fused_f32: (sum z^2 as an fp64 0-dim tensor, dLoss/dF [S,N,L], dLoss/dW [L,P]) of the LMC
+        likelihood loss = -sum log N(Y; F W, s) / S at upstream gradient 1, F_obs never formed"""
+        F, W, Y = self._c(F), self._c(W), self._c(Y)
+        S, N, L = F.shape
+        P = W.shape[1]
+        assert W.shape[0] == L and Y.shape == (N, P)
+        dev = F.device
+        nparts = int(self.lib.gpsa_quadform_elbo_parts())
+        zpart = torch.empty(nparts, dtype=torch.float64, device=dev)
+        dF, dW = torch.empty_like(F), torch.empty_like(W)
+        wsb = self.lib.gpsa_lmc_loglik_workspace(S * N, L, P, nparts)
+        ws = self._ws(wsb, F)
+        rc = self.lib.gpsa_lmc_loglik_fused_f32(_p(F), _p(W), _p(Y), _p(noise_u), S, N, L, P, _p(zpart), nparts, _p(dF),
+                                                _p(dW), _p(ws), ws.numel(), self._stream(F))
+        _lib.check(rc, "gpsa_lmc_loglik_fused_f32")
+        return zpart.sum(), dF, dW
+
     def quadform_bwd_alpha_kept(self, W, g, dcT=None, dmeanT=None):
         """2 sum_l g_l o W_l  (+ dcT dmeanT, the mean term's share of the alpha-gradient, in the same pass)"""
         W, g = self._c(W), self._c(g)

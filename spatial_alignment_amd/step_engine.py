@@ -291,6 +291,7 @@ class StepFn(torch.autograd.Function):
         # the likelihood finishes from, the draws are never materialised
         fuse = aux.get("fuse")
         fused = fuse["mods"] if fuse is not None else [False] * nm
+        lazy_obs = aux.get("lazy_obs") or [False] * nm
         if fuse is not None:
             io.fuse_elbo = 1
             nparts = int(lib.gpsa_quadform_elbo_parts())
@@ -312,9 +313,11 @@ class StepFn(torch.autograd.Function):
             outs["Gm"].append(Gm); outs["Gs"].append(Gs); outs["Fl"].append(Fl)
             io.G_means[i], io.G_samples[i] = _p(Gm), _p(Gs)
             if plan.lmc[i]:
-                Fo = empty(S, N, P)
+                # training through loss_fn: F_obs = F_latent W is not formed (lazy.LazyProduct forms it on demand,
+                # loss_fn runs gpsa_lmc_loglik_fused_f32 instead); the output slot stays, empty
+                Fo = torch.empty(0, dtype=f32, device=dev) if lazy_obs[i] else empty(S, N, P)
                 outs["Fo"].append(Fo)
-                io.F_obs[i] = _p(Fo)
+                io.F_obs[i] = 0 if lazy_obs[i] else _p(Fo)
             if plan.s_test:
                 io.G_test[i], io.eps_F_test[i] = _p(aux["G_test"][i]), _p(aux["eps_F_test"][i])
                 Flt = empty(plan.s_test, plan.n_test[i], L)
@@ -537,7 +540,7 @@ class ElboLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, aux, noise, kl, *Fs):
-        if aux.get("fuse") is not None:
+        if aux.get("fuse_mods") is not None:
             return ElboLossFn._forward_fused(ctx, aux, noise, kl, *Fs)
         lib = _lib.load()
         o = _ops_mod.get_ops()
@@ -570,12 +573,16 @@ class ElboLossFn(torch.autograd.Function):
         return loss.reshape(())
 
     @staticmethod
-    def _forward_fused(ctx, aux, noise, kl, *Fs):
-        """some terms arrive as the step's partial sums of z^2 (StepFn with aux["fuse"]) instead of draws"""
+    def _forward_fused(ctx, aux, noise, kl, *ins):
+        """some terms arrive as partial sums of z^2 instead of draws: from the step (StepFn with aux["fuse"]: the
+        likelihood rode in the data GP's pass), or - an LMC modality, aux["lmc"] = {term: index of its W among the
+        trailing inputs} - formed here from (F_latent, W, Y) without F_obs (gpsa_lmc_loglik_fused_f32)"""
         o = _ops_mod.get_ops()
-        fuse = aux["fuse"]
-        fused = [bool(z) for z in aux["fuse_mods"]]  # the modalities whose term comes as partial sums in THIS call
-        n = len(Fs)
+        fuse = aux.get("fuse")
+        lmc = aux.get("lmc") or {}
+        fused = [bool(z) for z in aux["fuse_mods"]]  # the terms that come as partial sums in THIS call
+        n = len(aux["Y"])
+        Fs, Ws = ins[:n], ins[n:]
         dev = Fs[0].device
         Fc = [f.detach() if (z or (f.dtype == torch.float32 and f.is_contiguous())) else f.detach().float().contiguous()
               for f, z in zip(Fs, fused)]
@@ -584,7 +591,18 @@ class ElboLossFn(torch.autograd.Function):
         nz = nz if (nz.dtype == torch.float32 and nz.is_contiguous()) else nz.float().contiguous()
         shapes = []
         for i in range(n):
-            shapes += list(fuse["shapes"][i]) if fused[i] else [int(d) for d in Fc[i].shape]
+            shapes += list(aux["term_shapes"][i]) if fused[i] else [int(d) for d in Fc[i].shape]
+        lmc_saved = {}
+        for i, wpos in lmc.items():
+            Fl, W = Fc[i], Ws[wpos].detach()
+            S_, N_, L_ = (int(d) for d in Fl.shape)
+            nparts = int(_lib.load().gpsa_quadform_elbo_parts())
+            zpart = torch.empty(nparts, dtype=torch.float64, device=dev)
+            dFl, dW = torch.empty_like(Fl), torch.empty_like(W)
+            wsl = o._ws(int(_lib.load().gpsa_lmc_loglik_workspace(S_ * N_, L_, int(W.shape[1]), nparts)), Fl)
+            torch.ops.gpsa.lmc_loglik_fused(Fl, W, Yc[i], nz, int(aux["noise_idx"][i]), zpart, dFl, dW, wsl)
+            lmc_saved[i] = (dFl, dW, wpos)
+            Fc[i] = zpart
         klc = None
         if kl is not None:
             klc = kl.detach()
@@ -596,6 +614,7 @@ class ElboLossFn(torch.autograd.Function):
         torch.ops.gpsa.elbo_loss_fused_fwd(Fc, Yc, nz, idx, shapes, [int(z) for z in fused], klc, float(aux["kl_scale"]),
                                            loss, ll, ws)
         ctx.aux, ctx.args = aux, (Fc, Yc, nz, idx, shapes, fused)
+        ctx.lmc, ctx.n_w = lmc_saved, len(Ws)
         ctx.n_kl = 0 if klc is None else klc.numel()
         ctx.noise_meta = (noise.shape, noise.dtype)
         return loss.reshape(())
@@ -604,14 +623,19 @@ class ElboLossFn(torch.autograd.Function):
     def _backward_fused(ctx, gloss):
         o = _ops_mod.get_ops()
         aux = ctx.aux
-        fuse = aux["fuse"]
+        fuse = aux.get("fuse")
         Fc, Yc, nz, idx, shapes, fused = ctx.args
         dev = Fc[0].device
         g = gloss.detach().reshape(1)
         g = g if g.dtype == torch.float32 else g.float()
-        # StepFn.backward hands it to the engine (gpsa_step_out_grads.gloss); loss_fn called twice on one forward: summed
-        fuse["gloss"] = g if fuse.get("gloss") is None else fuse["gloss"] + g
+        if fuse is not None and any(z and i not in ctx.lmc for i, z in enumerate(fused)):
+            # StepFn.backward hands it to the engine (gpsa_step_out_grads.gloss); loss_fn called twice on one forward: summed
+            fuse["gloss"] = g if fuse.get("gloss") is None else fuse["gloss"] + g
         dF = [placeholder_grad(dev, f.numel()) if z else torch.empty_like(f) for f, z in zip(Fc, fused)]
+        dWs = [None] * ctx.n_w
+        for i, (dFl, dW, wpos) in ctx.lmc.items():  # formed at upstream gradient 1 by the forward: scaled here
+            dF[i] = dFl * g
+            dWs[wpos] = dW * g
         dnoise = torch.empty(nz.numel(), dtype=torch.float32, device=dev)
         dkl = torch.empty(ctx.n_kl, dtype=torch.float64, device=dev) if ctx.n_kl else None
         ws = o._ws(8 * 4100 * len(Fc) + 64, g)
@@ -619,11 +643,11 @@ class ElboLossFn(torch.autograd.Function):
         torch.ops.gpsa.elbo_loss_fused_bwd(Fc, Yc, nz, idx, shapes, [int(z) for z in fused], g, int(ctx.n_kl),
                                            float(aux["kl_scale"]), real, dnoise, dkl, ws)
         shape, dt = ctx.noise_meta
-        return (None, dnoise.reshape(shape).to(dt), dkl) + tuple(dF)
+        return (None, dnoise.reshape(shape).to(dt), dkl) + tuple(dF) + tuple(dWs)
 
     @staticmethod
     def backward(ctx, gloss):
-        if ctx.aux.get("fuse") is not None:
+        if ctx.aux.get("fuse_mods") is not None:
             return ElboLossFn._backward_fused(ctx, gloss)
         lib = _lib.load()
         o = _ops_mod.get_ops()

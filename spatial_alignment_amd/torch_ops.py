@@ -384,6 +384,21 @@ _engine_op("elbo_loss_fused_bwd(Tensor[] Fs, Tensor[] Ys, Tensor noise, int[] no
            "Tensor(d!) ws) -> ()", _elbo_loss_fused_bwd)
 
 
+def _lmc_loglik_fused(F, W, Y, noise, noise_idx, zpart, dF, dW, ws):
+    """gpsa_lmc_loglik_fused_f32: an LMC modality's likelihood partial sums, dLoss/dF_latent and dLoss/dW in one pass
+    over (F_latent [S,N,L], W [L,P], Y [N,P]) - F_obs = F_latent W is never formed"""
+    S, N, L = (int(d) for d in F.shape)
+    _lib.check(_lib.load().gpsa_lmc_loglik_fused_f32(F.data_ptr(), W.data_ptr(), Y.data_ptr(),
+                                                     noise.data_ptr() + 4 * int(noise_idx), S, N, L, int(W.shape[1]),
+                                                     zpart.data_ptr(), zpart.numel(), dF.data_ptr(), dW.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), _raw_stream(F.device.index)),
+               "gpsa_lmc_loglik_fused_f32")
+
+
+_engine_op("lmc_loglik_fused(Tensor F, Tensor W, Tensor Y, Tensor noise, int noise_idx, Tensor(a!) zpart, Tensor(b!) dF, "
+           "Tensor(c!) dW, Tensor(d!) ws) -> ()", _lmc_loglik_fused)
+
+
 def _adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
     """torch.optim.Adam's update over all tensors in one launch, step counter on the device (gpsa_adam_step)"""
     n = len(params)

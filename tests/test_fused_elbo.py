@@ -236,3 +236,58 @@ def test_loss_fn_twice_on_one_forward():
     (l1 + l2).backward()
     one.loss_fn(dd1, out1[3]).backward()
     _same_grads(model, one, tol=1e-6, scale=2.0, need_all=False)
+
+
+# ---- LMC modalities: F_obs = F_latent W is a lazy product, loss_fn runs the likelihood without it ----------------------
+LMC = [c for c in TRAIN if any(v is not None for v in Golden(c).cfg["n_latent_gps"].values())]
+
+
+@pytest.mark.parametrize("name", LMC)
+def test_lmc_loss_without_F_obs_matches_separate_kernels_and_reference(name):
+    from spatial_alignment_amd.lazy import LazyProduct
+
+    g = Golden(name)
+    res = {}
+    for fuse in (True, False):
+        model, dd = build_model(g, device=DEV)
+        res[fuse], _, F = run(model, dd, g, fuse)
+        lmc_mods = [m for m in g.mods if model.n_latent_gps[m] is not None]
+        for m in lmc_mods:
+            assert isinstance(F[m], LazyProduct) == fuse
+            if fuse:
+                assert not F[m].is_materialized          # loss_fn never formed F_obs
+                assert model.F_latent_samples[m].dim() == 3 and not isinstance(model.F_latent_samples[m], LazyProduct)
+                res[fuse][f"F_obs/{m}"] = F[m].detach().cpu().numpy()   # ... and it is there when somebody looks
+    for k, want in res[False].items():
+        got = res[True][k]
+        if np.linalg.norm(want.astype(np.float64)) == 0:
+            continue
+        assert rel(got, want) <= (3e-5 if k.startswith("grad/") else 2e-6), (k, rel(got, want))
+    bad, errs = compare(res[True], g, tol_out=1e-4, tol_grad=1e-4)
+    print(name, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert any(k.startswith("F_obs/") for k in errs) and not bad, bad
+
+
+def test_lmc_handle_used_before_loss_fn_is_an_ordinary_product():
+    if not LMC:
+        pytest.skip("no LMC golden case")
+    g = Golden(LMC[0])
+    out = {}
+    for fuse in (True, False):
+        model, dd = build_model(g, device=DEV)
+        model.fuse_elbo = fuse
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+        model.inject_noise(g.eps_G, g.eps_F, None)
+        o = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)
+        m = [k for k in g.mods if model.n_latent_gps[k] is not None][0]
+        extra = (o[3][m] ** 2).mean()                      # touches F_obs: the product is formed, differentiable
+        loss = model.loss_fn(dd, o[3]) + extra
+        loss.backward()
+        out[fuse] = (loss.detach(), _grads(model))
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-6)
+    for k, b in out[False][1].items():
+        a = out[True][1][k]
+        if b is None or float(b.norm()) == 0:
+            continue
+        assert float((a.double() - b.double()).norm() / b.double().norm()) <= 1e-5, k

@@ -250,6 +250,35 @@ def test_quadform_elbo(hip, M, N, S, L):
                           eps.to(DEV), Y.to(DEV), noise_u.to(DEV))
 
 
+@pytest.mark.parametrize("S,N,L,P", [(2, 100, 3, 7), (5, 1000, 10, 500), (1, 333, 20, 1100), (3, 17, 8, 512),
+                                     (2, 50, 32, 40), (1, 1, 1, 1), (2, 4000, 10, 513)])
+def test_lmc_loglik_fused(hip, S, N, L, P):
+    """the LMC likelihood without F_obs (gpsa_lmc_loglik_fused_f32): sum z^2, dLoss/dF_latent and dLoss/dW against
+    autograd of the reference's own expressions (vgpsa.py:428-432, 532-538) in fp64"""
+    F = rnd(S, N, L, seed=1)
+    W = rnd(L, P, seed=2)
+    Y = rnd(N, P, seed=3)
+    noise_u = torch.tensor([-0.4])
+    z2, dF, dW = hip.lmc_loglik_fused(F.to(DEV), W.to(DEV), Y.to(DEV), noise_u.to(DEV))
+    Fd, Wd = F.double().requires_grad_(), W.double().requires_grad_()
+    s = noise_u.double().exp() + 1e-5
+    Fobs = Fd @ Wd
+    ll = torch.distributions.Normal(Fobs, s).log_prob(Y.double()).sum() / S
+    (-ll).backward()
+    close(z2.reshape(1), (((Y.double() - Fobs) / s) ** 2).sum().detach().reshape(1), 2e-6)
+    close(dF, Fd.grad, 5e-6)
+    close(dW, Wd.grad, 5e-6)
+    z2b, dFb, dWb = hip.lmc_loglik_fused(F.to(DEV), W.to(DEV), Y.to(DEV), noise_u.to(DEV))
+    assert torch.equal(dF, dFb) and torch.equal(dW, dWb) and torch.equal(z2, z2b)  # fixed-order reductions
+    if L <= 32:
+        return
+
+
+def test_lmc_loglik_fused_refuses_more_than_32_latent_outputs(hip):
+    with pytest.raises(Exception):
+        hip.lmc_loglik_fused(rnd(1, 8, 33).to(DEV), rnd(33, 4).to(DEV), rnd(8, 4).to(DEV), torch.tensor([0.0]).to(DEV))
+
+
 @pytest.mark.parametrize("M,n0,n1", [(5, 3, 2), (200, 4, 50), (72, 1, 1)])
 def test_omega_two_segments(hip, M, n0, n1):
     """gpsa_omega_fwd2 / _bwd2: two parameter tensors in one launch == the two single-segment calls, bit for bit"""
