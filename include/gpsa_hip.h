@@ -491,6 +491,14 @@ typedef struct gpsa_step_io {
   double* ll_part[GPSA_MAX_MODS];           /* out [gpsa_quadform_elbo_parts()] */
   float* F_fused_T[GPSA_MAX_MODS];          /* out, optional: [L_m][S N_m] the draws of a fused modality, F[s][n][l] at
                                                    [l][s N_m + n] (gpsa_quadform_elbo_f32's FT) */
+  /* One optimiser step as several forward / backward passes over row slices (train.Microbatches) that CLOSE once:
+   * bwd_acc = gpsa_step_bwd_acc_bytes(plan) bytes the caller keeps across the slices' gpsa_step_backward calls;
+   * bwd_acc_mode 1: first slice (its N-scaled gradient pieces are stored there, nothing else is done: ``grads`` is not
+   * written), 2: a middle slice (added), 3: the last slice (the accumulator is added to its own pieces, then the M x M
+   * closing - KL backward, prior covariances' backward, dOmega -> dA, finalisation - runs once and ``grads`` is written),
+   * 0: an ordinary backward.  The KL terms' gradient og->dkl belongs to the LAST slice's call. */
+  double* bwd_acc;
+  int bwd_acc_mode;
 } gpsa_step_io;
 
 typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */
@@ -513,6 +521,7 @@ long long gpsa_step_saved_bytes(const void* plan);
 long long gpsa_step_saved_bytes_nokeep(const void* plan);  /* arena of a forward with io.keep_products == 0 */
 int gpsa_step_fused(const void* plan, int m);         /* 1: modality m's training pass can run the fused ELBO kernel */
 long long gpsa_step_scratch_bytes(const void* plan);
+long long gpsa_step_bwd_acc_bytes(const void* plan);  /* gpsa_step_io.bwd_acc */
 int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
 /* stages: bit 0 = the M x M factorisations, the KL terms and the warp GPs (everything ``flag`` depends on),

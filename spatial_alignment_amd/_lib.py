@@ -104,7 +104,7 @@ class StepIO(C.Structure):
         ("F_latent", _vp * MAX_MODS), ("F_obs", _vp * MAX_MODS), ("F_latent_test", _vp * MAX_MODS),
         ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp), ("keep_products", _i),
         ("reuse_mm", _i), ("fuse_elbo", _i), ("Y", _vp * MAX_MODS), ("noise_u", _vp * MAX_MODS),
-        ("ll_part", _vp * MAX_MODS), ("F_fused_T", _vp * MAX_MODS),
+        ("ll_part", _vp * MAX_MODS), ("F_fused_T", _vp * MAX_MODS), ("bwd_acc", _vp), ("bwd_acc_mode", _i),
     ]
 
 
@@ -153,6 +153,7 @@ SIGNATURES.update({
     "gpsa_quadform_elbo_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _ll, _vp]),
     "gpsa_step_scratch_bytes": (_ll, [_vp]),
+    "gpsa_step_bwd_acc_bytes": (_ll, [_vp]),
     "gpsa_step_n_kl": (_i, [_vp]),
     "gpsa_step_eps_g_numel": (_ll, [_vp]),
     "gpsa_step_timing": (_i, [_vp, _i]),

@@ -309,6 +309,12 @@ __global__ void __launch_bounds__(256) add_inplace_kernel(double* __restrict__ o
   if (i < n) out[i] += in[i];
 }
 
+__global__ void __launch_bounds__(256) add_inplace_f32_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                              long long n) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i < n) out[i] += in[i];
+}
+
 template <typename TS, typename TD>
 __global__ void __launch_bounds__(256) convert_kernel_step(const TS* __restrict__ src, long long n,
                                                            TD* __restrict__ dst) {
@@ -539,6 +545,7 @@ struct Plan {
   long long o_apk_w = 0, o_apk_d = 0;  // packed inverses of the projection kernel: forward packs, backward reuses
   long long nbad = 0;
   long long scratch_bytes = 0;
+  long long bwd_acc_bytes = 0;  // accumulator of a microbatched step's slices (step_backward: io.bwd_acc)
   // device tables
   char* dev = nullptr;
   ViewTab tab;
@@ -1603,9 +1610,15 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   B.dZ_df = sc.get<double>((long long)(npass > 0 ? npass : 1) * Mg * D);
   B.dpar_df = sc.get<double>(2LL * (npass > 0 ? npass : 1));
   B.dvar_ds = sc.get<float>(npass > 0 ? npass : 1);
+  const long long zf = (long long)(reinterpret_cast<char*>(B.dvar_ds) - sc.base);  // doubles up to here, floats behind
   sc.get<char>(256);  // (round the region up to the arena's 256-byte granule: the runtime fills an unaligned tail
   const long long z1 = (sc.off + 255) & ~255LL;  //  with a second launch)
   if (!dry) GPSA_CK((int)hipMemsetAsync(sc.base + z0, 0, (size_t)(z1 - z0), st));
+  if (dry) {
+    long long ab = z1 - z0;
+    for (int m = 0; m < P.nm; ++m) ab += ((long long)Mg * P.d.n_latent[m] * 4 + 255) & ~255LL;
+    P.bwd_acc_bytes = ab + 256;
+  }
   B.dZ_wu = sc.get<double>(nwz);
   B.dpar_wu = sc.get<double>(2LL * (nf > 0 ? nf : 1));
   B.dZ_du = sc.get<double>((long long)Mg * D); B.dpar_du = sc.get<double>(2);
@@ -1646,6 +1659,46 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   }
   // ---- warp GPs
   GPSA_CK(warp_stage_bwd(c, og, B));
+  // ---- one optimiser step as several passes over row slices (train.Microbatches): everything N-scaled of this
+  //      slice is in the region [z0, z1) (fp64 pieces, then the samplers' fp32 scalars) and in ddc_F.  A slice that is not
+  //      the last adds it to the caller's accumulator and is done; the last one adds the accumulator to its own and
+  //      closes ONCE for all of them - KL backward, prior covariances' backward, dOmega -> dA (36 ms at BASELINE config 5),
+  //      the fp64 -> fp32 finalisation - instead of once per slice
+  if (io.bwd_acc_mode != 0 && io.bwd_acc != nullptr && !dry) {
+    char* accb = reinterpret_cast<char*>(io.bwd_acc);
+    const long long nD = (zf - z0) / 8, nF = (long long)(npass > 0 ? npass : 1);
+    double* rD = reinterpret_cast<double*>(sc.base + z0);
+    float* rF = B.dvar_ds;
+    double* aD = reinterpret_cast<double*>(accb);
+    float* aF = reinterpret_cast<float*>(accb + (zf - z0));  // (the accumulator mirrors the region byte for byte)
+    long long aoff = z1 - z0;
+    if (io.bwd_acc_mode == 1) {
+      GPSA_CK((int)hipMemcpyAsync(aD, rD, (size_t)(nD * 8), hipMemcpyDeviceToDevice, st));
+      GPSA_CK((int)hipMemcpyAsync(aF, rF, (size_t)(nF * 4), hipMemcpyDeviceToDevice, st));
+    } else {
+      double* dst = io.bwd_acc_mode == 2 ? aD : rD;
+      const double* src = io.bwd_acc_mode == 2 ? rD : aD;
+      add_inplace_kernel<<<(unsigned)cdiv(nD, 256), 256, 0, st>>>(dst, src, nD);
+      GPSA_LAUNCH_CHECK();
+      add_inplace_f32_kernel<<<(unsigned)cdiv(nF, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? aF : rF,
+                                                                       io.bwd_acc_mode == 2 ? rF : aF, nF);
+      GPSA_LAUNCH_CHECK();
+    }
+    for (int m = 0; m < P.nm; ++m) {
+      const long long n = (long long)Mg * P.d.n_latent[m];
+      float* a = reinterpret_cast<float*>(accb + aoff);
+      aoff += (n * 4 + 255) & ~255LL;
+      if (!B.have_ddc[m]) continue;
+      if (io.bwd_acc_mode == 1) {
+        GPSA_CK((int)hipMemcpyAsync(a, B.ddc_F[m], (size_t)(n * 4), hipMemcpyDeviceToDevice, st));
+      } else {
+        add_inplace_f32_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? a : B.ddc_F[m],
+                                                                        io.bwd_acc_mode == 2 ? B.ddc_F[m] : a, n);
+        GPSA_LAUNCH_CHECK();
+      }
+    }
+    if (io.bwd_acc_mode != 3) return 0;
+  }
   // ---- KL terms
   if (kl && P.side != nullptr) {  // join: add the side stream's share (same layout as dstack) in one pass
     if (fork) GPSA_CK((int)hipStreamWaitEvent(st, P.sev[4], 0));
@@ -1825,6 +1878,7 @@ int gpsa_step_fused(const void* plan, int m) {
     if (q.m == m && !q.test) return q.o_fuse >= 0 ? 1 : 0;
   return 0;
 }
+long long gpsa_step_bwd_acc_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->bwd_acc_bytes : -1; }
 long long gpsa_step_scratch_bytes(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->scratch_bytes : -1; }
 int gpsa_step_n_kl(const void* plan) {
   if (!plan) return -1;

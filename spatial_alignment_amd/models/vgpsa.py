@@ -657,7 +657,8 @@ class VariationalGPSA(GPSA):
                    G_test=Gt if G_test is not None else None, eps_F_test=eps_Ft,
                    slopes=self.mean_slopes.contiguous(), intercepts=self.mean_intercepts.contiguous(),
                    want_kl=not prediction_mode, check=check, no_keep=not self.keep_products,
-                   mm_epoch=self.__dict__.get("_mm_epoch"),
+                   mm_epoch=self.__dict__.get("_mm_epoch"), bwd_acc=self.__dict__.get("_bwd_acc"),
+                   shared_arena=self.__dict__.get("_mb_arena") if self.__dict__.get("_mm_epoch") is not None else None,
                    flag_slot=self.__dict__.get("_flag_slot", 0),
                    fuse=self._fuse_setup(plan, S, G_test, prediction_mode),
                    lazy_obs=self._lazy_obs(plan, G_test, prediction_mode))

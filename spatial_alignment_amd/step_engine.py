@@ -44,6 +44,7 @@ class StepPlan:
         self.saved_bytes = int(lib.gpsa_step_saved_bytes(self.handle))
         self.saved_bytes_nokeep = int(lib.gpsa_step_saved_bytes_nokeep(self.handle))
         self.scratch_bytes = int(lib.gpsa_step_scratch_bytes(self.handle))
+        self.bwd_acc_bytes = int(lib.gpsa_step_bwd_acc_bytes(self.handle))
         self.n_kl = int(lib.gpsa_step_n_kl(self.handle))
         self.eps_g_numel = int(lib.gpsa_step_eps_g_numel(self.handle))
 
@@ -178,8 +179,14 @@ def keep_budget_bytes(model, desc, keep_gb=None):
     desc.keep_budget_bytes = -1
     if _lib.load().gpsa_step_describe(C.byref(desc), out) != 0:
         return -1
+    # memory this model's own plans hold idle is memory this plan can have: arenas parked on sibling plans are let go
+    # on demand (_take_arena), and a microbatched step's slices share ONE arena (train.Microbatches) whatever their plan
+    held = sum(q.__dict__["_parked"].numel() for q in model.__dict__.get("_step_plans", {}).values()
+               if q.__dict__.get("_parked") is not None)
+    shared = model.__dict__.get("_mb_arena")
+    held += shared.numel() if shared is not None else 0
     params = sum(p.numel() * p.element_size() for p in model.parameters())
-    budget = int(avail - 0.1 * total) - int(out[6]) - int(out[1]) - 3 * params
+    budget = int(avail + held - 0.1 * total) - int(out[6]) - int(out[1]) - 3 * params
     return budget if budget > 0 else -1
 
 
@@ -344,18 +351,30 @@ class StepFn(torch.autograd.Function):
             keep = False
         io.keep_products = 1 if keep else 0
         sib = [q for q in model.__dict__.get("_step_plans", {}).values() if q is not plan]
-        saved = _take_arena(plan, plan.saved_bytes if keep else plan.saved_bytes_nokeep, dev, siblings=sib)
+        need = plan.saved_bytes if keep else plan.saved_bytes_nokeep
+        shared = aux.get("shared_arena")  # a microbatched step's slices run in ONE arena, whatever their plan
+        if shared is not None and shared.device == dev and shared.numel() >= need:
+            saved, plan._took_parked = shared, True
+        else:
+            shared = None
+            saved = _take_arena(plan, need, dev, siblings=sib)
         if saved is None:  # the device cannot hold the kept products after all (other tenants, fragmentation)
             keep = False
             io.keep_products = 0
             saved = _take_arena(plan, plan.saved_bytes_nokeep, dev, must=True, siblings=sib)
         scratch = o._ws(plan.scratch_bytes, saved)
         # the slices of one microbatched step (train.Microbatches) run on the same parameters: when this forward got
-        # the very arena the previous slice filled, the M x M stage (factorisations, inverses, KL terms) is still in it
+        # the very arena the previous slice filled, the M x M stage (factorisations, inverses, KL terms) is still in it.
+        # The stage sits at the head of the arena at offsets that depend on (V, D, M, L, kinds, fixed views) only, not
+        # on the slice's row counts: a slice of another shape (the remainder) - another plan - finds it there too
         epoch = aux.get("mm_epoch")
-        token = (saved.data_ptr(), saved.numel(), epoch, tuple(t.data_ptr() for t in tensors))
-        io.reuse_mm = 1 if (epoch is not None and plan._took_parked and plan.__dict__.get("_mm_token") == token) else 0
-        plan._mm_token = token if epoch is not None else None
+        k = plan.key
+        stage_sig = (k[0], k[1], k[2], k[4], k[5], k[6], k[7], k[8], k[10], k[14], k[15])
+        token = (saved.data_ptr(), saved.numel(), epoch, tuple(t.data_ptr() for t in tensors), stage_sig)
+        io.reuse_mm = 1 if (epoch is not None and plan._took_parked
+                            and model.__dict__.get("_mm_token") == token) else 0
+        model.__dict__["_mm_token"] = token if epoch is not None else None
+        ctx.shared_arena = shared is not None
         STATS["mm_reused"] += int(io.reuse_mm)
         pending = None
         # the C entry point is reached through the dispatcher (torch.ops.gpsa.step_forward, torch_ops.py): the
@@ -512,6 +531,17 @@ class StepFn(torch.autograd.Function):
                     views[kk].zero_()  # no gradient reached F_obs: the engine leaves dW untouched
                 kk += 1
         scratch = o._ws(plan.scratch_bytes, flat)
+        # one optimiser step as several slices that close once (train.Microbatches; gpsa_step_io.bwd_acc): a slice that
+        # is not the last leaves its gradient pieces in the accumulator and hands autograd nothing
+        acc = aux.get("bwd_acc")
+        closes = True
+        if acc is not None:
+            buf, mode = acc
+            if buf.numel() < plan.bwd_acc_bytes:
+                raise _lib.GpsaHipError("step engine: the microbatch accumulator is smaller than this plan needs")
+            keep.append(buf)
+            ctx.io.bwd_acc, ctx.io.bwd_acc_mode = buf.data_ptr(), int(mode)
+            closes = mode == 3
         call = TO.stash(dict(lib=lib, handle=plan.handle, prm=ctx.prm, io=ctx.io, og=og, grads=grads))
         try:
             torch.ops.gpsa.step_backward(list(tensors), keep, ctx.arena, flat, scratch, call)
@@ -519,13 +549,14 @@ class StepFn(torch.autograd.Function):
             TO.CALLS.pop(call, None)
         out = [None]
         for i, t in enumerate(tensors):
-            out.append(views[i].view(t.shape) if ctx.needs_input_grad[1 + i] else None)
+            out.append(views[i].view(t.shape) if (ctx.needs_input_grad[1 + i] and closes) else None)
         LAST_FLAT[dev.index] = flat
         LAST_USED[dev.index] = used
         # the arena (gigabytes when the data GPs keep their products) goes back to the allocator NOW: the node sits
         # in a reference cycle (model -> outputs -> grad_fn -> ctx -> aux -> model) that only the cyclic collector
         # would break, steps later
-        _give_arena(plan, ctx.arena, force=aux.get("mm_epoch") is not None)
+        if not getattr(ctx, "shared_arena", False):  # (a shared arena stays with train.Microbatches)
+            _give_arena(plan, ctx.arena, force=aux.get("mm_epoch") is not None)
         ctx.arena = None
         if fuse is not None:  # the arena is gone: so is the chance to materialise this forward's draws
             fuse["live"] = None

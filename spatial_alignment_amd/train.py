@@ -80,6 +80,62 @@ class Microbatches:
             vi, Ns, _, _ = model.create_view_idx_dict(dd)
             self.slices.append((dd, vi, Ns))
 
+    def _fold_buffer(self):
+        """the accumulator the slices' backwards share (None: per-layer path / CPU: every slice closes by itself)"""
+        model = self.model
+        if len(self.slices) < 2 or not getattr(model, "use_step_engine", False) or not model.Xtilde.is_cuda:
+            return None
+        plans = list(model.__dict__.get("_step_plans", {}).values())
+        need = max([p.bwd_acc_bytes for p in plans] or [0])
+        if need <= 0:  # (first step: no plan yet - it closes per slice, the next one folds)
+            return None
+        buf = self.__dict__.get("_fold")
+        if buf is None or buf.numel() < need:
+            buf = self.__dict__["_fold"] = torch.empty(need, dtype=torch.uint8, device=model.Xtilde.device)
+        return buf
+
+    def _ensure_plans(self, S):
+        """the slices' step plans exist before the first forward: the shared arena and the accumulator are sized from
+        them (otherwise the first step runs with an arena per plan - twice 100 GB at BASELINE config 5)"""
+        model = self.model
+        if self.__dict__.get("_planned") == S or not getattr(model, "use_step_engine", False) or not model.Xtilde.is_cuda:
+            return
+        from . import step_engine as SE
+
+        for dd, vi, Ns in self.slices:
+            Xs = {m: d["spatial_coords"] for m, d in dd.items()}
+            if not SE.eligible(model, Xs, vi, None):
+                return
+            rows = SE.view_rows(model, vi, Ns)
+            if rows is None:
+                return
+            SE.get_plan(model, rows, S, None, want_kl=True)
+        self.__dict__["_planned"] = S
+
+    def _shared_arena(self):
+        """ONE arena for all slices of a step (the largest any of their plans wants): slices of different shapes - the
+        remainder - are different plans, and with an arena parked per plan the second plan found the device full and
+        fell back to recomputing its products (BASELINE config 5: 100 GB per arena; one slice in eight ran the
+        no-keep path, +220 ms per step) and redid the M x M stage it could have found in the first slice's arena"""
+        model = self.model
+        if len(self.slices) < 2 or not getattr(model, "use_step_engine", False) or not model.Xtilde.is_cuda:
+            return None
+        plans = list(model.__dict__.get("_step_plans", {}).values())
+        if not plans:
+            return None
+        need = max(p.saved_bytes for p in plans)
+        buf = self.__dict__.get("_arena")
+        if buf is None or buf.numel() < need:
+            self.__dict__["_arena"] = buf = None
+            from .step_engine import release_arenas
+
+            release_arenas(model)  # (the per-plan parked blocks of earlier steps make room)
+            try:
+                buf = self.__dict__["_arena"] = torch.empty(need, dtype=torch.uint8, device=model.Xtilde.device)
+            except torch.OutOfMemoryError:
+                return None
+        return buf
+
     def step(self, optimizer, S=5, reducer=None, noise=None):
         """zero_grad, K accumulating passes, (all-reduce,) optimizer.step(); returns the summed loss (device tensor).
         ``noise``: per slice ``(eps_G, eps_F)`` for ``model.inject_noise`` (tests / reproducibility)."""
@@ -90,10 +146,18 @@ class Microbatches:
         self._stepno = getattr(self, "_stepno", 0) + 1
         try:
             # every slice runs on the same parameters: the engine keeps the M x M stage of the first slice (same plan,
-            # same parked arena) for the others; the KL terms are charged once, to the first slice
+            # same parked arena) for the others and CLOSES the backward once, with the last slice (gpsa_step_io.bwd_acc:
+            # the slices' N-scaled gradient pieces meet in an accumulator; KL backward, the prior covariances' backward,
+            # dOmega -> dA and the finalisation run once per step instead of once per slice); the KL terms are charged
+            # once, to the LAST slice - the one whose backward closes
             model.__dict__["_mm_epoch"] = (id(self), self._stepno)
+            self._ensure_plans(S)
+            fold = self._fold_buffer()
+            model.__dict__["_mb_arena"] = self._shared_arena()
             for k, (dd, vi, Ns) in enumerate(self.slices):
-                model.kl_scale = scale0 if k == 0 else 0.0
+                last = k == len(self.slices) - 1
+                model.kl_scale = scale0 if last else 0.0
+                model.__dict__["_bwd_acc"] = None if fold is None else (fold, 3 if last else (1 if k == 0 else 2))
                 if noise is not None:
                     model.inject_noise(noise[k][0], noise[k][1], None)
                 out = model.forward({m: d["spatial_coords"] for m, d in dd.items()}, view_idx=vi, Ns=Ns, S=S)
@@ -104,6 +168,8 @@ class Microbatches:
         finally:
             model.kl_scale = scale0
             model.__dict__["_mm_epoch"] = None
+            model.__dict__["_bwd_acc"] = None
+            model.__dict__["_mb_arena"] = None
         if reducer is not None:
             reducer()
         optimizer.step()

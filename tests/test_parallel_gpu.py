@@ -127,6 +127,8 @@ def test_microbatched_hip_step_equals_full_hip_step():
             a, b = want[k], opt.seen[id(p)]
             assert (a - b).norm() <= 1e-3 * max(float(a.norm()), 1e-6), (k, float((a - b).norm()), float(a.norm()))
     assert model.kl_scale == 1.0 and model.__dict__.get("_mm_epoch") is None
+    # the slices' backwards met in ONE accumulator and closed once per step (gpsa_step_io.bwd_acc)
+    assert mb.__dict__.get("_fold") is not None and model.__dict__.get("_bwd_acc") is None
 
 
 # ---------------------------------------------------------------------------------------------------------
