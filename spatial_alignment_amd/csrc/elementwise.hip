@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) elbo_loss_finish_kernel(ElboFinishArgs a)
 // g and dmeanT are scaled in place (they were formed at gl = 1)
 __global__ void __launch_bounds__(256)
 elbo_post_kernel(float* __restrict__ g, float* __restrict__ dmeanT, long long C, int L, const float* __restrict__ gloss,
-                 float* __restrict__ qbar, double* __restrict__ part) {
+                 float* __restrict__ qbar, double* __restrict__ part, float* __restrict__ abar, int M) {
   __shared__ double red[4];
   const float gl = gloss[0];
   const long long c = blockIdx.x * 256LL + threadIdx.x;
@@ -444,6 +444,7 @@ elbo_post_kernel(float* __restrict__ g, float* __restrict__ dmeanT, long long C,
         g[o] = v;
         dmeanT[o] *= gl;
       }
+      for (int m = 0; m < M; ++m) abar[(long long)m * C + c] *= gl;  // (was a launch of its own that exits when gl == 1)
     }
     qbar[c] = -s;
   }
@@ -798,9 +799,8 @@ int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long l
   if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* part = (double*)workspace;
-  gpsa::elbo_post_kernel<<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part);
+  gpsa::elbo_post_kernel<<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part, abar, M);
   gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
-  gpsa::scale_unless_one_kernel<<<2048, 256, 0, st>>>(abar, (long long)M * C, gloss);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
