@@ -510,7 +510,10 @@ def main():
         if fused and args.M <= 208:
             # the training helpers fold the likelihood into the data GP's pass (gpsa_quadform_elbo_f32): the full
             # product, closed and weighted into the alpha-gradient in the accumulators - nothing kept, nothing re-read
-            executed_ratio["quadform_fwd"] = (16.0 * MB / args.M) ** 2
+            # rows padded to 16 MB; the contraction index is NOT padded: the all-padding K steps of the last chunk are
+            # skipped (RL = 2 of 4 when M - 16 (MB - 1) <= 8)
+            k_eff = 16 * (MB - 1) + 4 * (2 if args.M - 16 * (MB - 1) <= 8 else 4)
+            executed_ratio["quadform_fwd"] = (16.0 * MB / args.M) * (k_eff / float(args.M))
             kernel_of["quadform_fwd"] = ("panel_elbo_kernel (gpsa_quadform_elbo_f32: the full 2*C*L*M^2 product, with the "
                                          "variance, draw, Gaussian likelihood, its gradient and abar = 2 sum_l g_l Omega_l "
                                          "alpha formed from the accumulators)")
