@@ -47,47 +47,55 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
   // wave w moves pieces w, w+4, ... (1 KiB each, lane-linear); every wave issues exactly NPW
   // operations per stage (the surplus ones re-load the last piece into an unused slot) so that a
   // counted vmcnt(NPW) means "everything but the newest stage has landed".
-#define GPSA_STAGE(Q, BUF)                                                                     \
-  {                                                                                            \
-    const float* src__ = Ppk + (long long)(Q) * CHUNK + lane * 4;                              \
-    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
-      const int piece = pc * 4 + w;                                                            \
-      glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                      \
-             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                \
-    }                                                                                          \
-  }
-  // the chunk stream of this workgroup follows the tile visiting order; staged two chunks ahead
+  // Ring slots are wave-major (round 4, as panel_elbo_kernel): wave w's pieces w, w + 4, ... are the NPW consecutive
+  // KiB at w * NPW, so that one m0 write reaches four of them through the instruction's immediate offset
+  // (qf_common.hpp: glds16_m0); row tile rt's fragment (piece rt) sits at KiB (rt & 3) * NPW + (rt >> 2).  The stage
+  // cursor is a pointer that advances by one chunk and a count of the chunks left in the step (the chunks of a step's
+  // outputs are consecutive in the packed operand); the next step is looked up when the count runs out.
+#define GPSA_POS(P_) (((P_) & 3) * NPW + ((P_) >> 2))
   const TileOrder ord(it0, it1, L);
   long long sstep = 0, stile_;
-  int sa_, sb_, skc = 0;
+  int sa_, sb_;
   ord.get(0, stile_, sa_, sb_);
-  int sl = sa_;
-  bool sdone = false;
+  const float* sp = Ppk + (long long)sa_ * MB * CHUNK + lane * 4;
+  int srem = (sb_ - sa_ + 1) * MB;
 #define GPSA_STAGE_PIECE(BUF, PC)                                                              \
   {                                                                                            \
-    const float* src__ = Ppk + ((long long)sl * MB + skc) * CHUNK + lane * 4;                  \
-    const int piece = (PC) * 4 + w;                                                            \
-    glds16(src__ + (piece < MB ? piece : MB - 1) * 256,                                        \
-           __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][piece * 256])));                  \
+    constexpr int pc__ = (PC);                                                                 \
+    if ((pc__ & 3) == 0)                                                                       \
+      dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][(w * NPW + pc__) * 256]))); \
+    const int piece = pc__ * 4 + w;                                                            \
+    glds16_m0<(pc__ & 3) * 1024>(sp + ((piece < MB ? piece : MB - 1) - (pc__ & 3)) * 256);     \
   }
+#define GPSA_STAGE_PIECE_RT(BUF, RT)                                                           \
+  switch (RT) { /* (a constant after unrolling: the immediate offset must be one) */           \
+    case 0: GPSA_STAGE_PIECE(BUF, 0) break;                                                    \
+    case 1: GPSA_STAGE_PIECE(BUF, (NPW > 1 ? 1 : 0)) break;                                    \
+    case 2: GPSA_STAGE_PIECE(BUF, (NPW > 2 ? 2 : 0)) break;                                    \
+    case 3: GPSA_STAGE_PIECE(BUF, (NPW > 3 ? 3 : 0)) break;                                    \
+    case 4: GPSA_STAGE_PIECE(BUF, (NPW > 4 ? 4 : 0)) break;                                    \
+    case 5: GPSA_STAGE_PIECE(BUF, (NPW > 5 ? 5 : 0)) break;                                    \
+    case 6: GPSA_STAGE_PIECE(BUF, (NPW > 6 ? 6 : 0)) break;                                    \
+    default: GPSA_STAGE_PIECE(BUF, (NPW > 7 ? 7 : 0)) break;                                   \
+  }
+  static_assert(NPW <= 8, "pieces per wave and stage");
 #define GPSA_STAGE_ADVANCE()                                                                   \
   {                                                                                            \
-    if (!sdone) {                                                                              \
-      if (skc + 1 < MB) ++skc;                                                                 \
-      else if (sl < sb_) { skc = 0; ++sl; }                                                    \
-      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl = sa_; skc = 0; } \
-      else sdone = true;                                                                       \
+    if (--srem > 0) {                                                                          \
+      sp += CHUNK;                                                                             \
+    } else if (sstep + 1 < ord.n) {                                                            \
+      ++sstep;                                                                                 \
+      ord.get(sstep, stile_, sa_, sb_);                                                        \
+      sp = Ppk + (long long)sa_ * MB * CHUNK + lane * 4;                                       \
+      srem = (sb_ - sa_ + 1) * MB;                                                             \
+    } else {                                                                                   \
+      srem = 0x7fffffff; /* nothing left: the surplus stages re-read the last chunk */         \
     }                                                                                          \
   }
 #define GPSA_STAGE_NEXT(BUF)                                                                   \
   {                                                                                            \
-    GPSA_STAGE((long long)sl * MB + skc, BUF)                                                  \
-    if (!sdone) {                                                                              \
-      if (skc + 1 < MB) ++skc;                                                                 \
-      else if (sl < sb_) { skc = 0; ++sl; }                                                    \
-      else if (sstep + 1 < ord.n) { ++sstep; ord.get(sstep, stile_, sa_, sb_); sl = sa_; skc = 0; } \
-      else sdone = true;                                                                       \
-    }                                                                                          \
+    _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) GPSA_STAGE_PIECE_RT(BUF, pc)            \
+    GPSA_STAGE_ADVANCE()                                                                       \
   }
   // flush the accumulators of column tile TILE (ACCUM / STORE).  PLAIN: this workgroup covered all l of
   // the tile -> straight to the output.  Otherwise the partial sum goes to one of this workgroup's two
@@ -175,7 +183,7 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
         const float* base = &lds[buf][lane * 4];
         // A fragments are read one row tile ahead of the MFMAs that consume them (LDS latency
         // hides under the previous tile's 4*NCT MFMAs instead of stalling the matrix pipe)
-        float4 a_nxt = *reinterpret_cast<const float4*>(base);
+        float4 a_nxt = *reinterpret_cast<const float4*>(base + GPSA_POS(0) * 256);
 #pragma unroll
         for (int rt = 0; rt < MB; ++rt) {
           const float4 a4 = a_nxt;
@@ -196,10 +204,10 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
             }
             __builtin_amdgcn_sched_barrier(0);
             if (r == 0) {
-              if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + (rt + 1) * 256);
+              if (rt + 1 < MB) a_nxt = *reinterpret_cast<const float4*>(base + GPSA_POS(rt + 1) * 256);
             } else if (r == 1) {
               if (MB >= NPW + 3) {
-                if (rt < NPW) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, rt)
+                if (rt < NPW) GPSA_STAGE_PIECE_RT(buf == 0 ? 2 : buf - 1, rt)
                 if (rt == NPW) GPSA_STAGE_ADVANCE()
               } else if (rt == 0) {
                 GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
@@ -247,7 +255,8 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
     }
   }
   GPSA_DMA_DRAIN();  // nothing may still be writing this workgroup's LDS when it exits
-#undef GPSA_STAGE
+#undef GPSA_POS
+#undef GPSA_STAGE_PIECE_RT
 #undef GPSA_STAGE_PIECE
 #undef GPSA_STAGE_ADVANCE
 #undef GPSA_STAGE_NEXT

@@ -46,15 +46,22 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] PACK_SY
     const float* m__ = Ppk + (long long)(LL) * PER_L + lane * 4;                               \
     const int p__ = (P), q__ = MB - 1 - p__;                                                   \
     const int n1__ = MB - p__, n2__ = (q__ != p__) ? p__ + 1 : 0;                              \
+    /* wave-major slots (round 4): slot sl = pc * 4 + w sits at KiB w * NPW + pc; m0 once per four pieces */ \
     _Pragma("unroll") for (int pc = 0; pc < NPW; ++pc) {                                       \
       const int sl = pc * 4 + w;                                                               \
       const int se = sl < n1__ + n2__ ? sl : 0;                                                \
       const int kc__ = se < n1__ ? q__ : p__;                                                  \
       const int rt__ = se < n1__ ? se : se - n1__;                                             \
-      glds16(m__ + (kc__ * MB + rt__) * 256,                                                   \
-             __builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][sl * 256])));                   \
+      if ((pc & 3) == 0)                                                                       \
+        dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(&lds[BUF][(w * NPW + pc) * 256]))); \
+      const float* g__ = m__ + (kc__ * MB + rt__) * 256;                                       \
+      if ((pc & 3) == 0) glds16_m0<0>(g__);                                                    \
+      if ((pc & 3) == 1) glds16_m0<1024>(g__ - 256);                                           \
+      if ((pc & 3) == 2) glds16_m0<2048>(g__ - 512);                                           \
+      if ((pc & 3) == 3) glds16_m0<3072>(g__ - 768);                                           \
     }                                                                                          \
   }
+#define GPSA_QS_POS(SL) (((SL) & 3) * NPW + ((SL) >> 2))
   // step stream of this workgroup (follows the tile visiting order), staged two steps ahead
   const TileOrder ord(it0, it1, L);
   long long sstep = 0, stile_;
@@ -114,14 +121,14 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] PACK_SY
         const float* base = &lds[buf][lane * 4];
         const int q = MB - 1 - p;
         const int n1 = MB - p, n2 = (q != p) ? p + 1 : 0;
-        float4 a_nxt = *reinterpret_cast<const float4*>(base);
+        float4 a_nxt = *reinterpret_cast<const float4*>(base + GPSA_QS_POS(0) * 256);
 #pragma unroll
         for (int sl = 0; sl < MB + 1; ++sl) {
           if (sl < n1 + n2) {
             const int kc = sl < n1 ? q : p;
             const int rt = sl < n1 ? sl : sl - n1;
             const float4 a4 = a_nxt;
-            if (sl + 1 < n1 + n2) a_nxt = *reinterpret_cast<const float4*>(base + (sl + 1) * 256);
+            if (sl + 1 < n1 + n2) a_nxt = *reinterpret_cast<const float4*>(base + GPSA_QS_POS(sl + 1) * 256);
             __builtin_amdgcn_sched_barrier(0);
             const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -159,6 +166,7 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] PACK_SY
   }
   GPSA_DMA_DRAIN();
 #undef GPSA_QS_STAGE
+#undef GPSA_QS_POS
 #undef GPSA_QS_STAGE_NEXT
 }
 

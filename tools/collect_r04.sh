@@ -30,5 +30,13 @@ bash tools/timeline.sh > /dev/null 2>&1
 cp gpurun_out/tl/k1.timeline.txt $O/${T}_step_timeline_k1.txt
 cp gpurun_out/tl/s8.timeline.txt $O/${T}_step_timeline_shard8.txt
 for k in 1 2 4 8; do python3 bench.py --no-cpu-baseline --no-extras --no-graph --blocks 3 --emulate-shard $k 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('shard 1/$k  ms_per_step', round(d['ms_per_step'],3), ' S=1', round(d['secondary_S1']['ms_per_step'],3))"; done > $O/${T}_strong_scaling_emulation.txt
+cp profiles/pmc_traffic.json $O/${T}_pmc_traffic.json
+{
+  echo "# full step with Adam, one MI355X (tools/run_config.py; config 3: bench.py --workload 3 above)"
+  for w in 4cut 5cut; do python3 tools/run_config.py $w 6 3 2>/dev/null | tail -1; done
+  python3 tools/run_config.py 4 3 2 2>/dev/null | tail -4
+  python3 tools/run_config.py 5 2 1 2>/dev/null | tail -4
+  GPSA_MICROBATCHES=8 python3 tools/run_config.py 5 3 2 2>/dev/null | tail -1
+} > $O/${T}_other_configs.txt
 rm -rf $O/stats $O/fetch $O/write $O/busy $O/c3
 ls -la $O
