@@ -163,7 +163,7 @@ int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long
  * all at upstream gradient dLoss = 1 (linear in it).  part: gpsa_quadform_elbo_parts() doubles (unused tail zeroed).
  * FT (optional, NULL = not wanted): [L][C], the draws themselves, F[s][n][l] at FT[l][s N + n] - for a caller that
  * looks at them afterwards; nothing on the path reads them.
- * M <= 208 (13 row tiles) only: GPSA_EUNSUPPORTED beyond. */
+ * M <= 256 (16 row tiles; round 3: 208) only: GPSA_EUNSUPPORTED beyond. */
 int gpsa_quadform_elbo_parts(void);
 long long gpsa_quadform_elbo_f32_workspace(int M, long long C, int L);
 int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
@@ -484,7 +484,7 @@ typedef struct gpsa_step_io {
    * written (the draws leave only through the optional F_fused_T[m]), ll_part[m] receives the partial sums of z^2 for
    * gpsa_elbo_loss_fused_fwd / _bwd, and gpsa_step_backward takes the loss's upstream gradient from
    * gpsa_step_out_grads.gloss instead of dF_latent[m].  Modalities the fused kernel does not cover (LMC, more than
-   * 208 inducing points: gpsa_step_fused(plan, m) == 0) run unfused and must be given F_latent[m] as usual. */
+   * 256 inducing points: gpsa_step_fused(plan, m) == 0) run unfused and must be given F_latent[m] as usual. */
   int fuse_elbo;
   const float* Y[GPSA_MAX_MODS];            /* in  [N_m, L_m] observations */
   const float* noise_u[GPSA_MAX_MODS];      /* in  [1] the likelihood's log "variance" of modality m */

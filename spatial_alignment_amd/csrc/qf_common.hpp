@@ -269,7 +269,7 @@ struct ElboArgs {
 
 template <int MB, int NCT, int RL>
 __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a);
-#define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2) X(13, 1)
+#define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2) X(13, 1) X(16, 2)
 #define GPSA_ELBO_EXTERN(MB, NCT)                                          \
   extern template __global__ void panel_elbo_kernel<MB, NCT, 2>(ElboArgs); \
   extern template __global__ void panel_elbo_kernel<MB, NCT, 4>(ElboArgs);

@@ -1121,11 +1121,11 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
 // wave and half the register file each (the other wave's MFMAs fill the matrix pipe during a wave's closing and ring issues)
 static inline int elbo_nct_for(int MB) {
   static const int nct13 = [] { const char* e = getenv("GPSA_ELBO_NCT"); return (e && e[0] == '1') ? 1 : 2; }();
-  return MB == 13 ? nct13 : 4;
+  return MB == 13 ? nct13 : (MB == 16 ? 2 : 4);  // (16 row tiles, M <= 256: 3 x 128 registers + the working set)
 }
 static inline bool elbo_path(int M) {
   const int MB = gpsa::mfma_mb_for(M);
-  return MB && MB <= 13 && !gpsa::force_generic();
+  return MB && MB <= 16 && !gpsa::force_generic();
 }
 
 int gpsa_quadform_elbo_parts(void) { return gpsa::num_cus() * 2; }
@@ -1175,6 +1175,7 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
     GPSA_ELBO_CASE(7, 4)
     GPSA_ELBO_CASE(13, 2)
     GPSA_ELBO_CASE(13, 1)
+    GPSA_ELBO_CASE(16, 2)
     default:
       return GPSA_EUNSUPPORTED;
   }

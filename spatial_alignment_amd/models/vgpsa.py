@@ -120,7 +120,7 @@ class VariationalGPSA(GPSA):
         # by itself when the products exceed the keep budget below)
         self.keep_products = True
         # A training forward leaves the data GP of every modality the fused kernel covers (Gaussian likelihood on
-        # F_latent, no LMC, M <= 208) to loss_fn, which is where the observations arrive (vgpsa.py:532-538): variance,
+        # F_latent, no LMC, M <= 256) to loss_fn, which is where the observations arrive (vgpsa.py:532-538): variance,
         # draw, likelihood, its gradient and the backward's alpha-gradient then ride in ONE pass over the products
         # Omega_l alpha (gpsa_quadform_elbo_f32) - nothing is kept, nothing streamed back.  F_samples come back as lazy
         # handles (lazy.LazyDraws) that loss_fn understands and that turn into real draws when anything else touches

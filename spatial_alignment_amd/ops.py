@@ -290,7 +290,7 @@ class HipOps:
         part = torch.empty(self.lib.gpsa_quadform_elbo_parts(), dtype=torch.float64, device=dev)
         wsb = self.lib.gpsa_quadform_elbo_f32_workspace(M, Cn, L)
         if wsb <= 0:
-            raise _lib.GpsaHipError("gpsa_quadform_elbo_f32: more than 13 row tiles (M > 208)")
+            raise _lib.GpsaHipError("gpsa_quadform_elbo_f32: more than 16 row tiles (M > 256)")
         ws = self._ws(wsb, alpha)
         FT = torch.empty(L, Cn, dtype=torch.float32, device=dev) if want_draws else None
         rc = self.lib.gpsa_quadform_elbo_f32(_dt(Omega), _p(alpha), _p(Omega), M, Cn, L, _p(meanT), _p(q), _p(var_u),
