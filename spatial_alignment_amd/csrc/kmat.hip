@@ -121,6 +121,17 @@ static inline int kb_rows(int M, long long C) {
   return (cdiv(C, 256) * cdiv(M, KB_MCHUNK) < 1024) ? KB_MCHUNK_SMALL : KB_MCHUNK;
 }
 constexpr int KB_MAXBX = 1024;  // column-block workgroups per row chunk (beyond: each walks several blocks)
+// the register-accumulating backward (kmat_bwd_d2_kernel): D = 2 and a problem big enough for KB_MCHUNK rows
+constexpr int KB_D2_ROWS = 16;  // (24 rows per workgroup spill: 300 us)
+static inline int kmat_bwd_d2_rows() { return KB_D2_ROWS; }
+static inline bool kmat_bwd_d2(int M, long long Ctot, int D) {
+  // (every size measured is faster this way: 117 -> 70 us at C = 100k, 41 -> 25 at 20k, 28 -> 19 at 12.5k,
+  //  15 -> 11 at 2.5k; M = 200.  GPSA_KMAT_BWD_D2=0: the older kernel)
+  static const bool off = [] { const char* e = getenv("GPSA_KMAT_BWD_D2"); return e && e[0] == '0'; }();
+  (void)M;
+  (void)Ctot;
+  return !off && D == 2;
+}
 
 // grid (column blocks of 256, row chunks of KB_MCHUNK): one thread per column c, looping over the
 // chunk's inducing rows.  Deterministic partials:
@@ -200,6 +211,155 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long 
   for (int i = threadIdx.x; i < mc * D; i += 256) {
     const int r = i / D, d = i % D;
     zrow[(long long)(m0 + r) * D + d] = acc[0][r][d] + acc[1][r][d] + acc[2][r][d] + acc[3][r][d];
+  }
+  T* sp = spart + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
+  T a = block_sum(s_ls, red);
+  if (threadIdx.x == 0) sp[0] = a;
+  T b2 = block_sum(s_var, red);
+  if (threadIdx.x == 0) sp[1] = b2;
+}
+
+// The same for D = 2 and KB_MCHUNK rows per workgroup (round 4): a thread keeps the 2 KB_MCHUNK dZ sums of its
+// columns in REGISTERS over all the column blocks its workgroup walks and the workgroup reduces them once, through
+// LDS, at the end - the kernel above pays two fp64 cross-lane reductions (~50 instructions) per (row, column block)
+// next to ~45 of covariance arithmetic.  Same partial arrays (zpart has gridDim.x rows: 6 times fewer at the
+// headline size, so the finishing launch shrinks with it), same fixed summation order from run to run.
+template <typename TI, typename T, int KIND, int MCH, typename TK = T, typename TX = TI>
+__global__ void __launch_bounds__(256, 2)
+kmat_bwd_d2_kernel(const TI* __restrict__ Z, int M, int rows, const TX* __restrict__ X, long long C,
+                   const TI* __restrict__ ls_u, const TI* __restrict__ var_u,
+                   const TK* __restrict__ Kbar, T* __restrict__ zpart, T* __restrict__ xpart,
+                   T* __restrict__ spart, KmatBatch bt) {
+  constexpr int D = 2;
+  static_assert(MCH % 8 == 0, "the closing reduction takes 8 rows at a time");
+  {
+    const long long b = blockIdx.z;
+    Z += b * bt.sZ;
+    X += b * bt.sX;
+    Kbar += b * bt.sK;
+    ls_u += b * bt.sP;
+    var_u += b * bt.sP;
+    zpart += b * (long long)gridDim.x * M * D;
+    if (xpart != nullptr) xpart += b * (long long)gridDim.y * C * D;
+    spart += b * (long long)gridDim.x * gridDim.y * 2;
+  }
+  const long long nlive = bt.ragged ? bt.n[blockIdx.z] : C;
+  constexpr int RSTR = 256 + 16;                // padded row of the reduction buffer (doubles)
+  __shared__ T Zs[MCH][MAXD];
+  __shared__ T rbuf[16 * RSTR];                 // 16 values x 256 threads at a time
+  __shared__ T red[4];
+  // rows <= MCH inducing rows per workgroup (the launcher spreads M evenly over the row chunks); the rows past mc
+  // run with weight zero on a clamped address - no branch in the row loop, so its loads can be issued ahead
+  const int m0 = blockIdx.y * rows;
+  const int mc = min(rows, M - m0);
+  const T ell = t_exp<T>((T)ls_u[0]), inv_ell = T(1) / ell, var = t_exp<T>((T)var_u[0]);
+  if (threadIdx.x < MCH * MAXD) {
+    const int r = threadIdx.x / MAXD, d = threadIdx.x % MAXD;
+    Zs[r][d] = (r < mc && d < D) ? (T)Z[(long long)(m0 + r) * D + d] : T(0);
+  }
+  __syncthreads();
+  T tz[MCH][D];
+#pragma unroll
+  for (int r = 0; r < MCH; ++r) tz[r][0] = tz[r][1] = T(0);
+  T s_ls = T(0), s_var = T(0);
+  const long long ncb = (C + 255) / 256;
+  // A column block's operands first - its gradient values as stored (fp32 panels: 2 MCH registers), the thread's
+  // point and column scale - then the arithmetic.
+  struct Col {
+    long long c;
+    bool live;
+    T x0, x1, axc;
+  };
+  const bool two = bt.axX != nullptr;  // (uniform)
+  auto load = [&](long long cb, TK(&kraw)[MCH], float(&araw)[MCH], Col& q) {
+    q.c = cb * 256 + threadIdx.x;
+    q.live = q.c < nlive;
+    q.x0 = q.x1 = q.axc = T(0);
+    const long long cc = q.live ? q.c : 0;
+    if (q.live) {
+      q.x0 = (T)X[q.c * D];
+      q.x1 = (T)X[q.c * D + 1];
+    }
+    // (ONE uniform branch around the loads: a select per row made each second-panel load a branch of its own with a
+    //  full wait behind it - sixteen memory latencies in a row)
+    if (two) {
+      if (q.live) q.axc = (T)bt.axs * (T)bt.axd[q.c];
+#pragma unroll
+      for (int r = 0; r < MCH; ++r) {
+        const long long o = (long long)min(m0 + r, M - 1) * C + cc;
+        kraw[r] = Kbar[o];
+        araw[r] = bt.axX[o];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < MCH; ++r) {
+        kraw[r] = Kbar[(long long)min(m0 + r, M - 1) * C + cc];
+        araw[r] = 0.f;
+      }
+    }
+  };
+  auto compute = [&](const TK(&kraw)[MCH], const float(&araw)[MCH], const Col& q) {
+    const T x[MAXD] = {q.x0, q.x1, T(0), T(0)};
+    T dx0 = T(0), dx1 = T(0);
+    // (the inducing rows are re-read from LDS in every column block: hoisted out of the loop they are 4 MCH more
+    //  registers next to the 4 MCH of the sums; the opaque zero keeps them inside)
+    int zo = 0;
+    asm volatile("" : "+v"(zo));
+    const T(*Zr)[MAXD] = Zs + zo;
+#pragma unroll
+    for (int r = 0; r < MCH; ++r) {
+      T k, cd, pl;
+      cov_eval<T, KIND>(Zr[r], x, D, ell, inv_ell, var, k, cd, pl);
+      const T kb = (q.live && r < mc) ? (T)kraw[r] + q.axc * (T)araw[r] : T(0);
+      s_ls += kb * pl;
+      s_var += kb * k;
+      const T wgt = kb * cd;
+      const T t0 = wgt * (Zr[r][0] - x[0]), t1 = wgt * (Zr[r][1] - x[1]);
+      dx0 -= t0;
+      dx1 -= t1;
+      tz[r][0] += t0;
+      tz[r][1] += t1;
+      // (four rows' worth of independent exp chains per scheduling region: all of them interleaved spill)
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (xpart != nullptr && q.c < C) {
+      T* xr = xpart + (long long)blockIdx.y * C * D;
+      xr[q.c * D] = dx0;
+      xr[q.c * D + 1] = dx1;
+    }
+  };
+  // (fetching the next block's operands while this one is worked on - a second register set - was slower:
+  //  99 against 70 us at the headline size, one workgroup per CU instead of two)
+  for (long long cb = blockIdx.x; cb < ncb; cb += gridDim.x) {
+    TK k0[MCH];
+    float a0[MCH];
+    Col q0;
+    load(cb, k0, a0, q0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(k0, a0, q0);
+  }
+  // the workgroup's sums, 8 rows (16 values) at a time: value v of every thread -> rbuf[v][thread]; thread t then
+  // adds the 16 entries (t & 15) + 16 i of value t >> 4 and the 16 lanes of a value meet through DPP
+  T* zrow = zpart + (long long)blockIdx.x * M * D;
+#pragma unroll
+  for (int r0 = 0; r0 < MCH; r0 += 8) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      rbuf[(2 * q) * RSTR + threadIdx.x] = tz[r0 + q][0];
+      rbuf[(2 * q + 1) * RSTR + threadIdx.x] = tz[r0 + q][1];
+    }
+    __syncthreads();
+    const int v = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    T a = T(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += rbuf[v * RSTR + sub + 16 * i];
+    a += dpp_move<0xB1>(a);
+    a += dpp_move<0x4E>(a);
+    a += dpp_move<0x141>(a);
+    a += dpp_move<0x140>(a);
+    const int r = r0 + (v >> 1);
+    if (sub == 0 && r < mc) zrow[(long long)(m0 + r) * D + (v & 1)] = a;
   }
   T* sp = spart + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * 2;
   T a = block_sum(s_ls, red);
@@ -303,15 +463,53 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TX* X, long long C, int 
                     long long sdZ = 0, long long sdX = 0) {
   if (batch < 1 || batch > KM_MAXB) return GPSA_EINVAL;
   const int mch = kb_rows(M, C * batch);
-  const long long ncb = cdiv(C, 256), nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX, nby = cdiv(M, mch);
+  const long long ncb = cdiv(C, 256), nby = cdiv(M, mch);
+  long long nbx = ncb < KB_MAXBX ? ncb : KB_MAXBX;
   const long long nz = (long long)M * D, nx = C * D;
   const long long need = (nbx * nz + nby * nx + nbx * nby * 2) * (long long)sizeof(T) * batch;
-  if (ws_bytes < need) return GPSA_EWORKSPACE;
+  const bool d2 = kmat_bwd_d2(M, C * batch, D);
+  if (!d2 && ws_bytes < need) return GPSA_EWORKSPACE;
   T* zpart = reinterpret_cast<T*>(ws);
   T* xpart = zpart + nbx * nz * batch;
   T* spart = xpart + nby * nx * batch;
-  dim3 grid((unsigned)nbx, (unsigned)nby, (unsigned)batch);
   T* xp = (dX || same) ? xpart : nullptr;  // K_uu: the X-side partials are folded into dZ
+  if (d2) {
+    // register-accumulating form (its own, finer row chunks: see kmat_bwd_d2_kernel)
+    const int mr = kmat_bwd_d2_rows();
+    const long long nby2 = cdiv(M, mr);
+    static const int per_env = [] { const char* e = getenv("GPSA_KMAT_BWD_PER"); return e ? atoi(e) : 0; }();
+    // column blocks per workgroup: ~400 workgroups (measured: 1 at C = 2.5k, 2 - 3 at 12.5k - 20k, 4 - 12 alike at 100k)
+    long long per = (ncb * nby2 * batch + 200) / 400;
+    per = per < 1 ? 1 : (per > 8 ? 8 : per);
+    if (per_env > 0) per = per_env;
+    nbx = cdiv(ncb, per);
+    const int rows = (int)cdiv(M, nby2);  // M spread evenly over the row chunks
+    if ((nbx * nz + nby2 * nx + nbx * nby2 * 2) * (long long)sizeof(T) * batch > ws_bytes) return GPSA_EWORKSPACE;
+    xpart = zpart + nbx * nz * batch;
+    spart = xpart + nby2 * nx * batch;
+    xp = (dX || same) ? xpart : nullptr;
+    dim3 grid((unsigned)nbx, (unsigned)nby2, (unsigned)batch);
+#define GPSA_KB_CASE(KIND)                                                                                     \
+  kmat_bwd_d2_kernel<TI, T, KIND, KB_D2_ROWS, TK, TX><<<grid, 256, 0, st>>>(Z, M, rows, X, C, ls_u, var_u, Kbar, \
+                                                                            zpart, xp, spart, kb);
+    switch (kind) {
+      case GPSA_K_RBF: GPSA_KB_CASE(GPSA_K_RBF) break;
+      case GPSA_K_MATERN12: GPSA_KB_CASE(GPSA_K_MATERN12) break;
+      case GPSA_K_MATERN32: GPSA_KB_CASE(GPSA_K_MATERN32) break;
+      default:
+        return GPSA_EINVAL;
+    }
+#undef GPSA_KB_CASE
+    GPSA_LAUNCH_CHECK();
+    const bool fold2 = same != 0;
+    if (fold2 && (nx != nz)) return GPSA_EINVAL;
+    dim3 fgrid2((unsigned)(cdiv(nz, 16) + cdiv(nx, 64) + 1), (unsigned)batch);
+    kmat_bwd_finish_kernel<T, TO><<<fgrid2, 256, 0, st>>>(zpart, nbx, nz, xp, nby2, nx, spart, nbx * nby2,
+                                                          fold2 ? 1 : 0, dZ, dX, dparams, sdZ, sdX);
+    GPSA_LAUNCH_CHECK();
+    return 0;
+  }
+  dim3 grid((unsigned)nbx, (unsigned)nby, (unsigned)batch);
 #define GPSA_KB_CASE(KIND)                                                                          \
   if (mch == KB_MCHUNK)                                                                             \
     kmat_bwd_kernel<TI, T, KIND, KB_MCHUNK, TK, TX><<<grid, 256, 0, st>>>(Z, M, X, C, D, ls_u, var_u, \
@@ -362,7 +560,9 @@ int gpsa_kmat(int dtype, int in_dtype, int kind, const void* Z, int M, const voi
 }
 
 long long gpsa_kmat_bwd_workspace(int dtype, int M, long long C, int D) {
-  const long long nbx = cdiv(C, 256), nby = cdiv(M, gpsa::kb_rows(M, C));
+  const long long nbx = cdiv(C, 256);
+  long long nby = cdiv(M, gpsa::kb_rows(M, C));
+  if (gpsa::kmat_bwd_d2(M, C, D)) nby = cdiv(M, gpsa::kmat_bwd_d2_rows());  // (finer row chunks: more dX partials)
   return (nbx * M * D + nby * C * D + nbx * nby * 2) * (dtype == GPSA_F64 ? 8 : 4);
 }
 
@@ -422,7 +622,9 @@ int gpsa_kmat_batched(int kind, const float* Z, long long strideZ, int M, const 
 
 long long gpsa_kmat_bwd_batched_workspace(int M, long long C, int D, int batch) {
   const int mch = gpsa::kb_rows(M, C * batch);
-  const long long ncb = cdiv(C, 256), nbx = ncb < gpsa::KB_MAXBX ? ncb : gpsa::KB_MAXBX, nby = cdiv(M, mch);
+  const long long ncb = cdiv(C, 256), nbx = ncb < gpsa::KB_MAXBX ? ncb : gpsa::KB_MAXBX;
+  long long nby = cdiv(M, mch);
+  if (gpsa::kmat_bwd_d2(M, C * batch, D)) nby = cdiv(M, gpsa::kmat_bwd_d2_rows());
   return (nbx * M * D + nby * C * D + nbx * nby * 2) * 8LL * batch;
 }
 

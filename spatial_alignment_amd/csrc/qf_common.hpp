@@ -294,8 +294,8 @@ GPSA_SYM_SHAPES(GPSA_SYM_EXTERN)
 // ---- Gram sums (M <= 256): qf_gram.hip
 constexpr int GR_KC = 64;  // columns per staged chunk (four 16-deep MFMA K blocks)
 template <int MB, bool ALIGNED, int NL>
-__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2) gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C, int L, int nsplit, float* __restrict__ part);
-#define GPSA_GRAM_SIG (const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C, int L, int nsplit, float* __restrict__ part)
+__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2) gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part);
+#define GPSA_GRAM_SIG (const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part)
 #define GPSA_GRAM_SHAPES(X) X(2, 2) X(4, 2) X(7, 2) X(13, 2) X(2, 1) X(4, 1) X(7, 1) X(13, 1) X(16, 1)
 #define GPSA_GRAM_EXTERN(MB, NL)                                                \
   extern template __global__ void gram_mfma_kernel<MB, true, NL> GPSA_GRAM_SIG; \

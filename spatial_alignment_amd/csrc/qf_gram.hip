@@ -3,6 +3,9 @@
 
 namespace gpsa {
 
+// 16 bytes of zeros: where the LDS-DMA of g is sent for the column groups past C (see gram_wave_run)
+__device__ __attribute__((aligned(16))) const float gram_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 // ------------------------------------------------------------------------------------------------
 // MFMA Gram kernel:  dOmega_l = sum_c g[l,c] alpha_c alpha_c^T   (lower-triangle 16x16 tiles)
 // grid (L, nsplit): workgroup (l, s) sweeps its share of the columns in 32-column chunks staged in
@@ -168,8 +171,8 @@ __device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS + GR_G], f
 // loop inside the per-wave instantiation the accumulators have one home.  (Barriers are counted per workgroup,
 // not per program counter: the four waves meet at theirs from four different loops.)
 template <int MB, bool ALIGNED, int NL, int W>
-__device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, const float* __restrict__ g, int M,
-                                              long long C, int L, int nsplit, float* __restrict__ part,
+__device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, const float* __restrict__ g,
+                                              long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part,
                                               float* __restrict__ sA_, float* __restrict__ sG_) {
   constexpr int MP = MB * 16;
   constexpr GramPlan<MB> PLAN{};
@@ -192,11 +195,14 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
 
   // staging (LDS-DMA, ALIGNED): rows >= M are clamped to row M-1 and columns >= C to the last aligned
   // group; the clamped rows only feed output rows/cols >= M (never read back) and the clamped columns
-  // meet g == 0 (g is zero-padded to a multiple of GR_KC columns by the launcher: gpad, row stride
-  // Cpad).  Every wave issues exactly NPW + 1 operations per stage (surplus pieces re-load piece 0 into
+  // meet g == 0 (gstride == C: g is the caller's [L, C] panel and the 16-byte groups past column C are fetched
+  // from a block of zeros instead - C is a multiple of 4 here, so no group straddles it; otherwise the launcher
+  // made a zero-padded copy with gstride = C rounded up to GR_KC columns).  Every wave issues exactly NPW + 1 operations per stage (surplus pieces re-load piece 0 into
   // an unused slot; all four waves DMA the same 128 bytes of g) so that a counted vmcnt(NPW+1) means
   // "everything but the newest stage has landed".
-  const long long Cpad = nch * GR_KC;
+  auto gsrc = [&](int lq, long long col) -> const float* {
+    return (gstride == C && col >= C) ? gram_zero16 : g + (long long)lq * gstride + col;
+  };
 #define GPSA_GR_STAGE(CH, BUF)                                                               \
   {                                                                                          \
     const long long cb__ = (long long)(CH) * GR_KC;                                          \
@@ -218,7 +224,7 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
       if (lane < NL * (GR_KC / 4)) {                                                         \
         const int lq__ = min(l0 + lane / (GR_KC / 4), L - 1);                                \
         dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sG_ + (BUF) * SG_STRIDE)));       \
-        glds16_m0<0>(g + (long long)lq__ * Cpad + cb__ + (lane % (GR_KC / 4)) * 4);          \
+        glds16_m0<0>(gsrc(lq__, cb__ + (lane % (GR_KC / 4)) * 4));          \
       }                                                                                      \
     } else {                                                                                 \
       for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
@@ -230,7 +236,7 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
             (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;                    \
       }                                                                                      \
       if (tid < NL * GR_KC)                                                                  \
-        sG_[(BUF) * SG_STRIDE + tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * Cpad + cb__ + tid % GR_KC]; \
+        sG_[(BUF) * SG_STRIDE + tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * gstride + cb__ + tid % GR_KC]; \
     }                                                                                        \
   }
 
@@ -268,7 +274,7 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
       } else if (kb == 0 && lane < NL * (GR_KC / 4)) {
         const int lq = min(l0 + lane / (GR_KC / 4), L - 1);
         dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sG_ + (buf ^ 1) * SG_STRIDE)));
-        glds16_m0<0>(g + (long long)lq * Cpad + (ch + 1) * GR_KC + (lane % (GR_KC / 4)) * 4);
+        glds16_m0<0>(gsrc(lq, (ch + 1) * GR_KC + (lane % (GR_KC / 4)) * 4));
       }
     };
     static_assert(NPW <= 16, "four pieces per K block of the chunk being multiplied");
@@ -289,8 +295,8 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
 
 template <int MB, bool ALIGNED, int NL>
 __global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2)
-gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, int M, long long C,
-                 int L, int nsplit, float* __restrict__ part) {
+gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M,
+                 long long C, int L, int nsplit, float* __restrict__ part) {
   constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;  // 1-KiB pieces (16 rows x 16 cols) per chunk
   // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
   // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
@@ -302,10 +308,10 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, i
   __shared__ __attribute__((aligned(16))) float sG[2][NL * GR_KC];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   switch (w) {
-    case 0: gram_wave_run<MB, ALIGNED, NL, 0>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
-    case 1: gram_wave_run<MB, ALIGNED, NL, 1>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
-    case 2: gram_wave_run<MB, ALIGNED, NL, 2>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
-    default: gram_wave_run<MB, ALIGNED, NL, 3>(alpha, g, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    case 0: gram_wave_run<MB, ALIGNED, NL, 0>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    case 1: gram_wave_run<MB, ALIGNED, NL, 1>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    case 2: gram_wave_run<MB, ALIGNED, NL, 2>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    default: gram_wave_run<MB, ALIGNED, NL, 3>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
   }
 }
 

@@ -736,20 +736,27 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
   const int nl = gram_nl(MBsel, L, C);
   const int ns = gram_nsplit(C, (L + nl - 1) / nl);
   const long long Cpad = cdiv(C, GR_KC) * GR_KC;
-  float* gpad = ws;
+  const float* gpad = ws;
+  long long gstride = Cpad;
   float* part = ws + ((gram_gpad_floats(C, L) + 63) / 64) * 64;
-  pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, gpad);
-  GPSA_LAUNCH_CHECK();
-  dim3 grid((unsigned)((L + nl - 1) / nl), (unsigned)ns);
   const bool al = (C % 4 == 0) && (C >= 8) && ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0);
+  if (al && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    // the kernel reads g where it lies (its column groups past C come from a block of zeros): no padded copy
+    gpad = g;
+    gstride = C;
+  } else {
+    pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, ws);
+    GPSA_LAUNCH_CHECK();
+  }
+  dim3 grid((unsigned)((L + nl - 1) / nl), (unsigned)ns);
 #define GPSA_GRAM_CASE(MBV)                                                                        \
   case MBV:                                                                                        \
     if (nl == 2 && MBV <= 13) {                                                                    \
-      if (al) gram_mfma_kernel<MBV, true, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part);  \
-      else gram_mfma_kernel<MBV, false, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part);    \
+      if (al) gram_mfma_kernel<MBV, true, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part);  \
+      else gram_mfma_kernel<MBV, false, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part);    \
     } else {                                                                                       \
-      if (al) gram_mfma_kernel<MBV, true, 1><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part); \
-      else gram_mfma_kernel<MBV, false, 1><<<grid, 256, 0, st>>>(alpha, gpad, M, C, L, ns, part);   \
+      if (al) gram_mfma_kernel<MBV, true, 1><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part); \
+      else gram_mfma_kernel<MBV, false, 1><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part);   \
     }                                                                                              \
     break;
   switch (MBsel) {

@@ -33,8 +33,11 @@ def test_workspace_queries_are_pure():
     assert lib.gpsa_gemm_workspace(0, 200, 200, 1, 1) == 0
     assert lib.gpsa_gemm_workspace(1, 200, 200, 2, 4) == 2 * 4 * 200 * 200 * 8
     # 4 column blocks x 7 row chunks would leave the chip nearly empty: 8-row chunks (25 of them)
-    assert lib.gpsa_kmat_bwd_workspace(0, 200, 1000, 2) == (4 * 400 + 25 * 2000 + 4 * 25 * 2) * 4
-    assert lib.gpsa_kmat_bwd_workspace(0, 200, 100000, 2) == (391 * 400 + 7 * 200000 + 391 * 7 * 2) * 4
+    # (D = 2: the register-accumulating backward, 16 inducing rows per workgroup -> 13 dX partials)
+    assert lib.gpsa_kmat_bwd_workspace(0, 200, 1000, 2) == (4 * 400 + 13 * 2000 + 4 * 13 * 2) * 4
+    assert lib.gpsa_kmat_bwd_workspace(0, 200, 1000, 3) == (4 * 600 + 25 * 3000 + 4 * 25 * 2) * 4
+    assert lib.gpsa_kmat_bwd_workspace(0, 200, 100000, 2) == (391 * 400 + 13 * 200000 + 391 * 13 * 2) * 4
+    assert lib.gpsa_kmat_bwd_workspace(0, 200, 100000, 3) == (391 * 600 + 7 * 300000 + 391 * 7 * 2) * 4
     assert lib.gpsa_quadform_workspace(0, 200, 1000, 50) >= 50 * 208 * 208 * 4
 
 
