@@ -194,7 +194,11 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
     return;
   typedef typename MfmaTile<TC>::vec acc_t;
   // K tile of 16 (32 was tried: fewer resident workgroups, 20-40 % slower on every shape used here; fetching TWO
-  // tiles ahead through a second register set was tried too: 10 % slower at M = 1000, no gain on the small batches;
+  // tiles ahead through a second register set was tried too: 10 % slower at M = 1000, no gain on the small batches
+  // (round 4, again: nor on the long-K fp64 products of the warp GPs' backward, which run the matrix pipe 39 % of the
+  // time, nor on the skinny fp32 products of the data GP's mean term; K tiles of 32 / 64 are 10 - 50 % slower there;
+  // one straight-line K loop per live-tile shape instead of a test in front of every MFMA: fp64 unchanged, the fp32
+  // products 12 - 20 % SLOWER - tools/microbench/gemm64_time.py, gemm32_skinny_time.py);
   // a 128 x 128 workgroup tile (4 x 4 MFMA tiles per wave, half the staged bytes per flop) was 2 % slower at
   // M = 500 and 8 % slower at M = 1000 end to end: the 64-tile is not bound by the operand traffic; an XCD-aware
   // block order (blocks with equal dispatch index mod 8 on adjacent tiles, short grid edge fastest) gained 7 % on

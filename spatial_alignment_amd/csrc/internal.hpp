@@ -30,4 +30,9 @@ int omega_fwd_dma_launch(const float* A0, int n0, double* O0, const float* A1, i
 int omega_bwd_dma_launch(const double* G0, const float* A0, float* D0, int n0, const double* G1, const float* A1,
                          float* D1, int n1, int M, hipStream_t st);
 
+// kl.hip: gpsa_mvn_kl_grouped_fwd that also writes the terms to kl_copy (may be NULL)
+int mvn_kl_grouped_fwd_copy(const double* mats, const double* inv, const double* logdet, const int* om_idx,
+                            const int* pr_idx, const double* D, int M, int T, double* kl, double* KD,
+                            double* kl_copy, hipStream_t st);
+
 }  // namespace gpsa

@@ -1006,14 +1006,12 @@ static int mm_stage_fwd(Ctx& c) {
   if (kl)
     for (int g = 0; g < P.ng; ++g) {
       Group& G = P.grp[g];
+      // (the terms also go to the arena's cache, for passes that reuse this stage: same launch, no copy)
       if (G.n_omega > 0)
-        GPSA_RUN(gpsa_mvn_kl_grouped_fwd(c.mats(G, 0), c.inv(G, 0), c.sv<double>(G.o_logdet), G.om_idx, G.pr_idx,
+        GPSA_RUN(mvn_kl_grouped_fwd_copy(c.mats(G, 0), c.inv(G, 0), c.sv<double>(G.o_logdet), G.om_idx, G.pr_idx,
                                          c.sv<double>(G.o_D), G.M, G.n_omega, c.io.kl + G.kl_off,
-                                         c.sv<double>(G.o_KD), (void*)sst));
+                                         c.sv<double>(G.o_KD), c.sv<double>(P.o_klcache) + G.kl_off, sst));
     }
-  if (kl && !dry)  // (stream-ordered behind the KL kernels; with the side stream: on it)
-    GPSA_CK((int)hipMemcpyAsync(c.sv<double>(P.o_klcache), c.io.kl, (size_t)((long long)V * D + P.Ltot) * 8,
-                                hipMemcpyDeviceToDevice, sst));
   if (fork) GPSA_CK((int)hipEventRecord(P.sev[2], P.side));
   return 0;
 }
