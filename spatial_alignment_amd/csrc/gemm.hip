@@ -421,8 +421,13 @@ int gemm_launch_scaled(int transA, int transB, int m, int n, long long k, double
                                                     C, ldc, sC, splitk, part, T(0), tri, kscale, sKs, cscale, sCs)
   // products with at least one MFMA tile in each direction run on the matrix cores (always with a triangle
   // mode or a scale vector: only that kernel knows them)
-  const bool mfma = (m >= 16 && n >= 16 && !gemm_force_vector()) || tri != GEMM_TRI_NONE || kscale != nullptr ||
-                    cscale != nullptr;
+  // (round 4: also products with fewer than 16 rows or columns - the matrix-core kernel pads them inside a tile and
+  //  is 1.1 - 2.3 times faster than the vector kernel on every such product of a step: the ten-latent-GP mean term
+  //  96 -> 42 us, its adjoint 122 -> 61, the LMC products 209 -> 114 and 255 -> 126, the warp GPs' [M, 2] gradient
+  //  14.0 -> 12.6; GPSA_GEMM_MFMA_MIN=16 restores the old rule)
+  static const int mfma_min = [] { const char* e = getenv("GPSA_GEMM_MFMA_MIN"); return e ? atoi(e) : 1; }();
+  const bool mfma = (m >= mfma_min && n >= mfma_min && !gemm_force_vector()) || tri != GEMM_TRI_NONE ||
+                    kscale != nullptr || cscale != nullptr;
   if (cscale != nullptr && splitk != 1) return GPSA_EINVAL;  // the split-K reduce does not know the scale
   if (mfma) {
     if (!transA && !transB) GPSA_GEMMX_CASE(false, false);

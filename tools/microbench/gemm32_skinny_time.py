@@ -45,6 +45,12 @@ for name, (ta, tb, m, n, k), sks in [
     ("ddelta NT 200x50x100000", (0, 1, 200, 50, 100000), (64, 128, 256)),
     ("ddelta NT 200x10x200000", (0, 1, 200, 10, 200000), (128, 256)),
     ("abar   NN 200x100000x50", (0, 0, 200, 100000, 50), (1,)),
+    ("abar   NN 200x200000x10", (0, 0, 200, 200000, 10), (1,)),
+    ("mean   TN  20x100000x200", (1, 0, 20, 100000, 200), (1,)),
+    ("dresid NT 200x2x10000", (0, 1, 200, 2, 10000), (32, 128)),
+    ("LMC    NN 200000x500x10", (0, 0, 200000, 500, 10), (1,)),
+    ("LMCb   NT 200000x10x500", (0, 1, 200000, 10, 500), (1,)),
+    ("LMCw   TN 10x500x200000", (1, 0, 10, 500, 200000), (64, 256)),
 ]:
     for sk in sks:
         us, gb, err = time_gemm(ta, tb, m, n, k, sk)
