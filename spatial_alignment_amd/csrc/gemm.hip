@@ -302,6 +302,25 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
 #undef GPSA_G64_FETCH
 #undef GPSA_G64_STASH
   // C/D layout: col = lane & 15; row = (lane >> 4) + 4 * reg (fp64) or 4 * (lane >> 4) + reg (fp32)
+  // beta != 0: all sixteen old values of this thread are requested first (clamped addresses, one uniform branch) -
+  // read inside the store loop, each load sat behind the previous store: sixteen memory round trips in a row at the
+  // end of a workgroup that lives for four K tiles (the data GP's abar += delta dmean^T: 66 -> 57 us for 100 MB;
+  // requesting ALL of a short K range's operand tiles up front as well changed nothing: 49 vs 51 us without beta)
+  TC cold[2][2][4];
+  const bool rmw = splitk == 1 && beta != TC(0);
+  if (rmw) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = m0 + wm + tm * 16 + MfmaTile<TC>::row(kq, r), col = n0 + wn + tn * 16 + j;
+          row = row < m ? row : m - 1;
+          col = col < n ? col : n - 1;
+          cold[tm][tn][r] = (TC)C[(long long)b * sC + (long long)row * ldc + col];
+        }
+  }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -314,7 +333,7 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
           if (cscale != nullptr) y *= (TC)cscale[(long long)b * sCs + col];
           if (splitk == 1) {
             TO* p = C + (long long)b * sC + (long long)row * ldc + col;
-            TC v = (beta == TC(0)) ? alpha * y : alpha * y + beta * (TC)(*p);
+            TC v = rmw ? alpha * y + beta * cold[tm][tn][r] : alpha * y;
             if (row == col) v += diag;
             *p = (TO)v;
             if (tri == GEMM_TRI_LTL) C[(long long)b * sC + (long long)col * ldc + row] = (TO)v;

@@ -11,15 +11,15 @@ st = torch.cuda.current_stream().cuda_stream
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 
 
-def time_gemm(ta, tb, m, n, k, sk, reps=30):
+def time_gemm(ta, tb, m, n, k, sk, reps=30, beta=0.0):
     A = torch.randn(*((k, m) if ta else (m, k)), dtype=torch.float32, device=dev)
     B = torch.randn(*((n, k) if tb else (k, n)), dtype=torch.float32, device=dev)
-    C = torch.empty(m, n, dtype=torch.float32, device=dev)
+    C = torch.zeros(m, n, dtype=torch.float32, device=dev)
     wsb = lib.gpsa_gemm_workspace(0, m, n, 1, sk)
     ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
 
     def run():
-        rc = lib.gpsa_gemm(0, ta, tb, m, n, k, 1.0, p(A), A.shape[1], 0, p(B), B.shape[1], 0, 0.0, p(C), n, 0, 1, sk,
+        rc = lib.gpsa_gemm(0, ta, tb, m, n, k, 1.0, p(A), A.shape[1], 0, p(B), B.shape[1], 0, beta, p(C), n, 0, 1, sk,
                            p(ws), wsb, ctypes.c_void_p(st))
         assert rc == 0, rc
     for _ in range(3):
@@ -32,6 +32,8 @@ def time_gemm(ta, tb, m, n, k, sk, reps=30):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1000 / reps
+    C.zero_()
+    run()
     ref = torch.matmul((A.t() if ta else A).double(), (B.t() if tb else B).double())
     err = ((C.double() - ref).abs().max() / ref.abs().max()).item()
     gb = (A.numel() + B.numel() + C.numel()) * 4 / us * 1e-3
@@ -55,3 +57,8 @@ for name, (ta, tb, m, n, k), sks in [
     for sk in sks:
         us, gb, err = time_gemm(ta, tb, m, n, k, sk)
         print(f"{name}  splitk {sk:3d}  {us:7.1f} us  {gb:6.0f} GB/s  err {err:.1e}")
+
+for name, (ta, tb, m, n, k) in [("abar   NN 200x100000x50  beta=1", (0, 0, 200, 100000, 50)),
+                                ("abar   NN 200x200000x10  beta=1", (0, 0, 200, 200000, 10))]:
+    us, gb, err = time_gemm(ta, tb, m, n, k, 1, beta=1.0)
+    print(f"{name}  {us:7.1f} us  err {err:.1e}")
