@@ -90,7 +90,9 @@ def test_kmat_batched_same_points(hip, kind, M, D, B):
         assert (dZ[b] - wZ).norm() <= 1e-12 * wZ.norm() and (dpar[b] - wp).norm() <= 1e-12 * wp.norm()
 
 
-@pytest.mark.parametrize("M,D,C", [(200, 2, 5000), (30, 3, 777)])
+# (200, 2, 20000): several column blocks per workgroup of the register-accumulating kernel; (50, 2, 3000): a last row
+# chunk that is not full
+@pytest.mark.parametrize("M,D,C", [(200, 2, 5000), (30, 3, 777), (200, 2, 20000), (50, 2, 3000)])
 def test_kmat_bwd_x64(hip, M, D, C):
     """the data GP's covariance backward: fp32 inducing points / panel, fp64 coordinates, fp64 results"""
     Z, X64 = rnd(M, D, seed=1, scale=3).to(DEV), rnd(C, D, dtype=f64, seed=2, scale=3).to(DEV)

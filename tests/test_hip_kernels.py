@@ -97,6 +97,22 @@ def test_gemm(hip, dtype, ta, tb):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(10, 300, 200), (200, 2, 1000), (3, 5, 7), (1, 70, 33)])
+def test_gemm_with_fewer_than_16_rows_or_columns(hip, dtype, ta, tb, m, n, k):
+    """products below one MFMA tile in a direction (the ten-latent-GP mean term, the [M, 2] gradients of the warp GPs):
+    they run on the matrix-core kernel too since round 4"""
+    A = rnd(*((k, m) if ta else (m, k)), dtype=dtype)
+    B = rnd(*((n, k) if tb else (k, n)), dtype=dtype, seed=3)
+    want = FK.gemm(A.double(), B.double(), bool(ta), bool(tb), alpha=1.3)
+    close(hip.gemm(A.to(DEV), B.to(DEV), bool(ta), bool(tb), alpha=1.3), want, TOL[dtype])
+    C0 = rnd(m, n, dtype=dtype, seed=4)
+    out = C0.clone().to(DEV)
+    hip.gemm(A.to(DEV), B.to(DEV), bool(ta), bool(tb), alpha=1.3, beta=-0.25, out=out)
+    close(out, want - 0.25 * C0.double(), TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_gemm_batched_broadcast_splitk(hip, dtype):
     A, B = rnd(5, 40, 40, dtype=dtype), rnd(40, 3000, dtype=dtype, seed=1)
     close(hip.gemm(A.to(DEV), B.to(DEV)), A.double() @ B.double(), TOL[dtype])
