@@ -222,8 +222,11 @@ def extra_workload(which, args):
     cut to what the default line carries for it"""
     import subprocess
 
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", which, "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--blocks", "3"]
+    # (config 1's step is ~0.6 ms of ~60 tiny launches: the first ~1000 steps of a process run 30-70 % slow on these
+    #  boxes (clocks), so its child warms up for 1000 steps and times blocks of at least 200)
+    steps, warm = (max(args.steps, 200), max(args.warmup, 1000)) if which == "1" else (args.steps, args.warmup)
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", which, "--steps", str(steps), "--warmup",
+           str(warm), "--blocks", "3"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
         last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

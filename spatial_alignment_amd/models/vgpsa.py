@@ -126,6 +126,11 @@ class VariationalGPSA(GPSA):
         # handles (lazy.LazyDraws) that loss_fn understands and that turn into real draws when anything else touches
         # them.  False (or GPSA_FUSE_ELBO=0): always the separate kernels
         self.fuse_elbo = os.environ.get("GPSA_FUSE_ELBO", "1") != "0"
+        # ... from the size where that pays: below ~5 GF of data-GP contraction per step (2 S N L M^2) the step is
+        # bound by its launches and the host, and the deferred second half costs 7-10 % (0.63 vs 0.58 ms at BASELINE
+        # config 1's size, 0.83 vs 0.77 at 2 x 900 spots; 0.85 vs 0.88 at 2 x 1600, 3.77 vs 4.11 at 2 x 4900:
+        # tools/fuse_threshold_probe.py).  GPSA_FUSE_MIN_FLOPS / this attribute move the line; 0 = always
+        self.fuse_min_flops = float(os.environ.get("GPSA_FUSE_MIN_FLOPS", "5e9"))
         self.keep_budget_gb = None  # HBM for those products: None = what the device can still give (step_engine.py)
         # the data GP's inducing-point gradient from the UNROUNDED projection (gpsa_step_desc.exact_inducing_grad):
         # True / False, or None = on when its one extra M x M x C fp64 product is under ~2 % of the step (L >= 128;
@@ -568,6 +573,9 @@ class VariationalGPSA(GPSA):
         nz = self.noise_variance
         if not any(flags) or nz.dtype != torch.float32 or not nz.is_contiguous():
             return None
+        Mg = int(self.Gtilde.shape[0])
+        if max(2.0 * S * plan.N[i] * plan.L[i] * Mg * Mg for i in range(len(mods)) if flags[i]) < self.fuse_min_flops:
+            return None  # a launch-bound step: the separate kernels in one go are cheaper (see fuse_min_flops)
         nn_ = nz.numel()
         return dict(mods=flags, Y=[None] * len(mods), noise=nz.detach(),
                     noise_ptr=[nz.data_ptr() + 4 * (nn_ - self.n_modalities + i) for i in range(len(mods))],  # quirk 5
@@ -722,8 +730,13 @@ class VariationalGPSA(GPSA):
         return hosts[slot]
 
     def _post_flag(self, host):
-        """an event behind the kernel that wrote ``host``; returns what _raise_on_flags waits on"""
-        ev = torch.cuda.Event()
+        """an event behind the kernel that wrote ``host``; returns what _raise_on_flags waits on.  The events are kept
+        (one per pinned word): a fresh torch.cuda.Event per forward cost 190 us of host time per step on this stack
+        (creation + first record) - a quarter of a step at BASELINE config 1's size."""
+        evs = self.__dict__.setdefault("_flag_events", {})
+        ev = evs.get(host.data_ptr())
+        if ev is None:
+            ev = evs[host.data_ptr()] = torch.cuda.Event()
         ev.record()
         return host, ev
 

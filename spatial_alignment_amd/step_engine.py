@@ -440,18 +440,9 @@ class StepFn(torch.autograd.Function):
             raise RuntimeError("GPSA step: backward through the same forward a second time - its saved arena was "
                                "released after the first backward (run forward again)")
         plan, model = aux["plan"], aux["model"]()
-        if aux.get("deferred") is not None:  # the forward's numerics word: raise before any gradient exists
-            pend, aux["deferred"] = aux["deferred"], None
-            if model is not None:
-                # only THIS forward's pending check is retired: a later forward whose backward has not run yet
-                # keeps its own (it is raised by that backward, or by the next forward)
-                if model.__dict__.get("_pending_flag") is pend:
-                    model._pending_flag = None
-                model._raise_on_flags(pend)
-            else:  # the model is gone (the node outlived it): the check itself needs no model
-                from .models.vgpsa import VariationalGPSA
-
-                VariationalGPSA._raise_on_flags(pend)
+        # the forward's numerics word: waited for AFTER this backward's launches are queued (below), raised before
+        # any gradient is handed to autograd
+        pend_check, aux["deferred"] = aux.get("deferred"), None
         lib = plan.lib
         tensors = ctx.saved_tensors[: ctx.n_in]
         dev = tensors[0].device
@@ -562,6 +553,21 @@ class StepFn(torch.autograd.Function):
             fuse["live"] = None
             fuse["gloss"] = None
         ctx.aux = ctx.io = ctx.prm = None
+        if pend_check is not None:
+            # (round 4: this wait used to open the backward.  On a launch-bound problem - BASELINE config 1's size - the
+            #  host then sat out the device's backlog before it queued a single backward launch, and the device idled
+            #  while it did: 1.00 ms/step against 0.69 without the check.  Behind the launches the wait is free, and an
+            #  exception still leaves from loss.backward() before AccumulateGrad has seen any of this node's gradients.)
+            if model is not None:
+                # only THIS forward's pending check is retired: a later forward whose backward has not run yet
+                # keeps its own (it is raised by that backward, or by the next forward)
+                if model.__dict__.get("_pending_flag") is pend_check:
+                    model._pending_flag = None
+                model._raise_on_flags(pend_check)
+            else:  # the model is gone (the node outlived it): the check itself needs no model
+                from .models.vgpsa import VariationalGPSA
+
+                VariationalGPSA._raise_on_flags(pend_check)
         return tuple(out)
 
 

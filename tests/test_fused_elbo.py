@@ -291,3 +291,21 @@ def test_lmc_handle_used_before_loss_fn_is_an_ordinary_product():
         if b is None or float(b.norm()) == 0:
             continue
         assert float((a.double() - b.double()).norm() / b.double().norm()) <= 1e-5, k
+
+
+def test_small_problems_take_the_separate_kernels_by_default():
+    """below ``fuse_min_flops`` of data-GP contraction per step (5 GF unless moved) a training forward hands out real
+    draws and the step runs unfused: launch-bound steps are cheaper that way"""
+    g = Golden("c1_example_fixed0")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+    model.fuse_min_flops = 5e9
+    out = model.forward(Xs, view_idx, Ns, S=2)
+    assert model._cache.fuse is None and type(out[3][g.mods[0]]) is torch.Tensor
+    model.loss_fn(dd, out[3]).backward()
+    model.fuse_min_flops = 0
+    out = model.forward(Xs, view_idx, Ns, S=2)
+    assert model._cache.fuse is not None and type(out[3][g.mods[0]]) is not torch.Tensor
+    model.loss_fn(dd, out[3]).backward()
+    assert "fused" in model._cache.fuse["state"]
