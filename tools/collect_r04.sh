@@ -8,7 +8,7 @@
 #   <tag>_strong_scaling_emulation.txt   rank 0's share of a K-way row sharding on one GPU
 #   <tag>_config3_kernel_stats.csv       BASELINE config 3 (bench.py --workload 3)
 set -u
-T=${1:-r04_d}
+T=${1:-r04_e}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04
 mkdir -p $O
