@@ -524,6 +524,14 @@ long long gpsa_step_scratch_bytes(const void* plan);
 long long gpsa_step_bwd_acc_bytes(const void* plan);  /* gpsa_step_io.bwd_acc */
 int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
+/* Where the step's factorisation batch sits in the ``saved`` arena, for the reference's forward -> loss_fn hand-off
+ * attributes Kuu_chol_list / curr_Omega_tril_list / Kuu_chol_F / curr_Omega_tril_F (vgpsa.py:237, 257, 321, 394, 412):
+ * the engine keeps the matrices (K_uu + 1e-5 I, Omega = A A^T + 1e-5 I; fp64, [B, M, M] per group) and their inverses,
+ * not the Cholesky factors, so the attributes are formed from these on access.  out[0] = number of groups (1: m_x ==
+ * m_g, one batch; 2: the warp GPs' group, then the data GP's); per group g at out[1 + 4 g]: M, priors, variational
+ * covariances, byte offset of the batch.  Order within a group: the priors (free views in order; the data GP's last /
+ * alone), then Omega_G rows 0 .. V*D-1 (group 0), then every modality's Omega_F rows. */
+int gpsa_step_batch_layout(const void* plan, long long* out);
 /* stages: bit 0 = the M x M factorisations, the KL terms and the warp GPs (everything ``flag`` depends on),
  * bit 1 = the data GPs.  3 = the whole forward; a caller that wants to look at ``flag`` while the data GPs
  * run enqueues the two stages with two calls and its flag copy in between.

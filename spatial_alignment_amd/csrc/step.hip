@@ -1580,7 +1580,11 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   BwdBufs B;
   memset(&B, 0, sizeof(B));
   const bool kl = P.d.want_kl != 0 && og.dkl != nullptr;
-  const bool fork = kl && P.side != nullptr && !dry;
+  // a slice of a microbatched step that does not close (bwd_acc_mode 1 / 2) leaves before the KL terms are joined:
+  // it must not start them either (its KL share is zero, and an unjoined fork would still be writing into the
+  // scratch arena when the next slice reuses it - and stays unjoined under stream capture)
+  const bool closes = io.bwd_acc == nullptr || io.bwd_acc_mode == 0 || io.bwd_acc_mode == 3;
+  const bool fork = kl && P.side != nullptr && !dry && closes;
   // the KL terms' backward runs on the side stream into buffers of its own (dKL: same layout as dstack)
   double* dKL[2] = {nullptr, nullptr};
   double* Skl[2] = {nullptr, nullptr};
@@ -1615,6 +1619,8 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   if (dry) {
     long long ab = z1 - z0;
     for (int m = 0; m < P.nm; ++m) ab += ((long long)Mg * P.d.n_latent[m] * 4 + 255) & ~255LL;
+    for (int m = 0; m < P.nm; ++m)  // dW [L, P] of the LMC modalities (written per slice, straight into out.W)
+      if (P.d.has_lmc[m]) ab += ((long long)P.d.n_latent[m] * P.d.n_out[m] * 4 + 255) & ~255LL;
     P.bwd_acc_bytes = ab + 256;
   }
   B.dZ_wu = sc.get<double>(nwz);
@@ -1629,7 +1635,7 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
     GPSA_CK((int)hipEventRecord(P.sev[3], st));
     GPSA_CK((int)hipStreamWaitEvent(P.side, P.sev[3], 0));
   }
-  for (int g = 0; g < P.ng && kl && P.side != nullptr; ++g) {
+  for (int g = 0; g < P.ng && kl && P.side != nullptr && closes; ++g) {
     Group& G = P.grp[g];
     if (G.n_omega == 0 || G.n_prior == 0) continue;
     const long long mm = (long long)G.M * G.M;
@@ -1686,12 +1692,31 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
       const long long n = (long long)Mg * P.d.n_latent[m];
       float* a = reinterpret_cast<float*>(accb + aoff);
       aoff += (n * 4 + 255) & ~255LL;
-      if (!B.have_ddc[m]) continue;
+      if (!B.have_ddc[m]) {  // no gradient reached this modality's draws in this slice
+        if (io.bwd_acc_mode == 1) GPSA_CK((int)hipMemsetAsync(a, 0, (size_t)(n * 4), st));
+        continue;
+      }
       if (io.bwd_acc_mode == 1) {
         GPSA_CK((int)hipMemcpyAsync(a, B.ddc_F[m], (size_t)(n * 4), hipMemcpyDeviceToDevice, st));
       } else {
         add_inplace_f32_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? a : B.ddc_F[m],
                                                                         io.bwd_acc_mode == 2 ? B.ddc_F[m] : a, n);
+        GPSA_LAUNCH_CHECK();
+      }
+    }
+    // dW = F^T dF_obs of an LMC modality goes straight into the caller's gradient (data_pass_bwd; the host zeroes it
+    // when no gradient reached F_obs): a slice that does not close hands autograd nothing, so its share travels here
+    for (int m = 0; m < P.nm; ++m) {
+      if (!P.d.has_lmc[m]) continue;
+      const long long n = (long long)P.d.n_latent[m] * P.d.n_out[m];
+      float* a = reinterpret_cast<float*>(accb + aoff);
+      aoff += (n * 4 + 255) & ~255LL;
+      if (out.W[m] == nullptr) continue;
+      if (io.bwd_acc_mode == 1) {
+        GPSA_CK((int)hipMemcpyAsync(a, out.W[m], (size_t)(n * 4), hipMemcpyDeviceToDevice, st));
+      } else {
+        add_inplace_f32_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? a : out.W[m],
+                                                                        io.bwd_acc_mode == 2 ? out.W[m] : a, n);
         GPSA_LAUNCH_CHECK();
       }
     }
@@ -1884,6 +1909,18 @@ int gpsa_step_n_kl(const void* plan) {
   return p->V * p->D + p->Ltot;
 }
 long long gpsa_step_eps_g_numel(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->eps_total : -1; }
+int gpsa_step_batch_layout(const void* plan, long long* out) {
+  if (!plan || !out) return GPSA_EINVAL;
+  const gpsa::Plan* p = reinterpret_cast<const gpsa::Plan*>(plan);
+  out[0] = p->ng;
+  for (int g = 0; g < p->ng; ++g) {
+    out[1 + 4 * g] = p->grp[g].M;
+    out[2 + 4 * g] = p->grp[g].n_prior;
+    out[3 + 4 * g] = p->grp[g].n_omega;
+    out[4 + 4 * g] = p->grp[g].o_mats;
+  }
+  return 0;
+}
 
 /* timing of the contraction kernels (diagnostic; bench.py): events around gpsa_quadform_fwd / _bwd_alpha /
  * _bwd_omega of the first data-GP pass for the next ``slots`` steps (a ring); 0 switches it off */

@@ -160,7 +160,10 @@ def materialize_values(rec, i, attach=False):
     io2 = _lib.StepIO.from_buffer_copy(io)
     io2.Y[i] = None
     io2.F_latent[i] = F.data_ptr()
-    io2.keep_products = 0
+    # attached: the forward's own io (and its keep_products) drives this pass's backward, which then streams the kept
+    # products back - they must be written now (the arena was sized for them: StepFn.forward's ``need``); a peek
+    # leaves nothing behind
+    io2.keep_products = io.keep_products if attach else 0
     o = _ops_mod.get_ops()
     scratch = o._ws(plan.scratch_bytes, saved)
     call = TO.stash(dict(lib=plan.lib, handle=plan.handle, prm=prm, io=io2))

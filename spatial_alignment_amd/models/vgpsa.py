@@ -133,10 +133,11 @@ class VariationalGPSA(GPSA):
         self.fuse_min_flops = float(os.environ.get("GPSA_FUSE_MIN_FLOPS", "5e9"))
         self.keep_budget_gb = None  # HBM for those products: None = what the device can still give (step_engine.py)
         # the data GP's inducing-point gradient from the UNROUNDED projection (gpsa_step_desc.exact_inducing_grad):
-        # True / False, or None = on when its one extra M x M x C fp64 product is under ~2 % of the step (L >= 128;
-        # 3.8 % at the 50 outputs of the headline configuration).
-        # Off, grad Gtilde carries ~1e-3 relative error at M >= 200 on ill-conditioned K_uu (every other gradient
-        # and every output are unaffected): its K_uu and K_uf shares cancel to 1e-4 .. 1e-5 of their size.
+        # None / True = on (round 5: the default everywhere, so that the step that is timed is the step every gradient
+        # of which the parity suite holds to 1e-4 of the reference's fp64 run); False (or GPSA_EXACT_GRAD=0) = off:
+        # grad Gtilde then carries ~1e-3 relative error at M >= 200 on ill-conditioned K_uu (every other gradient and
+        # every output are unaffected: its K_uu and K_uf shares cancel to 1e-4 .. 1e-5 of their size), the step is one
+        # M x M x C fp64 product and some fp64 panel traffic cheaper (bench.py reports both: "exact_inducing_grad").
         self.exact_inducing_grad = None
         self._noise = None  # injected Gaussian noise (tests / reproducibility), see inject_noise()
         self._cache = None
@@ -297,6 +298,98 @@ class VariationalGPSA(GPSA):
         if cache is None or cache.mu_z is None or (isinstance(cache.mu_z, list) and not cache.mu_z):
             raise AttributeError("mu_z_G is available after forward")
         return cache.mu_z if torch.is_tensor(cache.mu_z) else torch.stack(cache.mu_z)
+
+    # ---- the reference's forward -> loss_fn hand-off attributes (vgpsa.py:237, 257, 321, 353-355, 394, 412) ------------
+    # Kuu_chol_list [V, M_X, M_X] (NaN for fixed / empty views), curr_Omega_tril_list [V*D, M_X, M_X], Kuu_chol_F
+    # [M_G, M_G], curr_Omega_tril_F {mod: [L, M_G, M_G]}: the lower Cholesky factors of K_uu + 1e-5 I and of
+    # Omega = A A^T + 1e-5 I.  The step never forms them (its layers use explicit fp64 inverses, its KL the
+    # log-determinants): the engine keeps the MATRICES in its arena's fp64 batch and these properties factorise them on
+    # access (gpsa_chol_f64, once per forward, memoised), rounded to the parameters' dtype, detached.  While the
+    # forward's arena is alive (until its backward has run; parked arenas of a GiB and more stay valid until the next
+    # forward) they are the forward's own matrices; afterwards they are recomputed from the CURRENT parameters with the
+    # same kernels - equal to the reference's until the optimiser has stepped.
+    def _handoff_factors(self):
+        cache = self.__dict__.get("_cache")
+        if cache is None:
+            raise AttributeError("Kuu_chol_list / curr_Omega_tril_list / Kuu_chol_F / curr_Omega_tril_F are available "
+                                 "after forward")
+        memo = cache.__dict__.get("_handoff")
+        if memo is not None:
+            return memo
+        import ctypes as C_
+
+        mods = self.modality_names
+        V, D = self.n_views, self.n_spatial_dims
+        f64 = torch.float64
+        free = [v for v in range(V) if not self._is_fixed(v)]
+        o = E.ops()
+        arena_ref = cache.__dict__.get("arena_ref")
+        arena = arena_ref() if arena_ref is not None else None
+        plan = cache.__dict__.get("plan")
+        live = set(free)
+        if plan is not None:  # a view without rows in that forward is skipped by the reference (vgpsa.py:296-297)
+            live = {v for v in free if sum(plan.rows[i * V + v] for i in range(len(mods))) > 0}
+        with torch.no_grad():
+            if arena is not None and plan is not None:
+                lay = (C_.c_longlong * 9)()
+                if plan.lib.gpsa_step_batch_layout(plan.handle, lay) != 0:
+                    raise RuntimeError("gpsa_step_batch_layout refused the plan")
+                groups = []
+                for g in range(int(lay[0])):
+                    M, npri, nom, off = (int(lay[1 + 4 * g + j]) for j in range(4))
+                    nb = npri + nom
+                    groups.append((arena[off: off + nb * M * M * 8].view(f64).view(nb, M, M), npri))
+                merged = len(groups) == 1
+                (m0, np0), (m1, _) = groups[0], groups[-1]
+                Kw = {v: m0[b] for b, v in enumerate(free)}
+                KF = m1[len(free) if merged else 0]
+                OmG = m0[np0: np0 + V * D]
+                base = np0 + V * D if merged else 1
+                OmF = {}
+                for m in mods:
+                    L = int(self.n_latent_outputs[m])
+                    OmF[m] = m1[base: base + L]
+                    base += L
+            elif cache.data is not None:  # per-layer path: the matrices are on the cache
+                Kw = {v: kf[0] for v, kf in cache.warp.items()}
+                KF = cache.data[0]
+                OmG, OmF = cache.Omega_G, dict(cache.Omega_F)
+            else:  # the forward's arena is gone: the same kernels on the current parameters
+                wide = lambda t: t.double() if t.dtype == torch.float32 else t
+                Kw = {v: self._kmat("warp", wide(self.Xtilde[v]), wide(self.Xtilde[v]),
+                                    wide(self.warp_kernel_lengthscales[v]), wide(self.warp_kernel_variances[v]),
+                                    self.diagonal_offset, f64, True) for v in free}
+                KF = self._kmat("data", wide(self.Gtilde), wide(self.Gtilde), wide(self.data_kernel_lengthscale),
+                                wide(self.data_kernel_variance), self.diagonal_offset, f64, True)
+                OmG = E.OmegaFn.apply(self.Omega_sqt_G_list)
+                OmF = {m: E.OmegaFn.apply(self.Omega_sqt_F_dict[m]) for m in mods}
+            dt = self.Xtilde.dtype
+            chol = lambda A: o.chol(A.detach().to(f64).reshape(-1, A.shape[-1], A.shape[-1]))[0].to(dt)
+            Mx = int(self.Xtilde.shape[1])
+            Kl = torch.full([V, Mx, Mx], float("nan"), dtype=dt, device=self.Xtilde.device)
+            vs = [v for v in free if v in live and v in Kw]
+            if vs:
+                Kl[vs] = chol(torch.stack([Kw[v].detach().to(f64) for v in vs]))
+            memo = dict(Kuu_chol_list=Kl, curr_Omega_tril_list=chol(OmG), Kuu_chol_F=chol(KF)[0],
+                        curr_Omega_tril_F={m: chol(OmF[m]) for m in mods})
+        cache.__dict__["_handoff"] = memo
+        return memo
+
+    @property
+    def Kuu_chol_list(self):
+        return self._handoff_factors()["Kuu_chol_list"]
+
+    @property
+    def curr_Omega_tril_list(self):
+        return self._handoff_factors()["curr_Omega_tril_list"]
+
+    @property
+    def Kuu_chol_F(self):
+        return self._handoff_factors()["Kuu_chol_F"]
+
+    @property
+    def curr_Omega_tril_F(self):
+        return self._handoff_factors()["curr_Omega_tril_F"]
 
     def _side_streams(self, n, device):
         pool = self.__dict__.setdefault("_stream_pool", [])
@@ -688,6 +781,7 @@ class VariationalGPSA(GPSA):
         cache.kl = outs[k] if not prediction_mode else None
         cache.mu_z, cache.engine_flag = aux["mu_z"], aux["flag"]
         cache.fuse = aux["fuse"]
+        cache.plan, cache.arena_ref = plan, aux.get("arena_ref")  # (the hand-off attributes read the arena's batch)
         if cache.fuse is not None:
             # a fused modality's "F_latent" output is the vector of partial sums its likelihood finishes from: what the
             # caller gets is a handle with the draws' shape that loss_fn recognises and that materialises on any other use

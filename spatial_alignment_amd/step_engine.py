@@ -206,8 +206,8 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     exact = getattr(model, "exact_inducing_grad", None)
     if exact is None and os.environ.get("GPSA_EXACT_GRAD") in ("0", "1"):
         exact = os.environ["GPSA_EXACT_GRAD"] == "1"
-    if exact is None:  # automatic: on where it costs under ~1 % of the step (one M x M x C fp64 product next to 3 L of them)
-        exact = min(L) >= 128
+    if exact is None:  # the default: every gradient within 1e-4 of the reference's fp64 run
+        exact = True
     exact = int(bool(exact))
     key = (V, D, len(mods), int(S), int(model.Xtilde.shape[1]), int(model.Gtilde.shape[0]), kw, kd, L, P, lmc, N,
            s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index, keep_gb, exact)
@@ -419,6 +419,12 @@ class StepFn(torch.autograd.Function):
             fuse["live"] = dict(plan=plan, io=io, prm=prm, saved=saved, tensors=tensors,
                                 ins=[t for t in aux["X"] + list(aux["eps_F"]) + [aux["eps_G"]] if t is not None])
         aux["pending"], aux["mu_z"], aux["flag"] = pending, mu_z, flag
+        # what a SECOND backward through this node (retain_graph=True) needs to fill a fresh arena again: the call's
+        # tensor lists (aliases without a grad_fn: an output held here would close a cycle node -> ctx -> output)
+        aux["rerun"] = dict(ins=ins, outs=[t.detach() for t in flat_outs], keep=bool(keep), rest=rest)
+        import weakref
+
+        aux["arena_ref"] = weakref.ref(saved)
         ctx.aux, ctx.io, ctx.prm = aux, io, prm
         ctx.arena = saved
         flat = outs["Gm"] + outs["Gs"] + outs["Fl"] + outs["Fo"] + outs["Flt"] + outs["Fot"]
@@ -436,15 +442,14 @@ class StepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         aux = ctx.aux
-        if aux is None or ctx.arena is None:
-            raise RuntimeError("GPSA step: backward through the same forward a second time - its saved arena was "
-                               "released after the first backward (run forward again)")
         plan, model = aux["plan"], aux["model"]()
+        tensors = ctx.saved_tensors[: ctx.n_in]  # (a second backward without retain_graph=True: torch raises here)
+        if ctx.arena is None:
+            StepFn._refill(ctx, aux, plan, model, tensors)
         # the forward's numerics word: waited for AFTER this backward's launches are queued (below), raised before
         # any gradient is handed to autograd
         pend_check, aux["deferred"] = aux.get("deferred"), None
         lib = plan.lib
-        tensors = ctx.saved_tensors[: ctx.n_in]
         dev = tensors[0].device
         nm = len(plan.mods)
         f32 = torch.float32
@@ -552,7 +557,7 @@ class StepFn(torch.autograd.Function):
         if fuse is not None:  # the arena is gone: so is the chance to materialise this forward's draws
             fuse["live"] = None
             fuse["gloss"] = None
-        ctx.aux = ctx.io = ctx.prm = None
+        # (aux / io / prm stay: a second backward - retain_graph=True - fills a fresh arena from them, _refill)
         if pend_check is not None:
             # (round 4: this wait used to open the backward.  On a launch-bound problem - BASELINE config 1's size - the
             #  host then sat out the device's backlog before it queued a single backward launch, and the device idled
@@ -569,6 +574,41 @@ class StepFn(torch.autograd.Function):
 
                 VariationalGPSA._raise_on_flags(pend_check)
         return tuple(out)
+
+
+    @staticmethod
+    def _refill(ctx, aux, plan, model, tensors):
+        """A second backward through one forward (``retain_graph=True``; the reference's graph, holding every
+        intermediate, allows it - vgpsa.py:212-540): the arena went back to the allocator with the first backward, so
+        the forward's launches run once more - same parameters (torch's version check on the saved tensors has just
+        passed), same inputs, same draws, hence the same numbers into the same output buffers - into a fresh one."""
+        re = aux["rerun"]
+        dev = tensors[0].device
+        o = _ops_mod.get_ops()
+        sib = [q for q in (model.__dict__.get("_step_plans", {}).values() if model is not None else ()) if q is not plan]
+        need = plan.saved_bytes if re["keep"] else plan.saved_bytes_nokeep
+        saved = _take_arena(plan, need, dev, must=True, siblings=sib)
+        ctx.io.reuse_mm = 0
+        scratch = o._ws(plan.scratch_bytes, saved)
+        fuse = aux.get("fuse")
+        stages, extra = 3, []
+        if fuse is not None:
+            # stage 1, then the data GPs that ran: the ones forward itself ran (``rest``), the ones loss_fn ran fused
+            # (their observations are on the record) and the ones that were materialised (their io slots point at the
+            # real draws); an untouched lazy one is skipped by the backward anyway
+            mask = re["rest"] | sum(1 << (8 + i) for i, st in enumerate(fuse["state"]) if st in ("fused", "real"))
+            stages = 1 | ((2 | mask) if mask else 0)
+            extra = ([y for y in fuse["Y"] if y is not None] + [fuse["noise"]]
+                     + [f for f in fuse["F_real"] if f is not None] + [t for t in fuse["FT"] if t is not None])
+        call = TO.stash(dict(lib=plan.lib, handle=plan.handle, prm=ctx.prm, io=ctx.io))
+        try:
+            torch.ops.gpsa.step_forward(list(tensors), re["ins"] + extra, re["outs"], saved, scratch, call, stages)
+        finally:
+            TO.CALLS.pop(call, None)
+        ctx.arena = saved
+        ctx.shared_arena = False
+        if fuse is not None:
+            fuse["live"] = None
 
 
 class ElboLossFn(torch.autograd.Function):

@@ -53,12 +53,17 @@ class Microbatches:
         self.model, self.K = model, int(K)
         if self.K < 1:
             raise ValueError(f"Microbatches: K = {K} slices")
-        # every slice must hold rows: with sizes rounded up to ``quantum``, slice k of a view starts at k * per
-        biggest = max(int(n) for d in data_dict.values() for n in d["n_samples_list"])
-        per_max = -(-(-(-biggest // self.K)) // quantum) * quantum
-        if (self.K - 1) * per_max >= biggest:
-            raise ValueError(f"Microbatches: K = {self.K} slices of multiples of {quantum} rows leave the last slice(s) "
-                             f"empty in every view (largest view: {biggest} rows); use K <= {max(1, -(-biggest // quantum))}")
+        # every slice must hold rows OF EVERY MODALITY: a modality without rows in a slice drops that slice's data-GP
+        # pass from its plan, and the accumulator the slices' backwards share (gpsa_step_io.bwd_acc) mirrors the
+        # per-pass gradient pieces byte for byte across the slices' plans.  With sizes rounded up to ``quantum``,
+        # slice k of a view starts at k * per: a modality's last slice is non-empty iff its largest view reaches it
+        for mod, d in data_dict.items():
+            biggest = max(int(n) for n in d["n_samples_list"])
+            per_max = -(-(-(-biggest // self.K)) // quantum) * quantum
+            if (self.K - 1) * per_max >= biggest:
+                raise ValueError(f"Microbatches: K = {self.K} slices of multiples of {quantum} rows leave the last "
+                                 f"slice(s) without rows of modality {mod!r} (largest view: {biggest} rows); use "
+                                 f"K <= {max(1, -(-biggest // quantum))}")
         self.slices, self.bounds = [], []  # bounds[k][mod] = [(lo, hi) of slice k within view v]
         for k in range(self.K):
             dd = {}

@@ -90,3 +90,34 @@ def compare(res, g, tol_out, tol_grad, tag="ref64", ref32_bar=False):
         if not e <= t:
             bad[k] = (e, t)
     return bad, errs
+
+
+def _handoff_reference(g):
+    """the reference's forward -> loss_fn hand-off state from the fp64 oracle (vgpsa.py:237, 257, 321, 394, 412)"""
+    import torch
+    from oracle import gpsa_oracle as orc
+
+    st = {k: v.double() for k, v in g.full_state().items()}
+    view_idx, Ns = orc.make_view_index(g.cfg["n_samples"])
+    _, h = orc.forward_pass(st, g.oracle_cfg(), {m: g.X[m].double() for m in g.mods}, view_idx, Ns, g.S,
+                            [e.double() for e in g.eps_G], {m: e.double() for m, e in g.eps_F.items()})
+    return h
+
+
+def _check_handoff(model, h, tol=1e-5):
+    import torch
+
+    rel_ = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())
+    Kl = model.Kuu_chol_list
+    assert tuple(Kl.shape) == (model.n_views, model.Xtilde.shape[1], model.Xtilde.shape[1])
+    for v, Lk in enumerate(h["Kuu_chol_G"]):
+        if Lk is None:
+            assert torch.isnan(Kl[v]).all()      # fixed view: the reference leaves NaN (vgpsa.py:237, 262-273)
+        else:
+            assert rel_(Kl[v], Lk) < tol
+    assert rel_(model.curr_Omega_tril_list, h["Omega_tril_G"]) < tol
+    assert rel_(model.Kuu_chol_F, h["Kuu_chol_F"]) < tol
+    assert set(model.curr_Omega_tril_F) == set(h["Omega_tril_F"])
+    for m, Ot in h["Omega_tril_F"].items():
+        assert rel_(model.curr_Omega_tril_F[m], Ot) < tol
+    assert Kl.dtype == model.Xtilde.dtype and not Kl.requires_grad

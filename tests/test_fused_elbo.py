@@ -309,3 +309,36 @@ def test_small_problems_take_the_separate_kernels_by_default():
     assert model._cache.fuse is not None and type(out[3][g.mods[0]]) is not torch.Tensor
     model.loss_fn(dd, out[3]).backward()
     assert "fused" in model._cache.fuse["state"]
+
+
+def test_materialising_next_to_an_unfused_modality_keeps_its_products():
+    """a fusable modality next to an LMC one (``keep_products`` stays on for the step), touched before
+    loss_fn: the attached unfused pass must WRITE the products its backward then streams back (it ran with
+    keep_products = 0 and the backward read an unwritten region: garbage gradients, no error)"""
+    g = Golden("c5_two_modalities")
+    got = {}
+    for fuse in (True, False):
+        model, dd = build_model(g, device=DEV)
+        model.fuse_elbo, model.fuse_min_flops = fuse, 0
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+        model.inject_noise(g.eps_G, g.eps_F, None)
+        out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)
+        if fuse:
+            rec = model._cache.fuse
+            assert rec is not None and rec["mods"] == [True, False]
+            assert rec["live"]["io"].keep_products == 1          # the LMC modality keeps its products
+        peek = out[3]["rna"][0, :3].detach().clone()             # an index: the handle materialises, attached
+        if fuse:
+            assert rec["state"][0] == "real"
+        loss = model.loss_fn(dd, out[3])
+        loss.backward()
+        got[fuse] = (loss.detach().clone(), peek, _grads(model))
+    assert torch.allclose(got[True][0], got[False][0], rtol=1e-6)
+    assert torch.allclose(got[True][1], got[False][1], rtol=1e-5, atol=1e-6)
+    for k, b in got[False][2].items():
+        a = got[True][2][k]
+        if b is None or float(b.norm()) == 0:
+            continue
+        assert a is not None, k
+        assert float((a.double() - b.double()).norm() / b.double().norm()) <= 1e-5, k

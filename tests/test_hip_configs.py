@@ -46,7 +46,7 @@ def _step_vs_oracle(side, views, outputs, M, S, fixed, seed, kernel_warp=gp.rbf_
     model = make_model(dd, m=M, n_latent_gps={MOD: None}, fixed_view_idx=fixed, device="cpu", seed=seed,
                        kernel_func_warp=kernel_warp, kernel_func_data=gp.rbf_kernel)
     _perturb(model, seed + 1)
-    model.exact_inducing_grad = True  # (what the configurations' 2000 / 1000 outputs switch on by themselves)
+    assert model.exact_inducing_grad is None  # the default: exact
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     for name in ("mean_slopes", "mean_intercepts"):
         state.setdefault(name, getattr(model, name).detach().clone())
@@ -170,6 +170,63 @@ def test_config3_full_size_properties():
             p.add_(h * d)
         fd = float(lp - lm) / (2 * h)
         assert abs(fd - gdir) <= 3e-2 * max(abs(gdir), 1.0), (fd, gdir)
+
+
+@pytest.mark.parametrize("S", [1, 5])
+def test_config3_full_size_matches_fp64_oracle(S):
+    """BASELINE config 3 at FULL size - 4 views x 10 000 spots, 500 outputs through 10 latent GPs (LMC, W [10, 500]),
+    Matern-1/2 warp / RBF data, M = 200 - one training step (the reference's two calls: forward, then loss_fn, which
+    takes the LMC likelihood without forming F_obs) against the fp64 oracle, vgpsa.py:212-540 end to end: every output,
+    the ELBO and EVERY gradient, W_dict included, within 1e-4 norm-wise.  The oracle's [S, L, N, M] tensor is 0.64 GB
+    at S = 1 and 3.2 GB at S = 5 (the S the bench line's ``config3`` key times)."""
+    from oracle import gpsa_oracle as orc
+    from spatial_alignment_amd.lazy import LazyProduct
+
+    side, views, P, Lg, M = 100, 4, 500, 10, 200
+    if S > 1:
+        import psutil
+
+        if psutil.virtual_memory().available < 48 * 2**30:
+            pytest.skip("the fp64 oracle at S = 5 wants ~30 GB of host memory")
+    dd = make_grid_problem(side=side, n_views=views, n_outputs=P, device="cpu")
+    model = make_model(dd, m=M, n_latent_gps={MOD: Lg}, fixed_view_idx=None, device="cpu", seed=30,
+                       kernel_func_warp=gp.matern12_kernel, kernel_func_data=gp.rbf_kernel)
+    _perturb(model, 31)
+    assert model.exact_inducing_grad is None  # the default: exact
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for name in ("mean_slopes", "mean_intercepts"):
+        state.setdefault(name, getattr(model, name).detach().clone())
+    model = model.to(DEV)
+    n, N = side * side, side * side * views
+    gen = torch.Generator().manual_seed(32)
+    eps_G = [torch.randn(S, n, 2, generator=gen) for _ in range(views)]
+    eps_F = {MOD: torch.randn(S, N, Lg, generator=gen)}
+    ddd = {MOD: {"spatial_coords": dd[MOD]["spatial_coords"].to(DEV), "outputs": dd[MOD]["outputs"].to(DEV),
+                 "n_samples_list": dd[MOD]["n_samples_list"]}}
+    view_idx, Ns, _, _ = model.create_view_idx_dict(ddd)
+    model.inject_noise(eps_G, eps_F, None)
+    out = model.forward({MOD: ddd[MOD]["spatial_coords"]}, view_idx=view_idx, Ns=Ns, S=S)
+    assert isinstance(out[3][MOD], LazyProduct)
+    loss = model.loss_fn(ddd, out[3])
+    assert not out[3][MOD].is_materialized  # the fused LMC likelihood ran (gpsa_lmc_loglik_fused_f32)
+    loss.backward()
+    cfg = dict(modality_names=[MOD], n_views=views, n_spatial_dims=2, kernel_warp="matern12", kernel_data="rbf",
+               n_latent_gps={MOD: Lg}, fixed_view_idx=None)
+    ref = orc.evaluate(state, cfg, {MOD: dd[MOD]["spatial_coords"]}, {MOD: dd[MOD]["outputs"]},
+                       {MOD: dd[MOD]["n_samples_list"]}, S, eps_G, eps_F, dtype=torch.float64)
+    errs = {"G_means": rel(out[0][MOD].detach().cpu().numpy(), ref["G_means"][MOD].numpy()),
+            "G_samples": rel(out[1][MOD].detach().cpu().numpy(), ref["G_samples"][MOD].numpy()),
+            "F_latent": rel(out[2][MOD].detach().cpu().numpy(), ref["F_latent"][MOD].numpy()),
+            "F_samples": rel(out[3][MOD].detach().cpu().numpy(), ref["F_obs"][MOD].numpy()),
+            "loss": rel(loss.detach().cpu().numpy(), ref["loss"].numpy())}
+    gerr = {k: rel(p.grad.detach().cpu().numpy(), ref["grads"][k].numpy())
+            for k, p in model.named_parameters() if k in ref["grads"] and float(ref["grads"][k].norm()) > 0}
+    print(f"config 3, full size, S = {S}, vs fp64 oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
+    print("   gradients:", {k: f"{v:.1e}" for k, v in gerr.items()})
+    assert f"W_dict.{MOD}" in gerr
+    assert all(v < 1e-4 for v in errs.values()), errs
+    for k, e in gerr.items():
+        assert e < 1e-4, (k, e)
 
 
 # ---------------------------------------------------------------------------------------------------------

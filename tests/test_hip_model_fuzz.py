@@ -52,7 +52,7 @@ def test_random_configuration_matches_oracle(seed):
     for name in ("mean_slopes", "mean_intercepts"):
         state.setdefault(name, getattr(model, name).detach().clone())
     model = model.to(DEV)
-    model.exact_inducing_grad = True
+    assert model.exact_inducing_grad is None  # the default: exact
     S, L = c["S"], (c["latent"] or c["P"])
     free = [v for v in range(c["V"]) if v != c["fixed"]]
     eps_G = [torch.randn(S, c["ns"][v], c["D"], generator=gen) for v in free]

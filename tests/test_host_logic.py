@@ -197,3 +197,16 @@ def test_empty_free_view_keeps_its_kl_terms():
     assert torch.isfinite(loss)
     assert model.Xtilde.grad[1].abs().max() > 0 and model.delta_G_list.grad[1].abs().max() > 0
     assert model.Omega_sqt_G_list.grad.abs().sum((-1, -2)).min() > 0
+
+
+@pytest.mark.parametrize("name", ["c1_example_fixed0", "c5_two_modalities"])
+def test_handoff_attributes_match_reference(name):
+    """Kuu_chol_list / curr_Omega_tril_list / Kuu_chol_F / curr_Omega_tril_F exist after forward"""
+    from model_util import _check_handoff, _handoff_reference
+
+    g = Golden(name)
+    model, dd = build_model(g)
+    with pytest.raises(AttributeError):
+        model.Kuu_chol_F
+    run_step(model, dd, g)
+    _check_handoff(model, _handoff_reference(g))

@@ -251,3 +251,19 @@ def test_microbatched_step_accumulates_the_full_gradient():
             assert (got - want[k]).norm() <= 2e-3 * max(float(want[k].norm()), 1e-6), k
     finally:
         ops_mod.set_ops(None)
+
+
+def test_microbatches_refuse_a_slice_without_rows_of_a_modality():
+    """every modality must have rows in every slice (the accumulator mirrors the per-pass gradient pieces
+    across the slices' plans)"""
+    from spatial_alignment_amd.train import Microbatches
+
+    class M:  # (the constructor's check needs no model)
+        def create_view_idx_dict(self, dd):
+            raise AssertionError("reached slicing")
+
+    x = lambda n: torch.zeros(n, 2)
+    dd = {"a": {"spatial_coords": x(200), "outputs": x(200), "n_samples_list": [100, 100]},
+          "b": {"spatial_coords": x(16), "outputs": x(16), "n_samples_list": [8, 8]}}
+    with pytest.raises(ValueError, match="modality 'b'"):
+        Microbatches(M(), dd, 4)  # slices of 4 rows: modality b's views end after two of them

@@ -131,6 +131,58 @@ def test_microbatched_hip_step_equals_full_hip_step():
     assert mb.__dict__.get("_fold") is not None and model.__dict__.get("_bwd_acc") is None
 
 
+@pytest.mark.parametrize("fuse", [False, True])
+def test_microbatched_lmc_step_equals_full_step(fuse):
+    """an LMC modality's dW = F^T dF_obs is written per slice straight into the caller's gradient; the slices
+    that do not close hand autograd nothing, so their share must travel through the accumulator.  ``fuse`` False: the
+    separate kernels (dW from the engine); True: loss_fn's fused LMC likelihood (dW from its own node)."""
+    import __graft_entry__ as ge
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+    from spatial_alignment_amd.train import Microbatches
+
+    ge.build()
+    dev = torch.device("cuda:0")
+    dd = make_grid_problem(side=20, n_views=2, n_outputs=6)
+    model = make_model(dd, m=25, device=dev, n_latent_gps={"expression": 3})
+    dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
+              "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
+    gen = torch.Generator().manual_seed(12)
+    eG, eF = [torch.randn(3, 400, 2, generator=gen) for _ in range(2)], torch.randn(3, 800, 3, generator=gen)
+    model.fuse_elbo = fuse
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    model.inject_noise(eG, {"expression": eF})
+    model.zero_grad()
+    out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=3)
+    loss1 = model.loss_fn(dd, out[3])
+    loss1.backward()
+    want = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    assert float(want["W_dict.expression"].norm()) > 0
+
+    class Probe(torch.optim.Optimizer):
+        def __init__(self, params):
+            super().__init__(params, {})
+            self.seen = None
+
+        def step(self):
+            self.seen = {id(p): p.grad.detach().clone() for g in self.param_groups for p in g["params"] if p.grad is not None}
+
+    K = 4
+    mb = Microbatches(model, dd, K)
+    noise = []
+    for k in range(K):
+        b = mb.bounds[k]["expression"]
+        rows = torch.cat([400 * v + torch.arange(lo, hi) for v, (lo, hi) in enumerate(b)])
+        noise.append(([e[:, lo:hi] for e, (lo, hi) in zip(eG, b)], {"expression": eF[:, rows]}))
+    opt = Probe(model.parameters())
+    for rep in range(2):  # (the first step has no plan yet and closes per slice; the second folds)
+        total = mb.step(opt, S=3, noise=noise)
+        assert abs(float(total) - float(loss1)) <= 1e-5 * abs(float(loss1)), (float(total), float(loss1))
+        for k, p in model.named_parameters():
+            a, b = want[k], opt.seen[id(p)]
+            assert (a - b).norm() <= 1e-3 * max(float(a.norm()), 1e-6), (rep, k, float((a - b).norm()), float(a.norm()))
+    assert mb.__dict__.get("_fold") is not None
+
+
 # ---------------------------------------------------------------------------------------------------------
 # output (L-axis) sharding: BASELINE configs 4 / 5's scheme (parallel.shard_outputs / setup_output_sharding)
 # ---------------------------------------------------------------------------------------------------------
@@ -221,47 +273,3 @@ def test_output_sharded_hip_step_equals_full_hip_step():
             b = per_rank[0][k]
             assert np.array_equal(per_rank[0][k], per_rank[1][k]), k
         assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
-
-
-def _graph_worker(port, q):
-    """EXPERIMENT (tools/try_graph_step.py), not a test: one rank, RCCL backend, the sharded step WITH its
-    all-reduce captured into one hipGraph.  A bare all-reduce captures and replays fine on this build
-    (tools/try_graph_allreduce.py); inside the whole step torch's process-group watchdog polls an event that
-    was recorded in the capturing stream (hipErrorCapturedEvent) and aborts.  The eager step is the multi-GPU
-    path: its host cost (1 ms) is below its GPU time at every shard size, so a graph has nothing to win."""
-    import __graft_entry__ as ge
-    from spatial_alignment_amd.optim import FusedAdam
-    from spatial_alignment_amd.parallel import GradAllReducer
-    from spatial_alignment_amd.train import GraphedTrainStep, train_step
-
-    ge.build()
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    res = []
-    eG, eF = _noise()
-    eG, eF = [e.to(dev) for e in eG], eF.to(dev)
-    for mode in ("eager", "graph"):
-        dd, model = _problem(dev)
-        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
-        opt = FusedAdam(model.parameters(), lr=1e-2)
-        reducer = GradAllReducer(model.parameters(), always=True)
-        orig = model.forward
-
-        def fwd(*a, _orig=orig, _m=model, **k):  # same injected noise on every call
-            _m.inject_noise(eG, {"expression": eF})
-            return _orig(*a, **k)
-
-        model.forward = fwd
-        if mode == "eager":
-            for _ in range(4):
-                loss = train_step(model, opt, dd, view_idx, Ns, S=3, reducer=reducer)
-        else:
-            gs = GraphedTrainStep(model, opt, dd, view_idx, Ns, S=3, warmup=3, reducer=reducer)
-            loss = gs.step()
-            gs.check()
-        torch.cuda.synchronize()
-        res.append((float(loss), {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
-    q.put(res)
-    dist.destroy_process_group()

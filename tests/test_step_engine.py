@@ -110,11 +110,23 @@ def test_arenas_do_not_pile_up():
         assert used[-1] <= used[1] + (1 << 20), used
     finally:
         gc.enable()
-    out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
-    loss = model.loss_fn(dd, out[3])
-    loss.backward(retain_graph=True)
-    with pytest.raises(RuntimeError, match="second time"):
+    # a SECOND backward through one forward (retain_graph=True; the reference's graph allows it): the arena went back
+    # with the first one, the node fills a fresh one from the same inputs and draws - the gradients simply accumulate
+    for fuse in (True, False):
+        model.fuse_elbo = fuse
+        model.zero_grad(set_to_none=True)
+        out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=2)
+        loss = model.loss_fn(dd, out[3])
+        loss.backward(retain_graph=True)
+        once = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
         loss.backward()
+        for k, p in model.named_parameters():
+            if k in once and float(once[k].norm()) > 0:
+                err = float((p.grad - 2 * once[k]).norm() / (2 * once[k]).norm())
+                assert err <= 1e-6, (fuse, k, err)
+        with pytest.raises(RuntimeError, match="second time"):  # (torch's own refusal: nothing was retained)
+            loss.backward()
+        del out, loss
 
 
 def test_engine_unequal_views_and_user_loss_on_G():
