@@ -340,6 +340,18 @@ int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long lon
 int gpsa_kmat_bwd_x64_f64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
                           const float* var_u, const double* Kbar, double* dZ, double* dX, double* dparams,
                           void* workspace, long long workspace_bytes, void* stream);
+/* ... the fp64 panel in two pieces, Kbar[m,c] + s * d[c] * X2[m,c] (X2 [M,C] fp64, d [C] fp32; both NULL: Kbar
+ * alone): the exact mode's dK_uf = K^-1 abar + 2 qbar o alpha on the unrounded projection, formed as it is read */
+int gpsa_kmat_bwd_x64_f64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                               const float* var_u, const double* Kbar, const double* X2, const float* d, double s,
+                               double* dZ, double* dX, double* dparams, void* workspace, long long workspace_bytes,
+                               void* stream);
+/* C += -(G + d o A) A^T: the exact mode's dK_uu = -(K^-1 abar + qbar o alpha) alpha^T (autograd of vgpsa.py:177-180
+ * through K_uu) as ONE C-long fp64 product whose left operand is formed from its two panels as it is staged.
+ * G, A [M, C] fp64, d [C] fp32, dK [M, M] fp64 (added to); workspace >= gpsa_exact_dkuu_workspace(M, C) bytes. */
+long long gpsa_exact_dkuu_workspace(int M, long long C);
+int gpsa_exact_dkuu_f64(const double* G, const double* A, const float* d, int M, long long C, double* dK,
+                        void* workspace, long long workspace_bytes, void* stream);
 /* ... with the gradient panel in two pieces, Kbar[m,c] + s * d[c] * X2[m,c] (X2 [M,C], d [C] fp32; both NULL: Kbar
  * alone): the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) formed as it is read */
 int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,

@@ -125,6 +125,10 @@ SIGNATURES.update({
                                    _vp, _ll, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64_f64": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_kmat_bwd_x64_f64_axpy": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _ll,
+                                        _vp]),
+    "gpsa_exact_dkuu_workspace": (_ll, [_i, _ll]),
+    "gpsa_exact_dkuu_f64": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64_axpy": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _ll,
                                     _vp]),
     "gpsa_whiten_f64_dual": (_i, [_vp, _vp, _i, _ll, _vp, _vp, _vp, _vp, _ll, _vp]),

@@ -178,7 +178,10 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
                  TO* __restrict__ C, long long ldc, long long sC, int splitk, TC* __restrict__ part,
                  TC diag = TC(0), int tri = 0, const TIB* __restrict__ kscale = nullptr, long long sKs = 0,
                  const TIB* __restrict__ cscale = nullptr, long long sCs = 0,
-                 GemmSeg2<TIA, TIB, TO> seg2 = GemmSeg2<TIA, TIB, TO>{0x7fffffff, nullptr, nullptr, nullptr}) {
+                 GemmSeg2<TIA, TIB, TO> seg2 = GemmSeg2<TIA, TIB, TO>{0x7fffffff, nullptr, nullptr, nullptr},
+                 const TIA* __restrict__ A2 = nullptr, const float* __restrict__ kscale32 = nullptr) {
+  // A2 + kscale32 (with !TA, batch 1): the left operand is A[m][k] + kscale32[k] * A2[m][k] (same layout as A), formed
+  //   as the tile is staged - the exact inducing-point gradient's W = gamma + qbar o alpha, never written out;
   // kscale (with !TA): the left operand is A[m][k] * kscale[b][k] (a column-scaled panel alpha o g contracted
   //   along its columns without materialising it: the Gram product sum_c g a a^T);
   // cscale: the result's column n is scaled by cscale[b][n] (Omega (alpha o g) = (Omega alpha) o g).
@@ -253,6 +256,12 @@ gemm_mfma_kernel(int m, int n, long long k, TC alpha, const TIA* __restrict__ A,
     if (!TA && kscale != nullptr) {                                                       \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
         if (i < lim_a) ra[g_][i] *= (TC)kscale[(long long)b * sKs + gk + i];              \
+    }                                                                                     \
+    if (!TA && A2 != nullptr) {                                                           \
+      TC r2[4];                                                                           \
+      load4<TIA, TC>(A2 + gr * lda + gk, va_ok, lim_a, r2);                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
+        if (i < lim_a) ra[g_][i] += (TC)kscale32[gk + i] * r2[i];                         \
     }                                                                                     \
     if (SYMA) {                                                                           \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
@@ -544,6 +553,29 @@ GPSA_G64_INST(float, float, double)   // dK_uu = -W alpha^T on few columns; dc d
 GPSA_G64_INST(double, double, float)  // alpha = K^-1 K_uf stored fp32 beyond the projection kernel's size
 #undef GPSA_G64_INST
 
+// C += alpha (A + d o A2) B^T, [m, k] x [n, k]^T in fp64 with deterministic split-K (exact_dkuu below)
+static int gemm_sum2_launch(int m, int n, long long k, double alpha, const double* A, const double* A2, const float* d,
+                            const double* B, long long ld, double* C, long long ldc, int splitk, void* ws,
+                            long long ws_bytes, hipStream_t st) {
+  if (m < 1 || n < 1 || k < 1 || splitk < 1 || splitk > 65535) return GPSA_EINVAL;
+  double* part = nullptr;
+  if (splitk > 1) {
+    if (ws_bytes < (long long)splitk * m * n * 8) return GPSA_EWORKSPACE;
+    part = reinterpret_cast<double*>(ws);
+  }
+  dim3 grid((unsigned)cdiv(n, GB_N), (unsigned)cdiv(m, GB_M), (unsigned)splitk);
+  gemm_mfma_kernel<double, false, true, double, double, double, false><<<grid, 256, 0, st>>>(
+      m, n, k, alpha, A, ld, 0, B, ld, 0, 1.0, C, ldc, 0, splitk, part, 0.0, 0, nullptr, 0, nullptr, 0,
+      GemmSeg2<double, double, double>{0x7fffffff, nullptr, nullptr, nullptr}, A2, d);
+  GPSA_LAUNCH_CHECK();
+  if (splitk > 1) {
+    splitk_reduce_kernel<double><<<(unsigned)cdiv((long long)m * n, 64), 256, 0, st>>>(part, 1, splitk, m, n, alpha, 1.0,
+                                                                                       C, ldc, 0);
+    GPSA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // explicit instantiations used from other translation units
 template int gemm_launch_scaled<float>(int, int, int, int, long long, double, const float*, long long, long long,
                                        const float*, long long, long long, double, float*, long long, long long,
@@ -573,6 +605,28 @@ extern "C" {
 long long gpsa_gemm_workspace(int dtype, int m, int n, int batch, int splitk) {
   if (splitk <= 1) return 0;
   return (long long)batch * splitk * m * n * (dtype == GPSA_F64 ? 8 : 4);
+}
+
+/* split of the C-long contraction: many short K slices (measured at the headline size, round 3: 32 slices 301 us,
+ * 64: 200 us, 128 / 256 the same) */
+static int exact_dkuu_splitk(int M, long long C) {
+  const long long tiles = cdiv(M, gpsa::GB_M) * cdiv(M, gpsa::GB_N);
+  long long s = cdiv(512, tiles > 0 ? tiles : 1);
+  if (s > 256) s = 256;
+  const long long want = C / 64 < 64 ? C / 64 : 64;
+  if (s < want) s = want;
+  if (s > C / 64) s = C / 64;
+  return (int)(s < 1 ? 1 : s);
+}
+long long gpsa_exact_dkuu_workspace(int M, long long C) {
+  const int sk = exact_dkuu_splitk(M, C);
+  return sk > 1 ? (long long)sk * M * M * 8 : 0;
+}
+int gpsa_exact_dkuu_f64(const double* G, const double* A, const float* d, int M, long long C, double* dK,
+                        void* workspace, long long workspace_bytes, void* stream) {
+  if (!G || !A || !d || !dK || M < 1 || C < 1) return GPSA_EINVAL;
+  return gpsa::gemm_sum2_launch(M, M, C, -1.0, G, A, d, A, C, dK, M, exact_dkuu_splitk(M, C), workspace,
+                                workspace_bytes, as_stream(stream));
 }
 
 int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, double alpha,

@@ -56,9 +56,10 @@ struct KmatBatch {
   long long sZ, sX, sK;
   int sP, ragged;  // ragged: use n[]; otherwise every problem has C live columns
   long long n[KM_MAXB];
-  // backward only, optional: the gradient panel is Kbar[m,c] + axs * axd[c] * axX[m,c] (fp32 panel and vector) -
-  // the data GP's dK_uf = gamma + 2 qbar o alpha formed while it is read, in the kernel's arithmetic type
-  const float* axX;
+  // backward only, optional: the gradient panel is Kbar[m,c] + axs * axd[c] * axX[m,c] (axX: a panel of Kbar's own
+  // storage type - fp32 next to an fp32 Kbar, fp64 next to the exact mode's fp64 one; axd: fp32 vector) - the data
+  // GP's dK_uf = gamma + 2 qbar o alpha formed while it is read, in the kernel's arithmetic type
+  const void* axX;
   const float* axd;
   float axs;
 };
@@ -66,7 +67,8 @@ static inline KmatBatch kmat_single() {
   KmatBatch kb;
   kb.sZ = kb.sX = kb.sK = 0;
   kb.sP = kb.ragged = 0;
-  kb.axX = kb.axd = nullptr;
+  kb.axX = nullptr;
+  kb.axd = nullptr;
   kb.axs = 0.f;
   for (int i = 0; i < KM_MAXB; ++i) kb.n[i] = 0;
   return kb;
@@ -188,7 +190,8 @@ kmat_bwd_kernel(const TI* __restrict__ Z, int M, const TX* __restrict__ X, long 
       T k, cd, pl;
       cov_eval<T, KIND>(Zs[r], x, D, ell, inv_ell, var, k, cd, pl);
       T kb = live ? (T)Kbar[(long long)(m0 + r) * C + c] : T(0);
-      if (bt.axX != nullptr && live) kb += axc * (T)bt.axX[(long long)(m0 + r) * C + c];  // uniform branch
+      if (bt.axX != nullptr && live)  // uniform branch
+        kb += axc * (T)reinterpret_cast<const TK*>(bt.axX)[(long long)(m0 + r) * C + c];
       s_ls += kb * pl;
       s_var += kb * k;
       T wgt = kb * cd;
@@ -271,7 +274,8 @@ kmat_bwd_d2_kernel(const TI* __restrict__ Z, int M, int rows, const TX* __restri
     T x0, x1, axc;
   };
   const bool two = bt.axX != nullptr;  // (uniform)
-  auto load = [&](long long cb, TK(&kraw)[MCH], float(&araw)[MCH], Col& q) {
+  const TK* __restrict__ axp = reinterpret_cast<const TK*>(bt.axX);
+  auto load = [&](long long cb, TK(&kraw)[MCH], TK(&araw)[MCH], Col& q) {
     q.c = cb * 256 + threadIdx.x;
     q.live = q.c < nlive;
     q.x0 = q.x1 = q.axc = T(0);
@@ -288,17 +292,17 @@ kmat_bwd_d2_kernel(const TI* __restrict__ Z, int M, int rows, const TX* __restri
       for (int r = 0; r < MCH; ++r) {
         const long long o = (long long)min(m0 + r, M - 1) * C + cc;
         kraw[r] = Kbar[o];
-        araw[r] = bt.axX[o];
+        araw[r] = axp[o];
       }
     } else {
 #pragma unroll
       for (int r = 0; r < MCH; ++r) {
         kraw[r] = Kbar[(long long)min(m0 + r, M - 1) * C + cc];
-        araw[r] = 0.f;
+        araw[r] = TK(0);
       }
     }
   };
-  auto compute = [&](const TK(&kraw)[MCH], const float(&araw)[MCH], const Col& q) {
+  auto compute = [&](const TK(&kraw)[MCH], const TK(&araw)[MCH], const Col& q) {
     const T x[MAXD] = {q.x0, q.x1, T(0), T(0)};
     T dx0 = T(0), dx1 = T(0);
     // (the inducing rows are re-read from LDS in every column block: hoisted out of the loop they are 4 MCH more
@@ -332,7 +336,7 @@ kmat_bwd_d2_kernel(const TI* __restrict__ Z, int M, int rows, const TX* __restri
   //  99 against 70 us at the headline size, one workgroup per CU instead of two)
   for (long long cb = blockIdx.x; cb < ncb; cb += gridDim.x) {
     TK k0[MCH];
-    float a0[MCH];
+    TK a0[MCH];
     Col q0;
     load(cb, k0, a0, q0);
     __builtin_amdgcn_sched_barrier(0);
@@ -652,10 +656,25 @@ int gpsa_kmat_bwd_x64(int kind, const float* Z, int M, const double* X, long lon
 int gpsa_kmat_bwd_x64_f64(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
                           const float* var_u, const double* Kbar, double* dZ, double* dX, double* dparams,
                           void* workspace, long long workspace_bytes, void* stream) {
+  return gpsa_kmat_bwd_x64_f64_axpy(kind, Z, M, X, C, D, ls_u, var_u, Kbar, nullptr, nullptr, 0.0, dZ, dX, dparams,
+                                    workspace, workspace_bytes, stream);
+}
+
+/* ... with the fp64 panel given in two pieces, Kbar[m,c] + s * d[c] * X2[m,c] (X2 [M,C] fp64, d [C] fp32): the exact
+ * inducing-point gradient's dK_uf = K^-1 abar + 2 qbar o alpha on the UNROUNDED projection, without the pass that
+ * wrote it out (round 5) */
+int gpsa_kmat_bwd_x64_f64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,
+                               const float* var_u, const double* Kbar, const double* X2, const float* d, double s,
+                               double* dZ, double* dX, double* dparams, void* workspace, long long workspace_bytes,
+                               void* stream) {
   if (D < 1 || D > gpsa::MAXD || M < 1 || C < 1) return GPSA_EINVAL;
+  if ((X2 == nullptr) != (d == nullptr)) return GPSA_EINVAL;
+  gpsa::KmatBatch kb = gpsa::kmat_single();
+  kb.axX = X2;
+  kb.axd = d;
+  kb.axs = (float)s;
   return gpsa::kmat_bwd_launch<float, double, double, double, double>(
-      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, dX, dparams, 0, workspace, workspace_bytes, as_stream(stream), 1,
-      gpsa::kmat_single());
+      kind, Z, M, X, C, D, ls_u, var_u, Kbar, dZ, dX, dparams, 0, workspace, workspace_bytes, as_stream(stream), 1, kb);
 }
 
 /* the same with the gradient panel given in two pieces: Kbar[m,c] + s * d[c] * X2[m,c]  (X2 [M,C], d [C] fp32; both

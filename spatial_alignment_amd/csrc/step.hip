@@ -1341,7 +1341,6 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   if (exact) {
     const double* a64 = c.sv<double>(ps.o_alpha64);
     gamma64 = c.sc.get<double>((long long)Mg * C);
-    double* qbar64 = c.sc.get<double>(C);
     const long long wsb = gpsa_whiten_workspace(Mg);
     if (wsb > 0) {
       GPSA_RUN(gpsa_whiten_f64(nullptr, GPSA_F32, abar, Mg, C, GPSA_F64, gamma64, nullptr, c.sv<char>(P.o_apk_d), wsb,
@@ -1357,25 +1356,28 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, abar64, C, 0, 0.0, gamma64, C, 0, 1, 1));
       c.sc.release(mk2);
     }
-    if (!dry) {
-      convert_kernel_step<float, double><<<(unsigned)cdiv(C, 256), 256, 0, c.st>>>(qbar, C, qbar64);
-      GPSA_LAUNCH_CHECK();
-    }
-    // W = gamma + qbar alpha (for dK_uu) and dK_uf = W + qbar alpha in ONE pass over the two panels
-    double* W64 = c.sc.get<double>((long long)Mg * C);
-    if (!dry) {
-      dim3 grid((unsigned)cdiv(C, 256), (unsigned)((Mg < 64) ? Mg : 64));
-      exact_axpy2_kernel<<<grid, 256, 0, c.st>>>(gamma64, a64, qbar64, Mg, C, W64, gamma64);
-      GPSA_LAUNCH_CHECK();
-    }
+    // dK_uu = -(gamma + qbar o alpha64) alpha64^T as ONE C-long fp64 product whose left operand is formed while it is
+    // staged, and dK_uf = gamma + 2 qbar o alpha64 formed inside the covariance backward as it reads its two panels
+    // (round 5: a pass of its own read both panels and wrote W and dK_uf out - 640 MB at the headline size)
     {
-      // a C-long fp64 product with a small M x M result: more, shorter K slices than the generic rule
-      // (measured at the headline size: 32 slices 301 us, 64: 200 us, 128 / 256: the same)
-      int sk = splitk_for(C, Mg, Mg);
-      const int want = (int)(C / 64 < 64 ? C / 64 : 64);
-      if (sk < want) sk = want;
-      if (sk < 1) sk = 1;
-      GPSA_CK(gemm64(c, 0, 1, Mg, Mg, C, -1.0, W64, C, 0, a64, C, 0, 1.0, dKuu, Mg, 0, 1, sk));
+      const long long wsb2 = gpsa_exact_dkuu_workspace(Mg, C);
+      const long long mk2 = c.sc.mark();
+      void* ws2 = c.sc.get<char>(wsb2);
+      GPSA_RUN(gpsa_exact_dkuu_f64(gamma64, a64, qbar, Mg, C, dKuu, ws2, wsb2, c.stv()));
+      c.sc.release(mk2);
+    }
+    if (ps.test) {  // a test pass's covariance backward is the plain entry point: it takes dK_uf written out
+      const long long mk2 = c.sc.mark();
+      double* qbar64 = c.sc.get<double>(C);
+      double* W64 = c.sc.get<double>((long long)Mg * C);
+      if (!dry) {
+        convert_kernel_step<float, double><<<(unsigned)cdiv(C, 256), 256, 0, c.st>>>(qbar, C, qbar64);
+        GPSA_LAUNCH_CHECK();
+        dim3 grid((unsigned)cdiv(C, 256), (unsigned)((Mg < 64) ? Mg : 64));
+        exact_axpy2_kernel<<<grid, 256, 0, c.st>>>(gamma64, a64, qbar64, Mg, C, W64, gamma64);
+        GPSA_LAUNCH_CHECK();
+      }
+      c.sc.release(mk2);
     }
   }
   // gamma = K^-1 abar (fp64 product on the fp32 panel).  With many columns dK_uu comes from the identity below
@@ -1480,8 +1482,9 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       GPSA_RUN(gpsa_kmat_bwd(GPSA_F64, GPSA_F32_OUT64, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D,
                              c.prm.data_ls, c.prm.data_var, gamma64, 0, dZ, nullptr, dpar, ws, wsb, c.stv()));
     } else if (exact) {
-      GPSA_RUN(gpsa_kmat_bwd_x64_f64(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
-                                     c.prm.data_var, gamma64, dZ, B.dG64[m], dpar, ws, wsb, c.stv()));
+      GPSA_RUN(gpsa_kmat_bwd_x64_f64_axpy(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
+                                          c.prm.data_var, gamma64, c.sv<double>(ps.o_alpha64), qbar, 2.0, dZ, B.dG64[m],
+                                          dpar, ws, wsb, c.stv()));
       B.have_dG[m] = true;
     } else if (ps.test) {
       GPSA_RUN(gpsa_kmat_bwd(GPSA_F64, GPSA_F32_ACC64, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D,

@@ -119,6 +119,46 @@ def test_kmat_bwd_x64(hip, M, D, C):
         assert (a - w).norm() <= 1e-12 * w.norm()
 
 
+@pytest.mark.parametrize("M,D,C", [(200, 2, 5000), (30, 3, 777), (200, 2, 20000)])
+def test_kmat_bwd_x64_f64_panel_in_two_pieces(hip, M, D, C):
+    """the exact mode's covariance backward: an fp64 panel Kbar + s * d o X2 (X2 fp64, d fp32) formed as it is read"""
+    Z, X64 = rnd(M, D, seed=1, scale=3).to(DEV), rnd(C, D, dtype=f64, seed=2, scale=3).to(DEV)
+    ls, var = rnd(1, seed=3, scale=0.3).to(DEV), rnd(1, seed=4, scale=0.3).to(DEV)
+    Kbar, X2, d = rnd(M, C, dtype=f64, seed=5).to(DEV), rnd(M, C, dtype=f64, seed=6).to(DEV), rnd(C, seed=7).to(DEV)
+    dZ, dX = torch.empty(M, D, dtype=f64, device=DEV), torch.empty(C, D, dtype=f64, device=DEV)
+    dpar = torch.empty(2, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_kmat_bwd_workspace(1, M, C, D))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.lib.gpsa_kmat_bwd_x64_f64_axpy(0, p(Z), M, p(X64), C, D, p(ls), p(var), p(Kbar), p(X2), p(d), 2.0, p(dZ),
+                                            p(dX), p(dpar), p(ws), wsb, stream())
+    assert rc == 0
+    full = Kbar + 2.0 * d.double()[None, :] * X2
+    wZ, wX, wp = hip.kmat_bwd("rbf", Z.double(), X64, ls.double(), var.double(), full)
+    for a, w in ((dZ, wZ), (dX, wX), (dpar, wp)):
+        assert (a - w).norm() <= 1e-12 * w.norm()
+    rc = hip.lib.gpsa_kmat_bwd_x64_f64(0, p(Z), M, p(X64), C, D, p(ls), p(var), p(full), p(dZ), p(dX), p(dpar), p(ws),
+                                       wsb, stream())
+    assert rc == 0
+    for a, w in ((dZ, wZ), (dX, wX), (dpar, wp)):
+        assert (a - w).norm() <= 1e-12 * w.norm()
+
+
+@pytest.mark.parametrize("M,C", [(200, 100000), (200, 20000), (25, 1000), (300, 777), (500, 40328)])
+def test_exact_dkuu(hip, M, C):
+    """dK += -(G + d o A) A^T: the exact inducing-point gradient's C-long fp64 product, left operand formed as staged"""
+    G, A, d = rnd(M, C, dtype=f64, seed=1).to(DEV), rnd(M, C, dtype=f64, seed=2).to(DEV), rnd(C, seed=3).to(DEV)
+    dK0 = rnd(M, M, dtype=f64, seed=4).to(DEV)
+    dK = dK0.clone()
+    wsb = int(hip.lib.gpsa_exact_dkuu_workspace(M, C))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=DEV)
+    assert hip.lib.gpsa_exact_dkuu_f64(p(G), p(A), p(d), M, C, p(dK), p(ws), wsb, stream()) == 0
+    want = dK0 - (G + d.double()[None, :] * A) @ A.t()
+    assert (dK - want).norm() <= 1e-12 * want.norm()
+    dK2 = dK0.clone()  # bitwise repeatable (fixed-order split-K)
+    assert hip.lib.gpsa_exact_dkuu_f64(p(G), p(A), p(d), M, C, p(dK2), p(ws), wsb, stream()) == 0
+    assert torch.equal(dK, dK2)
+
+
 @pytest.mark.parametrize("M,Cs,B", [(200, 640, 3), (50, 64, 5), (300, 128, 2)])
 def test_whiten_batched(hip, M, Cs, B):
     A = rnd(B, M, M, dtype=f64, seed=1).to(DEV)
