@@ -44,6 +44,9 @@ def parse():
                          "median block, min / max reported")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the config1 / config3 extra keys (BASELINE configs 1 and 3 on this GPU)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling: only the headline blocks (no helper / verbatim / exact-mode / S = 1 / graph / config "
+                         "legs, no CPU baseline)")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--static-grads", action="store_true", help="diagnostic: zero_grad(set_to_none=False)")
     ap.add_argument("--overlap", action="store_true", help="diagnostic: per-view side streams in eager mode too")
@@ -60,6 +63,8 @@ def parse():
                          "the line is then NOT the contract metric")
     args = ap.parse_args()
     args.fixed, args.latent, args.warp = None, None, "rbf"
+    if args.headline_only:
+        args.no_s1 = args.no_graph = args.no_extras = args.no_cpu_baseline = True
     if args.workload == "1":    # examples/grid_example.py: 2 views x 100 spots, 30 outputs, M = 25, fixed_view_idx = 0
         args.side, args.views, args.outputs, args.M, args.fixed = 10, 2, 30, 25, 0
     elif args.workload == "3":  # 4 views x 10k spots, 500 outputs through 10 latent GPs, Matern-1/2 warp, M = 200
@@ -202,8 +207,7 @@ def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
     loss = model.loss_fn(dd, out[3])
     loss.backward()
     fuse = getattr(model._cache, "fuse", None)
-    plan = [p for p in model.__dict__.get("_step_plans", {}).values() if p.S == S]
-    exact = bool(plan[-1].key[-1]) if plan else None
+    exact = bool(model._cache.plan.key[-1])  # (the plan this very forward ran)
     cfg = dict(modality_names=[m], n_views=args.views, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
                n_latent_gps={m: None}, fixed_view_idx=None)
     ref = orc.evaluate(state, cfg, {m: dd_cpu[m]["spatial_coords"]}, {m: dd_cpu[m]["outputs"]},
@@ -218,6 +222,11 @@ def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
                F_rel=rel(out[3][m], ref["F_obs"][m]), loss_rel=rel(loss.reshape(1), ref["loss"].reshape(1)),
                grad_rel_max=max(gerr.values()), grad_rel_worst=max(gerr, key=gerr.get),
                grad_rel={k: float(f"{v:.2e}") for k, v in gerr.items()},
+               # the scalar hyper-parameters' gradients themselves, [this step, fp64 oracle]: a relative error on a
+               # scalar that is passing through zero (a trained model's stationary point) says little by itself
+               grad_scalars={k: [p.grad.detach().cpu().double().reshape(-1).tolist(), ref["grads"][k].reshape(-1).tolist()]
+                             for k, p in model.named_parameters()
+                             if p.grad is not None and k in ref["grads"] and p.numel() <= 2},
                tolerance=1e-4, against="oracle/gpsa_oracle.py in fp64, same trained parameters, same injected draws",
                seconds=round(time.time() - t0, 1))
     model.zero_grad(set_to_none=True)
@@ -476,10 +485,11 @@ def main():
         ks_head = timer.summary(args.M, args.S * int(sum(dd["expression"]["n_samples_list"])),  # this rank's columns
                                 int(args.latent or dd["expression"]["outputs"].shape[1]))       # and (latent) outputs
     # the package's own helper around the same two calls (what round 3's line timed): same kernels, one launch less
-    helper = summary(time_blocks(helper_step, args.S, min(nblk, 3))[0]) if args.workload == "2" else None
+    helper = summary(time_blocks(helper_step, args.S, min(nblk, 3))[0]) if (args.workload == "2" and
+                                                                            not args.headline_only) else None
     # the reference's loop verbatim (torch.optim.Adam + a host read of the loss every step)
     verbatim = None
-    if args.workload in ("1", "2"):
+    if args.workload in ("1", "2") and not args.headline_only:
         vb = summary(time_blocks(verbatim_step, args.S, min(nblk, 3))[0])
         verbatim = dict(value=vb["value"], ms_per_step=vb["ms_per_step"],
                         ms_per_step_min_max=[vb["ms_per_step_min"], vb["ms_per_step_max"]],
@@ -488,8 +498,8 @@ def main():
                              "forward; loss_fn; optimizer.zero_grad(); loss.backward(); optimizer.step(); loss.item()")
     # the same loop with the inducing-point gradient in the other mode (model.exact_inducing_grad)
     exact_info = None
-    if args.workload == "2":
-        timed_exact = bool([p for p in model.__dict__.get("_step_plans", {}).values() if p.S == args.S][-1].key[-1])
+    if args.workload == "2" and not args.headline_only:
+        timed_exact = bool(model._cache.plan.key[-1])  # (the plan the last timed step ran)
         saved_mode = model.exact_inducing_grad
         model.exact_inducing_grad = not timed_exact
         try:

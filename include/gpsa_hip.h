@@ -207,9 +207,12 @@ int gpsa_col_axpy(int dtype, const void* Y, const void* X, const void* d, double
 int gpsa_data_sample_fwd(const float* meanT, const float* v, const double* q, const float* var_u,
                          const float* eps, long long C, int L, float* F, float* Sigma, void* stream);
 /* given dF [C,L]:  g[l,c] = dF*eps/(2 sqrt(Sigma)),  dmeanT[l,c] = dF[c,l],  qbar[c] = -sum_l g,
- *   dvar_u (device scalar, overwritten) = exp(var_u) * sum g.   workspace >= 8*(C/32+2) bytes */
+ *   dvar_u (device scalar of type dvar_dtype - GPSA_F32 or GPSA_F64 -, overwritten) = exp(var_u) * sum g: the step
+ *   engine takes it in fp64 - this share of the data kernel variance's gradient cancels against the covariance
+ *   shares to ~1e-3 of its size near a stationary point, and its fp32 rounding alone then shows at 1e-4 of the sum
+ *   (round 5).   workspace >= 8*(C/32+2) bytes */
 int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, const float* var_u,
-                         long long C, int L, float* g, float* dmeanT, float* qbar, float* dvar_u,
+                         long long C, int L, float* g, float* dmeanT, float* qbar, int dvar_dtype, void* dvar_u,
                          void* workspace, long long workspace_bytes, void* stream);
 /* warp GP (vgpsa.py:186-191, 334-351; variance used as the std), fp64 inside, with the
  * linear mean function of the view (vgpsa.py:283-289 mean_slopes / mean_intercepts) evaluated in place:
@@ -607,7 +610,8 @@ int gpsa_lmc_loglik_fused_f32(const float* F, const float* W, const float* Y, co
 /* the fused forward's outputs (formed at upstream gradient 1) as the backward wants them: g, dmeanT, abar scaled by the
  * loss's upstream gradient (untouched when it is 1), g_ext row L = qbar = -sum_l g, dvar_u = exp(var_u) sum g */
 int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
-                         const float* var_u, float* dvar_u, void* workspace, long long workspace_bytes, void* stream);
+                         const float* var_u, int dvar_dtype, void* dvar_u, void* workspace, long long workspace_bytes,
+                         void* stream);
 
 /* ---- fused Adam over a list of tensors (torch.optim.Adam, no weight decay / amsgrad; the optimiser step of
  * the reference loop, examples/grid_example.py:59-78), ONE launch: for every element

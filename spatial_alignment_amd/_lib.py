@@ -43,7 +43,7 @@ SIGNATURES = {
     "gpsa_panel_mm": (_i, [_i, _i, _i, _vp, _vp, _i, _ll, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_col_axpy": (_i, [_i, _vp, _vp, _vp, _d, _i, _ll, _vp, _vp]),
     "gpsa_data_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
-    "gpsa_data_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_data_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _ll, _vp]),
     "gpsa_warp_sample_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpsa_warp_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _ll, _vp]),
@@ -174,7 +174,7 @@ SIGNATURES.update({
                                       _d, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_elbo_loss_fused_bwd": (_i, [_i, _pp, _pp, _pp, C.POINTER(_i), C.POINTER(_ll), C.POINTER(_i), _pp, _i, _vp, _i,
                                       _d, _pp, _pp, _vp, _i, _vp, _vp, _ll, _vp]),
-    "gpsa_elbo_fused_post": (_i, [_vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "gpsa_elbo_fused_post": (_i, [_vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _i, _vp, _vp, _ll, _vp]),
     "gpsa_step_fused": (_i, [_vp, _i]),
     "gpsa_adam_step": (_i, [_i, _pp, _pp, _pp, _pp, C.POINTER(_ll), _d, _d, _d, _d, _vp, _vp]),
 })

@@ -629,15 +629,18 @@ int gpsa_data_sample_fwd(const float* meanT, const float* v, const double* q, co
 }
 
 int gpsa_data_sample_bwd(const float* dF, const float* eps, const float* Sigma, const float* var_u,
-                         long long C, int L, float* g, float* dmeanT, float* qbar, float* dvar_u,
+                         long long C, int L, float* g, float* dmeanT, float* qbar, int dvar_dtype, void* dvar_u,
                          void* workspace, long long workspace_bytes, void* stream) {
-  if (C < 1 || L < 1) return GPSA_EINVAL;
+  if (C < 1 || L < 1 || (dvar_dtype != GPSA_F32 && dvar_dtype != GPSA_F64)) return GPSA_EINVAL;
   const long long nb = cdiv(C, 32);
   if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* part = (double*)workspace;
   gpsa::data_sample_bwd_kernel<<<(unsigned)nb, 256, 0, st>>>(dF, eps, Sigma, C, L, g, dmeanT, qbar, part);
-  gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
+  if (dvar_dtype == GPSA_F64)
+    gpsa::sum_scale_kernel<float, double><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, (double*)dvar_u);
+  else
+    gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, (float*)dvar_u);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -793,14 +796,19 @@ int gpsa_elbo_loss_bwd(int n_ll, const float* const* F, const float* const* Y, c
  * loss's upstream gradient (nothing is touched when that is 1), qbar = -sum_l g, dvar_u = exp(var_u) sum g.
  * g_ext: [L+1][C], row L receives qbar.  abar: [M][C].  workspace: 8 * ceil(C/256) bytes */
 int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
-                         const float* var_u, float* dvar_u, void* workspace, long long workspace_bytes, void* stream) {
+                         const float* var_u, int dvar_dtype, void* dvar_u, void* workspace, long long workspace_bytes,
+                         void* stream) {
   if (M < 1 || C < 1 || L < 1 || !g_ext || !dmeanT || !abar || !gloss || !var_u || !dvar_u) return GPSA_EINVAL;
+  if (dvar_dtype != GPSA_F32 && dvar_dtype != GPSA_F64) return GPSA_EINVAL;
   const long long nb = cdiv(C, 256);
   if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* part = (double*)workspace;
   gpsa::elbo_post_kernel<<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part, abar, M);
-  gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, dvar_u);
+  if (dvar_dtype == GPSA_F64)
+    gpsa::sum_scale_kernel<float, double><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, (double*)dvar_u);
+  else
+    gpsa::sum_scale_kernel<float, float><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, (float*)dvar_u);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

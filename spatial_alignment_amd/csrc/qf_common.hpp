@@ -18,6 +18,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
 
+// The register-resident panel kernels address a tile's alpha slab as (wave-uniform row base) + (this lane's 32-bit
+// offset (4 kq C + c) * 4 bytes): columns beyond this take the generic paths
+#define GPSA_PANEL_MAX_C (1LL << 26)
+
 // src [L][M][M] (row-major) -> dst fp32, zero padded, in MFMA-fragment order:
 //   dst[l][kc][rt][kq][j][r] = P_l[16 rt + j][16 kc + 4 kq + r]      (PACK_KSTEP: ... + 4 r + kq)
 // so that K chunk kc of matrix l is one contiguous MP*64-byte block made of MB 1-KiB pieces, and

@@ -615,6 +615,7 @@ template <int MODE>
 int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* g, int M,
                       long long C, int L, float* out, float* colsq, float scale, float* slab,
                       hipStream_t st, float* keep = nullptr) {
+  if (C > GPSA_PANEL_MAX_C) return GPSA_EUNSUPPORTED;  // (the slab loads' 32-bit lane offsets: qf_common.hpp)
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
   case MBV:                                                                                     \
     if constexpr (MBV <= 16 || MODE == MODE_ACCUM) {  /* 24 / 32 row tiles: accumulate only */  \
@@ -665,6 +666,7 @@ static inline long long accum_slab_floats(int MB) {
 
 static int quad_sym_launch(int MBsel, const float* Ppk, const float* X, int M, long long C, int L,
                            float* out, hipStream_t st) {
+  if (C > GPSA_PANEL_MAX_C) return GPSA_EUNSUPPORTED;
 #define GPSA_QS_CASE(MBV, NCTV)                                                                  \
   case MBV: {                                                                                    \
     const long long T = cdiv(C, 64 * NCTV) * L;                                                  \
@@ -1138,7 +1140,7 @@ static inline bool elbo_path(int M) {
 int gpsa_quadform_elbo_parts(void) { return gpsa::num_cus() * 2; }
 
 long long gpsa_quadform_elbo_f32_workspace(int M, long long C, int L) {
-  if (M < 1 || C < 1 || L < 1 || !elbo_path(M)) return 0;
+  if (M < 1 || C < 1 || L < 1 || !elbo_path(M) || C > GPSA_PANEL_MAX_C) return 0;
   const int MB = gpsa::mfma_mb_for(M), nct = elbo_nct_for(MB);
   const long long G = gpsa_quadform_elbo_parts();
   return ((long long)L * MB * 16 * MB * 16 + G * 2 * (long long)MB * 16 * 64 * nct) * 4;
@@ -1152,7 +1154,7 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
   if (M < 1 || C < 1 || L < 1 || N < 1 || S < 1 || !alpha || !Omega || !meanT || !q || !var_u || !eps || !Y ||
       !noise_u || !g || !dmeanT || !abar || !part)
     return GPSA_EINVAL;
-  if (!elbo_path(M)) return GPSA_EUNSUPPORTED;
+  if (!elbo_path(M) || C > GPSA_PANEL_MAX_C) return GPSA_EUNSUPPORTED;
   if (workspace_bytes < gpsa_quadform_elbo_f32_workspace(M, C, L)) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const int MB = mfma_mb_for(M);

@@ -369,7 +369,7 @@ struct FinalArgs {
   const double* dresid;                                        // [V, Mx, D] layer's share (free views)
   const double* dD_w;                                          // [V*D, Mx] KL's share, row j*V+v (or NULL)
   const double *dZ_df, *dpar_df;                               // per pass: [Mg, D], [2]
-  const float* dvar_ds;                                        // per pass: [1] (fp32 scalar of the sampler)
+  const double* dvar_ds;                                       // per pass: [1] (the sampler's share, fp64: round 5)
   const double *dZ_du, *dpar_du;                               // K_uu of the data GP
   const float* ddc_F[MAXMODS];                                 // [Mg, L] or NULL (no gradient reached F)
   const double* dD_d;                                          // [sum L, Mg] or NULL
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) step_finalize_kernel(FinalArgs a) {
     double gsum = a.dpar_du[e];
     for (int p = 0; p < a.npass; ++p) {
       gsum += a.dpar_df[(long long)p * 2 + e];
-      if (e == 1) gsum += (double)a.dvar_ds[p];
+      if (e == 1) gsum += a.dvar_ds[p];
     }
     float* dst = e == 0 ? a.out.data_ls : a.out.data_var;
     if (dst != nullptr) dst[0] = (float)gsum;
@@ -1250,7 +1250,7 @@ struct BwdBufs {          // fp64 pieces of the parameter gradients (scratch, al
   double* dstack[2];      // gradient wrt every matrix of the groups' batches
   double *dZ_wf, *dZ_wu, *dpar_wf, *dpar_wu, *dvar_ws, *dresid;
   double *dZ_df, *dpar_df, *dZ_du, *dpar_du;
-  float* dvar_ds;
+  double* dvar_ds;
   float* ddc_F[MAXMODS];
   double* dG64[MAXMODS];
   double* dD[2];
@@ -1297,7 +1297,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   if (!fusedp) {
     const long long wsb = 8 * (C / 32 + 2);
     void* ws = c.sc.get<char>(wsb);
-    GPSA_RUN(gpsa_data_sample_bwd(dFl, eps, Sigma, c.prm.data_var, C, L, g_ext, dmeanT, qbar,
+    GPSA_RUN(gpsa_data_sample_bwd(dFl, eps, Sigma, c.prm.data_var, C, L, g_ext, dmeanT, qbar, GPSA_F64,
                                   B.dvar_ds + pass_idx, ws, wsb, c.stv()));
   }
   // abar = delta_F dmean + 2 sum_l g_l Omega_l alpha
@@ -1309,8 +1309,8 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     void* ws = c.sc.get<char>(wsb);
     const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(1, 0, false, c.st);  // (slot 1: what is left of the alpha-gradient - the mean term's share)
-    GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, B.dvar_ds + pass_idx, ws, wsb,
-                                  c.stv()));
+    GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, GPSA_F64, B.dvar_ds + pass_idx,
+                                  ws, wsb, c.stv()));
     GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
     if (timed) P.tick(1, 1, false, c.st);
   } else {
@@ -1614,8 +1614,8 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   B.dresid = sc.get<double>((long long)V * Mx * D);
   B.dZ_df = sc.get<double>((long long)(npass > 0 ? npass : 1) * Mg * D);
   B.dpar_df = sc.get<double>(2LL * (npass > 0 ? npass : 1));
-  B.dvar_ds = sc.get<float>(npass > 0 ? npass : 1);
-  const long long zf = (long long)(reinterpret_cast<char*>(B.dvar_ds) - sc.base);  // doubles up to here, floats behind
+  B.dvar_ds = sc.get<double>(npass > 0 ? npass : 1);
+  const long long zf = sc.off;  // the region is all doubles (the samplers' scalars were fp32 until round 5)
   sc.get<char>(256);  // (round the region up to the arena's 256-byte granule: the runtime fills an unaligned tail
   const long long z1 = (sc.off + 255) & ~255LL;  //  with a second launch)
   if (!dry) GPSA_CK((int)hipMemsetAsync(sc.base + z0, 0, (size_t)(z1 - z0), st));
@@ -1673,22 +1673,16 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   //      the fp64 -> fp32 finalisation - instead of once per slice
   if (io.bwd_acc_mode != 0 && io.bwd_acc != nullptr && !dry) {
     char* accb = reinterpret_cast<char*>(io.bwd_acc);
-    const long long nD = (zf - z0) / 8, nF = (long long)(npass > 0 ? npass : 1);
+    const long long nD = (zf - z0) / 8;
     double* rD = reinterpret_cast<double*>(sc.base + z0);
-    float* rF = B.dvar_ds;
-    double* aD = reinterpret_cast<double*>(accb);
-    float* aF = reinterpret_cast<float*>(accb + (zf - z0));  // (the accumulator mirrors the region byte for byte)
+    double* aD = reinterpret_cast<double*>(accb);  // (the accumulator mirrors the region byte for byte)
     long long aoff = z1 - z0;
     if (io.bwd_acc_mode == 1) {
       GPSA_CK((int)hipMemcpyAsync(aD, rD, (size_t)(nD * 8), hipMemcpyDeviceToDevice, st));
-      GPSA_CK((int)hipMemcpyAsync(aF, rF, (size_t)(nF * 4), hipMemcpyDeviceToDevice, st));
     } else {
       double* dst = io.bwd_acc_mode == 2 ? aD : rD;
       const double* src = io.bwd_acc_mode == 2 ? rD : aD;
       add_inplace_kernel<<<(unsigned)cdiv(nD, 256), 256, 0, st>>>(dst, src, nD);
-      GPSA_LAUNCH_CHECK();
-      add_inplace_f32_kernel<<<(unsigned)cdiv(nF, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? aF : rF,
-                                                                       io.bwd_acc_mode == 2 ? rF : aF, nF);
       GPSA_LAUNCH_CHECK();
     }
     for (int m = 0; m < P.nm; ++m) {

@@ -406,7 +406,7 @@ class HipOps:
         dvar = torch.empty(1, dtype=torch.float32, device=Sigma.device)
         ws = self._ws(8 * (Cn // 32 + 2), Sigma)
         rc = self.lib.gpsa_data_sample_bwd(_p(dF), _p(eps), _p(Sigma), _p(var_u), Cn, L, _p(g_ext),
-                                           _p(dmeanT), g_ext.data_ptr() + 4 * L * Cn, _p(dvar), _p(ws),
+                                           _p(dmeanT), g_ext.data_ptr() + 4 * L * Cn, 0, _p(dvar), _p(ws),  # (0 = GPSA_F32)
                                            ws.numel(), self._stream(Sigma))
         _lib.check(rc, "gpsa_data_sample_bwd")
         return g_ext, dmeanT, dvar

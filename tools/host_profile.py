@@ -1,5 +1,6 @@
 """Host-side cost of the reference loop on a launch-bound problem (BASELINE config 1's size): cProfile of N steps.
-    python tools/host_profile.py [steps]"""
+    python tools/host_profile.py [steps] [verbatim]
+``verbatim``: examples/grid_example.py:59-78 as written - torch.optim.Adam and a host read of the loss every step."""
 import cProfile
 import os
 import pstats
@@ -19,8 +20,9 @@ dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"]
       for m, d in dd.items()}
 view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
 Xs = {m: d["spatial_coords"] for m, d in dd.items()}
-opt = FusedAdam(model.parameters(), lr=1e-2)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+VERBATIM = "verbatim" in sys.argv[1:]
+opt = torch.optim.Adam(model.parameters(), lr=1e-2) if VERBATIM else FusedAdam(model.parameters(), lr=1e-2)
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 300
 
 
 def step():
@@ -29,8 +31,12 @@ def step():
     opt.zero_grad()
     loss.backward()
     opt.step()
+    if VERBATIM:
+        loss.item()
 
 
+for _ in range(1000):  # (the first ~1000 steps of a process run slow on these boxes)
+    step()
 for fuse in (True, False):
     model.fuse_elbo = fuse
     for _ in range(20):
@@ -72,7 +78,7 @@ for fuse in (True, False):
     for _ in range(10):
         step()
     torch.cuda.synchronize()
-    acc = [0.0] * 5
+    acc = [0.0] * 6
     for _ in range(n):
         t = [time.perf_counter()]
         out = model.forward(X_spatial=Xs, view_idx=view_idx, Ns=Ns, S=5); t.append(time.perf_counter())
@@ -80,8 +86,11 @@ for fuse in (True, False):
         opt.zero_grad(); t.append(time.perf_counter())
         loss.backward(); t.append(time.perf_counter())
         opt.step(); t.append(time.perf_counter())
-        for i in range(5):
+        if VERBATIM:
+            loss.item()
+        t.append(time.perf_counter())
+        for i in range(6):
             acc[i] += t[i + 1] - t[i]
     torch.cuda.synchronize()
     print(f"fuse_elbo={fuse}: host us/step  forward {1e6*acc[0]/n:.0f}  loss_fn {1e6*acc[1]/n:.0f}  zero_grad {1e6*acc[2]/n:.0f}  "
-          f"backward {1e6*acc[3]/n:.0f}  opt.step {1e6*acc[4]/n:.0f}")
+          f"backward {1e6*acc[3]/n:.0f}  opt.step {1e6*acc[4]/n:.0f}  loss.item {1e6*acc[5]/n:.0f}")

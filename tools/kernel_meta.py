@@ -53,6 +53,7 @@ def kernels(elf):
                     res.append(dict(name=k[".name"], vgpr=k.get(".vgpr_count", 0), agpr=k.get(".agpr_count", 0),
                                     sgpr=k.get(".sgpr_count", 0), scratch=k.get(".private_segment_fixed_size", 0),
                                     lds=k.get(".group_segment_fixed_size", 0),
+                                    sgpr_spill=k.get(".sgpr_spill_count", 0), vgpr_spill=k.get(".vgpr_spill_count", 0),
                                     max_wg=k.get(".max_flat_workgroup_size", 0)))
     return res
 

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/tl
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-A="--no-cpu-baseline --no-graph --no-s1 --no-extras --blocks 1 --steps 6 --warmup 3"
+A="--headline-only --blocks 1 --steps 6 --warmup 3"
 rocprofv3 --kernel-trace --output-format csv -d $O/s8 -o t -- python3 $R/bench.py $A --emulate-shard 8 > $O/s8.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/k1 -o t -- python3 $R/bench.py $A > $O/k1.log 2>&1
 cd $R
