@@ -18,10 +18,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { MODE_QUAD = 0, MODE_ACCUM = 1, MODE_STORE = 2 };
 
-// The register-resident panel kernels address a tile's alpha slab as (wave-uniform row base) + (this lane's 32-bit
-// offset (4 kq C + c) * 4 bytes): columns beyond this take the generic paths
-#define GPSA_PANEL_MAX_C (1LL << 26)
-
 // src [L][M][M] (row-major) -> dst fp32, zero padded, in MFMA-fragment order:
 //   dst[l][kc][rt][kq][j][r] = P_l[16 rt + j][16 kc + 4 kq + r]      (PACK_KSTEP: ... + 4 r + kq)
 // so that K chunk kc of matrix l is one contiguous MP*64-byte block made of MB 1-KiB pieces, and
@@ -78,6 +74,73 @@ __device__ __forceinline__ void glds4_m0(const float* gsrc_minus_imm) {
 #define GPSA_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(lds_ptr_t)(p);
+}
+
+// The alpha slab of a column tile for the register-resident panel kernels: xb[ct][t][r] = X[row][c], row = 16 t +
+// (QO ? 4 kq + r : 4 r + kq), c = cw + 16 ct + j, zero beyond M rows / C columns; 4 MB values per lane and column
+// group, every one its own 4-byte load.  All loads are issued back to back - one basic block, one wait - and the
+// padding is zeroed by selects at the end (round 5): with a bounds test around each load the compiler built a basic
+// block per load and - the 64-bit row offsets living in scratch by then - put an s_waitcnt vmcnt(0) in front of a
+// third of them: ~34 memory round trips in a row per tile change.  Every address is  (wave-uniform row base, clamped
+// to M - 1) + (this lane's 32-bit offset, its row part clamped to what is left of the matrix below the base): no
+// per-load 64-bit lane arithmetic (the allocator spilled it), no branch, every address inside the panel whatever MB
+// (the next SUPPORTED tile count: whole row tiles can lie beyond M).  The launchers refuse C > GPSA_PANEL_MAX_C
+// (the lane offset (12 C + c) * 4 bytes must fit 32 bits).
+#define GPSA_PANEL_MAX_C (1LL << 26)
+// FULLT: the caller guarantees M > 16 (MB - 1) - only the last row tile can be partial, the others need no clamp (the
+// headline shape's instantiation: the clamps of 4 MB row bases are ~700 scalar instructions whose results the
+// allocator parks in VGPR lanes and scratch).
+template <int MB, int NCT, bool QO, bool FULLT = false>
+__device__ __forceinline__ void load_alpha_slab(const float* __restrict__ X, int M, long long C, long long cw, int j,
+                                                int kq, float (&xb)[NCT][MB][4], bool (&okc)[NCT]) {
+  const int Mm1 = M - 1;
+  const unsigned Cu = (unsigned)C;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const long long c = cw + ct * 16 + j;
+    okc[ct] = c < C;
+    const unsigned cl = (unsigned)(okc[ct] ? c : C - 1);
+#pragma unroll
+    for (int t = 0; t < MB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int want = t * 16 + (QO ? r : r * 4);      // uniform part of the row
+        const int lane_row = QO ? kq * 4 : kq;
+        if (FULLT && t < MB - 1) {
+          xb[ct][t][r] = (X + (long long)want * C)[(unsigned)lane_row * Cu + cl];
+        } else {
+          const int bu = want < Mm1 ? want : Mm1;         // (scalar)
+          const int lp = lane_row < Mm1 - bu ? lane_row : Mm1 - bu;
+          xb[ct][t][r] = (X + (long long)bu * C)[(unsigned)lp * Cu + cl];
+        }
+      }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int t = 0; t < MB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        xb[ct][t][r] = (okc[ct] && t * 16 + (QO ? kq * 4 + r : r * 4 + kq) < M) ? xb[ct][t][r] : 0.f;
+}
+// the last row tile's rows in K-step order (4 r + kq), rows r < RL: xl[ct][r]; clamped lane addresses, zero padding
+template <int MB, int NCT, int NR>
+__device__ __forceinline__ void load_alpha_last(const float* __restrict__ X, int M, long long C, long long cw, int j,
+                                                int kq, int nlive, float (&xl)[NCT][NR]) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const long long c = cw + ct * 16 + j;
+    const bool ok = c < C;
+    const float* __restrict__ Xc = X + (ok ? c : C - 1);
+    float v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int row = (MB - 1) * 16 + r * 4 + kq;
+      v[r] = Xc[(long long)(row < M ? row : M - 1) * C];
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) xl[ct][r] = (r < nlive && ok && (MB - 1) * 16 + r * 4 + kq < M) ? v[r] : 0.f;
+  }
 }
 
 // Visiting order of a workgroup's column tiles.  The item range [it0, it1) covers tiles tile0..tile1;
@@ -271,7 +334,7 @@ struct ElboArgs {
   int nparts;
 };
 
-template <int MB, int NCT, int RL>
+template <int MB, int NCT, int RL, bool FULLT = false>
 __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a);
 #define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2) X(13, 1) X(16, 2)
 #define GPSA_ELBO_EXTERN(MB, NCT)                                          \
@@ -281,6 +344,9 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
   template __global__ void panel_elbo_kernel<MB, NCT, 2>(ElboArgs); \
   template __global__ void panel_elbo_kernel<MB, NCT, 4>(ElboArgs);
 GPSA_ELBO_SHAPES(GPSA_ELBO_EXTERN)
+// M > 16 (MB - 1) (every row tile but the last inside the matrix), the 13-tile shape: the headline configuration's
+extern template __global__ void panel_elbo_kernel<13, 2, 2, true>(ElboArgs);
+extern template __global__ void panel_elbo_kernel<13, 2, 4, true>(ElboArgs);
 
 // ---- symmetric quadratic form: qf_sym.hip
 template <int MB, int NCT, int RL>

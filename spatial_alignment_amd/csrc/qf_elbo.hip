@@ -20,7 +20,7 @@ namespace gpsa {
 // too (4-byte gathers issued under the output's first chunk): a compiler-visible load there would make hipcc wait
 // for vmcnt(0), i.e. for the two ring stages in flight.
 
-template <int MB, int NCT, int RL>
+template <int MB, int NCT, int RL, bool FULLT>
 __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a) {
   constexpr int MP = MB * 16;
   constexpr int WGCOLS = 64 * NCT;
@@ -125,49 +125,14 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
     const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
     float resid[NCT];
     bool okc[NCT];
-    // The alpha slab of the tile: 4 MB (+ RL) values per lane and column group, every one its own 4-byte load.  All of
-    // them are issued back to back on clamped addresses and the padding is zeroed by selects afterwards (round 5): with
-    // the bounds test around each load the compiler built a basic block per load and - the 64-bit row offsets living
-    // in scratch by then - put an s_waitcnt vmcnt(0) in front of a third of them: ~34 memory round trips in a row per
-    // tile change, 3-5 % of the kernel.  Rows below the last row tile are always inside the matrix (M > 16 (MB - 1)):
-    // their address is a wave-uniform row base + this lane's 32-bit offset (the launcher refuses C beyond 2^26).
+    load_alpha_slab<MB, NCT, true, FULLT>(X, M, C, cw, j, kq, xb, okc);
+    if (RL < 4) load_alpha_last<MB, NCT, 4>(X, M, C, cw, j, kq, RL, xl);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const long long c = cw + ct * 16 + j;
-      okc[ct] = c < C;
-      const long long cl = okc[ct] ? c : C - 1;
       // sigma^2 - q formed in fp64 before rounding (data_sample_fwd_kernel)
-      const double qc = a.q[cl];
+      const double qc = a.q[okc[ct] ? c : C - 1];
       resid[ct] = okc[ct] ? (float)(var0 - qc) : 1.f;
-      const unsigned voff = (unsigned)((long long)(kq * 4) * C + cl);
-#pragma unroll
-      for (int t = 0; t < MB - 1; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[ct][t][r] = (X + (long long)(t * 16 + r) * C)[voff];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (MB - 1) * 16 + kq * 4 + r;
-        xb[ct][MB - 1][r] = X[(long long)(row < M ? row : M - 1) * C + cl];
-      }
-      if (RL < 4) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (MB - 1) * 16 + r * 4 + kq;
-          xl[ct][r] = (r < RL) ? X[(long long)(row < M ? row : M - 1) * C + cl] : 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-      for (int t = 0; t < MB - 1; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[ct][t][r] = okc[ct] ? xb[ct][t][r] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xb[ct][MB - 1][r] = (okc[ct] && (MB - 1) * 16 + kq * 4 + r < M) ? xb[ct][MB - 1][r] : 0.f;
-        if (RL < 4) xl[ct][r] = (r < RL && okc[ct] && (MB - 1) * 16 + r * 4 + kq < M) ? xl[ct][r] : 0.f;
-      }
     }
     // gather addresses of this lane for output l_lo: operation o moves element (o*64 + lane) of the wave's
     // [(ct*3 + kind)*16 + j] table; kind 0: mean[l][c] (next output: + C), 1: eps[c][l] (+ 1), 2: Y[c % N][l] (+ 1)
@@ -342,5 +307,7 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
 }
 
 GPSA_ELBO_SHAPES(GPSA_ELBO_DEFINE)
+template __global__ void panel_elbo_kernel<13, 2, 2, true>(ElboArgs);
+template __global__ void panel_elbo_kernel<13, 2, 4, true>(ElboArgs);
 
 }  // namespace gpsa

@@ -139,41 +139,22 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
     int l_lo, l_hi;  // inclusive
     ord.get(step, tile, l_lo, l_hi);
     const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
-    // the alpha slab of the tile: every load issued back to back on a clamped address, the padding zeroed by selects
-    // afterwards (round 5; qf_elbo.hip has the story: a bounds test around each load made a basic block per load and
-    // a full memory round trip in front of a third of them).  Rows below the last row tile are inside the matrix.
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const long long c = cw + ct * 16 + j;
-      const bool okc = c < C;
-      const long long cl = okc ? c : C - 1;
-      constexpr bool QO = MODE == MODE_QUAD;  // B operand of MFMA step r (the packed operand's K order)
-      const unsigned voff = (unsigned)((long long)(QO ? kq * 4 : kq) * C + cl);
 #pragma unroll
-      for (int t = 0; t < MB - 1; ++t)
+      for (int t = 0; t < MB; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xb[ct][t][r] = (X + (long long)(t * 16 + (QO ? r : r * 4)) * C)[voff];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (MB - 1) * 16 + (QO ? kq * 4 + r : r * 4 + kq);
-        xb[ct][MB - 1][r] = X[(long long)(row < M ? row : M - 1) * C + cl];
-      }
+        for (int r = 0; r < 4; ++r) {  // B operand of MFMA step r (the packed operand's K order)
+          const int row = t * 16 + ((MODE == MODE_QUAD) ? kq * 4 + r : r * 4 + kq);
+          xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
       if (MODE == MODE_QUAD && RL < 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = (MB - 1) * 16 + r * 4 + kq;
-          xl[ct][r] = (r < RL) ? X[(long long)(row < M ? row : M - 1) * C + cl] : 0.f;
+          xl[ct][r] = (r < RL && c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
-      }
-#pragma unroll
-      for (int t = 0; t < MB - 1; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[ct][t][r] = okc ? xb[ct][t][r] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xb[ct][MB - 1][r] = (okc && (MB - 1) * 16 + (QO ? kq * 4 + r : r * 4 + kq) < M) ? xb[ct][MB - 1][r] : 0.f;
-        if (MODE == MODE_QUAD && RL < 4)
-          xl[ct][r] = (r < RL && okc && (MB - 1) * 16 + r * 4 + kq < M) ? xl[ct][r] : 0.f;
       }
     }
 #pragma unroll

@@ -91,38 +91,22 @@ quad_sym_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MB][256] PACK_SY
     int l_lo, l_hi;
     ord.get(step, tile, l_lo, l_hi);
     const long long cw = tile * WGCOLS + (long long)w * (16 * NCT);
-    // the alpha slab of the tile, branch-free (round 5: see qf_elbo.hip)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const long long c = cw + ct * 16 + j;
-      const bool okc = c < C;
-      const long long cl = okc ? c : C - 1;
-      const unsigned voff = (unsigned)((long long)(kq * 4) * C + cl);
 #pragma unroll
-      for (int t = 0; t < MB - 1; ++t)
+      for (int t = 0; t < MB; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xb[ct][t][r] = (X + (long long)(t * 16 + r) * C)[voff];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (MB - 1) * 16 + kq * 4 + r;
-        xb[ct][MB - 1][r] = X[(long long)(row < M ? row : M - 1) * C + cl];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int row = t * 16 + kq * 4 + r;
+          xb[ct][t][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
+        }
       if (RL < 4) {
 #pragma unroll
         for (int r = 0; r < RL; ++r) {  // last chunk, K-step order: MFMA step r contracts rows 4 r .. 4 r + 3
           const int row = (MB - 1) * 16 + r * 4 + kq;
-          xk[ct][r] = X[(long long)(row < M ? row : M - 1) * C + cl];
+          xk[ct][r] = (c < C && row < M) ? X[(long long)row * C + c] : 0.f;
         }
-      }
-#pragma unroll
-      for (int t = 0; t < MB - 1; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[ct][t][r] = okc ? xb[ct][t][r] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xb[ct][MB - 1][r] = (okc && (MB - 1) * 16 + kq * 4 + r < M) ? xb[ct][MB - 1][r] : 0.f;
-      if (RL < 4) {
-#pragma unroll
-        for (int r = 0; r < RL; ++r) xk[ct][r] = (okc && (MB - 1) * 16 + r * 4 + kq < M) ? xk[ct][r] : 0.f;
       }
     }
 #pragma unroll

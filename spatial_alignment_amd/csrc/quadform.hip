@@ -615,7 +615,6 @@ template <int MODE>
 int panel_mfma_launch(int MBsel, const float* Ppk, const float* X, const float* g, int M,
                       long long C, int L, float* out, float* colsq, float scale, float* slab,
                       hipStream_t st, float* keep = nullptr) {
-  if (C > GPSA_PANEL_MAX_C) return GPSA_EUNSUPPORTED;  // (the slab loads' 32-bit lane offsets: qf_common.hpp)
 #define GPSA_PANEL_CASE(MBV, NCTV)                                                              \
   case MBV:                                                                                     \
     if constexpr (MBV <= 16 || MODE == MODE_ACCUM) {  /* 24 / 32 row tiles: accumulate only */  \
@@ -666,7 +665,6 @@ static inline long long accum_slab_floats(int MB) {
 
 static int quad_sym_launch(int MBsel, const float* Ppk, const float* X, int M, long long C, int L,
                            float* out, hipStream_t st) {
-  if (C > GPSA_PANEL_MAX_C) return GPSA_EUNSUPPORTED;
 #define GPSA_QS_CASE(MBV, NCTV)                                                                  \
   case MBV: {                                                                                    \
     const long long T = cdiv(C, 64 * NCTV) * L;                                                  \
@@ -1171,7 +1169,12 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
     const long long ntiles = cdiv(C, 64 * NCTV), T = ntiles * L;                                        \
     grid = (long long)num_cus() * ((MBV * NCTV >= 14) ? 1 : 2);                                         \
     if (grid > T) grid = T;                                                                             \
-    if (M - 16 * (MBV - 1) <= 8)                                                                        \
+    constexpr bool HEAD = MBV == 13 && NCTV == 2;  /* M > 16 (MB - 1): the instantiation without row clamps */ \
+    if (HEAD && M > 16 * (MBV - 1) && M - 16 * (MBV - 1) <= 8)                                          \
+      panel_elbo_kernel<MBV, NCTV, 2, HEAD><<<(unsigned)grid, 256, 0, st>>>(a);                         \
+    else if (HEAD && M > 16 * (MBV - 1))                                                                \
+      panel_elbo_kernel<MBV, NCTV, 4, HEAD><<<(unsigned)grid, 256, 0, st>>>(a);                         \
+    else if (M - 16 * (MBV - 1) <= 8)                                                                   \
       panel_elbo_kernel<MBV, NCTV, 2><<<(unsigned)grid, 256, 0, st>>>(a);                               \
     else                                                                                                \
       panel_elbo_kernel<MBV, NCTV, 4><<<(unsigned)grid, 256, 0, st>>>(a);                               \
