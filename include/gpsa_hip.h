@@ -355,6 +355,19 @@ int gpsa_kmat_bwd_x64_f64_axpy(int kind, const float* Z, int M, const double* X,
 long long gpsa_exact_dkuu_workspace(int M, long long C);
 int gpsa_exact_dkuu_f64(const double* G, const double* A, const float* d, int M, long long C, double* dK,
                         void* workspace, long long workspace_bytes, void* stream);
+/* Long-K fp64 products with a small square result, nprob of them in one launch (csrc/longk64.hip):
+ *     out[p] [M, M] = beta[p] out[p] + alpha[p] * sum_k (G[p][:, k] + d[p][k] B[p][:, k]) B[p][:, k]^T
+ * G[p], B[p]: [M, K] row-major fp64 panels with leading dimension ld (G == NULL: the left operand is d o B alone);
+ * d[p]: [K] of type d_dtype (GPSA_F32 / GPSA_F64; d == NULL: the left operand is G alone); sym != 0: the caller
+ * guarantees a symmetric result (the lower triangle is computed and mirrored).  The step's products of this shape:
+ * the warp GPs' dOmega_j = sum_c g_j alpha alpha^T and dK_uu = -(gamma + qbar o alpha) alpha^T, and the exact
+ * inducing-point gradient's dK_uu of the data GP (autograd of vgpsa.py:177-196 through K_uu and Omega).  alpha, beta,
+ * and the pointer arrays are HOST arrays of nprob entries.  gpsa_longk_f64_workspace == 0 / GPSA_EUNSUPPORTED: the
+ * shape is not covered (M > 256, odd or short K, unaligned panels) - use gpsa_gemm. */
+long long gpsa_longk_f64_workspace(int M, long long K, int nprob);
+int gpsa_longk_f64(int nprob, const double* const* G, const double* const* B, const void* const* d, int d_dtype,
+                   int M, long long K, long long ld, int sym, const double* alpha, const double* beta,
+                   double* const* out, void* workspace, long long workspace_bytes, void* stream);
 /* ... with the gradient panel in two pieces, Kbar[m,c] + s * d[c] * X2[m,c] (X2 [M,C], d [C] fp32; both NULL: Kbar
  * alone): the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) formed as it is read */
 int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, long long C, int D, const float* ls_u,

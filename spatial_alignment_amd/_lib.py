@@ -129,6 +129,8 @@ SIGNATURES.update({
                                         _vp]),
     "gpsa_exact_dkuu_workspace": (_ll, [_i, _ll]),
     "gpsa_exact_dkuu_f64": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _vp, _ll, _vp]),
+    "gpsa_longk_f64_workspace": (_ll, [_i, _ll, _i]),
+    "gpsa_longk_f64": (_i, [_i, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64_axpy": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _ll,
                                     _vp]),
     "gpsa_whiten_f64_dual": (_i, [_vp, _vp, _i, _ll, _vp, _vp, _vp, _vp, _ll, _vp]),

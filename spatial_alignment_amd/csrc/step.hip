@@ -887,6 +887,20 @@ static int gemmx(Ctx& c, int ta, int tb, int m, int n, long long k, double alpha
   return 0;
 }
 
+// long-K fp64 products through gpsa_longk_f64 (csrc/longk64.hip); rc == GPSA_EUNSUPPORTED: the shape is not covered and
+// the caller keeps its generic path.  The dry run reserves the workspace either way.
+static int longk(Ctx& c, int nprob, const double* const* G, const double* const* Bm, const void* const* d, int d_dtype,
+                 int M, long long K, long long ld, int sym, const double* alpha, const double* beta, double* const* out) {
+  const long long wsb = gpsa_longk_f64_workspace(M, K, nprob);
+  if (wsb == 0 || (ld & 1)) return GPSA_EUNSUPPORTED;
+  const long long mk = c.sc.mark();
+  void* ws = c.sc.get<char>(wsb);
+  int rc = 0;
+  if (!c.dry) rc = gpsa_longk_f64(nprob, G, Bm, d, d_dtype, M, K, ld, sym, alpha, beta, out, ws, wsb, c.stv());
+  c.sc.release(mk);
+  return rc;
+}
+
 // ---- M x M stage: every prior covariance and variational covariance of the step, factorised together ------
 static int mm_stage_fwd(Ctx& c) {
   Plan& P = c.P;
@@ -1360,11 +1374,21 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     // staged, and dK_uf = gamma + 2 qbar o alpha64 formed inside the covariance backward as it reads its two panels
     // (round 5: a pass of its own read both panels and wrote W and dK_uf out - 640 MB at the headline size)
     {
-      const long long wsb2 = gpsa_exact_dkuu_workspace(Mg, C);
-      const long long mk2 = c.sc.mark();
-      void* ws2 = c.sc.get<char>(wsb2);
-      GPSA_RUN(gpsa_exact_dkuu_f64(gamma64, a64, qbar, Mg, C, dKuu, ws2, wsb2, c.stv()));
-      c.sc.release(mk2);
+      const double* Gs[1] = {gamma64};
+      const double* Bs[1] = {a64};
+      const void* ds[1] = {qbar};
+      const double al[1] = {-1.0}, be[1] = {1.0};
+      double* os[1] = {dKuu};
+      int rc = longk(c, 1, Gs, Bs, ds, GPSA_F32, Mg, C, C, 0, al, be, os);
+      if (rc == GPSA_EUNSUPPORTED) {  // (M > 256, an odd or short C, an unaligned panel: the generic product)
+        const long long wsb2 = gpsa_exact_dkuu_workspace(Mg, C);
+        const long long mk2 = c.sc.mark();
+        void* ws2 = c.sc.get<char>(wsb2);
+        GPSA_RUN(gpsa_exact_dkuu_f64(gamma64, a64, qbar, Mg, C, dKuu, ws2, wsb2, c.stv()));
+        c.sc.release(mk2);
+      } else if (rc != 0) {
+        return rc;
+      }
     }
     if (ps.test) {  // a test pass's covariance backward is the plain entry point: it takes dK_uf written out
       const long long mk2 = c.sc.mark();
@@ -1539,22 +1563,61 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
                    0.0, B.dresid + (long long)r.v0 * Mx * D, D, (long long)Mx * D, r.cnt, splitk_for(Cs, Mx, D)));
     // gamma = K^-1 abar
     GPSA_CK(project_views(c, c.inv(GW, P.pos_Kw(r.b0)), abar + oMC, Mx, Cs, gamma + oMC, nullptr, r.cnt, r.b0, true));
-    // dOmega rows v*D + j (quirk 2)
-    {
-      const long long mk2 = c.sc.mark();
-      const long long wsb = gpsa_gram_batched_workspace(Mx, Cs, D, r.cnt);
-      void* ws = c.sc.get<char>(wsb);
-      GPSA_RUN(gpsa_gram_batched_f64(alpha + oMC, g + oDC, Mx, Cs, D, B.dstack[0] + (long long)P.pos_OmG(r.v0 * D) * mm,
-                                     r.cnt, ws, wsb, c.stv()));
-      c.sc.release(mk2);
+    // dOmega rows v*D + j (quirk 2) = sum_c g_j alpha alpha^T, and  W = gamma + qbar a;  dK_uu = -W a^T;
+    // dK_uf = W + qbar a.  Round 5: all cnt (D + 1) long-K products of the run in two launches of the LDS-DMA fp64
+    // kernel (csrc/longk64.hip), the scaled / summed left operands formed in registers - no alpha o g_j copies, one
+    // column update (gamma + 2 qbar a) instead of two
+    bool done = false;
+    if (r.cnt * (D + 1) <= 48) {
+      const double *Gs[48], *Bs[48];
+      const void* ds[48];
+      double al[48], be[48];
+      double* os[48];
+      int n = 0;
+      for (int i = 0; i < r.cnt; ++i)
+        for (int jj = 0; jj < D; ++jj, ++n) {
+          Gs[n] = nullptr;
+          Bs[n] = alpha + oMC + (long long)i * Mx * Cs;
+          ds[n] = g + oDC + ((long long)i * D + jj) * Cs;
+          al[n] = 1.0;
+          be[n] = 0.0;
+          os[n] = B.dstack[0] + ((long long)P.pos_OmG((r.v0 + i) * D + jj)) * mm;
+        }
+      int rc = longk(c, n, nullptr, Bs, ds, GPSA_F64, Mx, Cs, Cs, 1, al, be, os);
+      if (rc == 0) {
+        for (int i = 0; i < r.cnt; ++i) {
+          Gs[i] = gamma + oMC + (long long)i * Mx * Cs;
+          Bs[i] = alpha + oMC + (long long)i * Mx * Cs;
+          ds[i] = qbar + (long long)(r.b0 + i) * Cs;
+          al[i] = -1.0;
+          be[i] = 0.0;
+          os[i] = B.dstack[0] + (long long)P.pos_Kw(r.b0 + i) * mm;
+        }
+        rc = longk(c, r.cnt, Gs, Bs, ds, GPSA_F64, Mx, Cs, Cs, 0, al, be, os);
+        if (rc != 0) return rc == GPSA_EUNSUPPORTED ? GPSA_EINVAL : rc;  // (same shape as the first launch)
+        GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 2.0, Mx, Cs,
+                                           gamma + oMC, r.cnt, c.stv()));
+        done = true;
+      } else if (rc != GPSA_EUNSUPPORTED) {
+        return rc;
+      }
     }
-    // W = gamma + qbar a;  dK_uu = -W a^T;  dK_uf = W + qbar a
-    GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 1.0, Mx, Cs, gamma + oMC,
-                                       r.cnt, c.stv()));
-    GPSA_CK(gemm64(c, 0, 1, Mx, Mx, Cs, -1.0, gamma + oMC, Cs, (long long)Mx * Cs, alpha + oMC, Cs, (long long)Mx * Cs,
-                   0.0, B.dstack[0] + (long long)P.pos_Kw(r.b0) * mm, Mx, mm, r.cnt, splitk_for(Cs, Mx, Mx)));
-    GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 1.0, Mx, Cs, gamma + oMC,
-                                       r.cnt, c.stv()));
+    if (!done) {
+      {
+        const long long mk2 = c.sc.mark();
+        const long long wsb = gpsa_gram_batched_workspace(Mx, Cs, D, r.cnt);
+        void* ws = c.sc.get<char>(wsb);
+        GPSA_RUN(gpsa_gram_batched_f64(alpha + oMC, g + oDC, Mx, Cs, D, B.dstack[0] + (long long)P.pos_OmG(r.v0 * D) * mm,
+                                       r.cnt, ws, wsb, c.stv()));
+        c.sc.release(mk2);
+      }
+      GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 1.0, Mx, Cs, gamma + oMC,
+                                         r.cnt, c.stv()));
+      GPSA_CK(gemm64(c, 0, 1, Mx, Mx, Cs, -1.0, gamma + oMC, Cs, (long long)Mx * Cs, alpha + oMC, Cs, (long long)Mx * Cs,
+                     0.0, B.dstack[0] + (long long)P.pos_Kw(r.b0) * mm, Mx, mm, r.cnt, splitk_for(Cs, Mx, Mx)));
+      GPSA_RUN(gpsa_col_axpy_batched_f64(gamma + oMC, alpha + oMC, qbar + (long long)r.b0 * Cs, 1.0, Mx, Cs, gamma + oMC,
+                                         r.cnt, c.stv()));
+    }
     // covariance backward of K_uf
     {
       const long long mk2 = c.sc.mark();

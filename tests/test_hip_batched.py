@@ -159,6 +159,47 @@ def test_exact_dkuu(hip, M, C):
     assert torch.equal(dK, dK2)
 
 
+def _longk(hip, G, Bm, d, sym, alpha, beta, out):
+    """gpsa_longk_f64 on lists of per-product tensors (G / d may be None)"""
+    n = len(Bm)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    M, K = Bm[0].shape
+    wsb = int(hip.lib.gpsa_longk_f64_workspace(M, K, n))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=DEV)
+    dt = 0 if (d is None or d[0].dtype == f32) else 1
+    al, be = (C.c_double * n)(*alpha), (C.c_double * n)(*beta)
+    rc = hip.lib.gpsa_longk_f64(n, arr(G) if G is not None else None, arr(Bm), arr(d) if d is not None else None, dt,
+                                M, K, K, int(sym), al, be, arr(out), p(ws), wsb, stream())
+    return rc, wsb
+
+
+@pytest.mark.parametrize("M,K,n", [(200, 100000, 1), (200, 10048, 2), (25, 1000, 3), (100, 4098, 2), (256, 2048, 1),
+                                   (200, 1282, 6), (50, 20000, 4)])
+@pytest.mark.parametrize("mode", ["G+dB/f32", "G+dB/f64", "dB/sym", "G"])
+def test_longk_f64(hip, M, K, n, mode):
+    """out = beta out + alpha (G + d o B) B^T, nprob long-K fp64 products in one launch, left operand formed in registers;
+    K tails that are not a multiple of the 8-column group, every operand combination the step uses"""
+    Bm = [rnd(M, K, dtype=f64, seed=10 + i).to(DEV) for i in range(n)]
+    G = None if mode == "dB/sym" else [rnd(M, K, dtype=f64, seed=20 + i).to(DEV) for i in range(n)]
+    dty = f32 if mode == "G+dB/f32" else f64
+    d = None if mode == "G" else [rnd(K, dtype=dty, seed=30 + i).to(DEV) for i in range(n)]
+    out0 = [rnd(M, M, dtype=f64, seed=40 + i).to(DEV) for i in range(n)]
+    out = [o.clone() for o in out0]
+    alpha, beta = [(-1.0) ** i * (1.0 + 0.5 * i) for i in range(n)], [float(i % 2) for i in range(n)]
+    rc, wsb = _longk(hip, G, Bm, d, mode == "dB/sym", alpha, beta, out)
+    if wsb == 0:
+        assert rc != 0  # not covered: the caller keeps its generic path
+        pytest.skip("shape not covered by the long-K kernel")
+    assert rc == 0
+    for i in range(n):
+        A = (G[i] if G is not None else 0.0) + (d[i].double()[None, :] * Bm[i] if d is not None else 0.0)
+        want = beta[i] * out0[i] + alpha[i] * (A @ Bm[i].t())
+        assert (out[i] - want).norm() <= 1e-12 * want.norm(), (i, float((out[i] - want).norm() / want.norm()))
+    out2 = [o.clone() for o in out0]  # bitwise repeatable (fixed-order reduction)
+    assert _longk(hip, G, Bm, d, mode == "dB/sym", alpha, beta, out2)[0] == 0
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))
+
+
 @pytest.mark.parametrize("M,Cs,B", [(200, 640, 3), (50, 64, 5), (300, 128, 2)])
 def test_whiten_batched(hip, M, Cs, B):
     A = rnd(B, M, M, dtype=f64, seed=1).to(DEV)
