@@ -45,7 +45,7 @@ struct LongKArgs {
   const void* d[LK_MAXP];    // [K] float (DT == 1) or double (DT == 2); unused with DT == 0
   double* part;              // [nprob][nsplit][MP * MP]
   int M, nprob, nsplit, sym;
-  long long K, ld, gper;     // gper: K groups (8 columns) per split
+  long long K, ld, gper;     // gper: K stages (16 columns) per split
 };
 
 __device__ __forceinline__ void lk_set_m0(unsigned lds_base) {
@@ -59,19 +59,27 @@ template <int IMM>
 __device__ __forceinline__ void lk_glds4(const void* gsrc_minus_imm) {
   asm volatile("global_load_lds_dword %0, off offset:%1" ::"v"(gsrc_minus_imm), "n"(IMM) : "memory");
 }
-#define LK_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // MB: row tiles (M <= 16 MB); HASG: the left operand has its own panel G; DT: type of the scale vector d (0: none)
+//
+// Round-5 notes on the shape of the loop (measured at the exact inducing-point gradient's product, M = 200, K = 10^5:
+// the generic product 356 us; the first version of this kernel - K groups of 8 columns, three-slot ring, a test of the
+// wave's tile count in front of every tile - 238 us = 0.43 of the fp64-MFMA peak):
+//   * a stage is 16 K columns = BOTH 64-byte halves of every row's 128-byte line (a stage of 8 fetched half a line
+//     and came back for the other half one stage later, through L2), two slots: one barrier per 4 T / 8 MFMAs a wave;
+//   * every wave runs NT_MAX tiles (the last tile of a shorter run is repeated into an accumulator nobody stores: the
+//     wave would have waited at the barrier anyway), so the tile loop has no test of the run's length, and the B
+//     fragments of tile t + 1 are requested before the MFMAs of tile t.
 template <int MB, bool HASG, int DT>
 __global__ void __launch_bounds__(512) longk64_kernel(LongKArgs a) {
   static_assert(HASG || DT != 0, "a left operand");
   constexpr int MP = MB * 16;
-  constexpr int NPIECE = MB * (HASG ? 2 : 1);            // 1-KiB pieces of a stage: B tiles, then G tiles
-  constexpr int NPW = (NPIECE + LK_WAVES - 1) / LK_WAVES;  // LDS-DMA operations per wave and stage (uniform)
-  static_assert(NPW <= 4, "a wave's pieces of a stage lie within the 4 KiB an immediate offset reaches");
-  constexpr int DAREA = DT == 2 ? 1024 : 256;  // a wave's copy of the stage's scale values (one LDS-DMA operation)
+  constexpr int NOPD = HASG ? 2 : 1;                         // operands staged
+  constexpr int NPIECE = MB * NOPD * 2;                       // 1-KiB pieces of a stage: (operand, tile, half)
+  constexpr int NPW = (NPIECE + LK_WAVES - 1) / LK_WAVES;     // LDS-DMA operations per wave and stage (uniform)
+  static_assert(NPW <= 8, "two groups of four pieces per wave (an immediate offset reaches 4 KiB)");
+  constexpr int DAREA = DT == 2 ? 1024 : 256;  // a wave's copy of the stage's 16 scale values (one LDS-DMA operation)
   constexpr int STAGE_B = NPW * LK_WAVES * 1024 + (DT ? LK_WAVES * DAREA : 0);  // bytes per ring slot
-  constexpr int NOPS = NPW + (DT ? 1 : 0);
   constexpr int NT_MAX = (MB * MB + LK_WAVES - 1) / LK_WAVES;
   extern __shared__ __attribute__((aligned(16))) char lk_smem[];
 
@@ -83,7 +91,7 @@ __global__ void __launch_bounds__(512) longk64_kernel(LongKArgs a) {
   const long long K = a.K, ld = a.ld;
   const double* __restrict__ Bp = a.B[p];
   const double* __restrict__ Gp = HASG ? a.G[p] : nullptr;
-  const long long ng = (K + 7) >> 3;
+  const long long ng = (K + 15) >> 4;
   const long long g_lo = (long long)sp * a.gper;
   long long g_hi = g_lo + a.gper;
   if (g_hi > ng) g_hi = ng;
@@ -101,41 +109,51 @@ __global__ void __launch_bounds__(512) longk64_kernel(LongKArgs a) {
     i0 = t_lo / MB;
     j0 = t_lo - i0 * MB;
   }
+  if (cnt == 0) i0 = j0 = 0;  // (more waves than tiles: this one computes a tile into accumulators nobody stores)
 
-  // row pointers of this wave's pieces (piece q = w + 8 u; surplus operations re-fetch the last piece into a slot
-  // nobody reads): operand base + clamped row * ld + 2 kq
+  // row pointers of this wave's pieces: piece q = w + 8 u = ((operand * MB + tile) * 2 + half); surplus operations
+  // re-fetch the last piece into a slot nobody reads.  Pointer = operand base + clamped row * ld + 8 half + 2 kq
   const double* rp[NPW];
+  int koff[NPW];
 #pragma unroll
   for (int u = 0; u < NPW; ++u) {
     int q = w + LK_WAVES * u;
     q = q < NPIECE ? q : NPIECE - 1;
-    const bool isg = HASG && q >= MB;
-    const int t = isg ? q - MB : q;
+    const int h = q & 1, ot = q >> 1;
+    const bool isg = HASG && ot >= MB;
+    const int t = isg ? ot - MB : ot;
     int row = t * 16 + li;
     row = row < M ? row : M - 1;
-    rp[u] = (isg ? Gp : Bp) + (long long)row * ld + 2 * kq;
+    rp[u] = (isg ? Gp : Bp) + (long long)row * ld;
+    koff[u] = 8 * h + 2 * kq;
   }
-  const long long kmax2 = K - 2 - 2 * kq;  // largest in-bounds k0 for this lane's 16 bytes (K even, >= 2)
 
   // stage g -> ring slot s
   auto issue = [&](long long g, int s) {
-    long long k0 = g << 3;
-    k0 = k0 < kmax2 ? k0 : (kmax2 > 0 ? kmax2 : 0);  // beyond K: an in-bounds (finite) duplicate, masked below
-    lk_set_m0(__builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * STAGE_B + w * NPW * 1024)));
-    lk_glds16<0>(rp[0] + k0);
-    if (NPW > 1) lk_glds16<1024>(reinterpret_cast<const char*>(rp[NPW > 1 ? 1 : 0] + k0) - 1024);
-    if (NPW > 2) lk_glds16<2048>(reinterpret_cast<const char*>(rp[NPW > 2 ? 2 : 0] + k0) - 2048);
-    if (NPW > 3) lk_glds16<3072>(reinterpret_cast<const char*>(rp[NPW > 3 ? 3 : 0] + k0) - 3072);
+    const long long kb = g << 4;
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      if ((u & 3) == 0)
+        lk_set_m0(__builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * STAGE_B + (w * NPW + u) * 1024)));
+      long long k = kb + koff[u];
+      k = k < K - 2 ? k : K - 2;  // beyond K: an in-bounds (finite) duplicate, masked below
+      const char* src = reinterpret_cast<const char*>(rp[u] + k);
+      switch (u & 3) {
+        case 0: lk_glds16<0>(src); break;
+        case 1: lk_glds16<1024>(src - 1024); break;
+        case 2: lk_glds16<2048>(src - 2048); break;
+        default: lk_glds16<3072>(src - 3072); break;
+      }
+    }
     if (DT != 0) {
-      // the stage's 8 scale values, one copy per wave (no cross-wave dependency): lanes beyond the data re-fetch
+      // the stage's 16 scale values, one copy per wave (no cross-wave dependency): lanes beyond the data re-fetch
       lk_set_m0(__builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * STAGE_B + NPW * LK_WAVES * 1024 + w * DAREA)));
-      const long long kb = g << 3;
       if (DT == 1) {
-        long long k = kb + (lane & 7);
+        long long k = kb + (lane & 15);
         k = k < K ? k : K - 1;
         lk_glds4<0>(reinterpret_cast<const float*>(a.d[p]) + k);
       } else {
-        long long k = kb + 2 * (lane & 3);
+        long long k = kb + 2 * (lane & 7);
         k = k < K - 1 ? k : K - 2;
         lk_glds16<0>(reinterpret_cast<const double*>(a.d[p]) + k);
       }
@@ -148,63 +166,79 @@ __global__ void __launch_bounds__(512) longk64_kernel(LongKArgs a) {
 
   if (g_lo < g_hi) {
     issue(g_lo, 0);
-    issue(g_lo + 1 < g_hi ? g_lo + 1 : g_lo, 1);  // (a surplus stage re-reads: the wait counts stay uniform)
     int s = 0;
     for (long long g = g_lo; g < g_hi; ++g) {
-      LK_DMA_WAIT(NOPS);  // all but the newest stage's operations of this wave have landed
-      __syncthreads();    // ... everyone's; and every wave is done with the slot the next stage overwrites
-      {
-        const long long gn = g + 2;
-        issue(gn < g_hi ? gn : g_hi - 1, s == 0 ? 2 : s - 1);
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage g has landed
+      __syncthreads();  // ... everyone's; and every wave is done with the other slot (stage g - 1)
+      if (g + 1 < g_hi) issue(g + 1, s ^ 1);
       const char* slot = lk_smem + s * STAGE_B;
-      // this lane's two K columns of the group and their scale values
-      const long long k_a = (g << 3) + 2 * kq;
-      const bool v0 = k_a < K, v1 = k_a + 1 < K;
-      double d0 = 1.0, d1 = 1.0;
-      if (DT == 1) {
-        const lk_f32x2 dv = *reinterpret_cast<const lk_f32x2*>(slot + NPW * LK_WAVES * 1024 + w * DAREA + 8 * kq);
-        d0 = (double)dv.x;
-        d1 = (double)dv.y;
-      } else if (DT == 2) {
-        const lk_f64x2 dv = *reinterpret_cast<const lk_f64x2*>(slot + NPW * LK_WAVES * 1024 + w * DAREA + 16 * kq);
-        d0 = dv.x;
-        d1 = dv.y;
+      const char* dslot = slot + NPW * LK_WAVES * 1024 + w * DAREA;
+      // this lane's K columns of the stage - half h, MFMA step t: g 16 + 8 h + 2 kq + t - and their scale values
+      const long long k_a = (g << 4) + 2 * kq;
+      double dv[2][2] = {{1.0, 1.0}, {1.0, 1.0}};
+      bool ok[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ok[h][0] = k_a + 8 * h < K;
+        ok[h][1] = k_a + 8 * h + 1 < K;
+        if (DT == 1) {
+          const lk_f32x2 x = *reinterpret_cast<const lk_f32x2*>(dslot + 4 * (8 * h + 2 * kq));
+          dv[h][0] = (double)x.x;
+          dv[h][1] = (double)x.y;
+        } else if (DT == 2) {
+          const lk_f64x2 x = *reinterpret_cast<const lk_f64x2*>(dslot + 8 * (8 * h + 2 * kq));
+          dv[h][0] = x.x;
+          dv[h][1] = x.y;
+        }
       }
+      // piece (operand O, tile TL, half H) of this slot, this lane's 16 bytes
+#define LK_FRAG(O, TL, H)                                                                              \
+  (*reinterpret_cast<const lk_f64x2*>(slot + ((((((O) * MB + (TL)) * 2 + (H)) & 7) * NPW +             \
+                                                 ((((O) * MB + (TL)) * 2 + (H)) >> 3)) << 10) + lane * 16))
       int i = i0, j = j0, cur = -1;
-      double a0 = 0.0, a1 = 0.0;
-#define LK_PIECE(Q) (slot + ((((Q) & 7) * NPW + ((Q) >> 3)) << 10) + lane * 16)
+      double af[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+      lk_f64x2 bn0 = LK_FRAG(0, j, 0), bn1 = LK_FRAG(0, j, 1);
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
-        if (t < cnt) {  // wave-uniform
-          if (i != cur) {
-            cur = i;
-            const lk_f64x2 bi = *reinterpret_cast<const lk_f64x2*>(LK_PIECE(i));
+        if (i != cur) {  // (wave-uniform: a run of ~T / 8 row-major tiles changes row two or three times)
+          cur = i;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const lk_f64x2 bi = LK_FRAG(0, i, h);
+            double x0, x1;
             if (HASG) {
-              const lk_f64x2 gi = *reinterpret_cast<const lk_f64x2*>(LK_PIECE(MB + i));
-              a0 = DT ? fma(d0, bi.x, gi.x) : gi.x;
-              a1 = DT ? fma(d1, bi.y, gi.y) : gi.y;
+              const lk_f64x2 gi = LK_FRAG(1, i, h);
+              x0 = DT ? fma(dv[h][0], bi.x, gi.x) : gi.x;
+              x1 = DT ? fma(dv[h][1], bi.y, gi.y) : gi.y;
             } else {
-              a0 = d0 * bi.x;
-              a1 = d1 * bi.y;
+              x0 = dv[h][0] * bi.x;
+              x1 = dv[h][1] * bi.y;
             }
-            a0 = v0 ? a0 : 0.0;
-            a1 = v1 ? a1 : 0.0;
+            af[h][0] = ok[h][0] ? x0 : 0.0;
+            af[h][1] = ok[h][1] ? x1 : 0.0;
           }
-          const lk_f64x2 bj = *reinterpret_cast<const lk_f64x2*>(LK_PIECE(j));
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bj.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bj.y, acc[t], 0, 0, 0);
+        }
+        const lk_f64x2 b0 = bn0, b1 = bn1;
+        // the next tile of the run (a run shorter than NT_MAX repeats its last tile into a spare accumulator)
+        if (t + 1 < cnt) {
           ++j;
           if (a.sym ? j > i : j == MB) {
             ++i;
             j = 0;
           }
         }
+        if (t + 1 < NT_MAX) {
+          bn0 = LK_FRAG(0, j, 0);
+          bn1 = LK_FRAG(0, j, 1);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][0], b0.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][1], b0.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][0], b1.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][1], b1.y, acc[t], 0, 0, 0);
       }
-#undef LK_PIECE
-      s = s == 2 ? 0 : s + 1;
+#undef LK_FRAG
+      s ^= 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // partial result: D layout of the fp64 MFMA - column = lane & 15, rows (lane >> 4) + 4 r
   double* __restrict__ out = a.part + ((long long)p * a.nsplit + sp) * MP * MP;
@@ -228,18 +262,19 @@ struct LongKOut {
   double alpha[LK_MAXP], beta[LK_MAXP];
 };
 
-// out_p[r][c] = beta out_p[r][c] + alpha sum_s part[p][s][r][c]  (sym: the upper triangle mirrors the lower one)
+// out_p[r][c] = beta out_p[r][c] + alpha sum_s part[p][s][r][c]; sym: only the lower triangle was computed - the
+// threads of the upper triangle leave, the others write their sum to both halves (reading the mirrored partials
+// instead was a stride-MP read per split: 77 us for four 200 x 200 results of 64 splits)
 __global__ void __launch_bounds__(256)
 longk64_reduce_kernel(const double* __restrict__ part, int M, int MP, int nsplit, int sym, LongKOut o) {
   __shared__ double red[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int p = blockIdx.y;
   const long long e = blockIdx.x * 64LL + lane;
-  const bool ok = e < (long long)M * M;
-  const int r = ok ? (int)(e / M) : 0, c = ok ? (int)(e % M) : 0;
-  const long long src = (sym && c > r) ? (long long)c * MP + r : (long long)r * MP + c;
+  const int r = (int)(e / M), c = (int)(e % M);
+  const bool ok = e < (long long)M * M && !(sym && c > r);
   const long long mm = (long long)MP * MP;
-  const double* q = part + (long long)p * nsplit * mm + src;
+  const double* q = part + (long long)p * nsplit * mm + (long long)r * MP + c;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (ok) {
     int s = grp;
@@ -255,8 +290,13 @@ longk64_reduce_kernel(const double* __restrict__ part, int M, int MP, int nsplit
   __syncthreads();
   if (grp == 0 && ok) {
     const double sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const double al = o.alpha[p], be = o.beta[p];
     double* dst = o.out[p] + (long long)r * M + c;
-    *dst = (o.beta[p] == 0.0) ? o.alpha[p] * sum : o.alpha[p] * sum + o.beta[p] * (*dst);
+    *dst = (be == 0.0) ? al * sum : al * sum + be * (*dst);
+    if (sym && c < r) {
+      double* dm = o.out[p] + (long long)c * M + r;
+      *dm = (be == 0.0) ? al * sum : al * sum + be * (*dm);
+    }
   }
 }
 
@@ -273,16 +313,16 @@ static inline int longk_mb_for(int M) {
 // splits of K per product: fill the chip, but leave every workgroup enough K groups to amortise its ring fill and
 // its MP x MP partial
 static inline int longk_nsplit(long long K, int nprob) {
-  const long long ng = (K + 7) / 8;
+  const long long ng = (K + 15) / 16;
   long long s = (long long)num_cus() / (nprob > 0 ? nprob : 1);
-  if (s > ng / 8) s = ng / 8;
+  if (s > ng / 4) s = ng / 4;
   return (int)(s < 1 ? 1 : s);
 }
 
 template <int MB, bool HASG, int DT>
 static int longk64_launch_mb(const LongKArgs& a, hipStream_t st) {
-  constexpr int NPIECE = MB * (HASG ? 2 : 1), NPW = (NPIECE + LK_WAVES - 1) / LK_WAVES;
-  constexpr int lds = 3 * (NPW * LK_WAVES * 1024 + (DT ? LK_WAVES * (DT == 2 ? 1024 : 256) : 0));
+  constexpr int NPIECE = MB * (HASG ? 2 : 1) * 2, NPW = (NPIECE + LK_WAVES - 1) / LK_WAVES;
+  constexpr int lds = 2 * (NPW * LK_WAVES * 1024 + (DT ? LK_WAVES * (DT == 2 ? 1024 : 256) : 0));
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&longk64_kernel<MB, HASG, DT>),
@@ -358,7 +398,7 @@ int gpsa_longk_f64(int nprob, const double* const* G, const double* const* B, co
   a.sym = sym ? 1 : 0;
   a.K = K;
   a.ld = ld;
-  a.gper = cdiv(cdiv(K, 8), a.nsplit);
+  a.gper = cdiv(cdiv(K, 16), a.nsplit);
   hipStream_t st = as_stream(stream);
   int rc;
   if (G && d && d_dtype == GPSA_F32) rc = longk64_launch<true, 1>(MB, a, st);
