@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(512) longk64_kernel(LongKArgs a) {
   constexpr int DAREA = DT == 2 ? 1024 : 256;  // a wave's copy of the stage's 16 scale values (one LDS-DMA operation)
   constexpr int STAGE_B = NPW * LK_WAVES * 1024 + (DT ? LK_WAVES * DAREA : 0);  // bytes per ring slot
   constexpr int NT_MAX = (MB * MB + LK_WAVES - 1) / LK_WAVES;
+  constexpr int NT_SYM = (MB * (MB + 1) / 2 + LK_WAVES - 1) / LK_WAVES;  // tiles per wave of a symmetric result
   extern __shared__ __attribute__((aligned(16))) char lk_smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(512) longk64_kernel(LongKArgs a) {
       lk_f64x2 bn0 = LK_FRAG(0, j, 0), bn1 = LK_FRAG(0, j, 1);
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t) {
+        if (t >= NT_SYM && a.sym) break;  // (a test only behind the symmetric run's length: wave-uniform)
         if (i != cur) {  // (wave-uniform: a run of ~T / 8 row-major tiles changes row two or three times)
           cur = i;
 #pragma unroll

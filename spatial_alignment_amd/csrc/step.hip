@@ -1568,7 +1568,8 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
     // kernel (csrc/longk64.hip), the scaled / summed left operands formed in registers - no alpha o g_j copies, one
     // column update (gamma + 2 qbar a) instead of two
     bool done = false;
-    if (r.cnt * (D + 1) <= 48) {
+    // (both launches or neither: whether a shape is covered depends on the number of products too)
+    if (r.cnt * D <= 48 && gpsa_longk_f64_workspace(Mx, Cs, r.cnt * D) > 0 && gpsa_longk_f64_workspace(Mx, Cs, r.cnt) > 0) {
       const double *Gs[48], *Bs[48];
       const void* ds[48];
       double al[48], be[48];
