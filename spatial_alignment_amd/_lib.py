@@ -163,6 +163,7 @@ SIGNATURES.update({
     "gpsa_step_n_kl": (_i, [_vp]),
     "gpsa_step_eps_g_numel": (_ll, [_vp]),
     "gpsa_step_batch_layout": (_i, [_vp, C.POINTER(_ll)]),
+    "gpsa_step_graph": (_i, [_vp, _i, C.POINTER(_ll)]),
     "gpsa_step_timing": (_i, [_vp, _i]),
     "gpsa_step_timing_read": (_i, [_vp, _vp, _i]),
     "gpsa_step_forward": (_i, [_vp, C.POINTER(StepParams), C.POINTER(StepIO), _vp, _vp, _i, _vp]),

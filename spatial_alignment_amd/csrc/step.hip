@@ -564,6 +564,26 @@ struct Plan {
     (void)hipEventRecord(tev[(size_t)(slot * 3 + kernel) * 2 + edge], st);
   }
 
+  // hipGraph cache of the plan's launch sequences (round 5; see graph_call below)
+  struct GraphKey {
+    gpsa_step_params prm;
+    gpsa_step_io io;
+    gpsa_step_out_grads og;
+    gpsa_step_param_grads pg;
+    const void *saved, *scratch, *stream;
+    int stages, bwd;
+  };
+  struct GraphEntry {
+    GraphKey key;
+    hipGraphExec_t exec;
+    unsigned long long used;
+  };
+  std::vector<GraphEntry> graphs;
+  std::vector<GraphKey> seen;   // argument sets met once (a second meeting captures)
+  unsigned long long gtick = 0;
+  long long g_hits = 0, g_eager = 0, g_captures = 0, g_idle_captures = 0;
+  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default on)
+
   Group& gw() { return grp[0]; }
   Group& gd() { return merged ? grp[0] : grp[1]; }
   int pos_Kw(int b) const { return b; }
@@ -580,6 +600,8 @@ static void free_plan(Plan* p) {
   for (hipEvent_t e : p->tev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->sev)
     if (e != nullptr) (void)hipEventDestroy(e);
+  for (auto& ge : p->graphs)
+    if (ge.exec != nullptr) (void)hipGraphExecDestroy(ge.exec);
   if (p->side != nullptr) (void)hipStreamDestroy(p->side);
   delete p;
 }
@@ -1884,6 +1906,90 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
 
 }  // namespace gpsa
 
+/* ---- hipGraph cache of the engine's launch sequences (round 5) -------------------------------------------------------
+ * A call of gpsa_step_forward / _backward enqueues 20 - 45 launches; on a launch-bound problem (BASELINE config 1's size,
+ * a 1/8 row shard of the headline one, S = 1) the ~5 us of host time per launch ARE the step.  The launch sequence is a
+ * pure function of (plan, the four pointer structs, the two arenas, stages, stream): when a call arrives with an
+ * argument set that has been seen before - the caching allocator of a training loop hands out the same blocks step
+ * after step, or alternates between two sets - its sequence is captured once (hipStreamBeginCapture on the caller's
+ * stream, thread-local mode) and replayed as ONE hipGraphLaunch from then on.  A first sighting runs eagerly (one-off
+ * calls never pay for a capture); <= 16 graphs per plan, least recently used out; after 8 captures in a row that were
+ * never replayed the plan stops capturing.  Not used: inside somebody else's capture (train.GraphedTrainStep), with the
+ * side stream or the kernel timing on, GPSA_STEP_GRAPH=0 / gpsa_step_graph_enable(plan, 0).  Single host thread per
+ * plan, like everything else here. */
+namespace gpsa {
+
+static bool graph_usable(Plan& P, hipStream_t st) {
+  if (P.g_enabled < 0) {
+    const char* e = getenv("GPSA_STEP_GRAPH");
+    P.g_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!P.g_enabled || P.side != nullptr || P.tslots != 0 || P.g_idle_captures > 8) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  return true;
+}
+
+template <typename F>
+static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& enqueue) {
+  ++P.gtick;
+  for (auto& ge : P.graphs)
+    if (memcmp(&ge.key, &key, sizeof(key)) == 0) {
+      if (ge.used == 0) P.g_idle_captures = 0;
+      ge.used = P.gtick;
+      ++P.g_hits;
+      return (int)hipGraphLaunch(ge.exec, st);
+    }
+  bool met = false;
+  for (auto& k : P.seen)
+    if (memcmp(&k, &key, sizeof(key)) == 0) { met = true; break; }
+  if (!met) {
+    if (P.seen.size() >= 32) P.seen.erase(P.seen.begin());
+    P.seen.push_back(key);
+    ++P.g_eager;
+    return enqueue();
+  }
+  // second sighting: capture, instantiate, replay
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    ++P.g_eager;
+    return enqueue();
+  }
+  const int rc = enqueue();
+  hipGraph_t g = nullptr;
+  const hipError_t ec = hipStreamEndCapture(st, &g);
+  if (rc != 0 || ec != hipSuccess || g == nullptr) {
+    if (g != nullptr) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    if (rc != 0) return rc;  // the sequence itself failed: nothing has run, the caller sees its error
+    P.g_enabled = 0;         // capture is not available here: eager from now on
+    ++P.g_eager;
+    return enqueue();
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ei != hipSuccess || exec == nullptr) {
+    (void)hipGetLastError();
+    P.g_enabled = 0;
+    ++P.g_eager;
+    return enqueue();
+  }
+  if (P.graphs.size() >= 16) {
+    size_t lru = 0;
+    for (size_t i = 1; i < P.graphs.size(); ++i)
+      if (P.graphs[i].used < P.graphs[lru].used) lru = i;
+    (void)hipGraphExecDestroy(P.graphs[lru].exec);
+    P.graphs.erase(P.graphs.begin() + (long)lru);
+  }
+  P.graphs.push_back(Plan::GraphEntry{key, exec, 0});  // used == 0: captured, not replayed yet
+  ++P.g_captures;
+  ++P.g_idle_captures;
+  return (int)hipGraphLaunch(exec, st);
+}
+
+}  // namespace gpsa
+
 extern "C" {
 
 static gpsa::Plan* plan_with_sizes(const gpsa_step_desc* desc, bool host_only);
@@ -2030,9 +2136,19 @@ int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_ste
   if (!plan || !params || !io || !saved || !scratch) return GPSA_EINVAL;
   Plan& P = *reinterpret_cast<Plan*>(plan);
   if (P.d.want_kl && io->kl == nullptr) return GPSA_EINVAL;
-  Arena a;
-  a.base = reinterpret_cast<char*>(scratch);
-  return step_forward(P, *params, *io, reinterpret_cast<char*>(saved), a, as_stream(stream), stages);
+  hipStream_t st = as_stream(stream);
+  auto enqueue = [&]() {
+    Arena a;
+    a.base = reinterpret_cast<char*>(scratch);
+    return step_forward(P, *params, *io, reinterpret_cast<char*>(saved), a, st, stages);
+  };
+  if (!graph_usable(P, st)) return enqueue();
+  Plan::GraphKey key;
+  memset(&key, 0, sizeof(key));
+  memcpy(&key.prm, params, sizeof(*params));
+  memcpy(&key.io, io, sizeof(*io));
+  key.saved = saved; key.scratch = scratch; key.stream = stream; key.stages = stages; key.bwd = 0;
+  return graph_call(P, key, st, enqueue);
 }
 
 int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_step_io* io,
@@ -2041,9 +2157,37 @@ int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_st
   using namespace gpsa;
   if (!plan || !params || !io || !og || !saved || !scratch || !grads) return GPSA_EINVAL;
   Plan& P = *reinterpret_cast<Plan*>(plan);
-  Arena a;
-  a.base = reinterpret_cast<char*>(scratch);
-  return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, as_stream(stream));
+  hipStream_t st = as_stream(stream);
+  auto enqueue = [&]() {
+    Arena a;
+    a.base = reinterpret_cast<char*>(scratch);
+    return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, st);
+  };
+  if (!graph_usable(P, st)) return enqueue();
+  Plan::GraphKey key;
+  memset(&key, 0, sizeof(key));
+  memcpy(&key.prm, params, sizeof(*params));
+  memcpy(&key.io, io, sizeof(*io));
+  memcpy(&key.og, og, sizeof(*og));
+  memcpy(&key.pg, grads, sizeof(*grads));
+  key.saved = saved; key.scratch = scratch; key.stream = stream; key.stages = 0; key.bwd = 1;
+  return graph_call(P, key, st, enqueue);
+}
+
+/* the cache's switch and counters: enable != 0 / 0 (-1: leave as it is); out[0..3] = replays, eager calls, captures,
+ * graphs held (out may be NULL) */
+int gpsa_step_graph(void* plan, int enable, long long* out) {
+  using namespace gpsa;
+  if (!plan) return GPSA_EINVAL;
+  Plan& P = *reinterpret_cast<Plan*>(plan);
+  if (enable >= 0) {
+    P.g_enabled = enable ? 1 : 0;
+    P.g_idle_captures = 0;
+  }
+  if (out) {
+    out[0] = P.g_hits; out[1] = P.g_eager; out[2] = P.g_captures; out[3] = (long long)P.graphs.size();
+  }
+  return 0;
 }
 
 int gpsa_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
