@@ -13,6 +13,7 @@
 // Math and precision plan: as spatial_alignment_amd/engine.py documents (fp64 factorisations, fp64 warp GP,
 // fp64 projection + fp32 matrix-core contractions in the data GP, fp64 gradient sums).
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -582,7 +583,7 @@ struct Plan {
   std::vector<GraphKey> seen;   // argument sets met once (a second meeting captures)
   unsigned long long gtick = 0;
   long long g_hits = 0, g_eager = 0, g_captures = 0, g_idle_captures = 0;
-  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default on)
+  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default off)
 
   Group& gw() { return grp[0]; }
   Group& gd() { return merged ? grp[0] : grp[1]; }
@@ -1906,23 +1907,27 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
 
 }  // namespace gpsa
 
-/* ---- hipGraph cache of the engine's launch sequences (round 5) -------------------------------------------------------
+/* ---- hipGraph cache of the engine's launch sequences (round 5; OFF by default) ---------------------------------------
  * A call of gpsa_step_forward / _backward enqueues 20 - 45 launches; on a launch-bound problem (BASELINE config 1's size,
- * a 1/8 row shard of the headline one, S = 1) the ~5 us of host time per launch ARE the step.  The launch sequence is a
- * pure function of (plan, the four pointer structs, the two arenas, stages, stream): when a call arrives with an
- * argument set that has been seen before - the caching allocator of a training loop hands out the same blocks step
- * after step, or alternates between two sets - its sequence is captured once (hipStreamBeginCapture on the caller's
+ * a 1/8 row shard of the headline one, S = 1) the ~5 us of host time per launch are a large part of the step.  The launch
+ * sequence is a pure function of (plan, the four pointer structs, the two arenas, stages, stream): when a call arrives
+ * with an argument set that has been seen before, its sequence is captured once (hipStreamBeginCapture on the caller's
  * stream, thread-local mode) and replayed as ONE hipGraphLaunch from then on.  A first sighting runs eagerly (one-off
  * calls never pay for a capture); <= 16 graphs per plan, least recently used out; after 8 captures in a row that were
- * never replayed the plan stops capturing.  Not used: inside somebody else's capture (train.GraphedTrainStep), with the
- * side stream or the kernel timing on, GPSA_STEP_GRAPH=0 / gpsa_step_graph_enable(plan, 0).  Single host thread per
- * plan, like everything else here. */
+ * never replayed the plan stops capturing.  Never used inside somebody else's capture (train.GraphedTrainStep), with
+ * the side stream or the kernel timing on.
+ * MEASURED (tools/graph_probe.py, BASELINE config 1's size, 1600 steps of the reference's loop): 4803 eager calls, 0
+ * replays - the outputs, draws and gradient buffers of a PyTorch step are fresh allocations whose addresses do not come
+ * back within 32 calls, so the model's own path never meets an argument set twice.  The cache therefore is OFF unless
+ * switched on (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)): it is for callers of the C ABI that own their
+ * buffers (fixed outputs and arenas: every step after the second replays); the model's route to one launch per step is
+ * the whole-step graph, train.GraphedTrainStep / fit(graphed=True), which owns static buffers by construction. */
 namespace gpsa {
 
 static bool graph_usable(Plan& P, hipStream_t st) {
   if (P.g_enabled < 0) {
     const char* e = getenv("GPSA_STEP_GRAPH");
-    P.g_enabled = (e && e[0] == '0') ? 0 : 1;
+    P.g_enabled = (e && e[0] == '1') ? 1 : 0;
   }
   if (!P.g_enabled || P.side != nullptr || P.tslots != 0 || P.g_idle_captures > 8) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1944,6 +1949,20 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
   for (auto& k : P.seen)
     if (memcmp(&k, &key, sizeof(key)) == 0) { met = true; break; }
   if (!met) {
+    static const bool dbg = [] { const char* e = getenv("GPSA_STEP_GRAPH_DEBUG"); return e && e[0] == '1'; }();
+    if (dbg) {  // which 8-byte words differ from the most recent call of the same kind
+      for (size_t q = P.seen.size(); q-- > 0;) {
+        const Plan::GraphKey& o = P.seen[q];
+        if (o.bwd != key.bwd || o.stages != key.stages) continue;
+        const unsigned long long* x = reinterpret_cast<const unsigned long long*>(&o);
+        const unsigned long long* y = reinterpret_cast<const unsigned long long*>(&key);
+        fprintf(stderr, "[step graph] %s stages %d differs from its last sighting at words:", key.bwd ? "bwd" : "fwd", key.stages);
+        for (size_t i = 0; i < sizeof(key) / 8; ++i)
+          if (x[i] != y[i]) fprintf(stderr, " %zu(+%zu)", i, i * 8 < sizeof(key.prm) ? i * 8 : (i * 8 < sizeof(key.prm) + sizeof(key.io) ? i * 8 - sizeof(key.prm) : i * 8 - sizeof(key.prm) - sizeof(key.io)));
+        fprintf(stderr, "  [prm %zu B, io %zu B, og %zu B, pg %zu B]\n", sizeof(key.prm), sizeof(key.io), sizeof(key.og), sizeof(key.pg));
+        break;
+      }
+    }
     if (P.seen.size() >= 32) P.seen.erase(P.seen.begin());
     P.seen.push_back(key);
     ++P.g_eager;
