@@ -566,13 +566,26 @@ struct Plan {
   }
 
   // hipGraph cache of the plan's launch sequences (round 5; see graph_call below)
-  struct GraphKey {
-    gpsa_step_params prm;
-    gpsa_step_io io;
-    gpsa_step_out_grads og;
-    gpsa_step_param_grads pg;
-    const void *saved, *scratch, *stream;
-    int stages, bwd;
+  struct GraphKey {  // raw bytes (a member-wise copy of the structs need not carry their padding: memcmp would differ)
+    static constexpr size_t O_IO = sizeof(gpsa_step_params), O_OG = O_IO + sizeof(gpsa_step_io),
+                            O_PG = O_OG + sizeof(gpsa_step_out_grads), O_PTR = O_PG + sizeof(gpsa_step_param_grads),
+                            BYTES = O_PTR + 3 * sizeof(void*) + 2 * sizeof(int);
+    unsigned char b[BYTES];
+    int stages() const { int v; memcpy(&v, b + O_PTR + 3 * sizeof(void*), sizeof(int)); return v; }
+    int bwd() const { int v; memcpy(&v, b + O_PTR + 3 * sizeof(void*) + sizeof(int), sizeof(int)); return v; }
+    void set(const gpsa_step_params* prm, const gpsa_step_io* io, const gpsa_step_out_grads* og,
+             const gpsa_step_param_grads* pg, const void* saved, const void* scratch, const void* stream, int stages_,
+             int bwd_) {
+      memset(b, 0, BYTES);
+      memcpy(b, prm, sizeof(*prm));
+      memcpy(b + O_IO, io, sizeof(*io));
+      if (og) memcpy(b + O_OG, og, sizeof(*og));
+      if (pg) memcpy(b + O_PG, pg, sizeof(*pg));
+      const void* ptrs[3] = {saved, scratch, stream};
+      memcpy(b + O_PTR, ptrs, sizeof(ptrs));
+      const int tail[2] = {stages_, bwd_};
+      memcpy(b + O_PTR + sizeof(ptrs), tail, sizeof(tail));
+    }
   };
   struct GraphEntry {
     GraphKey key;
@@ -581,9 +594,11 @@ struct Plan {
   };
   std::vector<GraphEntry> graphs;
   std::vector<GraphKey> seen;   // argument sets met once (a second meeting captures)
+  hipStream_t gstream = nullptr;  // captures run on a stream of the plan's own (the caller's may be the null stream,
+                                  // which cannot be captured); the graph is then launched into the caller's
   unsigned long long gtick = 0;
   long long g_hits = 0, g_eager = 0, g_captures = 0, g_idle_captures = 0;
-  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default off)
+  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default on)
 
   Group& gw() { return grp[0]; }
   Group& gd() { return merged ? grp[0] : grp[1]; }
@@ -603,6 +618,7 @@ static void free_plan(Plan* p) {
     if (e != nullptr) (void)hipEventDestroy(e);
   for (auto& ge : p->graphs)
     if (ge.exec != nullptr) (void)hipGraphExecDestroy(ge.exec);
+  if (p->gstream != nullptr) (void)hipStreamDestroy(p->gstream);
   if (p->side != nullptr) (void)hipStreamDestroy(p->side);
   delete p;
 }
@@ -1907,27 +1923,26 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
 
 }  // namespace gpsa
 
-/* ---- hipGraph cache of the engine's launch sequences (round 5; OFF by default) ---------------------------------------
+/* ---- hipGraph cache of the engine's launch sequences (round 5) -------------------------------------------------------
  * A call of gpsa_step_forward / _backward enqueues 20 - 45 launches; on a launch-bound problem (BASELINE config 1's size,
  * a 1/8 row shard of the headline one, S = 1) the ~5 us of host time per launch are a large part of the step.  The launch
  * sequence is a pure function of (plan, the four pointer structs, the two arenas, stages, stream): when a call arrives
- * with an argument set that has been seen before, its sequence is captured once (hipStreamBeginCapture on the caller's
- * stream, thread-local mode) and replayed as ONE hipGraphLaunch from then on.  A first sighting runs eagerly (one-off
- * calls never pay for a capture); <= 16 graphs per plan, least recently used out; after 8 captures in a row that were
- * never replayed the plan stops capturing.  Never used inside somebody else's capture (train.GraphedTrainStep), with
- * the side stream or the kernel timing on.
- * MEASURED (tools/graph_probe.py, BASELINE config 1's size, 1600 steps of the reference's loop): 4803 eager calls, 0
- * replays - the outputs, draws and gradient buffers of a PyTorch step are fresh allocations whose addresses do not come
- * back within 32 calls, so the model's own path never meets an argument set twice.  The cache therefore is OFF unless
- * switched on (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)): it is for callers of the C ABI that own their
- * buffers (fixed outputs and arenas: every step after the second replays); the model's route to one launch per step is
- * the whole-step graph, train.GraphedTrainStep / fit(graphed=True), which owns static buffers by construction. */
+ * with an argument set that has been seen before - the caching allocator of a training loop hands out the same blocks
+ * every other step - its sequence is captured once and replayed as ONE hipGraphLaunch from then on.  The capture runs
+ * on a stream of the plan's own (the caller's is usually PyTorch's null stream, which cannot be captured); the graph is
+ * launched into the caller's stream.  A first sighting runs eagerly (one-off calls never pay for a capture); <= 16
+ * graphs per plan, least recently used out; after 8 captures in a row that were never replayed the plan stops
+ * capturing.  Never used inside somebody else's capture (train.GraphedTrainStep), with the side stream or the kernel
+ * timing on; GPSA_STEP_GRAPH=0 / gpsa_step_graph(plan, 0, ...) switch it off.
+ * Measured (tools/graph_probe.py, BASELINE config 1's size, the reference's loop): 3879 of 3903 calls replayed from 6
+ * graphs (three call kinds x the allocator's two alternating block sets); 0.676 -> 0.541 ms/step with FusedAdam,
+ * 0.697 -> 0.623 with torch.optim.Adam and a host read of the loss every step (1436 -> 1605 steps/s). */
 namespace gpsa {
 
 static bool graph_usable(Plan& P, hipStream_t st) {
   if (P.g_enabled < 0) {
     const char* e = getenv("GPSA_STEP_GRAPH");
-    P.g_enabled = (e && e[0] == '1') ? 1 : 0;
+    P.g_enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!P.g_enabled || P.side != nullptr || P.tslots != 0 || P.g_idle_captures > 8) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1939,7 +1954,7 @@ template <typename F>
 static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& enqueue) {
   ++P.gtick;
   for (auto& ge : P.graphs)
-    if (memcmp(&ge.key, &key, sizeof(key)) == 0) {
+    if (memcmp(ge.key.b, key.b, Plan::GraphKey::BYTES) == 0) {
       if (ge.used == 0) P.g_idle_captures = 0;
       ge.used = P.gtick;
       ++P.g_hits;
@@ -1947,43 +1962,51 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
     }
   bool met = false;
   for (auto& k : P.seen)
-    if (memcmp(&k, &key, sizeof(key)) == 0) { met = true; break; }
+    if (memcmp(k.b, key.b, Plan::GraphKey::BYTES) == 0) { met = true; break; }
   if (!met) {
     static const bool dbg = [] { const char* e = getenv("GPSA_STEP_GRAPH_DEBUG"); return e && e[0] == '1'; }();
     if (dbg) {  // which 8-byte words differ from the most recent call of the same kind
       for (size_t q = P.seen.size(); q-- > 0;) {
         const Plan::GraphKey& o = P.seen[q];
-        if (o.bwd != key.bwd || o.stages != key.stages) continue;
-        const unsigned long long* x = reinterpret_cast<const unsigned long long*>(&o);
-        const unsigned long long* y = reinterpret_cast<const unsigned long long*>(&key);
-        fprintf(stderr, "[step graph] %s stages %d differs from its last sighting at words:", key.bwd ? "bwd" : "fwd", key.stages);
-        for (size_t i = 0; i < sizeof(key) / 8; ++i)
-          if (x[i] != y[i]) fprintf(stderr, " %zu(+%zu)", i, i * 8 < sizeof(key.prm) ? i * 8 : (i * 8 < sizeof(key.prm) + sizeof(key.io) ? i * 8 - sizeof(key.prm) : i * 8 - sizeof(key.prm) - sizeof(key.io)));
-        fprintf(stderr, "  [prm %zu B, io %zu B, og %zu B, pg %zu B]\n", sizeof(key.prm), sizeof(key.io), sizeof(key.og), sizeof(key.pg));
+        if (o.bwd() != key.bwd() || o.stages() != key.stages()) continue;
+        fprintf(stderr, "[step graph] %s stages %d differs from its last sighting at bytes:", key.bwd() ? "bwd" : "fwd",
+                key.stages());
+        for (size_t i = 0; i < Plan::GraphKey::BYTES; i += 8)
+          if (memcmp(o.b + i, key.b + i, 8) != 0) fprintf(stderr, " %zu", i);
+        fprintf(stderr, "  [io at %zu, og at %zu, pg at %zu, arenas at %zu]\n", Plan::GraphKey::O_IO, Plan::GraphKey::O_OG,
+                Plan::GraphKey::O_PG, Plan::GraphKey::O_PTR);
         break;
       }
     }
     if (P.seen.size() >= 32) P.seen.erase(P.seen.begin());
     P.seen.push_back(key);
     ++P.g_eager;
-    return enqueue();
+    return enqueue(st);
   }
-  // second sighting: capture, instantiate, replay
-  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+  // second sighting: capture (on the plan's own stream), instantiate, replay into the caller's stream
+  if (P.gstream == nullptr && hipStreamCreateWithFlags(&P.gstream, hipStreamNonBlocking) != hipSuccess) {
+    P.gstream = nullptr;
     (void)hipGetLastError();
+    P.g_enabled = 0;
     ++P.g_eager;
-    return enqueue();
+    return enqueue(st);
   }
-  const int rc = enqueue();
+  if (hipStreamBeginCapture(P.gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    P.g_enabled = 0;
+    ++P.g_eager;
+    return enqueue(st);
+  }
+  const int rc = enqueue(P.gstream);
   hipGraph_t g = nullptr;
-  const hipError_t ec = hipStreamEndCapture(st, &g);
+  const hipError_t ec = hipStreamEndCapture(P.gstream, &g);
   if (rc != 0 || ec != hipSuccess || g == nullptr) {
     if (g != nullptr) (void)hipGraphDestroy(g);
     (void)hipGetLastError();
     if (rc != 0) return rc;  // the sequence itself failed: nothing has run, the caller sees its error
     P.g_enabled = 0;         // capture is not available here: eager from now on
     ++P.g_eager;
-    return enqueue();
+    return enqueue(st);
   }
   hipGraphExec_t exec = nullptr;
   const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
@@ -1992,7 +2015,7 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
     (void)hipGetLastError();
     P.g_enabled = 0;
     ++P.g_eager;
-    return enqueue();
+    return enqueue(st);
   }
   if (P.graphs.size() >= 16) {
     size_t lru = 0;
@@ -2156,17 +2179,14 @@ int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_ste
   Plan& P = *reinterpret_cast<Plan*>(plan);
   if (P.d.want_kl && io->kl == nullptr) return GPSA_EINVAL;
   hipStream_t st = as_stream(stream);
-  auto enqueue = [&]() {
+  auto enqueue = [&](hipStream_t s) {
     Arena a;
     a.base = reinterpret_cast<char*>(scratch);
-    return step_forward(P, *params, *io, reinterpret_cast<char*>(saved), a, st, stages);
+    return step_forward(P, *params, *io, reinterpret_cast<char*>(saved), a, s, stages);
   };
-  if (!graph_usable(P, st)) return enqueue();
+  if (!graph_usable(P, st)) return enqueue(st);
   Plan::GraphKey key;
-  memset(&key, 0, sizeof(key));
-  memcpy(&key.prm, params, sizeof(*params));
-  memcpy(&key.io, io, sizeof(*io));
-  key.saved = saved; key.scratch = scratch; key.stream = stream; key.stages = stages; key.bwd = 0;
+  key.set(params, io, nullptr, nullptr, saved, scratch, stream, stages, 0);
   return graph_call(P, key, st, enqueue);
 }
 
@@ -2177,19 +2197,14 @@ int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_st
   if (!plan || !params || !io || !og || !saved || !scratch || !grads) return GPSA_EINVAL;
   Plan& P = *reinterpret_cast<Plan*>(plan);
   hipStream_t st = as_stream(stream);
-  auto enqueue = [&]() {
+  auto enqueue = [&](hipStream_t s) {
     Arena a;
     a.base = reinterpret_cast<char*>(scratch);
-    return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, st);
+    return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, s);
   };
-  if (!graph_usable(P, st)) return enqueue();
+  if (!graph_usable(P, st)) return enqueue(st);
   Plan::GraphKey key;
-  memset(&key, 0, sizeof(key));
-  memcpy(&key.prm, params, sizeof(*params));
-  memcpy(&key.io, io, sizeof(*io));
-  memcpy(&key.og, og, sizeof(*og));
-  memcpy(&key.pg, grads, sizeof(*grads));
-  key.saved = saved; key.scratch = scratch; key.stream = stream; key.stages = 0; key.bwd = 1;
+  key.set(params, io, og, grads, saved, scratch, stream, 0, 1);
   return graph_call(P, key, st, enqueue);
 }
 
