@@ -141,6 +141,23 @@ def view_rows(model, view_idx, Ns):
     import numpy as np
 
     V = model.n_views
+    # a training loop passes the same index objects every step: the answer for them is remembered (keyed by the objects'
+    # identities and lengths; held alive by the memo so that an id cannot come back on another object)
+    memo = model.__dict__.setdefault("_view_rows_memo", {})
+    key = tuple((id(view_idx[m][v]), len(view_idx[m][v])) for m in model.modality_names for v in range(V)) + \
+        tuple(int(Ns[m]) for m in model.modality_names)
+    hit = memo.get(key)
+    if hit is not None:
+        return hit[0]
+    res = _view_rows(model, view_idx, Ns, np)
+    if len(memo) >= 8:
+        memo.clear()
+    memo[key] = (res, [view_idx[m][v] for m in model.modality_names for v in range(V)])
+    return res
+
+
+def _view_rows(model, view_idx, Ns, np):
+    V = model.n_views
     out = []
     for m in model.modality_names:
         edge = 0
