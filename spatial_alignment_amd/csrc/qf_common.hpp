@@ -334,7 +334,7 @@ struct ElboArgs {
   int nparts;
 };
 
-template <int MB, int NCT, int RL, bool FULLT = false>
+template <int MB, int NCT, int RL, bool FULLT = false, bool PAIRB = false>
 __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a);
 #define GPSA_ELBO_SHAPES(X) X(2, 4) X(4, 4) X(7, 4) X(13, 2) X(13, 1) X(16, 2)
 #define GPSA_ELBO_EXTERN(MB, NCT)                                          \
@@ -347,6 +347,9 @@ GPSA_ELBO_SHAPES(GPSA_ELBO_EXTERN)
 // M > 16 (MB - 1) (every row tile but the last inside the matrix), the 13-tile shape: the headline configuration's
 extern template __global__ void panel_elbo_kernel<13, 2, 2, true>(ElboArgs);
 extern template __global__ void panel_elbo_kernel<13, 2, 4, true>(ElboArgs);
+// ... with one barrier per two K chunks (qf_elbo.hip: PAIRB)
+extern template __global__ void panel_elbo_kernel<13, 2, 2, true, true>(ElboArgs);
+extern template __global__ void panel_elbo_kernel<13, 2, 4, true, true>(ElboArgs);
 
 // ---- symmetric quadratic form: qf_sym.hip
 template <int MB, int NCT, int RL>

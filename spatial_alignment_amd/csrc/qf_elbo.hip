@@ -20,7 +20,12 @@ namespace gpsa {
 // too (4-byte gathers issued under the output's first chunk): a compiler-visible load there would make hipcc wait
 // for vmcnt(0), i.e. for the two ring stages in flight.
 
-template <int MB, int NCT, int RL, bool FULLT>
+// PAIRB (round 5): ONE barrier per TWO K chunks.  The ring then has six one-chunk slots and four stages in flight; the
+// wait + barrier in front of a chunk's last row tile is taken only by the odd chunks (and by an output's last chunk:
+// MB may be odd) and covers the next two chunks: at most the two newest stages (chunks c + 3, c + 4) stay outstanding.
+// A chunk's pieces go to the slot of chunk c - 2, which every wave has finished before the barrier it has last
+// passed (at the end of chunk c - 1 or c - 2).
+template <int MB, int NCT, int RL, bool FULLT, bool PAIRB>
 __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kernel(ElboArgs a) {
   constexpr int MP = MB * 16;
   constexpr int WGCOLS = 64 * NCT;
@@ -28,7 +33,8 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
   constexpr int NPW = (MB + 3) / 4;
   constexpr int BUFF = NPW * 4 * 256;
   constexpr int NGATHER = (3 * NCT * 16 + 63) / 64;  // 4-byte LDS-DMA operations per wave and output
-  __shared__ __attribute__((aligned(16))) float lds[3][BUFF];
+  constexpr int NSLOT = PAIRB ? 6 : 3, AHEAD = PAIRB ? 4 : 2;  // ring slots, stages in flight
+  __shared__ __attribute__((aligned(16))) float lds[NSLOT][BUFF];
   __shared__ __attribute__((aligned(16))) float sgat[4][NGATHER * 64];  // [wave][(ct*3 + kind)*16 + j]: mean, eps, Y
   __shared__ double red[4];
 
@@ -110,7 +116,13 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
   int buf = 0;
   GPSA_STAGE_NEXT(0)
   GPSA_STAGE_NEXT(1)
-  GPSA_DMA_WAIT(NPW);
+  if (PAIRB) {
+    GPSA_STAGE_NEXT(2)
+    GPSA_STAGE_NEXT(3)
+    GPSA_DMA_WAIT(2 * NPW);
+  } else {
+    GPSA_DMA_WAIT(NPW);
+  }
   __syncthreads();
   // The fragment of row tile 0 of the NEXT chunk is read during the last row tile of the current one: the chunk's
   // wait + barrier sit in FRONT of that last row tile (every wave has then issued - and, by its lgkmcnt wait,
@@ -167,7 +179,8 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) bv[ct][r] = (RL < 4 && kc == MB - 1) ? xl[ct][r] : xb[ct][kc][r];
         const float* base = &lds[buf][lane * 4];
-        const float* nbase = &lds[buf == 2 ? 0 : buf + 1][lane * 4];
+        const float* nbase = &lds[buf == NSLOT - 1 ? 0 : buf + 1][lane * 4];
+        const int sbuf = buf + AHEAD >= NSLOT ? buf + AHEAD - NSLOT : buf + AHEAD;  // the slot this chunk's stage fills
         if (kc == 0) {
           // this output's mean / eps / Y: BEFORE the chunk's ring stage is issued, so that the counted wait at the
           // end of the chunk (all but the newest NPW operations) covers them
@@ -188,9 +201,10 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
         for (int rt = 0; rt < MB; ++rt) {
           const float4 a4 = a_nxt;
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-          if (rt == MB - 1) {
+          if (rt == MB - 1 && (!PAIRB || (kc & 1) || kc == MB - 1)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's last read of the current slot is in
-            GPSA_DMA_WAIT(NPW);
+            if (PAIRB) GPSA_DMA_WAIT(2 * NPW);
+            else GPSA_DMA_WAIT(NPW);
             __syncthreads();
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -208,19 +222,19 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
                                                                     : nbase + GPSA_POS(0) * 256));
             } else if (r == 1) {
               if (MB >= NPW + 3) {
-                if (rt == 0) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, 0)
-                if (rt == 1 && NPW > 1) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, (NPW > 1 ? 1 : 0))
-                if (rt == 2 && NPW > 2) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, (NPW > 2 ? 2 : 0))
-                if (rt == 3 && NPW > 3) GPSA_STAGE_PIECE(buf == 0 ? 2 : buf - 1, (NPW > 3 ? 3 : 0))
+                if (rt == 0) GPSA_STAGE_PIECE(sbuf, 0)
+                if (rt == 1 && NPW > 1) GPSA_STAGE_PIECE(sbuf, (NPW > 1 ? 1 : 0))
+                if (rt == 2 && NPW > 2) GPSA_STAGE_PIECE(sbuf, (NPW > 2 ? 2 : 0))
+                if (rt == 3 && NPW > 3) GPSA_STAGE_PIECE(sbuf, (NPW > 3 ? 3 : 0))
                 if (rt == NPW) GPSA_STAGE_ADVANCE()
               } else if (rt == 0) {
-                GPSA_STAGE_NEXT(buf == 0 ? 2 : buf - 1)
+                GPSA_STAGE_NEXT(sbuf)
               }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        buf = (buf == 2) ? 0 : buf + 1;
+        buf = (buf == NSLOT - 1) ? 0 : buf + 1;
       }
       // closing of output l: v, the draw, its likelihood term and gradient, and g_l W_l into the second set
       float z2l = 0.f;
@@ -309,5 +323,7 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
 GPSA_ELBO_SHAPES(GPSA_ELBO_DEFINE)
 template __global__ void panel_elbo_kernel<13, 2, 2, true>(ElboArgs);
 template __global__ void panel_elbo_kernel<13, 2, 4, true>(ElboArgs);
+template __global__ void panel_elbo_kernel<13, 2, 2, true, true>(ElboArgs);
+template __global__ void panel_elbo_kernel<13, 2, 4, true, true>(ElboArgs);
 
 }  // namespace gpsa

@@ -1170,7 +1170,12 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
     grid = (long long)num_cus() * ((MBV * NCTV >= 14) ? 1 : 2);                                         \
     if (grid > T) grid = T;                                                                             \
     constexpr bool HEAD = MBV == 13 && NCTV == 2;  /* M > 16 (MB - 1): the instantiation without row clamps */ \
-    if (HEAD && M > 16 * (MBV - 1) && M - 16 * (MBV - 1) <= 8)                                          \
+    static const bool pair = [] { const char* e = getenv("GPSA_ELBO_PAIR"); return !(e && e[0] == '0'); }();  \
+    if (HEAD && pair && M > 16 * (MBV - 1) && M - 16 * (MBV - 1) <= 8)                                  \
+      panel_elbo_kernel<MBV, NCTV, 2, HEAD, HEAD><<<(unsigned)grid, 256, 0, st>>>(a);                   \
+    else if (HEAD && pair && M > 16 * (MBV - 1))                                                        \
+      panel_elbo_kernel<MBV, NCTV, 4, HEAD, HEAD><<<(unsigned)grid, 256, 0, st>>>(a);                   \
+    else if (HEAD && M > 16 * (MBV - 1) && M - 16 * (MBV - 1) <= 8)                                     \
       panel_elbo_kernel<MBV, NCTV, 2, HEAD><<<(unsigned)grid, 256, 0, st>>>(a);                         \
     else if (HEAD && M > 16 * (MBV - 1))                                                                \
       panel_elbo_kernel<MBV, NCTV, 4, HEAD><<<(unsigned)grid, 256, 0, st>>>(a);                         \
