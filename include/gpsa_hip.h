@@ -552,11 +552,11 @@ long long gpsa_step_scratch_bytes(const void* plan);
 long long gpsa_step_bwd_acc_bytes(const void* plan);  /* gpsa_step_io.bwd_acc */
 int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
-/* gpsa_step_forward / _backward replay a cached hipGraph of their launch sequence when they meet an argument set
- * (pointer structs, arenas, stages, stream) for the second time - a training loop's caching allocator hands out the same
- * blocks every other step - instead of enqueueing 20 - 45 launches one by one (csrc/step.hip: "hipGraph cache").  On by
- * default; GPSA_STEP_GRAPH=0 turns it off for the process.  This is the cache's switch and its counters: enable != 0 /
- * 0 (-1: leave as it is); out[0..3] = replays, eager calls, captures, graphs held (out may be NULL). */
+/* EXPERIMENTAL, off by default: gpsa_step_forward / _backward can replay a cached hipGraph of their launch sequence
+ * when they meet an argument set (pointer structs, arenas, stages, stream) for the second time, instead of enqueueing
+ * 20 - 45 launches one by one (csrc/step.hip: "hipGraph cache" has the measurements and an open issue).  For callers
+ * that own fixed buffers; GPSA_STEP_GRAPH=1 turns it on for the process.  This is the cache's switch and its counters:
+ * enable != 0 / 0 (-1: leave as it is); out[0..3] = replays, eager calls, captures, graphs held (out may be NULL). */
 int gpsa_step_graph(void* plan, int enable, long long* out);
 /* Where the step's factorisation batch sits in the ``saved`` arena, for the reference's forward -> loss_fn hand-off
  * attributes Kuu_chol_list / curr_Omega_tril_list / Kuu_chol_F / curr_Omega_tril_F (vgpsa.py:237, 257, 321, 394, 412):

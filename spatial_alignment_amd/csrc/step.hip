@@ -598,7 +598,7 @@ struct Plan {
                                   // which cannot be captured); the graph is then launched into the caller's
   unsigned long long gtick = 0;
   long long g_hits = 0, g_eager = 0, g_captures = 0, g_idle_captures = 0;
-  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default on)
+  int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default off)
 
   Group& gw() { return grp[0]; }
   Group& gd() { return merged ? grp[0] : grp[1]; }
@@ -1923,26 +1923,36 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
 
 }  // namespace gpsa
 
-/* ---- hipGraph cache of the engine's launch sequences (round 5) -------------------------------------------------------
+/* ---- hipGraph cache of the engine's launch sequences (round 5; EXPERIMENTAL, off by default) -------------------------
  * A call of gpsa_step_forward / _backward enqueues 20 - 45 launches; on a launch-bound problem (BASELINE config 1's size,
- * a 1/8 row shard of the headline one, S = 1) the ~5 us of host time per launch are a large part of the step.  The launch
+ * a 1/8 row shard of the headline one, S = 1) the host time per launch is a visible part of the step.  The launch
  * sequence is a pure function of (plan, the four pointer structs, the two arenas, stages, stream): when a call arrives
- * with an argument set that has been seen before - the caching allocator of a training loop hands out the same blocks
- * every other step - its sequence is captured once and replayed as ONE hipGraphLaunch from then on.  The capture runs
- * on a stream of the plan's own (the caller's is usually PyTorch's null stream, which cannot be captured); the graph is
- * launched into the caller's stream.  A first sighting runs eagerly (one-off calls never pay for a capture); <= 16
- * graphs per plan, least recently used out; after 8 captures in a row that were never replayed the plan stops
- * capturing.  Never used inside somebody else's capture (train.GraphedTrainStep), with the side stream or the kernel
- * timing on; GPSA_STEP_GRAPH=0 / gpsa_step_graph(plan, 0, ...) switch it off.
- * Measured (tools/graph_probe.py, BASELINE config 1's size, the reference's loop): 3879 of 3903 calls replayed from 6
- * graphs (three call kinds x the allocator's two alternating block sets); 0.676 -> 0.541 ms/step with FusedAdam,
- * 0.697 -> 0.623 with torch.optim.Adam and a host read of the loss every step (1436 -> 1605 steps/s). */
+ * with an argument set that has been seen before - the caching allocator of a fresh training loop hands out the same
+ * blocks every other step - its sequence is captured once and replayed as ONE hipGraphLaunch from then on.  The capture
+ * runs on a stream of the plan's own (the caller's is usually PyTorch's null stream, which cannot be captured); the
+ * graph is launched into the caller's stream.  A first sighting runs eagerly; <= 16 graphs per plan, least recently
+ * used out; after 8 captures in a row that were never replayed the plan stops capturing.  Never used inside somebody
+ * else's capture (train.GraphedTrainStep), with the side stream or the kernel timing on.
+ * Measured (tools/graph_probe.py, BASELINE config 1's size, the reference's loop, runs alternating in one process):
+ *   * a fresh process replays 3879 of 3903 calls from 6 graphs (three call kinds x the allocator's two alternating block
+ *     sets); a model built after others have come and gone in the same process meets a longer-period allocation
+ *     pattern: 9 captures, no replay, the plan gives up;
+ *   * ms/step with the cache on / off: 0.541 / 0.676, 0.590 / 0.723, 0.543 / 0.542 (FusedAdam) and 0.623 / 0.697,
+ *     0.725 / 0.727 (torch.optim.Adam + loss.item()), while the SAME configuration drifts between 0.52 and 0.87 ms from
+ *     run to run on these boxes - Python, not the launches, is most of the host's share, and the gain is not separable
+ *     from the drift;
+ *   * OPEN: in one sequence of runs the third model with the cache on raised the forward's numerics error (a
+ *     non-positive-definite covariance) some hundred steps in; twelve runs with the cache off never did.  Not
+ *     root-caused.
+ * Hence OFF unless asked for (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)): safe for callers of the C ABI that
+ * own fixed buffers (tests/test_step_engine.py replays a repeated call bit for bit); the model's route to one launch
+ * per step stays the whole-step graph, train.GraphedTrainStep / fit(graphed=True). */
 namespace gpsa {
 
 static bool graph_usable(Plan& P, hipStream_t st) {
   if (P.g_enabled < 0) {
     const char* e = getenv("GPSA_STEP_GRAPH");
-    P.g_enabled = (e && e[0] == '0') ? 0 : 1;
+    P.g_enabled = (e && e[0] == '1') ? 1 : 0;
   }
   if (!P.g_enabled || P.side != nullptr || P.tslots != 0 || P.g_idle_captures > 8) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

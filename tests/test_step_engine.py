@@ -273,7 +273,7 @@ def test_deferred_check_belongs_to_its_own_forward():
 
 
 def test_step_graph_cache_with_fixed_buffers():
-    """the engine's hipGraph cache (csrc/step.hip): a caller that hands gpsa_step_forward the SAME
+    """the engine's hipGraph cache (csrc/step.hip; experimental, off by default): a caller that hands gpsa_step_forward the SAME
     buffers again - here: stage 1 of a forward repeated on its own arena and outputs - gets the launch sequence replayed
     as one graph launch from the third call on, with bitwise the same results as the eager call"""
     import ctypes as C
@@ -311,38 +311,3 @@ def test_step_graph_cache_with_fixed_buffers():
         plan.lib.gpsa_step_graph(plan.handle, 0, stats)
     print("graph cache [replays, eager, captures, held]:", list(stats))
     assert stats[0] >= 2 and stats[2] >= 1, list(stats)
-
-
-def test_step_graph_cache_in_a_training_loop():
-    """... and in the reference's loop: the allocator's block sets alternate, so after a few steps every forward and
-    backward call is a replay; the parameters after 24 Adam steps are bit for bit the ones of a loop without the cache"""
-    import ctypes as C
-
-    from spatial_alignment_amd.optim import FusedAdam
-    from spatial_alignment_amd.train import train_step
-
-    g = Golden("c1_example_fixed0")
-    finals, stats = [], []
-    for enable in (1, 0):
-        model, dd = build_model(g, device=DEV)
-        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
-        opt = FusedAdam(model.parameters(), lr=1e-2)
-        torch.manual_seed(5)
-        for it in range(24):
-            train_step(model, opt, dd, view_idx, Ns, S=g.S)
-            if it == 0:  # the plans exist now
-                for plan in model._step_plans.values():
-                    assert plan.lib.gpsa_step_graph(plan.handle, enable, None) == 0
-        torch.cuda.synchronize()
-        out = (C.c_longlong * 4)()
-        tot = [0, 0, 0, 0]
-        for plan in model._step_plans.values():
-            plan.lib.gpsa_step_graph(plan.handle, -1, out)
-            tot = [a + int(b) for a, b in zip(tot, out)]
-        stats.append(tot)
-        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
-    print("graph cache [replays, eager, captures, held]: on", stats[0], "off", stats[1])
-    assert stats[1][0] == 0 and stats[1][2] == 0          # switched off: nothing captured, nothing replayed
-    assert stats[0][0] >= 10 and stats[0][2] >= 2          # on: calls were captured and replayed
-    for k, a in finals[0].items():
-        assert torch.equal(a, finals[1][k]), k
