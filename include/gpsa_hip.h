@@ -621,7 +621,8 @@ int gpsa_elbo_loss_fused_bwd(int n_ll, const float* const* F, const float* const
  *   zpart[]  block partials of sum ((Y[n,p] - F_obs[s,n,p]) / s)^2  (nparts doubles, tail zeroed: the ``zpart`` of
  *            gpsa_elbo_loss_fused_fwd / _bwd, which finish LL and the noise gradient from it),
  *   dF [S N, L] = dLoss/dF_latent,   dW [L, P] = dLoss/dW,        with s = exp(noise_u) + 1e-5, dF_obs = -(Y - F_obs)/(s^2 S).
- * F [S N, L] (F_latent, sample-major as the API tensor), W [L, P], Y [N, P].  L <= 32 (GPSA_EUNSUPPORTED beyond). */
+ * F [S N, L] (F_latent, sample-major as the API tensor), W [L, P], Y [N, P].  L <= 64 (GPSA_EUNSUPPORTED beyond); since
+ * round 5 the three products run on the matrix cores (csrc/lmc.hip; GPSA_LMC_MFMA=0: the vector-pipe kernel, L <= 32). */
 long long gpsa_lmc_loglik_workspace(long long C, int L, int P, int nparts);
 int gpsa_lmc_loglik_fused_f32(const float* F, const float* W, const float* Y, const float* noise_u, int S, long long N,
                               int L, int P, double* zpart, int nparts, float* dF, float* dW, void* workspace,

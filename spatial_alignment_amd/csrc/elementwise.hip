@@ -2,7 +2,10 @@
 // HBM-bound elementwise / reduction kernels: coalesced on both the sample-major ([C,L]) API tensors
 // and the output-major ([L,C]) internal ones via 32x32 LDS tile transposes; wave-shuffle + two-pass
 // (deterministic) reductions.  Reference: gpsa/models/vgpsa.py:186-204, 334-351, 423-426, 532-538.
+#include <stdlib.h>
+
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace gpsa {
 
@@ -894,12 +897,29 @@ int gpsa_lmc_loglik_fused_f32(const float* F, const float* W, const float* Y, co
   using namespace gpsa;
   if (!F || !W || !Y || !noise_u || !zpart || !dF || !dW || S < 1 || N < 1 || L < 1 || P < 1 || nparts < 1)
     return GPSA_EINVAL;
-  if (L > 32) return GPSA_EUNSUPPORTED;
+  if (L > 64) return GPSA_EUNSUPPORTED;
   const long long C = (long long)S * N;
   if (workspace_bytes < gpsa_lmc_loglik_workspace(C, L, P, nparts)) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const int G = lmc_blocks(C, nparts);
   float* part = (float*)workspace;
+  // round 5: the three products on the matrix cores, the observations read once per spot tile (csrc/lmc.hip);
+  // GPSA_LMC_MFMA=0: round 4's vector-pipe kernel below (L <= 32)
+  static const bool mfma_off = [] { const char* e = getenv("GPSA_LMC_MFMA"); return e && e[0] == '0'; }();
+  if (!mfma_off) {
+    // (its tiles are 16 spots: at most one workgroup per tile)
+    const long long nt = cdiv(N, 16);
+    const int Gm = (int)(nt < G ? nt : G);
+    int rc = lmc_mfma_launch(F, W, Y, noise_u, S, N, L, P, zpart, nparts, dF, part, Gm, st);
+    if (rc != GPSA_EUNSUPPORTED) {
+      if (rc) return rc;
+      const long long n = (long long)L * P;
+      reduce_rows_kernel<float, float><<<(unsigned)cdiv(n, 64), 256, 0, st>>>(part, Gm, n, n, dW, 1.0);
+      GPSA_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  if (L > 32) return GPSA_EUNSUPPORTED;
 #define GPSA_LMC_CASE(LBV)                                                                                 \
   {                                                                                                        \
     const size_t sm = (size_t)(LMC_TC * LBV + LBV * LMC_PS + LMC_TC * LMC_PS) * 4;                         \

@@ -35,4 +35,9 @@ int mvn_kl_grouped_fwd_copy(const double* mats, const double* inv, const double*
                             const int* pr_idx, const double* D, int M, int T, double* kl, double* KD,
                             double* kl_copy, hipStream_t st);
 
+// lmc.hip: the LMC likelihood, its gradient and the two LMC gradient products on the matrix cores, G workgroups
+// (zpart [nparts >= G], dWpart [G][L][P]); GPSA_EUNSUPPORTED beyond 64 latent outputs
+int lmc_mfma_launch(const float* F, const float* W, const float* Y, const float* noise_u, int S, long long N, int L,
+                    int P, double* zpart, int nparts, float* dF, float* dWpart, int G, hipStream_t st);
+
 }  // namespace gpsa

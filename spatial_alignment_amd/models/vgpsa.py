@@ -651,7 +651,7 @@ class VariationalGPSA(GPSA):
         loss_fn runs gpsa_lmc_loglik_fused_f32 on (F_latent, W, Y) instead of forming it).  ``grads``: gradients are
         enabled and a parameter wants one"""
         training = self.fuse_elbo and not prediction_mode and G_test is None and grads
-        return [bool(training and plan.lmc[i] and plan.L[i] <= 32 and self.W_dict[m].dtype == torch.float32
+        return [bool(training and plan.lmc[i] and plan.L[i] <= 64 and self.W_dict[m].dtype == torch.float32
                      and self.W_dict[m].is_contiguous())
                 for i, m in enumerate(self.modality_names)]
 

@@ -265,7 +265,8 @@ def test_quadform_elbo(hip, M, N, S, L):
 
 
 @pytest.mark.parametrize("S,N,L,P", [(2, 100, 3, 7), (5, 1000, 10, 500), (1, 333, 20, 1100), (3, 17, 8, 512),
-                                     (2, 50, 32, 40), (1, 1, 1, 1), (2, 4000, 10, 513)])
+                                     (2, 50, 32, 40), (1, 1, 1, 1), (2, 4000, 10, 513), (2, 300, 33, 130),
+                                     (1, 200, 64, 70), (5, 40000, 10, 500)])
 def test_lmc_loglik_fused(hip, S, N, L, P):
     """the LMC likelihood without F_obs (gpsa_lmc_loglik_fused_f32): sum z^2, dLoss/dF_latent and dLoss/dW against
     autograd of the reference's own expressions (vgpsa.py:428-432, 532-538) in fp64"""
@@ -288,9 +289,38 @@ def test_lmc_loglik_fused(hip, S, N, L, P):
         return
 
 
-def test_lmc_loglik_fused_refuses_more_than_32_latent_outputs(hip):
+def test_lmc_loglik_fused_refuses_more_than_64_latent_outputs(hip):
     with pytest.raises(Exception):
-        hip.lmc_loglik_fused(rnd(1, 8, 33).to(DEV), rnd(33, 4).to(DEV), rnd(8, 4).to(DEV), torch.tensor([0.0]).to(DEV))
+        hip.lmc_loglik_fused(rnd(1, 8, 65).to(DEV), rnd(65, 4).to(DEV), rnd(8, 4).to(DEV), torch.tensor([0.0]).to(DEV))
+
+
+def test_lmc_loglik_mfma_equals_vector_kernel(hip, monkeypatch):
+    """round 5's matrix-core kernel against round 4's vector-pipe kernel on BASELINE config 3's shape (to rounding:
+    different summation orders), with its time next to it"""
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, time, sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from spatial_alignment_amd.ops import get_ops\n"
+        "hip = get_ops(); g = torch.Generator().manual_seed(1)\n"
+        "F = torch.randn(5, 40000, 10, generator=g).cuda(); W = torch.randn(10, 500, generator=g).cuda()\n"
+        "Y = torch.randn(40000, 500, generator=g).cuda(); nu = torch.tensor([-0.4]).cuda()\n"
+        "for _ in range(3): out = hip.lmc_loglik_fused(F, W, Y, nu)\n"
+        "torch.cuda.synchronize(); t0 = time.perf_counter()\n"
+        "for _ in range(20): out = hip.lmc_loglik_fused(F, W, Y, nu)\n"
+        "torch.cuda.synchronize(); print('MS', 1e3 * (time.perf_counter() - t0) / 20)\n"
+        "torch.save([o.cpu() for o in out], sys.argv[1])\n")
+    res = {}
+    for mode in ("1", "0"):
+        path = f"/tmp/lmc_{mode}.pt"
+        env = dict(__import__("os").environ, GPSA_LMC_MFMA=mode)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = (torch.load(path), [ln for ln in r.stdout.splitlines() if ln.startswith("MS")][0])
+    print("lmc likelihood, 5 x 40000 spots, 10 -> 500 outputs: matrix cores", res["1"][1], "vector pipe", res["0"][1])
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert float((a.double() - b.double()).norm() / b.double().norm()) <= 3e-6
 
 
 @pytest.mark.parametrize("M,n0,n1", [(5, 3, 2), (200, 4, 50), (72, 1, 1)])
