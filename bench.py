@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--headline-only", action="store_true",
                     help="profiling: only the headline blocks (no helper / verbatim / exact-mode / S = 1 / graph / config "
                          "legs, no CPU baseline)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live rocprofv3 --pmc passes for roofline.traffic (the committed file is quoted instead)")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--static-grads", action="store_true", help="diagnostic: zero_grad(set_to_none=False)")
     ap.add_argument("--overlap", action="store_true", help="diagnostic: per-view side streams in eager mode too")
@@ -231,6 +233,45 @@ def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
                seconds=round(time.time() - t0, 1))
     model.zero_grad(set_to_none=True)
     return res
+
+
+def measure_traffic(args):
+    """HBM-side bytes per launch of the contraction kernels, MEASURED NOW: two child runs of this file's headline loop
+    under ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE: separate passes, as MI355X_MICROARCH.md's HBM section
+    prescribes), summarised by profiles/pmc_summarize.py's rules (KiB -> bytes, FETCH doubled on gfx950).  None when
+    rocprofv3 is not on this box or a pass fails (the line then falls back to the committed profiles/pmc_traffic.json
+    and says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    try:
+        import pmc_summarize as PS
+
+        t0 = time.time()
+        tmp = tempfile.mkdtemp(prefix="gpsa_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        acc = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--headline-only", "--blocks", "1", "--steps", "3", "--warmup", "1",
+                   "--S", str(args.S), "--side", str(args.side), "--views", str(args.views), "--outputs",
+                   str(args.outputs), "--M", str(args.M)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return dict(error=f"rocprofv3 --pmc {counter}: rc={r.returncode}", stderr=r.stderr[-300:])
+            acc[counter] = PS.per_kernel(d, counter)
+        out = PS.summarise(acc["FETCH_SIZE"], acc["WRITE_SIZE"])
+        out["seconds"] = round(time.time() - t0, 1)
+        shutil.rmtree(tmp, ignore_errors=True)
+        return out
+    except Exception as e:  # the contract line must not die with its extra
+        return dict(error=f"{type(e).__name__}: {e}"[:300])
 
 
 def extra_workload(which, args):
@@ -537,12 +578,22 @@ def main():
     if rank == 0:
         N = int(sum(dd_full["expression"]["n_samples_list"]))
         ks = ks_head
-        pmc = None
+        pmc, pmc_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_cfg = (args.S, args.side, args.views, args.outputs, args.M, world) == (5, 100, 2, 50, 200, 1)
-        if os.path.exists(pmc_path) and default_cfg:  # the counters were collected on the default workload
+        if world == 1 and emu == 1 and args.workload == "2" and not args.headline_only and not args.no_traffic:
+            live = measure_traffic(args)
+            if live is not None and "error" not in live:
+                pmc = live
+                pmc_source = (f"measured in this run: two child passes of the headline loop under rocprofv3 --pmc "
+                              f"(FETCH_SIZE, WRITE_SIZE), {live.get('seconds')} s")
+            elif live is not None:
+                pmc_source = f"live measurement failed ({live.get('error')}); "
+        if pmc is None and os.path.exists(pmc_path) and default_cfg:  # the counters were collected on the default workload
             try:
                 pmc = json.load(open(pmc_path))
+                pmc_source = (pmc_source or "") + ("profiles/pmc_traffic.json (builder-collected rocprofv3 --pmc passes "
+                                                   "on this workload, not measured in this run)")
             except Exception:
                 pmc = None
         # flops a launch EXECUTES relative to the nominal 2*C*L*M^2: the forward form and the Gram kernel walk
@@ -617,8 +668,7 @@ def main():
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         executed_frac=ex(dname) / PEAK_F32_MFMA_TFLOPS,
                         traffic=((pmc or {}).get("hbm_bytes_per_launch") or {}).get(dname),
-                        traffic_source="profiles/pmc_traffic.json (builder-collected rocprofv3 --pmc passes on "
-                                       "this workload, not measured in this run)",
+                        traffic_source=pmc_source,
                         traffic_note=(pmc or {}).get("note"),
                         avg_launch_ms=dom["avg_ms"], flops_per_launch=dom["flops"],
                         flops_note="achieved / frac: algorithmic 2*C*L*M^2 per launch (C = S*N columns); "

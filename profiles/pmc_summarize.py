@@ -24,8 +24,7 @@ def per_kernel(d, counter):
     return acc
 
 
-def main():
-    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+def summarise(fetch, write):
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH doubled "
                    "(gfx950 correction, MI355X_MICROARCH.md HBM section); per launch averages", "kernels": {}}
     for k in fetch:
@@ -42,6 +41,12 @@ def main():
             bl["quadform_bwd_alpha"] = fb + wb
         elif "gram_mfma_kernel" in k:
             bl["quadform_bwd_omega"] = fb + wb
+    return out
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = summarise(fetch, write)
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json"), "w"), indent=1)
     for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["fetch_bytes"])[:12]:
         print("%-100s fetch %9.1f MB write %9.1f MB" % (k[:100], v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6))
