@@ -248,6 +248,8 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None  # this process is itself being profiled: no profiler inside the profiler
     sys.path.insert(0, os.path.join(ROOT, "profiles"))
     try:
         import pmc_summarize as PS

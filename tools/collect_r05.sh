@@ -15,7 +15,7 @@ mkdir -p $O
 cd $R
 python3 bench.py > $O/${T}_default_bench_line.json 2> $O/${T}_bench.log
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-graph --no-s1 --no-extras --blocks 1"
+B="$R/bench.py --headline-only --blocks 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $B --steps 10 --warmup 2 > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${T}_default_bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $B --steps 3 --warmup 1 > $O/fetch.log 2>&1
