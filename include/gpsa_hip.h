@@ -527,6 +527,15 @@ typedef struct gpsa_step_io {
    * 0: an ordinary backward.  The KL terms' gradient og->dkl belongs to the LAST slice's call. */
   double* bwd_acc;
   int bwd_acc_mode;
+  /* Data-parallel overlap (round 5; parallel.GradAllReducer(overlap=True)): with f_event (a hipEvent_t) given,
+   * gpsa_step_backward finishes the DATA GP's span of the gradients first - Omega_sqt_F, delta_F, W: 97 % of the bytes
+   * at the headline configuration - and records the event on the caller's stream behind it, so that the caller can
+   * start reducing that span on another stream while the warp GPs' backward, the priors' covariance backward and the
+   * rest run.  The KL backward then runs in front of the warp GPs' backward, whose products are added to its shares
+   * instead of overwriting them: the fp64 sums meet in another order (results equal to rounding, not bitwise).  The
+   * event is recorded at the very end when the early order is not available (a microbatched step, the side stream, a
+   * shape the long-K kernel does not cover).  NULL: the ordinary order. */
+  void* f_event;
 } gpsa_step_io;
 
 typedef struct gpsa_step_out_grads {        /* gradients of the caller's scalar wrt the forward's outputs */
@@ -558,6 +567,8 @@ long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.
  * that own fixed buffers; GPSA_STEP_GRAPH=1 turns it on for the process.  This is the cache's switch and its counters:
  * enable != 0 / 0 (-1: leave as it is); out[0..3] = replays, eager calls, captures, graphs held (out may be NULL). */
 int gpsa_step_graph(void* plan, int enable, long long* out);
+/* backwards of this plan that took the early order of gpsa_step_io.f_event (the data GP's gradients finished first) */
+long long gpsa_step_early_backwards(const void* plan);
 /* Where the step's factorisation batch sits in the ``saved`` arena, for the reference's forward -> loss_fn hand-off
  * attributes Kuu_chol_list / curr_Omega_tril_list / Kuu_chol_F / curr_Omega_tril_F (vgpsa.py:237, 257, 321, 394, 412):
  * the engine keeps the matrices (K_uu + 1e-5 I, Omega = A A^T + 1e-5 I; fp64, [B, M, M] per group) and their inverses,

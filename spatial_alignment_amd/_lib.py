@@ -105,6 +105,7 @@ class StepIO(C.Structure):
         ("F_obs_test", _vp * MAX_MODS), ("mu_z", _vp), ("kl", _vp), ("flag", _vp), ("keep_products", _i),
         ("reuse_mm", _i), ("fuse_elbo", _i), ("Y", _vp * MAX_MODS), ("noise_u", _vp * MAX_MODS),
         ("ll_part", _vp * MAX_MODS), ("F_fused_T", _vp * MAX_MODS), ("bwd_acc", _vp), ("bwd_acc_mode", _i),
+        ("f_event", _vp),
     ]
 
 
@@ -164,6 +165,7 @@ SIGNATURES.update({
     "gpsa_step_eps_g_numel": (_ll, [_vp]),
     "gpsa_step_batch_layout": (_i, [_vp, C.POINTER(_ll)]),
     "gpsa_step_graph": (_i, [_vp, _i, C.POINTER(_ll)]),
+    "gpsa_step_early_backwards": (_ll, [_vp]),
     "gpsa_step_timing": (_i, [_vp, _i]),
     "gpsa_step_timing_read": (_i, [_vp, _vp, _i]),
     "gpsa_step_forward": (_i, [_vp, C.POINTER(StepParams), C.POINTER(StepIO), _vp, _vp, _i, _vp]),

@@ -363,6 +363,7 @@ exact_axpy2_kernel(const double* G, const double* __restrict__ A, const double* 
 //   Gtilde      = sum_passes dZ(K_uf) + dZ(K_uu);  data_ls / data_var likewise (+ the samplers' share)
 //   delta_F[m]  = ddc (layer, fp32 [Mg, L]) + KL's dD rows ([L, Mg], transposed)
 struct FinalArgs {
+  int part;  // 0: everything; 1: only delta_F (the data GP's span, finished early); 2: everything but delta_F
   int V, D, Mx, Mg, nm, nf, npass;
   const int* bidx;
   const float* slopes;
@@ -382,6 +383,9 @@ __global__ void __launch_bounds__(256) step_finalize_kernel(FinalArgs a) {
   const int D = a.D;
   const long long nX = (long long)a.V * a.Mx * D;
   long long e = blockIdx.x * 256LL + threadIdx.x;
+  const long long nsmall = nX + 2LL * a.V + (long long)a.Mg * D + 2;  // everything in front of delta_F
+  if (a.part == 1) e += nsmall;          // (the launch covers the delta_F entries only)
+  if (a.part == 2 && e >= nsmall) return;
   // --- Xtilde / delta_G
   if (e < nX) {
     const int v = (int)(e / ((long long)a.Mx * D));
@@ -599,6 +603,7 @@ struct Plan {
   unsigned long long gtick = 0;
   long long g_hits = 0, g_eager = 0, g_captures = 0, g_idle_captures = 0;
   int g_enabled = -1;           // -1: GPSA_STEP_GRAPH decides (default off)
+  long long n_early = 0;        // backwards that took the early order (gpsa_step_io.f_event)
 
   Group& gw() { return grp[0]; }
   Group& gd() { return merged ? grp[0] : grp[1]; }
@@ -1563,7 +1568,8 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   return 0;
 }
 
-static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
+// acc: the products are ADDED to what the gradient batch already holds (the early order: the KL backward ran first)
+static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B, bool acc) {
   Plan& P = c.P;
   const bool dry = c.dry;
   const int D = P.D, Mx = P.Mx, nf = P.nf;
@@ -1620,7 +1626,7 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
           Bs[n] = alpha + oMC + (long long)i * Mx * Cs;
           ds[n] = g + oDC + ((long long)i * D + jj) * Cs;
           al[n] = 1.0;
-          be[n] = 0.0;
+          be[n] = acc ? 1.0 : 0.0;
           os[n] = B.dstack[0] + ((long long)P.pos_OmG((r.v0 + i) * D + jj)) * mm;
         }
       int rc = longk(c, n, nullptr, Bs, ds, GPSA_F64, Mx, Cs, Cs, 1, al, be, os);
@@ -1630,7 +1636,7 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
           Bs[i] = alpha + oMC + (long long)i * Mx * Cs;
           ds[i] = qbar + (long long)(r.b0 + i) * Cs;
           al[i] = -1.0;
-          be[i] = 0.0;
+          be[i] = acc ? 1.0 : 0.0;
           os[i] = B.dstack[0] + (long long)P.pos_Kw(r.b0 + i) * mm;
         }
         rc = longk(c, r.cnt, Gs, Bs, ds, GPSA_F64, Mx, Cs, Cs, 0, al, be, os);
@@ -1643,6 +1649,7 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
       }
     }
     if (!done) {
+      if (acc) return GPSA_EINVAL;  // (the early order is only taken when every run is covered: warp_runs_longk)
       {
         const long long mk2 = c.sc.mark();
         const long long wsb = gpsa_gram_batched_workspace(Mx, Cs, D, r.cnt);
@@ -1675,6 +1682,15 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B) {
   }
   c.sc.release(mk);
   return 0;
+}
+
+// every run of free views takes the long-K kernel for its backward products (the early order needs their beta)
+static bool warp_runs_longk(const Plan& P) {
+  for (const Run& r : P.runs)
+    if (!(r.cnt * P.D <= 48 && gpsa_longk_f64_workspace(P.Mx, P.Cs, r.cnt * P.D) > 0 &&
+          gpsa_longk_f64_workspace(P.Mx, P.Cs, r.cnt) > 0))
+      return false;
+  return true;
 }
 
 static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_io& io,
@@ -1767,8 +1783,14 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
     GPSA_CK(data_pass_bwd(c, ps, pi, dFl, dFo, B, out, !seen[ps.m], og.gloss));
     seen[ps.m] = true;
   }
-  // ---- warp GPs
-  GPSA_CK(warp_stage_bwd(c, og, B));
+  // ---- order of the rest.  Ordinary: warp GPs' backward, KL backward, priors' covariance backward, dOmega -> dA,
+  //      finalisation.  EARLY (io.f_event: a data-parallel caller wants to start reducing the data GP's span of the
+  //      gradients - Omega_sqt_F, delta_F, W: 97 % of the bytes - while the rest still runs): KL backward first, then
+  //      dOmega -> dA and the finalisation of the data GP's parameters, the event, and only then the warp GPs' backward
+  //      (its products ADDED to the KL shares already in the batch), the priors' backward and everything else.
+  const bool early = io.f_event != nullptr && !dry && (io.bwd_acc == nullptr || io.bwd_acc_mode == 0) &&
+                     P.side == nullptr && warp_runs_longk(P);
+  if (!early) GPSA_CK(warp_stage_bwd(c, og, B, false));
   // ---- one optimiser step as several passes over row slices (train.Microbatches): everything N-scaled of this
   //      slice is in the region [z0, z1) (fp64 pieces, then the samplers' fp32 scalars) and in ddc_F.  A slice that is not
   //      the last adds it to the caller's accumulator and is done; the last one adds the accumulator to its own and
@@ -1822,62 +1844,70 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
     }
     if (io.bwd_acc_mode != 3) return 0;
   }
+  auto kl_backward = [&]() -> int {
   // ---- KL terms
-  if (kl && P.side != nullptr) {  // join: add the side stream's share (same layout as dstack) in one pass
-    if (fork) GPSA_CK((int)hipStreamWaitEvent(st, P.sev[4], 0));
-    for (int g = 0; g < P.ng; ++g) {
+    if (kl && P.side != nullptr) {  // join: add the side stream's share (same layout as dstack) in one pass
+      if (fork) GPSA_CK((int)hipStreamWaitEvent(st, P.sev[4], 0));
+      for (int g = 0; g < P.ng; ++g) {
+        Group& G = P.grp[g];
+        if (G.n_omega == 0 || G.n_prior == 0 || dry) continue;
+        const long long n = (long long)G.nb() * G.M * G.M;
+        add_inplace_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(B.dstack[g], dKL[g], n);
+        GPSA_LAUNCH_CHECK();
+      }
+    }
+    for (int g = 0; g < P.ng && kl && P.side == nullptr; ++g) {  // single stream: accumulate in place
       Group& G = P.grp[g];
-      if (G.n_omega == 0 || G.n_prior == 0 || dry) continue;
-      const long long n = (long long)G.nb() * G.M * G.M;
-      add_inplace_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(B.dstack[g], dKL[g], n);
-      GPSA_LAUNCH_CHECK();
+      if (G.n_omega == 0 || G.n_prior == 0) continue;
+      const long long mm = (long long)G.M * G.M;
+      const long long mk = sc.mark();
+      double* S = sc.get<double>((long long)G.n_prior * mm);
+      double* T1 = sc.get<double>((long long)G.n_prior * mm);
+      GPSA_RUN(gpsa_mvn_kl_grouped_bwd_acc(c.mats(G, 0), c.inv(G, 0), G.om_idx, G.pr_list, G.grp_off, G.order,
+                                           c.sv<double>(G.o_D), c.sv<double>(G.o_KD), og.dkl + G.kl_off, G.M, G.n_omega,
+                                           G.n_prior, B.dstack[g] + (long long)G.n_prior * mm, B.dD[g], S, 1, c.stv()));
+      GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 1.0, c.inv(G, 0), G.M, mm, S, G.M, mm, 0.0, T1, G.M, mm, G.n_prior,
+                     splitk_small(G.M, G.M, G.M, G.n_prior)));
+      GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 0.5, T1, G.M, mm, c.inv(G, 0), G.M, mm, 1.0, B.dstack[g], G.M, mm, G.n_prior,
+                     splitk_small(G.M, G.M, G.M, G.n_prior)));
+      sc.release(mk);
     }
-  }
-  for (int g = 0; g < P.ng && kl && P.side == nullptr; ++g) {  // single stream: accumulate in place
-    Group& G = P.grp[g];
-    if (G.n_omega == 0 || G.n_prior == 0) continue;
-    const long long mm = (long long)G.M * G.M;
-    const long long mk = sc.mark();
-    double* S = sc.get<double>((long long)G.n_prior * mm);
-    double* T1 = sc.get<double>((long long)G.n_prior * mm);
-    GPSA_RUN(gpsa_mvn_kl_grouped_bwd_acc(c.mats(G, 0), c.inv(G, 0), G.om_idx, G.pr_list, G.grp_off, G.order,
-                                         c.sv<double>(G.o_D), c.sv<double>(G.o_KD), og.dkl + G.kl_off, G.M, G.n_omega,
-                                         G.n_prior, B.dstack[g] + (long long)G.n_prior * mm, B.dD[g], S, 1, c.stv()));
-    GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 1.0, c.inv(G, 0), G.M, mm, S, G.M, mm, 0.0, T1, G.M, mm, G.n_prior,
-                   splitk_small(G.M, G.M, G.M, G.n_prior)));
-    GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 0.5, T1, G.M, mm, c.inv(G, 0), G.M, mm, 1.0, B.dstack[g], G.M, mm, G.n_prior,
-                   splitk_small(G.M, G.M, G.M, G.n_prior)));
-    sc.release(mk);
-  }
+    return 0;
+  };
+  auto priors_backward = [&]() -> int {
   // ---- prior covariances: K_uu of the free views and of the data GP
-  {
-    Group& GW = P.gw();
-    Group& GD = P.gd();
-    for (const Run& r : P.runs) {
-      const long long mk = sc.mark();
-      const long long wsb = gpsa_kmat_bwd_batched_workspace(Mx, Mx, D, r.cnt);
-      void* ws = sc.get<char>(wsb);
-      GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_warp, prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
-                                     prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx, D, prm.warp_ls + r.v0,
-                                     prm.warp_var + r.v0, 1, nullptr, r.cnt,
-                                     B.dstack[0] + (long long)P.pos_Kw(r.b0) * Mx * Mx, (long long)Mx * Mx, 1,
-                                     B.dZ_wu + (long long)r.b0 * Mx * D, (long long)Mx * D, B.dpar_wu + (long long)r.b0 * 2,
-                                     ws, wsb, c.stv()));
-      sc.release(mk);
-    }
     {
-      const long long mk = sc.mark();
-      const long long wsb = gpsa_kmat_bwd_batched_workspace(Mg, Mg, D, 1);
-      void* ws = sc.get<char>(wsb);
-      GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_data, prm.Gtilde, 0, Mg, prm.Gtilde, 0, Mg, D, prm.data_ls, prm.data_var, 0,
-                                     nullptr, 1, B.dstack[P.merged ? 0 : 1] + (long long)P.pos_KF() * Mg * Mg, 0, 1,
-                                     B.dZ_du, 0, B.dpar_du, ws, wsb, c.stv()));
-      sc.release(mk);
+      for (const Run& r : P.runs) {
+        const long long mk = sc.mark();
+        const long long wsb = gpsa_kmat_bwd_batched_workspace(Mx, Mx, D, r.cnt);
+        void* ws = sc.get<char>(wsb);
+        GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_warp, prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx,
+                                       prm.Xtilde + (long long)r.v0 * Mx * D, (long long)Mx * D, Mx, D, prm.warp_ls + r.v0,
+                                       prm.warp_var + r.v0, 1, nullptr, r.cnt,
+                                       B.dstack[0] + (long long)P.pos_Kw(r.b0) * Mx * Mx, (long long)Mx * Mx, 1,
+                                       B.dZ_wu + (long long)r.b0 * Mx * D, (long long)Mx * D, B.dpar_wu + (long long)r.b0 * 2,
+                                       ws, wsb, c.stv()));
+        sc.release(mk);
+      }
+      {
+        const long long mk = sc.mark();
+        const long long wsb = gpsa_kmat_bwd_batched_workspace(Mg, Mg, D, 1);
+        void* ws = sc.get<char>(wsb);
+        GPSA_RUN(gpsa_kmat_bwd_batched(P.d.kind_data, prm.Gtilde, 0, Mg, prm.Gtilde, 0, Mg, D, prm.data_ls, prm.data_var, 0,
+                                       nullptr, 1, B.dstack[P.merged ? 0 : 1] + (long long)P.pos_KF() * Mg * Mg, 0, 1,
+                                       B.dZ_du, 0, B.dpar_du, ws, wsb, c.stv()));
+        sc.release(mk);
+      }
     }
-    // variational covariances: d Omega_sqt = (G + G^T) A = 2 G A (every gradient that reaches Omega is symmetric)
+    return 0;
+  };
+  // variational covariances: d Omega_sqt = (G + G^T) A = 2 G A (every gradient that reaches Omega is symmetric);
+  // which: 1 = the warp GPs' factors, 2 = the modalities', 3 = both (one launch with the first modality's when the
+  // sizes agree)
+  auto omega_backward = [&](int which) -> int {
     int m_first = 0;
-    if (out.Omega_sqt_G != nullptr) {
-      if (Mx == Mg && P.nm > 0 && out.Omega_sqt_F[0] != nullptr) {  // one launch with the first modality's
+    if ((which & 1) && out.Omega_sqt_G != nullptr) {
+      if ((which & 2) && Mx == Mg && P.nm > 0 && out.Omega_sqt_F[0] != nullptr) {
         m_first = 1;
         GPSA_RUN(gpsa_omega_bwd2(B.dstack[0] + (long long)P.pos_OmG(0) * Mx * Mx, prm.Omega_sqt_G, out.Omega_sqt_G, V * D,
                                  B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(0, 0) * Mg * Mg, prm.Omega_sqt_F[0],
@@ -1887,16 +1917,17 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
                                 out.Omega_sqt_G, c.stv()));
       }
     }
-    for (int m = m_first; m < P.nm; ++m)
-      if (out.Omega_sqt_F[m] != nullptr)
-        GPSA_RUN(gpsa_omega_bwd(B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(m, 0) * Mg * Mg, prm.Omega_sqt_F[m], Mg,
-                                P.d.n_latent[m], 1, out.Omega_sqt_F[m], c.stv()));
-    (void)GW; (void)GD;
-  }
-  // ---- small parameters
-  {
+    if (which & 2)
+      for (int m = m_first; m < P.nm; ++m)
+        if (out.Omega_sqt_F[m] != nullptr)
+          GPSA_RUN(gpsa_omega_bwd(B.dstack[P.merged ? 0 : 1] + (long long)P.pos_OmF(m, 0) * Mg * Mg, prm.Omega_sqt_F[m], Mg,
+                                  P.d.n_latent[m], 1, out.Omega_sqt_F[m], c.stv()));
+    return 0;
+  };
+  auto finalize = [&](int part) -> int {
     FinalArgs a;
     memset(&a, 0, sizeof(a));
+    a.part = part;
     a.V = V; a.D = D; a.Mx = Mx; a.Mg = Mg; a.nm = P.nm; a.nf = nf; a.npass = npass;
     a.bidx = P.tab.bidx;
     a.slopes = prm.slopes;
@@ -1905,18 +1936,38 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
     a.dD_w = kl ? B.dD[0] : nullptr;
     a.dZ_df = B.dZ_df; a.dpar_df = B.dpar_df; a.dvar_ds = B.dvar_ds; a.dZ_du = B.dZ_du; a.dpar_du = B.dpar_du;
     a.dD_d = kl ? (P.merged ? B.dD[0] + (long long)V * D * Mx : B.dD[1]) : nullptr;
-    long long tot = (long long)V * Mx * D + 2LL * V + (long long)Mg * D + 2;
+    const long long nsmall = (long long)V * Mx * D + 2LL * V + (long long)Mg * D + 2;
+    long long nF = 0;
     for (int m = 0; m < P.nm; ++m) {
       a.ddc_F[m] = B.have_ddc[m] ? B.ddc_F[m] : nullptr;
       a.L[m] = P.d.n_latent[m];
       a.Loff[m] = P.Loff[m];
-      tot += (long long)Mg * P.d.n_latent[m];
+      nF += (long long)Mg * P.d.n_latent[m];
     }
     a.out = out;
-    if (!dry) {
+    const long long tot = part == 1 ? nF : (part == 2 ? nsmall : nsmall + nF);
+    if (!dry && tot > 0) {
       step_finalize_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(a);
       GPSA_LAUNCH_CHECK();
     }
+    return 0;
+  };
+  if (early) {
+    ++P.n_early;
+    GPSA_CK(kl_backward());
+    GPSA_CK(omega_backward(2));
+    GPSA_CK(finalize(1));
+    GPSA_CK((int)hipEventRecord(reinterpret_cast<hipEvent_t>(io.f_event), st));
+    GPSA_CK(warp_stage_bwd(c, og, B, true));
+    GPSA_CK(priors_backward());
+    GPSA_CK(omega_backward(1));
+    GPSA_CK(finalize(2));
+  } else {
+    GPSA_CK(kl_backward());
+    GPSA_CK(priors_backward());
+    GPSA_CK(omega_backward(3));
+    GPSA_CK(finalize(0));
+    if (io.f_event != nullptr && !dry) GPSA_CK((int)hipEventRecord(reinterpret_cast<hipEvent_t>(io.f_event), st));
   }
   return 0;
 }
@@ -2128,6 +2179,9 @@ int gpsa_step_n_kl(const void* plan) {
   return p->V * p->D + p->Ltot;
 }
 long long gpsa_step_eps_g_numel(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->eps_total : -1; }
+long long gpsa_step_early_backwards(const void* plan) {
+  return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->n_early : -1;
+}
 int gpsa_step_batch_layout(const void* plan, long long* out) {
   if (!plan || !out) return GPSA_EINVAL;
   const gpsa::Plan* p = reinterpret_cast<const gpsa::Plan*>(plan);

@@ -105,11 +105,38 @@ class GradAllReducer:
     buffer itself is reduced in place - no pack, no unpack.  Otherwise: pack, reduce, unpack.
     Every call inside it (copies, the RCCL all-reduce) is capturable into a hipGraph."""
 
-    def __init__(self, params, always=False):
+    def __init__(self, params, always=False, overlap=False, model=None):
+        """``overlap`` (with ``model``, a VariationalGPSA on the step engine): the data GP's span of the flat gradient
+        buffer (Omega_sqt_F, delta_F, W: 97 % of the bytes at the headline configuration) is reduced on a side stream
+        while the rest of the backward - the warp GPs' backward, the priors' covariance backward - still runs; the
+        engine finishes that span first and records this reducer's event behind it (gpsa_step_io.f_event).  ``__call__``
+        then reduces what is left and joins the side stream."""
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         self.always = always  # reduce even in a 1-rank group (tests of the capture path)
+        self.overlap = bool(overlap) and model is not None and self.params and self.params[0].is_cuda
+        self._early = None    # (flat, lo, hi) of the span whose all-reduce is in flight on the side stream
+        if self.overlap:
+            self._side = torch.cuda.Stream(device=self.params[0].device)
+            self._event = torch.cuda.Event()
+            self._event.record()  # (creates the underlying hipEvent: its handle goes to the engine)
+            model.__dict__["_early_reducer"] = self
+
+    def event_handle(self):
+        return int(self._event.cuda_event)
+
+    def start_early(self, flat, lo, hi):
+        """called by StepFn.backward right after the engine's launches are queued: reduce flat[lo:hi] behind the event"""
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.always):
+            return
+        if hi <= lo:
+            return
+        self._side.wait_event(self._event)
+        flat.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM)
+        self._early = (flat, lo, hi)
 
     def _engine_bucket(self):
         """(flat buffer, parameters outside it) when the gradients are views of one step-engine buffer"""
@@ -159,6 +186,27 @@ class GradAllReducer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         bucket = self._engine_bucket()
+        if self._early is not None:
+            eflat, lo, hi = self._early
+            self._early = None
+            main = torch.cuda.current_stream(eflat.device)
+            if bucket is not None and bucket[0] is eflat and bucket[3] is None:
+                # the rest of the buffer - the small parameters and Omega_sqt_G in front of the early span, the
+                # outsiders behind it - on this stream, then the join
+                flat, used, outside, _ = bucket
+                if lo > 0:
+                    dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM)
+                if outside:
+                    tail = flat[used: used + sum(p.numel() for p in outside)]
+                    torch.cat([p.grad.view(-1) for p in outside], out=tail)
+                    dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+                    torch._foreach_copy_([p.grad.view(-1) for p in outside],
+                                         list(tail.split([p.numel() for p in outside])))
+                main.wait_stream(self._side)
+                return
+            main.wait_stream(self._side)  # (not the layout this shortcut knows: the span is reduced, undo nothing -
+            # the general path below would reduce it a second time, so bring it back to the local share first)
+            raise RuntimeError("GradAllReducer(overlap=True): the gradients are not the step engine's single bucket")
         if bucket is not None and bucket[3] is not None:
             flat, used, outside, spans = bucket
             for a, b in spans:

@@ -555,11 +555,21 @@ class StepFn(torch.autograd.Function):
             keep.append(buf)
             ctx.io.bwd_acc, ctx.io.bwd_acc_mode = buf.data_ptr(), int(mode)
             closes = mode == 3
+        # data-parallel overlap (parallel.GradAllReducer(overlap=True)): the engine finishes the data GP's span of the
+        # flat buffer - everything from Omega_sqt_F on - first and records the reducer's event behind it; the reducer
+        # starts that span's all-reduce on its own stream while the rest of this backward runs
+        early = model.__dict__.get("_early_reducer") if model is not None else None
+        if early is not None and closes:
+            ctx.io.f_event = early.event_handle()
+        else:
+            ctx.io.f_event = None
         call = TO.stash(dict(lib=lib, handle=plan.handle, prm=ctx.prm, io=ctx.io, og=og, grads=grads))
         try:
             torch.ops.gpsa.step_backward(list(tensors), keep, ctx.arena, flat, scratch, call)
         finally:
             TO.CALLS.pop(call, None)
+        if early is not None and closes:
+            early.start_early(flat, offs[8], used)
         out = [None]
         for i, t in enumerate(tensors):
             out.append(views[i].view(t.shape) if (ctx.needs_input_grad[1 + i] and closes) else None)

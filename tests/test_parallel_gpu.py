@@ -11,19 +11,23 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _problem(dev):
+SIDE = 20  # (the overlap variants run a larger grid: the early order needs the long-K kernel, i.e. >= 1536 spots a shard)
+
+
+def _problem(dev, side=None):
     from spatial_alignment_amd.synthetic import make_grid_problem, make_model
 
-    dd = make_grid_problem(side=20, n_views=2, n_outputs=6)
+    dd = make_grid_problem(side=side or SIDE, n_views=2, n_outputs=6)
     model = make_model(dd, m=25, device=dev)
     dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
               "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
     return dd, model
 
 
-def _noise():
+def _noise(side=None):
+    n = (side or SIDE) ** 2
     gen = torch.Generator().manual_seed(11)
-    return [torch.randn(3, 400, 2, generator=gen) for _ in range(2)], torch.randn(3, 800, 6, generator=gen)
+    return [torch.randn(3, n, 2, generator=gen) for _ in range(2)], torch.randn(3, 2 * n, 6, generator=gen)
 
 
 def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False):
@@ -40,7 +44,7 @@ def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False):
     return loss.detach()
 
 
-def _worker(rank, world, port, q, fuse=False):
+def _worker(rank, world, port, q, fuse=False, overlap=False):
     import __graft_entry__ as ge
     from spatial_alignment_amd.parallel import GradAllReducer, shard_data_dict, shard_rows
 
@@ -48,13 +52,23 @@ def _worker(rank, world, port, q, fuse=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
-    dd, model = _problem(dev)
-    eG, eF = _noise()
+    side = 56 if overlap else None
+    n = (side or SIDE) ** 2
+    dd, model = _problem(dev, side)
+    eG, eF = _noise(side)
     sdd = shard_data_dict(dd, rank, world)
-    lo, hi = shard_rows(400, rank, world)
-    rows = torch.cat([torch.arange(lo, hi), 400 + torch.arange(lo, hi)])
+    lo, hi = shard_rows(n, rank, world)
+    rows = torch.cat([torch.arange(lo, hi), n + torch.arange(lo, hi)])
+    # overlap: the data GP's span of the flat buffer is reduced on a side stream while the rest of the backward runs
+    # (the engine finishes it first: gpsa_step_io.f_event); the reducer must exist BEFORE the backward
+    reducer = GradAllReducer(model.parameters(), overlap=overlap, model=model)
     loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0 / world, fuse=fuse)
-    GradAllReducer(model.parameters())()
+    if overlap:
+        assert reducer._early is not None, "the early all-reduce was not started by the backward"
+        plan = next(iter(model._step_plans.values()))
+        assert plan.lib.gpsa_step_early_backwards(plan.handle) == 1, "the backward did not take the early order"
+    reducer()
+    torch.cuda.synchronize()
     dist.all_reduce(loss)
     if rank == 0:
         q.put((float(loss), {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}))
@@ -62,8 +76,8 @@ def _worker(rank, world, port, q, fuse=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fuse", [False, True])
-def test_row_sharded_hip_step_equals_full_hip_step(fuse):
+@pytest.mark.parametrize("fuse,overlap", [(False, False), (True, False), (True, True), (False, True)])
+def test_row_sharded_hip_step_equals_full_hip_step(fuse, overlap):
     """two ranks' row shards + one all-reduce against the single-process step (the full step always through the
     separate kernels: ``fuse`` also pins the fused ELBO step to them across processes)"""
     import __graft_entry__ as ge
@@ -71,16 +85,16 @@ def test_row_sharded_hip_step_equals_full_hip_step(fuse):
     ge.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + (7 if fuse else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fuse)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + (7 if fuse else 0) + (13 if overlap else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fuse, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     loss2, g2 = q.get(timeout=600)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    dd, model = _problem(torch.device("cuda:0"))
-    eG, eF = _noise()
+    dd, model = _problem(torch.device("cuda:0"), 56 if overlap else None)
+    eG, eF = _noise(56 if overlap else None)
     loss1 = _grads(model, dd, eG, eF, 1.0)
     assert abs(float(loss1) - loss2) <= 1e-5 * abs(float(loss1))
     for k, p in model.named_parameters():
