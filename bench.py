@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--headline-only", action="store_true",
                     help="profiling: only the headline blocks (no helper / verbatim / exact-mode / S = 1 / graph / config "
                          "legs, no CPU baseline)")
+    ap.add_argument("--overlap-reduce", action="store_true",
+                    help="N > 1: reduce the data GP's span of the gradient buffer on a side stream while the rest of the "
+                         "backward runs (parallel.GradAllReducer(overlap=True)); off by default: never run on N > 1 "
+                         "distinct devices by the builder")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live rocprofv3 --pmc passes for roofline.traffic (the committed file is quoted instead)")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
@@ -448,7 +452,8 @@ def main():
     from spatial_alignment_amd.train import train_step
 
     opt = FusedAdam(model.parameters(), lr=1e-2)  # torch.optim.Adam's update as one HIP launch
-    reducer = out_reducer if out_reducer is not None else GradAllReducer(model.parameters())
+    reducer = out_reducer if out_reducer is not None else GradAllReducer(
+        model.parameters(), overlap=args.overlap_reduce and world > 1, model=model)
     timer = KernelTimer(model, args.steps * max(1, args.blocks))
     timer.S = args.S
 
@@ -748,7 +753,8 @@ def main():
                             + (f", fixed_view_idx={args.fixed}" if args.fixed is not None else "")
                             + f", S={args.S}, forward+ELBO+backward+Adam",
                 "n_spots_total": N,
-                **({"world_size": dist.get_world_size(), "rank_devices": rank_devices} if world > 1 else {}),
+                **({"world_size": dist.get_world_size(), "rank_devices": rank_devices,
+                    "overlapped_reduce": bool(args.overlap_reduce)} if world > 1 else {}),
                 "parallelism": ("single GPU" if world == 1 else
                                 f"outputs sharded x{world}, 1 all-reduce/step of the shared parameters' gradients" if by_outputs
                                 else f"rows-of-views sharded x{world}, 1 all-reduce/step"),

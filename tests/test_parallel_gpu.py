@@ -76,6 +76,51 @@ def _worker(rank, world, port, q, fuse=False, overlap=False):
     dist.destroy_process_group()
 
 
+def _nccl_one_rank_worker(port, q):
+    """RCCL itself (one rank: it refuses two ranks on one device): the overlapped reducer's calls - an all-reduce on a
+    side stream behind the engine's event, the rest on the main stream, the join - against a loop without a reducer"""
+    import __graft_entry__ as ge
+    from spatial_alignment_amd.optim import FusedAdam
+    from spatial_alignment_amd.parallel import GradAllReducer
+    from spatial_alignment_amd.train import train_step
+
+    ge.build()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    res = []
+    for overlap in (True, False):
+        dd, model = _problem(dev, 56)
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        opt = FusedAdam(model.parameters(), lr=1e-2)
+        reducer = GradAllReducer(model.parameters(), always=True, overlap=True, model=model) if overlap else None
+        eG, eF = _noise(56)
+        for _ in range(3):
+            model.inject_noise(eG, {"expression": eF})
+            train_step(model, opt, dd, view_idx, Ns, S=3, reducer=reducer)
+        torch.cuda.synchronize()
+        plan = next(iter(model._step_plans.values()))
+        res.append((int(plan.lib.gpsa_step_early_backwards(plan.handle)),
+                    {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_on_rccl_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(35500 + (os.getpid() % 2000), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    (n_early, a), (n_plain, b) = res
+    assert n_early == 3 and n_plain == 0
+    for k in a:  # (the early order sums the KL and the warp GPs' shares in another order: equal to rounding)
+        assert np.linalg.norm(a[k] - b[k]) <= 1e-5 * max(np.linalg.norm(b[k]), 1e-6), k
+
+
 @pytest.mark.parametrize("fuse,overlap", [(False, False), (True, False), (True, True), (False, True)])
 def test_row_sharded_hip_step_equals_full_hip_step(fuse, overlap):
     """two ranks' row shards + one all-reduce against the single-process step (the full step always through the
