@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
   const long long nch = (C + 15) / 16;
   const long long ch0 = (long long)sp * nch / a.nsplit, ch1 = (long long)(sp + 1) * nch / a.nsplit;
   const float* gl = a.g + (long long)l * a.Cpad;
+  big_phase_prologue(a.phase);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -298,6 +299,7 @@ __global__ void __launch_bounds__(256, 2) big_quad_kernel(BigQuadArgs a) {
   const long long c0 = ctile * 128;
   const float* Pl = a.P + (long long)l * M * Mp;
   const int nch = Mp / 16, nrb = (M + 127) / 128;
+  big_phase_prologue(a.phase);
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -465,6 +467,7 @@ __global__ void __launch_bounds__(256, 2) big_accum_kernel(BigAccumArgs a) {
   const long long c0 = ct * 128;
   const int l0 = (int)((long long)sp * a.L / a.nsplit), l1 = (int)((long long)(sp + 1) * a.L / a.nsplit);
   const int nch = Mp / 16;
+  big_phase_prologue(a.phase);
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)

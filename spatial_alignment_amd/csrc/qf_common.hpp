@@ -202,6 +202,7 @@ struct GramBigArgs {
   long long C, Cpad;
   int lb;  // > 0: 1-D grid, workgroups that share an XCD (ids equal mod 8) come in runs of ``lb`` outputs of ONE
            // (block pair, column split): they read the same rows of alpha at about the same time, from that XCD's L2
+  int phase = 0;  // experiment knob (big_phase()): see big_phase_prologue
 };
 __global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
                                 float* __restrict__ gpad);
@@ -218,6 +219,31 @@ __global__ void __launch_bounds__(256, 2) prod_big_kernel(ProdBigArgs a);
 template <typename TO>
 __global__ void __launch_bounds__(256) gram_big_reduce_kernel(const float* __restrict__ part, int M, int nsplit, TO* __restrict__ out);
 // outputs per run of same-XCD workgroups in the large-M kernels (GPSA_BIG_LB; 0 = the plain 3-D / 2-D grids)
+// The in-phase experiment on the two-workgroups-per-CU kernels (round-4 verdict item 7 (i)): the wave that sits in
+// an ODD wave slot of its SIMD (HW_ID.wave_id: the second of the two co-resident workgroups) can be started late
+// (GPSA_BIG_PHASE = n: n x 256 cycles of s_sleep, half a 64-MFMA chunk = 4) and / or raised to s_setprio 1 for its
+// whole life (GPSA_BIG_PRIO = 1; MI355X_MICROARCH.md "Two waves per SIMD" item 4).  Default 0 / 0: measured, no gain
+// (docs/LAB_NOTES.md, round 5).
+static inline int big_phase() {
+  static const int v = [] {
+    const char* e = getenv("GPSA_BIG_PHASE");
+    const char* q = getenv("GPSA_BIG_PRIO");
+    int r = e ? atoi(e) & 0xff : 0;
+    if (q && q[0] == '1') r |= 0x100;
+    return r;
+  }();
+  return v;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void big_phase_prologue(int phase) {
+  if (phase == 0) return;
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_REG_HW_ID bits [3:0]: the SIMD's wave slot
+  if (slot & 1) {
+    if (phase & 0x100) __builtin_amdgcn_s_setprio(1);
+    for (int i = 0; i < (phase & 0xff); ++i) __builtin_amdgcn_s_sleep(4);
+  }
+}
+#endif
 static inline int big_remap_lb() {
   static const int v = [] { const char* e = getenv("GPSA_BIG_LB"); return e ? atoi(e) : 16; }();
   return v;
@@ -236,6 +262,7 @@ struct BigQuadArgs {
   long long C;
   int lb;  // > 0: 1-D grid; same-XCD workgroups come in runs of ``lb`` outputs of ONE column tile (they share its
            // alpha tile in that XCD's L2; each U_l / Omega_l is then shared by the few column tiles the XCD works on)
+  int phase = 0;
 };
 
 struct BigAccumArgs {
@@ -246,6 +273,7 @@ struct BigAccumArgs {
   int M, Mp, L, nrb, nsplit;
   long long C, ctiles;
   float scale;
+  int phase = 0;
 };
 
 __global__ void __launch_bounds__(256) big_accum_reduce_kernel(const float* __restrict__ part, int nsplit, long long n4, float* __restrict__ out);

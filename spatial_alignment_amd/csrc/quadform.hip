@@ -363,7 +363,7 @@ int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, i
       float* gpad = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_b);
       pad_rows_kernel<<<(unsigned)cdiv((long long)L * Cpad, 256), 256, 0, st>>>(g, L, C, Cpad, gpad);
       GPSA_LAUNCH_CHECK();
-      GramBigArgs a{alpha, gpad, reinterpret_cast<float*>(ws), M, L, (int)ns, nblk, C, Cpad, 0};
+      GramBigArgs a{alpha, gpad, reinterpret_cast<float*>(ws), M, L, (int)ns, nblk, C, Cpad, 0, big_phase()};
       const int lb = big_remap_lb();
       const long long combos = (long long)pairs * ns * cdiv(L, lb > 0 ? lb : 1);
       if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
@@ -901,7 +901,7 @@ static int big_accum_launch(int omega_dtype, const float* alpha, const void* Ome
     pad_k_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
   GPSA_LAUNCH_CHECK();
   const long long ctiles = cdiv(C, 128), ct8 = cdiv(ctiles, 8);
-  BigAccumArgs aa{Pp, alpha, g, part, M, Mp, L, nrb, ns, C, ctiles, 2.f};
+  BigAccumArgs aa{Pp, alpha, g, part, M, Mp, L, nrb, ns, C, ctiles, 2.f, big_phase()};
   // (measured, no faster: 3 workgroups per CU; a 4-slot ring with three stages in flight)
   big_accum_kernel<3><<<(unsigned)(8 * nrb * ct8 * ns), 256, 0, st>>>(aa);
   GPSA_LAUNCH_CHECK();
@@ -991,7 +991,7 @@ int gpsa_quadform_fwd(int dtype, int omega_dtype, const void* alpha, const void*
         else
           pad_k_tri_kernel<float><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((const float*)Omega, M, Mp, L, Pp);
         GPSA_LAUNCH_CHECK();
-        BigQuadArgs qa{Pp, (const float*)alpha, (float*)v, nullptr, M, Mp, L, C, 0};
+        BigQuadArgs qa{Pp, (const float*)alpha, (float*)v, nullptr, M, Mp, L, C, 0, big_phase()};
         const int lb = big_remap_lb();
         const long long combos = cdiv(C, 128) * cdiv(L, lb > 0 ? lb : 1);
         if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
@@ -1083,7 +1083,7 @@ int gpsa_quadform_fwd_keep_f32(int omega_dtype, const float* alpha, const void* 
       GPSA_LAUNCH_CHECK();
       static const bool old_pb = [] { const char* e = getenv("GPSA_PROD_BIG"); return e && e[0] == '1'; }();
       if (!old_pb && big_panel_ok(M, C, L, alpha)) {  // product, kept copy and the closing column sums in one kernel
-        BigQuadArgs qa{Pp, alpha, v, W, M, Mp, L, C, 0};
+        BigQuadArgs qa{Pp, alpha, v, W, M, Mp, L, C, 0, big_phase()};
         const int lb = big_remap_lb();
         const long long combos = ctiles * cdiv(L, lb > 0 ? lb : 1);
         if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
