@@ -12,7 +12,9 @@
 // C/D layout of the fp64 MFMA (row = (lane>>4) + 4*reg) coincides with the B operand's K layout
 // (k = 4*step + (lane>>4)), so q closes in registers: q = sum acc[rt][reg] * xb[4*rt + reg], then two
 // cross-lane adds.
-#include "common.hpp"
+#include <type_traits>
+
+#include "internal.hpp"
 
 namespace gpsa {
 
@@ -268,6 +270,10 @@ template <typename TI, typename TO>
 static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
                          double* q, hipStream_t st, int batch = 1, long long sX = 0,
                          WhitenAxpy ax = WhitenAxpy{nullptr, nullptr, 0.f}) {
+  if constexpr (std::is_same<TO, double>::value) {  // long panels: the persistent output-stationary kernel (proj64.hip)
+    if (ax.X2 == nullptr && proj64_ok(MB, C, batch))
+      return proj64_launch<TI>(MB, Apk, X, M, C, alpha, ax.out32, q, batch, sX, st);
+  }
   const dim3 grid((unsigned)cdiv(C, 64), (unsigned)batch);
   bool stream = q == nullptr || (long long)grid.x * batch > num_cus();
   // at most one workgroup per CU and no second pass needed for q: split the rows over wave pairs (RS)

@@ -200,7 +200,7 @@ def test_longk_f64(hip, M, K, n, mode):
     assert all(torch.equal(a, b) for a, b in zip(out, out2))
 
 
-@pytest.mark.parametrize("M,Cs,B", [(200, 640, 3), (50, 64, 5), (300, 128, 2)])
+@pytest.mark.parametrize("M,Cs,B", [(200, 640, 3), (50, 64, 5), (300, 128, 2), (200, 49201, 2), (100, 33000, 3)])
 def test_whiten_batched(hip, M, Cs, B):
     A = rnd(B, M, M, dtype=f64, seed=1).to(DEV)
     Kinv = (A @ A.transpose(1, 2) / M + torch.eye(M, dtype=f64, device=DEV)).contiguous()
@@ -216,6 +216,29 @@ def test_whiten_batched(hip, M, Cs, B):
         assert (alpha[b] - wa).norm() <= 1e-13 * wa.norm() and (q[b] - wq).norm() <= 1e-13 * wq.norm()
         ref = Kinv[b] @ Kuf[b]
         assert (alpha[b] - ref).norm() <= 1e-12 * ref.norm()
+
+
+@pytest.mark.parametrize("M,C", [(200, 3000), (200, 98401), (100, 98400)])
+def test_whiten_dual_store(hip, M, C):
+    """gpsa_whiten_f64_dual: the projection kept twice from the same accumulators (fp64 and its fp32 rounding); the long
+    panels run the persistent kernel (csrc/proj64.hip), whose column tiles may be cut between two workgroups (q then
+    closes by two atomic adds onto a zeroed word: bitwise repeatable)."""
+    A = rnd(M, M, dtype=f64, seed=1).to(DEV)
+    Kinv = (A @ A.t() / M + torch.eye(M, dtype=f64, device=DEV)).contiguous()
+    Kuf = rnd(M, C, dtype=f64, seed=2).to(DEV)
+    a64, a32 = torch.empty_like(Kuf), torch.empty(M, C, dtype=f32, device=DEV)
+    q = torch.full((C,), 7.0, dtype=f64, device=DEV)
+    wsb = int(hip.lib.gpsa_whiten_workspace(M))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    assert hip.lib.gpsa_whiten_f64_dual(p(Kinv), p(Kuf), M, C, p(a64), p(a32), p(q), p(ws), wsb, stream()) == 0
+    ref = Kinv @ Kuf
+    assert (a64 - ref).norm() <= 1e-13 * ref.norm()
+    assert torch.equal(a32, a64.float())
+    rq = (Kuf * ref).sum(0)
+    assert (q - rq).norm() <= 1e-13 * rq.norm()
+    b64, b32, q2 = torch.empty_like(a64), torch.empty_like(a32), torch.empty_like(q)
+    assert hip.lib.gpsa_whiten_f64_dual(None, p(Kuf), M, C, p(b64), p(b32), p(q2), p(ws), wsb, stream()) == 0  # packed already
+    assert torch.equal(b64, a64) and torch.equal(b32, a32) and torch.equal(q2, q)
 
 
 @pytest.mark.parametrize("M,C", [(200, 5000), (50, 333), (300, 1000)])
