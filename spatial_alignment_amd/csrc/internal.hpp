@@ -41,10 +41,11 @@ int lmc_mfma_launch(const float* F, const float* W, const float* Y, const float*
                     int P, double* zpart, int nparts, float* dF, float* dWpart, int G, hipStream_t st);
 
 // proj64.hip: alpha = Kinv X (fp64 matrix cores) as a persistent output-stationary kernel over pack_whiten_kernel's
-// packed inverse(s); proj64_ok says which shapes it takes (GPSA_PROJ64=0: none)
+// packed inverse(s); proj64_ok says which shapes it takes (GPSA_PROJ64=0: none); q is closed by atomic adds onto
+// zero: q_zeroed says an earlier launch on the stream has cleared it (else a memset node goes in front)
 bool proj64_ok(int MB, long long C, int batch);
 template <typename TI>
 int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, double* alpha, float* out32, double* q,
-                  int batch, long long sX, hipStream_t st);
+                  int batch, long long sX, hipStream_t st, bool q_zeroed);
 
 }  // namespace gpsa

@@ -267,7 +267,7 @@ bool proj64_ok(int MB, long long C, int batch) {
 
 template <typename TI>
 int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, double* alpha, float* out32, double* q,
-                  int batch, long long sX, hipStream_t st) {
+                  int batch, long long sX, hipStream_t st, bool q_zeroed) {
   ProjArgs a;
   a.Apk = Apk;
   a.X = X;
@@ -285,7 +285,7 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
   static const int occ = [] { const char* e = getenv("GPSA_PROJ64_OCC"); return e && e[0] == '2' ? 2 : 3; }();
   long long grid = (long long)occ * num_cus();
   if (grid > (long long)batch * a.T) grid = (long long)batch * a.T;
-  if (q != nullptr) {
+  if (q != nullptr && !q_zeroed) {
     hipError_t e = hipMemsetAsync(q, 0, (size_t)((long long)batch * C * 8), st);
     if (e != hipSuccess) return (int)e;
   }
@@ -305,8 +305,8 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
 }
 
 template int proj64_launch<double>(int, const double*, const double*, int, long long, double*, float*, double*, int,
-                                   long long, hipStream_t);
+                                   long long, hipStream_t, bool);
 template int proj64_launch<float>(int, const double*, const float*, int, long long, double*, float*, double*, int,
-                                  long long, hipStream_t);
+                                  long long, hipStream_t, bool);
 
 }  // namespace gpsa

@@ -36,10 +36,16 @@ __device__ __forceinline__ void glds16_f64_m0(const double* gsrc_minus_imm) {
 
 // Kinv [M][M] row-major -> Apk[kc][ks][rt][lane] = Kinv[16 rt + (lane&15)][16 kc + 4 ks + (lane>>4)]
 // (zero padded to MP = 16 MB): the A-operand fragment of every MFMA is one lane-linear 512-byte row.
+// qz (optional): nq doubles to zero on the way - the persistent projection kernel (proj64.hip) closes q by atomic adds
 __global__ void pack_whiten_kernel(const double* __restrict__ Kinv, int M, int MB, double* __restrict__ Apk,
-                                   long long sKinv) {
+                                   long long sKinv, double* __restrict__ qz, long long nq) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long tot = (long long)MB * 4 * MB * 64;
+  if (qz != nullptr) {
+    const long long nth = (long long)gridDim.x * gridDim.y * blockDim.x;
+    for (long long i = (blockIdx.y * (long long)gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < nq; i += nth)
+      qz[i] = 0.0;
+  }
   if (idx >= tot) return;
   Kinv += blockIdx.y * sKinv;  // problem blockIdx.y of a batch (the views' warp GPs)
   Apk += blockIdx.y * tot;
@@ -269,10 +275,10 @@ static inline int whiten_mb_for(int M) {
 template <typename TI, typename TO>
 static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long long C, TO* alpha,
                          double* q, hipStream_t st, int batch = 1, long long sX = 0,
-                         WhitenAxpy ax = WhitenAxpy{nullptr, nullptr, 0.f}) {
+                         WhitenAxpy ax = WhitenAxpy{nullptr, nullptr, 0.f}, bool q_zeroed = false) {
   if constexpr (std::is_same<TO, double>::value) {  // long panels: the persistent output-stationary kernel (proj64.hip)
     if (ax.X2 == nullptr && proj64_ok(MB, C, batch))
-      return proj64_launch<TI>(MB, Apk, X, M, C, alpha, ax.out32, q, batch, sX, st);
+      return proj64_launch<TI>(MB, Apk, X, M, C, alpha, ax.out32, q, batch, sX, st, q_zeroed);
   }
   const dim3 grid((unsigned)cdiv(C, 64), (unsigned)batch);
   bool stream = q == nullptr || (long long)grid.x * batch > num_cus();
@@ -324,6 +330,11 @@ static int whiten_launch(int MB, const double* Apk, const TI* X, int M, long lon
   return 0;
 }
 
+// the pack launch of a call that the persistent kernel will take zeroes q for it
+static inline double* pack_zeroes_q(int MB, long long C, int batch, double* q, bool fp64_out, bool axpy) {
+  return (q != nullptr && fp64_out && !axpy && proj64_ok(MB, C, batch)) ? q : nullptr;
+}
+
 }  // namespace gpsa
 
 extern "C" {
@@ -346,18 +357,21 @@ int gpsa_whiten_f64(const double* Kinv, int in_dtype, const void* Kuf, int M, lo
   hipStream_t st = as_stream(stream);
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
+  double* qz = nullptr;
   if (Kinv != nullptr) {  // NULL: the workspace still holds the packed inverse of an earlier call
-    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+    qz = pack_zeroes_q(MB, C, 1, q, alpha_dtype == GPSA_F64, false);
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0, qz, C);
     GPSA_LAUNCH_CHECK();
   }
+  const WhitenAxpy ax0{nullptr, nullptr, 0.f};
   if (in_dtype == GPSA_F64) {
     if (alpha_dtype == GPSA_F32)
       return whiten_launch<double, float>(MB, Apk, (const double*)Kuf, M, C, (float*)alpha, q, st);
-    return whiten_launch<double, double>(MB, Apk, (const double*)Kuf, M, C, (double*)alpha, q, st);
+    return whiten_launch<double, double>(MB, Apk, (const double*)Kuf, M, C, (double*)alpha, q, st, 1, 0, ax0, qz != nullptr);
   }
   if (alpha_dtype == GPSA_F32)
     return whiten_launch<float, float>(MB, Apk, (const float*)Kuf, M, C, (float*)alpha, q, st);
-  return whiten_launch<float, double>(MB, Apk, (const float*)Kuf, M, C, (double*)alpha, q, st);
+  return whiten_launch<float, double>(MB, Apk, (const float*)Kuf, M, C, (double*)alpha, q, st, 1, 0, ax0, qz != nullptr);
 }
 
 /* alpha = Kinv Kuf (fp64 panel) stored TWICE from the same accumulators: unrounded (alpha64) and rounded to fp32
@@ -372,13 +386,15 @@ int gpsa_whiten_f64_dual(const double* Kinv, const double* Kuf, int M, long long
   hipStream_t st = as_stream(stream);
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
+  double* qz = nullptr;
   if (Kinv != nullptr) {
-    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+    qz = pack_zeroes_q(MB, C, 1, q, true, false);
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0, qz, C);
     GPSA_LAUNCH_CHECK();
   }
   WhitenAxpy ax{nullptr, nullptr, 0.f};
   ax.out32 = alpha32;
-  return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha64, q, st, 1, 0, ax);
+  return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha64, q, st, 1, 0, ax, qz != nullptr);
 }
 
 /* gamma = Kinv X (fp32 panel, fp64 arithmetic) with the column-scaled update fused into the store:
@@ -396,7 +412,7 @@ int gpsa_whiten_axpy_f32(const double* Kinv, const float* X, int M, long long C,
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
   if (Kinv != nullptr) {
-    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0);
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0, nullptr, 0);
     GPSA_LAUNCH_CHECK();
   }
   return whiten_launch<float, float>(MB, Apk, X, M, C, out, nullptr, st, 1, 0, WhitenAxpy{X2, d, (float)s});
@@ -417,11 +433,14 @@ int gpsa_whiten_batched_f64(const double* Kinv, long long strideKinv, const doub
   double* Apk = (double*)workspace;
   const long long tot = (long long)MB * 4 * MB * 64;
   dim3 pgrid((unsigned)cdiv(tot, 256), (unsigned)batch);
+  double* qz = nullptr;
   if (Kinv != nullptr) {
-    pack_whiten_kernel<<<pgrid, 256, 0, st>>>(Kinv, M, MB, Apk, strideKinv);
+    qz = pack_zeroes_q(MB, C, batch, q, true, false);
+    pack_whiten_kernel<<<pgrid, 256, 0, st>>>(Kinv, M, MB, Apk, strideKinv, qz, (long long)batch * C);
     GPSA_LAUNCH_CHECK();
   }
-  return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha, q, st, batch, strideX);
+  return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha, q, st, batch, strideX, WhitenAxpy{nullptr, nullptr, 0.f},
+                                       qz != nullptr);
 }
 
 }  // extern "C"
