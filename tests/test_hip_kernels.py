@@ -526,7 +526,7 @@ def test_quadform_fp64_omega_fp32_alpha(hip, M, C, L):
 @pytest.mark.parametrize("M,C", [(12, 50), (30, 64), (50, 1000), (100, 333), (200, 4100), (256, 129), (200, 20001), (100, 17000),
                                  (300, 500), (384, 129), (380, 17000),
                                  # long panels: the persistent output-stationary kernel (csrc/proj64.hip; fp64 results)
-                                 (200, 98403), (197, 100000), (100, 98500)])
+                                 (200, 98403), (197, 100000), (100, 98500), (120, 98400)])
 def test_whiten_f64_mfma(hip, out_dtype, M, C):
     """alpha = Kinv Kuf and q = diag(Kuf^T alpha) on the fp64 matrix cores vs a CPU fp64 product."""
     f64 = torch.float64
