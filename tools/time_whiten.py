@@ -80,6 +80,17 @@ case("data GP forward (dual, q)", 200, 100000, "dual")
 case("data GP backward (fp32 in)", 200, 100000, "bwd")
 if os.environ.get("GPSA_TW_SHORT") == "1":
     sys.exit(0)
+if os.environ.get("GPSA_TW_SHORT") == "3":  # the row pitch: one 400 000-column panel against 40 panels of 10 000 columns
+    case("1 x 400 000 columns", 200, 400000, "batched", 1)
+    case("40 x 10 000 columns", 200, 10000, "batched", 40)
+    case("1 x 100 000 columns", 200, 100000, "batched", 1)
+    case("10 x 10 000 columns", 200, 10000, "batched", 10)
+    case("25 x 4 000 columns", 200, 4000, "batched", 25)
+    sys.exit(0)
+if os.environ.get("GPSA_TW_SHORT") == "2":  # long panels only: ramp and tail amortised
+    case("backward, C = 400 000", 200, 400000, "bwd")
+    case("forward, C = 400 000", 200, 400000, "dual")
+    sys.exit(0)
 case("config 3 forward (dual, q)", 200, 200000, "dual")
 case("S=1 forward (dual, q)", 200, 20000, "dual")
 case("1/8 shard forward (dual, q)", 200, 12500, "dual")
