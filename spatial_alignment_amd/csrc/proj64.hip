@@ -282,7 +282,10 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
   static const int dbg = [] { const char* e = getenv("GPSA_PROJ64_SKIP"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   // at least MB units per workgroup: a column tile (MB consecutive units) then meets at most two workgroups
-  static const int occ = [] { const char* e = getenv("GPSA_PROJ64_OCC"); return e && e[0] == '2' ? 2 : 3; }();
+  static const int occ = [] {
+    const char* e = getenv("GPSA_PROJ64_OCC");
+    return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 3;
+  }();
   long long grid = (long long)occ * num_cus();
   if (grid > (long long)batch * a.T) grid = (long long)batch * a.T;
   if (q != nullptr && !q_zeroed) {
@@ -291,7 +294,8 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
   }
   switch (MB) {
     case 13:
-      if (occ == 2) proj64_kernel<13, TI, 2><<<(unsigned)grid, 256, 0, st>>>(a);
+      if (occ == 1) proj64_kernel<13, TI, 1><<<(unsigned)grid, 256, 0, st>>>(a);
+      else if (occ == 2) proj64_kernel<13, TI, 2><<<(unsigned)grid, 256, 0, st>>>(a);
       else proj64_kernel<13, TI, 3><<<(unsigned)grid, 256, 0, st>>>(a);
       break;
     case 7:

@@ -49,6 +49,9 @@ def case(name, M, C, kind, B=1):
     A = torch.randn(B, M, M, dtype=f64, generator=g).to(dev)
     Kinv = (A @ A.transpose(1, 2) / M + torch.eye(M, dtype=f64, device=dev)).contiguous()
     X = torch.randn(B, M, C, dtype=f64, generator=g).to(dev)
+    if os.environ.get("GPSA_TW_CONST") == "1":  # constant operands (the microbenchmarks' regime): is the rate data-dependent?
+        X = torch.ones_like(X)
+        Kinv = torch.full_like(Kinv, 2.0)
     wsb = int(lib.gpsa_whiten_workspace(M)) * B
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     a64 = torch.empty(B, M, C, dtype=f64, device=dev)
