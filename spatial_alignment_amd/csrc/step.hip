@@ -597,6 +597,13 @@ struct Plan {
     unsigned long long used;
   };
   std::vector<GraphEntry> graphs;
+  // executable graphs dropped from the cache while a launch of theirs may still be queued on the caller's stream: each
+  // waits here behind an event recorded on that stream and is destroyed once the event has fired
+  struct Retired {
+    hipGraphExec_t exec;
+    hipEvent_t ev;
+  };
+  std::vector<Retired> retired;
   std::vector<GraphKey> seen;   // argument sets met once (a second meeting captures)
   hipStream_t gstream = nullptr;  // captures run on a stream of the plan's own (the caller's may be the null stream,
                                   // which cannot be captured); the graph is then launched into the caller's
@@ -621,8 +628,13 @@ static void free_plan(Plan* p) {
   for (hipEvent_t e : p->tev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->sev)
     if (e != nullptr) (void)hipEventDestroy(e);
+  if (!p->graphs.empty() || !p->retired.empty()) (void)hipDeviceSynchronize();  // nothing of theirs is in flight any more
   for (auto& ge : p->graphs)
     if (ge.exec != nullptr) (void)hipGraphExecDestroy(ge.exec);
+  for (auto& r : p->retired) {
+    (void)hipGraphExecDestroy(r.exec);
+    (void)hipEventDestroy(r.ev);
+  }
   if (p->gstream != nullptr) (void)hipStreamDestroy(p->gstream);
   if (p->side != nullptr) (void)hipStreamDestroy(p->side);
   delete p;
@@ -1981,8 +1993,8 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
  * with an argument set that has been seen before - the caching allocator of a fresh training loop hands out the same
  * blocks every other step - its sequence is captured once and replayed as ONE hipGraphLaunch from then on.  The capture
  * runs on a stream of the plan's own (the caller's is usually PyTorch's null stream, which cannot be captured); the
- * graph is launched into the caller's stream.  A first sighting runs eagerly; <= 16 graphs per plan, least recently
- * used out; after 8 captures in a row that were never replayed the plan stops capturing.  Never used inside somebody
+ * graph is launched into the caller's stream.  A first sighting runs eagerly; <= 32 graphs per plan
+ * (GPSA_STEP_GRAPH_MAX), least recently used out - retired behind an event, never destroyed under a queued launch; after 8 captures in a row that were never replayed the plan stops capturing.  Never used inside somebody
  * else's capture (train.GraphedTrainStep), with the side stream or the kernel timing on.
  * Measured (tools/graph_probe.py, BASELINE config 1's size, the reference's loop, runs alternating in one process):
  *   * a fresh process replays 3879 of 3903 calls from 6 graphs (three call kinds x the allocator's two alternating block
@@ -1994,7 +2006,11 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
  *     from the drift;
  *   * OPEN: in one sequence of runs the third model with the cache on raised the forward's numerics error (a
  *     non-positive-definite covariance) some hundred steps in; twelve runs with the cache off never did.  Not
- *     root-caused.
+ *     reproduced since (36 model runs of tools/graph_probe.py with the eviction of that day and with the current one;
+ *     tools/graph_stress.py and tests/test_step_engine.py train models twice from one seed, cache off / on, and
+ *     compare the loss trajectories bit for bit).  One real hazard of that day's code is closed: an evicted graph
+ *     was destroyed at once, possibly under a launch of its own still queued behind the host - it now retires behind
+ *     an event.
  * Hence OFF unless asked for (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)): safe for callers of the C ABI that
  * own fixed buffers (tests/test_step_engine.py replays a repeated call bit for bit); the model's route to one launch
  * per step stays the whole-step graph, train.GraphedTrainStep / fit(graphed=True). */
@@ -2014,6 +2030,16 @@ static bool graph_usable(Plan& P, hipStream_t st) {
 template <typename F>
 static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& enqueue) {
   ++P.gtick;
+  for (size_t i = 0; i < P.retired.size();) {  // dropped graphs whose last launch has completed
+    if (hipEventQuery(P.retired[i].ev) == hipSuccess) {
+      (void)hipGraphExecDestroy(P.retired[i].exec);
+      (void)hipEventDestroy(P.retired[i].ev);
+      P.retired.erase(P.retired.begin() + (long)i);
+    } else {
+      (void)hipGetLastError();  // hipErrorNotReady
+      ++i;
+    }
+  }
   for (auto& ge : P.graphs)
     if (memcmp(ge.key.b, key.b, Plan::GraphKey::BYTES) == 0) {
       if (ge.used == 0) P.g_idle_captures = 0;
@@ -2039,7 +2065,7 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
         break;
       }
     }
-    if (P.seen.size() >= 32) P.seen.erase(P.seen.begin());
+    if (P.seen.size() >= 96) P.seen.erase(P.seen.begin());
     P.seen.push_back(key);
     ++P.g_eager;
     return enqueue(st);
@@ -2078,11 +2104,28 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
     ++P.g_eager;
     return enqueue(st);
   }
-  if (P.graphs.size() >= 16) {
+  static const size_t gmax = [] {
+    const char* e = getenv("GPSA_STEP_GRAPH_MAX");
+    const int v = e ? atoi(e) : 32;
+    return (size_t)(v < 1 ? 1 : v);
+  }();
+  if (P.graphs.size() >= gmax) {
     size_t lru = 0;
     for (size_t i = 1; i < P.graphs.size(); ++i)
       if (P.graphs[i].used < P.graphs[lru].used) lru = i;
-    (void)hipGraphExecDestroy(P.graphs[lru].exec);
+    // The dropped graph's latest launch may still be queued (the host runs steps ahead of the device): destroying it
+    // now pulls the kernel arguments from under that launch (round 5's unexplained numerics errors "with the cache
+    // on, in models built after others" - the models whose allocation pattern has more than 16 distinct argument sets
+    // and therefore evicts).  It retires behind an event on the stream it was launched into instead.
+    static const bool unsafe = [] { const char* e = getenv("GPSA_STEP_GRAPH_UNSAFE_DESTROY"); return e && e[0] == '1'; }();
+    hipEvent_t ev = nullptr;
+    if (!unsafe && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, st) == hipSuccess) {
+      P.retired.push_back(Plan::Retired{P.graphs[lru].exec, ev});
+    } else {
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+      if (!unsafe) (void)hipStreamSynchronize(st);
+      (void)hipGraphExecDestroy(P.graphs[lru].exec);
+    }
     P.graphs.erase(P.graphs.begin() + (long)lru);
   }
   P.graphs.push_back(Plan::GraphEntry{key, exec, 0});  // used == 0: captured, not replayed yet

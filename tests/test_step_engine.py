@@ -311,3 +311,49 @@ def test_step_graph_cache_with_fixed_buffers():
         plan.lib.gpsa_step_graph(plan.handle, 0, stats)
     print("graph cache [replays, eager, captures, held]:", list(stats))
     assert stats[0] >= 2 and stats[2] >= 1, list(stats)
+
+
+def test_step_graph_cache_training_trajectory_is_bitwise():
+    """Two models in one process, each trained twice from the same seed with the host running ahead of the device: the
+    engine's hipGraph cache on (replaying most calls, evicting the least recently used graphs of a deliberately small
+    pool) against off - the loss trajectories agree bit for bit (tools/graph_stress.py is the long form)."""
+    import ctypes as C
+
+    from spatial_alignment_amd.optim import FusedAdam
+    from spatial_alignment_amd.synthetic import make_grid_problem, make_model
+
+    def run(seed, enable):
+        torch.manual_seed(seed)
+        dd = make_grid_problem(side=10, n_views=2, n_outputs=30, device="cpu")
+        model = make_model(dd, m=25, device=DEV, fixed_view_idx=0)
+        dd = {m: {"spatial_coords": d["spatial_coords"].to(DEV), "outputs": d["outputs"].to(DEV),
+                  "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
+        view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+        Xs = {m: d["spatial_coords"] for m, d in dd.items()}
+        opt = FusedAdam(model.parameters(), lr=1e-2)
+        kept = []
+        for i in range(240):
+            out = model.forward(X_spatial=Xs, view_idx=view_idx, Ns=Ns, S=5)
+            loss = model.loss_fn(dd, out[3])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if i == 0:
+                for plan in model._step_plans.values():
+                    assert plan.lib.gpsa_step_graph(plan.handle, enable, None) == 0
+            if i % 20 == 19:
+                kept.append(loss.detach())
+        torch.cuda.synchronize()
+        tot = [0, 0, 0, 0]
+        cnt = (C.c_longlong * 4)()
+        for plan in model._step_plans.values():
+            plan.lib.gpsa_step_graph(plan.handle, 0, cnt)
+            tot = [a + int(b) for a, b in zip(tot, cnt)]
+        return [float(x) for x in kept], tot
+
+    for k in range(2):
+        ref, _ = run(7 + k, 0)
+        got, tot = run(7 + k, 1)
+        print("graph cache [replays, eager, captures, held]:", tot)
+        assert got == ref, (k, ref[-3:], got[-3:])
+        assert tot[0] > 100, tot  # most calls were replays
