@@ -170,6 +170,17 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
                            const float* meanT, const double* q, const float* var_u, const float* eps, const float* Y,
                            long long N, int S, const float* noise_u, float* g, float* dmeanT, float* abar, double* part,
                            float* FT, void* workspace, long long workspace_bytes, void* stream);
+/* The same with the mean formed by the kernel itself: delta [M][L] (delta_F of vgpsa.py:194-196: mean = K_fu K_uu^-1
+ * delta = delta^T alpha) is packed into the first padding row of every Omega_l, so that row M of the product
+ * Omega_l alpha - MFMAs the padding of the last row tile executes anyway - is delta_l^T alpha_c; no [L,C] mean is read
+ * and the caller's [L,M] x [M,C] product goes away.  Only when M is not a multiple of 16 and row M lies in the kernel's
+ * last row tile (gpsa_quadform_elbo_takes_delta(M) != 0; M = 200: yes); GPSA_EUNSUPPORTED otherwise. */
+int gpsa_quadform_elbo_takes_delta(int M);
+int gpsa_quadform_elbo_delta_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                                 const float* delta, const double* q, const float* var_u, const float* eps,
+                                 const float* Y, long long N, int S, const float* noise_u, float* g, float* dmeanT,
+                                 float* abar, double* part, float* FT, void* workspace, long long workspace_bytes,
+                                 void* stream);
 /* dOmega[l] = sum_c g[l,c] * alpha[:,c] alpha[:,c]^T  (full symmetric [L,M,M]), stored as out_dtype
  * (out_dtype != dtype only on the fp32 MFMA path, whose partial sums are widened while they are added:
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */

@@ -159,6 +159,9 @@ SIGNATURES.update({
     "gpsa_quadform_elbo_f32_workspace": (_ll, [_i, _ll, _i]),
     "gpsa_quadform_elbo_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _ll, _vp]),
+    "gpsa_quadform_elbo_takes_delta": (_i, [_i]),
+    "gpsa_quadform_elbo_delta_f32": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _ll, _vp]),
     "gpsa_step_scratch_bytes": (_ll, [_vp]),
     "gpsa_step_bwd_acc_bytes": (_ll, [_vp]),
     "gpsa_step_n_kl": (_i, [_vp]),

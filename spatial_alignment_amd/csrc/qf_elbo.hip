@@ -157,9 +157,11 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
       const int ct = e / 48, kind = (e % 48) / 16, jj = e % 16;
       long long c = cw + ct * 16 + jj;
       c = c < C ? c : C - 1;
-      gp[o] = kind == 0 ? a.meanT + (long long)l_lo * C + c
+      // (meanT == nullptr: the mean is row M of this kernel's own product - the caller packed delta_l^T there - and
+      //  the gather's kind-0 slots fetch a second copy of eps that nobody reads)
+      gp[o] = kind == 0 ? (a.meanT != nullptr ? a.meanT + (long long)l_lo * C + c : a.eps + c * L + l_lo)
                         : (kind == 1 ? a.eps + c * L + l_lo : a.Y + (c % a.N) * L + l_lo);
-      gstep[o] = kind == 0 ? C : 1;
+      gstep[o] = (kind == 0 && a.meanT != nullptr) ? C : 1;
     }
 #pragma unroll
     for (int rt = 0; rt < MB; ++rt)
@@ -250,7 +252,17 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
         float s = (s2a.x + s2a.y) + (s2b.x + s2b.y);
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        const float mean = sgat[w][(ct * 3 + 0) * 16 + j];
+        float mean;
+        if (a.meanT != nullptr) {  // (uniform)
+          mean = sgat[w][(ct * 3 + 0) * 16 + j];
+        } else {
+          // row M = 16 (MB - 1) + lr of the product: C layout row 4 kq + r -> lane j + 16 (lr >> 2), component lr & 3
+          const int lr = M - 16 * (MB - 1);
+          const f32x4 t4 = acc[MB - 1][ct];
+          const int r0 = lr & 3;
+          const float pick = r0 == 0 ? t4.x : (r0 == 1 ? t4.y : (r0 == 2 ? t4.z : t4.w));
+          mean = __shfl(pick, j + 16 * (lr >> 2), 64);
+        }
         const float e = sgat[w][(ct * 3 + 1) * 16 + j];
         const float y = sgat[w][(ct * 3 + 2) * 16 + j];
         const float var = resid[ct] + s + 2e-5f;  // TWO_JITTER (elementwise.hip)

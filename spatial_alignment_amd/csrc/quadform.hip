@@ -428,7 +428,7 @@ colsq_kernel(const T* __restrict__ Y, int M, long long C, T* __restrict__ q) {
 
 template <typename TS>
 __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, int L, int transpose,
-                                   float* __restrict__ dst, int layout) {
+                                   float* __restrict__ dst, int layout, const float* __restrict__ drow) {
   const int MP = MB * 16;
   const long long per = (long long)MP * MP;
   const long long idx = blockIdx.x * 256LL + threadIdx.x;
@@ -445,6 +445,10 @@ __global__ void pack_panels_kernel(const TS* __restrict__ src, int M, int MB, in
   if (i < M && k < M) {
     const TS* sp = src + (long long)l * M * M;
     v = (float)(transpose ? sp[(long long)k * M + i] : sp[(long long)i * M + k]);
+  } else if (drow != nullptr && i == M && k < M) {
+    // row M of operand l (the first padding row) carries delta[:, l] ([M][L] row-major): the product's row M is then
+    // delta_l^T alpha - the data GP's mean, out of MFMAs the padding executes anyway (panel_elbo_kernel)
+    v = drow[(long long)k * L + l];
   }
   // symmetric quadratic form: only tiles kc >= rt are used; off-diagonal ones count twice
   if (layout & PACK_SYM_UPPER) v = (kc > rt) ? 2.f * v : (rt == kc ? v : 0.f);
@@ -788,13 +792,13 @@ static inline long long gram_ws_bytes(int MB, long long C, int L) {
 // The M x M operands (Omega_l, L^-1) may arrive in either precision: the MFMA paths convert while
 // packing, the generic paths take a converted copy from the head of the workspace.
 static int pack_any(int p_dtype, const void* src, int M, int MB, int L, int transpose, float* dst,
-                    hipStream_t st, int layout = 0) {
+                    hipStream_t st, int layout = 0, const float* drow = nullptr) {
   const long long tot = (long long)L * MB * 16 * MB * 16;
   const unsigned grid = (unsigned)cdiv(tot, 256);
   if (p_dtype == GPSA_F32)
-    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, layout);
+    pack_panels_kernel<float><<<grid, 256, 0, st>>>((const float*)src, M, MB, L, transpose, dst, layout, drow);
   else if (p_dtype == GPSA_F64)
-    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, layout);
+    pack_panels_kernel<double><<<grid, 256, 0, st>>>((const double*)src, M, MB, L, transpose, dst, layout, drow);
   else
     return GPSA_EINVAL;
   GPSA_LAUNCH_CHECK();
@@ -1144,14 +1148,24 @@ long long gpsa_quadform_elbo_f32_workspace(int M, long long C, int L) {
   return ((long long)L * MB * 16 * MB * 16 + G * 2 * (long long)MB * 16 * 64 * nct) * 4;
 }
 
-int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
-                           const float* meanT, const double* q, const float* var_u, const float* eps, const float* Y,
-                           long long N, int S, const float* noise_u, float* g, float* dmeanT, float* abar, double* part,
-                           float* FT, void* workspace, long long workspace_bytes, void* stream) {
+// the mean can ride in the product's first padding row (gpsa_quadform_elbo_delta_f32) when row M lies in the LAST row tile
+static inline bool elbo_delta_ok(int M) {
+  const int MB = gpsa::mfma_mb_for(M);
+  static const bool off = [] { const char* e = getenv("GPSA_ELBO_DELTA"); return e && e[0] == '0'; }();
+  return !off && elbo_path(M) && M > 16 * (MB - 1) && M < 16 * MB;
+}
+
+int gpsa_quadform_elbo_takes_delta(int M) { return M >= 1 && elbo_delta_ok(M) ? 1 : 0; }
+
+static int elbo_launch(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                       const float* meanT, const float* delta, const double* q, const float* var_u, const float* eps,
+                       const float* Y, long long N, int S, const float* noise_u, float* g, float* dmeanT, float* abar,
+                       double* part, float* FT, void* workspace, long long workspace_bytes, void* stream) {
   using namespace gpsa;
-  if (M < 1 || C < 1 || L < 1 || N < 1 || S < 1 || !alpha || !Omega || !meanT || !q || !var_u || !eps || !Y ||
+  if (M < 1 || C < 1 || L < 1 || N < 1 || S < 1 || !alpha || !Omega || (!meanT && !delta) || !q || !var_u || !eps || !Y ||
       !noise_u || !g || !dmeanT || !abar || !part)
     return GPSA_EINVAL;
+  if (delta != nullptr && !elbo_delta_ok(M)) return GPSA_EUNSUPPORTED;
   if (!elbo_path(M) || C > GPSA_PANEL_MAX_C) return GPSA_EUNSUPPORTED;
   if (workspace_bytes < gpsa_quadform_elbo_f32_workspace(M, C, L)) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
@@ -1159,8 +1173,9 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
   float* Ppk = (float*)workspace;
   float* slab = Ppk + (long long)L * MB * 16 * MB * 16;
   const int klast = (M - 16 * (MB - 1) <= 8) ? PACK_KSTEP_LAST : 0;
-  int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, klast);
+  int rc = pack_any(omega_dtype, Omega, M, MB, L, 0, Ppk, st, klast, delta);
   if (rc) return rc;
+  if (delta != nullptr) meanT = nullptr;  // the kernel reads the mean from row M of its own product
   const int gmax = gpsa_quadform_elbo_parts();
   ElboArgs a{Ppk, alpha, M, C, L, meanT, q, var_u, eps, Y, noise_u, N, S, g, dmeanT, FT, abar, slab, part, gmax};
   long long grid = 0;
@@ -1199,6 +1214,25 @@ int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omeg
 #undef GPSA_ELBO_CASE
   GPSA_LAUNCH_CHECK();
   return 0;
+}
+
+int gpsa_quadform_elbo_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                           const float* meanT, const double* q, const float* var_u, const float* eps, const float* Y,
+                           long long N, int S, const float* noise_u, float* g, float* dmeanT, float* abar, double* part,
+                           float* FT, void* workspace, long long workspace_bytes, void* stream) {
+  if (!meanT) return GPSA_EINVAL;
+  return elbo_launch(omega_dtype, alpha, Omega, M, C, L, meanT, nullptr, q, var_u, eps, Y, N, S, noise_u, g, dmeanT, abar,
+                     part, FT, workspace, workspace_bytes, stream);
+}
+
+int gpsa_quadform_elbo_delta_f32(int omega_dtype, const float* alpha, const void* Omega, int M, long long C, int L,
+                                 const float* delta, const double* q, const float* var_u, const float* eps,
+                                 const float* Y, long long N, int S, const float* noise_u, float* g, float* dmeanT,
+                                 float* abar, double* part, float* FT, void* workspace, long long workspace_bytes,
+                                 void* stream) {
+  if (!delta) return GPSA_EINVAL;
+  return elbo_launch(omega_dtype, alpha, Omega, M, C, L, nullptr, delta, q, var_u, eps, Y, N, S, noise_u, g, dmeanT, abar,
+                     part, FT, workspace, workspace_bytes, stream);
 }
 
 int gpsa_quadform_bwd_alpha_kept_f32(const float* W, const float* g, int M, long long C, int L, const float* dcT,

@@ -1255,8 +1255,11 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
   }
   float* meanT = c.sc.get<float>((long long)L * C);
   float* v = c.sc.get<float>((long long)L * C);
-  // mean[l,c] = sum_m delta_F[m,l] alpha[m,c]   (mu_z = 0 for the data GP)
-  GPSA_CK(gemm32(c, 1, 0, L, (int)C, Mg, 1.0, c.prm.delta_F[m], L, 0, alpha, C, 0, 0.0, meanT, C, 0, 1, 1));
+  // mean[l,c] = sum_m delta_F[m,l] alpha[m,c]   (mu_z = 0 for the data GP) - unless the fused kernel forms it itself: with
+  // delta_l^T packed into the first padding row of Omega_l, the product's row M IS the mean (MFMAs the padding runs anyway)
+  const bool mean_in_product = ps.fused(c.io) && gpsa_quadform_elbo_takes_delta(Mg) != 0;
+  if (!mean_in_product)
+    GPSA_CK(gemm32(c, 1, 0, L, (int)C, Mg, 1.0, c.prm.delta_F[m], L, 0, alpha, C, 0, 0.0, meanT, C, 0, 1, 1));
   if (ps.fused(c.io)) {
     // variance, draw, likelihood and the backward's abar in one pass over the products: F and Sigma are never written
     if (c.io.noise_u[m] == nullptr || c.io.ll_part[m] == nullptr) return GPSA_EINVAL;
@@ -1267,9 +1270,14 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
     void* ws = c.sc.get<char>(wsb);
     const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(0, 0, true, c.st);
-    GPSA_RUN(gpsa_quadform_elbo_f32(GPSA_F64, alpha, Om, Mg, C, L, meanT, q, c.prm.data_var, eps, c.io.Y[m],
-                                    (long long)(C / P.S), P.S, c.io.noise_u[m], g_ext, dmeanT, abar, c.io.ll_part[m],
-                                    c.io.F_fused_T[m], ws, wsb, c.stv()));
+    if (mean_in_product)
+      GPSA_RUN(gpsa_quadform_elbo_delta_f32(GPSA_F64, alpha, Om, Mg, C, L, c.prm.delta_F[m], q, c.prm.data_var, eps,
+                                            c.io.Y[m], (long long)(C / P.S), P.S, c.io.noise_u[m], g_ext, dmeanT, abar,
+                                            c.io.ll_part[m], c.io.F_fused_T[m], ws, wsb, c.stv()));
+    else
+      GPSA_RUN(gpsa_quadform_elbo_f32(GPSA_F64, alpha, Om, Mg, C, L, meanT, q, c.prm.data_var, eps, c.io.Y[m],
+                                      (long long)(C / P.S), P.S, c.io.noise_u[m], g_ext, dmeanT, abar, c.io.ll_part[m],
+                                      c.io.F_fused_T[m], ws, wsb, c.stv()));
     if (timed) { P.tick(0, 1, true, c.st); ++P.tfwd; }
     c.sc.release(mk);
     return 0;

@@ -271,15 +271,19 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_fwd_keep")
         return (v, W) if dcT is None else (v, W, meanT)
 
-    def quadform_elbo(self, alpha, Omega, meanT, q, var_u, eps, Y, noise_u, want_draws=False):
+    def quadform_elbo(self, alpha, Omega, meanT, q, var_u, eps, Y, noise_u, want_draws=False, delta=None):
         """The data GP's variance, draw, Gaussian likelihood and the backward's abar in one pass over the products
         Omega_l alpha (gpsa_quadform_elbo_f32; alpha fp32 [M,C], Omega [L,M,M], meanT [L,C], q fp64 [C], eps [S,N,L] or
         [C,L], Y [N,L]).  Returns (g [L,C], dmeanT [L,C], abar [M,C], z2 = sum ((Y - F)/s)^2 as an fp64 0-dim tensor), all at
-        upstream gradient 1 of loss = -LL; with ``want_draws`` also the draws, transposed: FT [L,C]."""
+        upstream gradient 1 of loss = -LL; with ``want_draws`` also the draws, transposed: FT [L,C].
+        ``delta`` [M,L] instead of ``meanT`` (None): the kernel forms mean = delta^T alpha itself, in the padding row of its
+        product (gpsa_quadform_elbo_delta_f32; only where gpsa_quadform_elbo_takes_delta(M))."""
         alpha, Omega = self._c(alpha), self._c(Omega)
         M, Cn = alpha.shape
         L = Omega.shape[0]
-        meanT, q, eps, Y = self._c(meanT), self._c(q), self._c(eps), self._c(Y)
+        q, eps, Y = self._c(q), self._c(eps), self._c(Y)
+        meanT = self._c(meanT) if meanT is not None else None
+        delta = self._c(delta) if delta is not None else None
         N = Y.shape[0]
         assert Cn % N == 0 and eps.numel() == Cn * L and Y.shape == (N, L) and q.dtype == torch.float64
         S = Cn // N
@@ -293,6 +297,13 @@ class HipOps:
             raise _lib.GpsaHipError("gpsa_quadform_elbo_f32: more than 16 row tiles (M > 256)")
         ws = self._ws(wsb, alpha)
         FT = torch.empty(L, Cn, dtype=torch.float32, device=dev) if want_draws else None
+        if delta is not None:
+            assert meanT is None and tuple(delta.shape) == (M, L) and delta.dtype == torch.float32
+            rc = self.lib.gpsa_quadform_elbo_delta_f32(_dt(Omega), _p(alpha), _p(Omega), M, Cn, L, _p(delta), _p(q),
+                                                       _p(var_u), _p(eps), _p(Y), N, S, _p(noise_u), _p(g), _p(dm),
+                                                       _p(abar), _p(part), _p(FT), _p(ws), ws.numel(), self._stream(alpha))
+            _lib.check(rc, "gpsa_quadform_elbo_delta_f32")
+            return (g, dm, abar, part.sum(), FT) if want_draws else (g, dm, abar, part.sum())
         rc = self.lib.gpsa_quadform_elbo_f32(_dt(Omega), _p(alpha), _p(Omega), M, Cn, L, _p(meanT), _p(q), _p(var_u),
                                              _p(eps), _p(Y), N, S, _p(noise_u), _p(g), _p(dm), _p(abar), _p(part),
                                              _p(FT), _p(ws), ws.numel(), self._stream(alpha))

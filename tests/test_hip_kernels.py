@@ -259,6 +259,30 @@ def test_quadform_elbo(hip, M, N, S, L):
     g2 = hip.quadform_elbo(al.to(DEV), Om.to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV), eps.to(DEV), Y.to(DEV),
                            noise_u.to(DEV))  # without the draws: the same numbers, bit for bit
     assert torch.equal(g2[0], g) and torch.equal(g2[2], abar)
+    # the mean formed inside the kernel (delta^T alpha in the product's first padding row): where M allows it, the same
+    # results as with the mean handed in - up to the rounding of the mean itself (fp32 matrix cores there, fp64 here)
+    delta = rnd(M, L, seed=7)
+    takes = bool(hip.lib.gpsa_quadform_elbo_takes_delta(M))
+    assert takes == (M % 16 != 0 and M > 16 * ({2: 2, 4: 4, 7: 7, 13: 13, 16: 16}[min(k for k in (2, 4, 7, 13, 16) if 16 * k >= M)] - 1))
+    if not takes:
+        with pytest.raises(Exception):
+            hip.quadform_elbo(al.to(DEV), Om.to(DEV), None, q.to(DEV), var_u.to(DEV), eps.to(DEV), Y.to(DEV), noise_u.to(DEV),
+                              delta=delta.to(DEV))
+    else:
+        mean_d = (delta.double().to(rd).t() @ ad)                       # [L, C]
+        g3, dm3, abar3, z3, FT3 = hip.quadform_elbo(al.to(DEV), Om.to(DEV), None, q.to(DEV), var_u.to(DEV), eps.to(DEV),
+                                                    Y.to(DEV), noise_u.to(DEV), want_draws=True, delta=delta.to(DEV))
+        F3 = mean_d + var.sqrt() * e
+        r3 = Y.double().t().repeat(1, S) - F3
+        dF3 = -r3 / (sN * sN * S)
+        gw3 = dF3 * e * 0.5 / var.sqrt()
+        close(FT3, F3, 2e-6)
+        close(dm3, dF3, 5e-6)
+        close(g3, gw3, 5e-6)
+        want3 = 2.0 * torch.einsum("lc,lmc->mc", gw3, W) if W is not None else \
+            2.0 * sum(Om[l] @ (ad * gw3[l][None]) for l in range(L))
+        close(abar3, want3, 8e-6)
+        close(z3.reshape(1), ((r3 / sN) ** 2).sum().reshape(1), 2e-6)
     with pytest.raises(Exception):  # beyond 16 row tiles: refused, not wrong
         hip.quadform_elbo(rnd(272, C).to(DEV), rnd(L, 272, 272).to(DEV), meanT.to(DEV), q.to(DEV), var_u.to(DEV),
                           eps.to(DEV), Y.to(DEV), noise_u.to(DEV))
