@@ -186,6 +186,17 @@ int gpsa_quadform_elbo_delta_f32(int omega_dtype, const float* alpha, const void
  * GPSA_EUNSUPPORTED otherwise, and the caller converts) */
 int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const void* g, int M, long long C,
                             int L, void* dOmega, void* workspace, long long workspace_bytes, void* stream);
+/* The same (fp32 operands, fp32 matrix cores) with the mean term's gradient riding along:
+ *   ddelta[m,l] = dbeta * ddelta[m,l] + sum_c alpha[m,c] dmeanT[l,c]      (d delta_F of mean = delta^T alpha, [M][L])
+ * comes out of row M of the padded dOmega_l tiles - the first padding row of the kernel's last row tile takes dmeanT[l,c]
+ * as its scaled row fragment - so the caller's C-long [M,C] x [C,L] product goes away.  Workspace as
+ * gpsa_quadform_workspace(GPSA_F32, M, C, L).  Only where gpsa_quadform_bwd_omega_takes_delta(M, C) != 0 (M not a
+ * multiple of 16 and in the kernel's last row tile, M <= 256, C a multiple of 4, 16-byte aligned operands);
+ * GPSA_EUNSUPPORTED otherwise. */
+int gpsa_quadform_bwd_omega_takes_delta(int M, long long C);
+int gpsa_quadform_bwd_omega_delta_f32(int out_dtype, const float* alpha, const float* g, const float* dmeanT, int M,
+                                      long long C, int L, void* dOmega, float* ddelta, double dbeta, void* workspace,
+                                      long long workspace_bytes, void* stream);
 
 /* alpha = Kinv Kuf on the fp64 matrix cores, with Kinv [M,M] = K_uu^-1 (fp64, from gpsa_chol_inv_f64 +
  * L^-T L^-1) and Kuf [M,C] stored as in_dtype (widened on the fly); alpha [M,C] is stored as alpha_dtype

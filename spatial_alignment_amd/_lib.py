@@ -38,6 +38,8 @@ SIGNATURES = {
     "gpsa_quadform_fwd_keep": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpsa_quadform_bwd_alpha_kept": (_i, [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     "gpsa_quadform_bwd_omega": (_i, [_i, _i, _vp, _vp, _i, _ll, _i, _vp, _vp, _ll, _vp]),
+    "gpsa_quadform_bwd_omega_takes_delta": (_i, [_i, _ll]),
+    "gpsa_quadform_bwd_omega_delta_f32": (_i, [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _d, _vp, _ll, _vp]),
     "gpsa_whiten_workspace": (_ll, [_i]),
     "gpsa_whiten_f64": (_i, [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_panel_mm": (_i, [_i, _i, _i, _vp, _vp, _i, _ll, _vp, _vp, _vp, _ll, _vp]),

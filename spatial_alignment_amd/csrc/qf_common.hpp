@@ -395,8 +395,8 @@ GPSA_SYM_SHAPES(GPSA_SYM_EXTERN)
 // ---- Gram sums (M <= 256): qf_gram.hip
 constexpr int GR_KC = 64;  // columns per staged chunk (four 16-deep MFMA K blocks)
 template <int MB, bool ALIGNED, int NL>
-__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2) gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part);
-#define GPSA_GRAM_SIG (const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part)
+__global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2) gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part, const float* __restrict__ dmean);
+#define GPSA_GRAM_SIG (const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part, const float* __restrict__ dmean)
 #define GPSA_GRAM_SHAPES(X) X(2, 2) X(4, 2) X(7, 2) X(13, 2) X(2, 1) X(4, 1) X(7, 1) X(13, 1) X(16, 1)
 #define GPSA_GRAM_EXTERN(MB, NL)                                                \
   extern template __global__ void gram_mfma_kernel<MB, true, NL> GPSA_GRAM_SIG; \
@@ -406,8 +406,9 @@ __global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2) gram_mfma_k
   template __global__ void gram_mfma_kernel<MB, false, NL> GPSA_GRAM_SIG;
 GPSA_GRAM_SHAPES(GPSA_GRAM_EXTERN)
 template <typename TO>
-__global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit, TO* __restrict__ out);
-extern template __global__ void gram_reduce_kernel<float>(const float* __restrict__, int, int, int, int, float* __restrict__);
-extern template __global__ void gram_reduce_kernel<double>(const float* __restrict__, int, int, int, int, double* __restrict__);
+__global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit, TO* __restrict__ out,
+                                   float* __restrict__ ddelta, float dbeta);
+extern template __global__ void gram_reduce_kernel<float>(const float* __restrict__, int, int, int, int, float* __restrict__, float* __restrict__, float);
+extern template __global__ void gram_reduce_kernel<double>(const float* __restrict__, int, int, int, int, double* __restrict__, float* __restrict__, float);
 
 }  // namespace gpsa

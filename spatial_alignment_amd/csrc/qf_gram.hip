@@ -68,10 +68,14 @@ constexpr int GR_G = 4;
 // ``stage(kb, gp)``: the caller's LDS-DMA issues for the NEXT chunk, one per group of the first groups of every K
 // block, pinned between the groups' MFMAs (in one clump in front of the chunk they cost 8 % of the kernel: 14 issues
 // with the matrix pipe idle, 156 times per workgroup; without any staging the kernel ran 1750 instead of 1900 us)
+// ``drow`` (>= 0: the d-delta option): row ``drow`` of the LAST tile row - the first padding row, M - 16 (MB - 1) - takes
+// dmean[l, c] as its (already "scaled") row fragment instead of g alpha: the tiles of that tile row then carry
+// sum_c dmean[l,c] alpha[col,c] = d delta_F[col, l] in their row M (MFMAs the padding runs anyway).  gvec holds the
+// NL rows of dmean behind the NL rows of g.
 template <int MB, int NKB, int W, int NS, int NL, typename STG>
 __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
                                                 const float* __restrict__ gvec, int kq,
-                                                f32x4 (&acc)[NL][NS + GR_G], STG&& stage) {
+                                                f32x4 (&acc)[NL][NS + GR_G], STG&& stage, int drow, int lane15) {
   constexpr GramPlan<MB> P{};
   constexpr int N = P.cnt[W];
   constexpr int NGRP = (((NS + GR_G - 1) / GR_G) + 1) & ~1;
@@ -96,6 +100,22 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
     gn[q] = gk[q] = *reinterpret_cast<const float4*>(gvec + q * GR_KC + kq * 4);
     arow[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // does this wave own the last tile row?  (compile time)
+  constexpr bool OWNS_LAST = [] {
+    constexpr GramPlan<MB> Q{};
+    for (int s = 0; s < Q.cnt[W]; ++s)
+      if (Q.rr[W][s] == MB - 1) return true;
+    return false;
+  }();
+  const bool dsel = OWNS_LAST && drow >= 0 && lane15 == drow;
+  // dmean of the K block being multiplied / of the next one (fetched with gn: no LDS round trip at the point of use)
+  float4 dk[OWNS_LAST ? NL : 1], dn[OWNS_LAST ? NL : 1];
+  if (OWNS_LAST) {
+#pragma unroll
+    for (int q = 0; q < NL; ++q)
+      dn[q] = dk[q] = drow >= 0 ? *reinterpret_cast<const float4*>(gvec + (NL + q) * GR_KC + kq * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #define GPSA_GR_FETCH(SLOT, KB, GP)                                                           \
   _Pragma("unroll") for (int u = 0; u < GR_G; ++u) {                                          \
     const int t__ = tile_of(GR_G * (GP) + u);                                                 \
@@ -107,6 +127,10 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int q = 0; q < NL; ++q) gk[q] = gn[q];
+    if (OWNS_LAST) {
+#pragma unroll
+      for (int q = 0; q < NL; ++q) dk[q] = dn[q];
+    }
 #pragma unroll
     for (int gp = 0; gp < NGRP; ++gp) {
       const int cur = gp & 1, nxt = cur ^ 1;
@@ -116,6 +140,11 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
 #pragma unroll
         for (int q = 0; q < NL; ++q)
           gn[q] = *reinterpret_cast<const float4*>(gvec + q * GR_KC + (kb + 1) * 16 + kq * 4);
+        if (OWNS_LAST && drow >= 0) {
+#pragma unroll
+          for (int q = 0; q < NL; ++q)
+            dn[q] = *reinterpret_cast<const float4*>(gvec + (NL + q) * GR_KC + (kb + 1) * 16 + kq * 4);
+        }
         GPSA_GR_FETCH(nxt, kb + 1, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -132,6 +161,12 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
           if (new_row(s_)) {
             const float4 r_ = araw[cur][u];
             arow[q] = make_float4(r_.x * gk[q].x, r_.y * gk[q].y, r_.z * gk[q].z, r_.w * gk[q].w);
+            if (OWNS_LAST && P.rr[W][s_ < N ? s_ : N - 1] == MB - 1 && drow >= 0) {  // (compile time && uniform)
+              const float4 d_ = dk[q];
+              // (component by component: a select between two float4 objects goes through scratch)
+              arow[q] = make_float4(dsel ? d_.x : arow[q].x, dsel ? d_.y : arow[q].y, dsel ? d_.z : arow[q].z,
+                                    dsel ? d_.w : arow[q].w);
+            }
           }
           a[q][u] = arow[q];
         }
@@ -173,13 +208,16 @@ __device__ __forceinline__ void gram_wave_store(const f32x4 (&acc)[NS + GR_G], f
 template <int MB, bool ALIGNED, int NL, int W>
 __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, const float* __restrict__ g,
                                               long long gstride, int M, long long C, int L, int nsplit, float* __restrict__ part,
-                                              float* __restrict__ sA_, float* __restrict__ sG_) {
+                                              float* __restrict__ sA_, float* __restrict__ sG_,
+                                              const float* __restrict__ dmean) {
   constexpr int MP = MB * 16;
   constexpr GramPlan<MB> PLAN{};
   constexpr int NS = PLAN.max_cnt();
   constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;
   constexpr int NPW = (NPIECE + 3) / 4;
-  constexpr int SA_STRIDE = NPW * 4 * 256, SG_STRIDE = NL * GR_KC;
+  constexpr int SA_STRIDE = NPW * 4 * 256, SG_STRIDE = 2 * NL * GR_KC;  // g rows, then dmean rows (d-delta option)
+  const int nstage = (dmean != nullptr ? 2 : 1) * NL * (GR_KC / 4);  // lanes of the g / dmean piece
+  const int drow = dmean != nullptr ? M - 16 * (MB - 1) : -1;
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int w = W;
   const int j = lane & 15, kq = lane >> 4;
@@ -200,7 +238,9 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
   // made a zero-padded copy with gstride = C rounded up to GR_KC columns).  Every wave issues exactly NPW + 1 operations per stage (surplus pieces re-load piece 0 into
   // an unused slot; all four waves DMA the same 128 bytes of g) so that a counted vmcnt(NPW+1) means
   // "everything but the newest stage has landed".
-  auto gsrc = [&](int lq, long long col) -> const float* {
+  auto gsrc = [&](int ln, long long col) -> const float* {  // lane ln of the piece: output ln / 16 of g, then of dmean
+    const int which = ln / (NL * (GR_KC / 4)), lq = min(l0 + (ln / (GR_KC / 4)) % NL, L - 1);
+    if (which == 1) return col >= C ? gram_zero16 : dmean + (long long)lq * C + col;
     return (gstride == C && col >= C) ? gram_zero16 : g + (long long)lq * gstride + col;
   };
 #define GPSA_GR_STAGE(CH, BUF)                                                               \
@@ -221,10 +261,9 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
         if ((pc & 3) == 2) glds16_m0<2048>(gp__ - 512);                                      \
         if ((pc & 3) == 3) glds16_m0<3072>(gp__ - 768);                                      \
       }                                                                                      \
-      if (lane < NL * (GR_KC / 4)) {                                                         \
-        const int lq__ = min(l0 + lane / (GR_KC / 4), L - 1);                                \
+      if (lane < nstage) {                                                                   \
         dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sG_ + (BUF) * SG_STRIDE)));       \
-        glds16_m0<0>(gsrc(lq__, cb__ + (lane % (GR_KC / 4)) * 4));          \
+        glds16_m0<0>(gsrc(lane, cb__ + (lane % (GR_KC / 4)) * 4));                           \
       }                                                                                      \
     } else {                                                                                 \
       for (int e = tid; e < NPIECE * 256; e += 256) {                                        \
@@ -235,7 +274,7 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
         sA_[(BUF) * SA_STRIDE + (kb * NPW + rb) * 256 + (e & 255)] =                         \
             (row < M && col < C) ? alpha[(long long)row * C + col] : 0.f;                    \
       }                                                                                      \
-      if (tid < NL * GR_KC)                                                                  \
+      if (tid < NL * GR_KC) /* (the d-delta option is for the aligned path only) */          \
         sG_[(BUF) * SG_STRIDE + tid] = g[(long long)min(l0 + tid / GR_KC, L - 1) * gstride + cb__ + tid % GR_KC]; \
     }                                                                                        \
   }
@@ -271,14 +310,13 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
           if (gp == 2) glds16_m0<2048>(gp__ - 512);
           if (gp == 3) glds16_m0<3072>(gp__ - 768);
         }
-      } else if (kb == 0 && lane < NL * (GR_KC / 4)) {
-        const int lq = min(l0 + lane / (GR_KC / 4), L - 1);
+      } else if (kb == 0 && lane < nstage) {
         dma_set_m0(__builtin_amdgcn_readfirstlane(lds_addr(sG_ + (buf ^ 1) * SG_STRIDE)));
-        glds16_m0<0>(gsrc(lq, (ch + 1) * GR_KC + (lane % (GR_KC / 4)) * 4));
+        glds16_m0<0>(gsrc(lane, (ch + 1) * GR_KC + (lane % (GR_KC / 4)) * 4));
       }
     };
     static_assert(NPW <= 16, "four pieces per K block of the chunk being multiplied");
-    gram_wave_chunk<MB, NKB, W, NS, NL>(img, sG_ + buf * SG_STRIDE, kq, acc, stage);
+    gram_wave_chunk<MB, NKB, W, NS, NL>(img, sG_ + buf * SG_STRIDE, kq, acc, stage, drow, lane & 15);
     GPSA_DMA_DRAIN();  // chunk ch+1 (issued a whole chunk of MFMAs ago) has landed
     __syncthreads();
     buf ^= 1;
@@ -296,7 +334,7 @@ __device__ __forceinline__ void gram_wave_run(const float* __restrict__ alpha, c
 template <int MB, bool ALIGNED, int NL>
 __global__ void __launch_bounds__(256, (MB >= 13 || NL > 1) ? 1 : 2)
 gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, long long gstride, int M,
-                 long long C, int L, int nsplit, float* __restrict__ part) {
+                 long long C, int L, int nsplit, float* __restrict__ part, const float* __restrict__ dmean) {
   constexpr int NKB = GR_KC / 16, NPIECE = MB * NKB;  // 1-KiB pieces (16 rows x 16 cols) per chunk
   // LDS image of a chunk: piece (rb, kb) at float offset (rb*NKB + kb)*256, stored in MFMA-fragment
   // order: lane j + 16 kq holds alpha[16 rb + j][cb + 16 kb + 4 kq .. +3]  => a fragment read is one
@@ -305,23 +343,32 @@ gram_mfma_kernel(const float* __restrict__ alpha, const float* __restrict__ g, l
   // two slots: the chunk being multiplied and the next one in flight (a chunk is ~12k MFMA cycles per
   // wave, far longer than the DMA latency, so one stage ahead is enough and the chunks can be big)
   __shared__ __attribute__((aligned(16))) float sA[2][NPW * 4 * 256];
-  __shared__ __attribute__((aligned(16))) float sG[2][NL * GR_KC];
+  __shared__ __attribute__((aligned(16))) float sG[2][2 * NL * GR_KC];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   switch (w) {
-    case 0: gram_wave_run<MB, ALIGNED, NL, 0>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
-    case 1: gram_wave_run<MB, ALIGNED, NL, 1>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
-    case 2: gram_wave_run<MB, ALIGNED, NL, 2>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
-    default: gram_wave_run<MB, ALIGNED, NL, 3>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0]); break;
+    case 0: gram_wave_run<MB, ALIGNED, NL, 0>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0], dmean); break;
+    case 1: gram_wave_run<MB, ALIGNED, NL, 1>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0], dmean); break;
+    case 2: gram_wave_run<MB, ALIGNED, NL, 2>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0], dmean); break;
+    default: gram_wave_run<MB, ALIGNED, NL, 3>(alpha, g, gstride, M, C, L, nsplit, part, &sA[0][0], &sG[0][0], dmean); break;
   }
 }
 
 template <typename TO>
 __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP, int L, int nsplit,
-                                   TO* __restrict__ out) {
+                                   TO* __restrict__ out, float* __restrict__ ddelta, float dbeta) {
   // grid: (ceil(M / 32) column blocks, M rows, L); threads 32 x 8 (8 rows per block in y)
   const int jj = blockIdx.x * 32 + (threadIdx.x & 31);
   const int i = blockIdx.y * 8 + (threadIdx.x >> 5);
   const int l = blockIdx.z;
+  if (ddelta != nullptr && i == M && jj < M) {  // the d-delta option: row M of the partials is d delta_F[:, l]
+    const float* p = part + (long long)l * nsplit * MP * MP + (long long)M * MP + jj;
+    const long long mm = (long long)MP * MP;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += (double)p[sp * mm];
+    float* d = ddelta + (long long)jj * L + l;
+    *d = dbeta != 0.f ? dbeta * *d + (float)s : (float)s;
+    return;
+  }
   if (i >= M || jj > i) return;
   const float* p = part + (long long)l * nsplit * MP * MP + (long long)i * MP + jj;
   // fp64 output: the partials are widened before they are added; four independent running sums (the
@@ -344,7 +391,7 @@ __global__ void gram_reduce_kernel(const float* __restrict__ part, int M, int MP
 
 
 GPSA_GRAM_SHAPES(GPSA_GRAM_DEFINE)
-template __global__ void gram_reduce_kernel<float>(const float* __restrict__, int, int, int, int, float* __restrict__);
-template __global__ void gram_reduce_kernel<double>(const float* __restrict__, int, int, int, int, double* __restrict__);
+template __global__ void gram_reduce_kernel<float>(const float* __restrict__, int, int, int, int, float* __restrict__, float* __restrict__, float);
+template __global__ void gram_reduce_kernel<double>(const float* __restrict__, int, int, int, int, double* __restrict__, float* __restrict__, float);
 
 }  // namespace gpsa

@@ -735,8 +735,11 @@ static inline int gram_nl(int MB, int L, long long C) {
   return (can && C >= 8192) ? 2 : 1;
 }
 
+// dmean / ddelta (both or neither; the d-delta option of gram_mfma_kernel): ddelta [M][L] = dbeta ddelta + alpha dmean^T
+// out of the first padding row of the LAST tile row; the caller has checked gram_delta_ok
 static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M, long long C, int L,
-                            void* dOmega, int out_dtype, float* ws, hipStream_t st) {
+                            void* dOmega, int out_dtype, float* ws, hipStream_t st, const float* dmean = nullptr,
+                            float* ddelta = nullptr, float dbeta = 0.f) {
   const int nl = gram_nl(MBsel, L, C);
   const int ns = gram_nsplit(C, (L + nl - 1) / nl);
   const long long Cpad = cdiv(C, GR_KC) * GR_KC;
@@ -744,6 +747,8 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
   long long gstride = Cpad;
   float* part = ws + ((gram_gpad_floats(C, L) + 63) / 64) * 64;
   const bool al = (C % 4 == 0) && (C >= 8) && ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0);
+  if (dmean != nullptr && !(al && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dmean)) & 15) == 0))
+    return GPSA_EUNSUPPORTED;
   if (al && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
     // the kernel reads g where it lies (its column groups past C come from a block of zeros): no padded copy
     gpad = g;
@@ -756,11 +761,11 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
 #define GPSA_GRAM_CASE(MBV)                                                                        \
   case MBV:                                                                                        \
     if (nl == 2 && MBV <= 13) {                                                                    \
-      if (al) gram_mfma_kernel<MBV, true, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part);  \
-      else gram_mfma_kernel<MBV, false, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part);    \
+      if (al) gram_mfma_kernel<MBV, true, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part, dmean);  \
+      else gram_mfma_kernel<MBV, false, (MBV <= 13 ? 2 : 1)><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part, nullptr);    \
     } else {                                                                                       \
-      if (al) gram_mfma_kernel<MBV, true, 1><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part); \
-      else gram_mfma_kernel<MBV, false, 1><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part);   \
+      if (al) gram_mfma_kernel<MBV, true, 1><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part, dmean); \
+      else gram_mfma_kernel<MBV, false, 1><<<grid, 256, 0, st>>>(alpha, gpad, gstride, M, C, L, ns, part, nullptr);   \
     }                                                                                              \
     break;
   switch (MBsel) {
@@ -774,11 +779,11 @@ static int gram_mfma_launch(int MBsel, const float* alpha, const float* g, int M
   }
 #undef GPSA_GRAM_CASE
   GPSA_LAUNCH_CHECK();
-  dim3 rgrid((unsigned)cdiv(M, 32), (unsigned)cdiv(M, 8), (unsigned)L);
+  dim3 rgrid((unsigned)cdiv(M, 32), (unsigned)cdiv(M + (ddelta != nullptr ? 1 : 0), 8), (unsigned)L);
   if (out_dtype == GPSA_F64)
-    gram_reduce_kernel<double><<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, (double*)dOmega);
+    gram_reduce_kernel<double><<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, (double*)dOmega, ddelta, dbeta);
   else
-    gram_reduce_kernel<float><<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, (float*)dOmega);
+    gram_reduce_kernel<float><<<rgrid, 256, 0, st>>>(part, M, MBsel * 16, L, ns, (float*)dOmega, ddelta, dbeta);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -1399,6 +1404,28 @@ int gpsa_quadform_bwd_omega(int dtype, int out_dtype, const void* alpha, const v
                                               (double*)dOmega, workspace, workspace_bytes, st);
   }
   return GPSA_EINVAL;
+}
+
+// the d-delta option of the Gram kernel: M in the last row tile with a padding row behind it, the MFMA path, 4-column alignment
+static inline bool gram_delta_ok(int M, long long C) {
+  static const bool off = [] { const char* e = getenv("GPSA_GRAM_DELTA"); return e && e[0] == '0'; }();
+  const int MB = gpsa::gram_mb_for(M);
+  return !off && MB != 0 && !gpsa::force_generic() && M > 16 * (MB - 1) && M < 16 * MB && (C % 4 == 0) && C >= 8;
+}
+
+int gpsa_quadform_bwd_omega_takes_delta(int M, long long C) { return M >= 1 && C >= 1 && gram_delta_ok(M, C) ? 1 : 0; }
+
+int gpsa_quadform_bwd_omega_delta_f32(int out_dtype, const float* alpha, const float* g, const float* dmeanT, int M,
+                                      long long C, int L, void* dOmega, float* ddelta, double dbeta, void* workspace,
+                                      long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || L < 1 || !alpha || !g || !dmeanT || !dOmega || !ddelta) return GPSA_EINVAL;
+  if (out_dtype != GPSA_F32 && out_dtype != GPSA_F64) return GPSA_EINVAL;
+  if (!gram_delta_ok(M, C)) return GPSA_EUNSUPPORTED;
+  const int MB = gram_mb_for(M);
+  if (workspace_bytes < gram_ws_bytes(MB, C, L)) return GPSA_EWORKSPACE;
+  return gram_mfma_launch(MB, alpha, g, M, C, L, dOmega, out_dtype, (float*)workspace, as_stream(stream), dmeanT, ddelta,
+                          (float)dbeta);
 }
 
 /* batched fp64 forms of the two calls above and of gpsa_col_axpy: ``batch`` layers with contiguous operands

@@ -1408,9 +1408,12 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     if (!kept)
       GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
   }
-  // d delta_F = alpha dmean^T
-  GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
-                 splitk_for(C, Mg, L)));
+  // d delta_F = alpha dmean^T - as a C-long product here, unless the Gram kernel below can carry it in the first padding
+  // row of its last tile row (gpsa_quadform_bwd_omega_delta_f32)
+  const bool ddelta_in_gram = gpsa_quadform_bwd_omega_takes_delta(Mg, C) != 0;
+  if (!ddelta_in_gram)
+    GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
+                   splitk_for(C, Mg, L)));
   B.have_ddc[m] = true;
   // exact_inducing_grad: gamma = K^-1 abar STORED in fp64, W = gamma + qbar alpha64, dK_uu = -W alpha64^T as one
   // C-long fp64 product, dK_uf = W + qbar alpha64 handed to the covariance backward as an fp64 panel
@@ -1501,7 +1504,18 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     double* dst = first_for_mod ? dOm : c.sc.get<double>((long long)L * mm);
     const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(2, 0, false, c.st);
-    int rc = dry ? 0 : gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F64, alpha, g_ext, Mg, C, L, dst, ws, wsb, c.stv());
+    int rc = 0;
+    if (!dry && ddelta_in_gram) {
+      rc = gpsa_quadform_bwd_omega_delta_f32(GPSA_F64, alpha, g_ext, dmeanT, Mg, C, L, dst, B.ddc_F[m],
+                                             first_for_mod ? 0.0 : 1.0, ws, wsb, c.stv());
+      if (rc == GPSA_EUNSUPPORTED) {  // (operand alignment): the product after all, then the plain call
+        GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, first_for_mod ? 0.0 : 1.0, B.ddc_F[m], L, 0, 1,
+                       splitk_for(C, Mg, L)));
+        rc = gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F64, alpha, g_ext, Mg, C, L, dst, ws, wsb, c.stv());
+      }
+    } else if (!dry) {
+      rc = gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F64, alpha, g_ext, Mg, C, L, dst, ws, wsb, c.stv());
+    }
     if (rc == GPSA_EUNSUPPORTED) {  // generic path stores in the compute type: convert
       float* tmp = c.sc.get<float>((long long)L * mm);
       GPSA_RUN(gpsa_quadform_bwd_omega(GPSA_F32, GPSA_F32, alpha, g_ext, Mg, C, L, tmp, ws, wsb, c.stv()));

@@ -357,6 +357,24 @@ class HipOps:
         _lib.check(rc, "gpsa_quadform_bwd_omega")
         return out
 
+    def quadform_bwd_omega_delta(self, alpha, g, dmeanT, ddelta=None, beta=0.0, out_dtype=torch.float64):
+        """gpsa_quadform_bwd_omega_delta_f32: (dOmega [L,M,M], ddelta [M,L] = beta ddelta + alpha dmeanT^T) from one Gram
+        launch (the mean term's gradient in the padding row of the kernel's last row tile); None where the shape does not
+        allow it (gpsa_quadform_bwd_omega_takes_delta)"""
+        alpha, g, dmeanT = self._c(alpha), self._c(g), self._c(dmeanT)
+        M, Cn = alpha.shape
+        L = g.shape[0]
+        if not self.lib.gpsa_quadform_bwd_omega_takes_delta(M, Cn):
+            return None
+        out = torch.empty(L, M, M, dtype=out_dtype, device=alpha.device)
+        if ddelta is None:
+            ddelta = torch.zeros(M, L, dtype=torch.float32, device=alpha.device)
+        ws = self._qf_ws(alpha, L)
+        rc = self.lib.gpsa_quadform_bwd_omega_delta_f32(_dt(out), _p(alpha), _p(g), _p(dmeanT), M, Cn, L, _p(out),
+                                                        _p(ddelta), float(beta), _p(ws), ws.numel(), self._stream(alpha))
+        _lib.check(rc, "gpsa_quadform_bwd_omega_delta_f32")
+        return out, ddelta
+
     def panel_mm(self, P, X, want_colsq=False, transP=False):
         """Y = op(P) @ X in X's dtype; P [M,M] may be stored in either precision"""
         P, X = self._c(P), self._c(X)

@@ -469,6 +469,30 @@ def test_quadform(hip, dtype, M, C, L):
         close(wide, FK.quadform_bwd_omega(al.double(), g.double()), t)
 
 
+@pytest.mark.parametrize("M,C,L", [(200, 2100, 7), (200, 20000, 50), (100, 5000, 3), (25, 1000, 5), (10, 100, 1), (250, 260, 2),
+                                   (200, 100000, 3), (208, 400, 2), (200, 2102, 2), (300, 400, 2), (120, 4000, 2)])
+def test_quadform_bwd_omega_with_ddelta(hip, M, C, L):
+    """gpsa_quadform_bwd_omega_delta_f32: the Gram sums and, out of the first padding row of the kernel's last row tile,
+    d delta_F = alpha dmean^T (accumulated onto a given ddelta with beta); refused (None) where M fills its last row tile,
+    lies before it, is beyond the kernel, or C is not a multiple of 4"""
+    al, g, dm = rnd(M, C), rnd(L, C, seed=2), rnd(L, C, seed=3)
+    mb = next((k for k in (2, 4, 7, 13, 16) if 16 * k >= M), 0)
+    takes = mb != 0 and M % 16 != 0 and M > 16 * (mb - 1) and C % 4 == 0
+    assert bool(hip.lib.gpsa_quadform_bwd_omega_takes_delta(M, C)) == takes
+    got = hip.quadform_bwd_omega_delta(al.to(DEV), g.to(DEV), dm.to(DEV))
+    if not takes:
+        assert got is None
+        return
+    dOm, dd = got
+    close(dOm, FK.quadform_bwd_omega(al.double(), g.double()), 3e-5)
+    want = al.double() @ dm.double().t()
+    close(dd, want, 3e-5)
+    assert torch.equal(dOm, hip.quadform_bwd_omega(al.to(DEV), g.to(DEV), out_dtype=torch.float64))  # the same Gram sums
+    base = rnd(M, L, seed=4).to(DEV)
+    _, dd2 = hip.quadform_bwd_omega_delta(al.to(DEV), g.to(DEV), dm.to(DEV), ddelta=base.clone(), beta=1.0)
+    close(dd2, base.double().cpu() + want, 3e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("M,C,L", [(12, 50, 1), (200, 1250, 2), (65, 777, 3)])
 def test_quadform_kept_products(hip, dtype, M, C, L):
