@@ -77,6 +77,10 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
   if (u0 >= u1) return;
   const long long C = a.C;
   const int M = a.M;
+  // M <= 16 (MB - 1) + 8: the last two K steps of a row tile meet only the packed inverse's zero padding (M = 200: k =
+  // 200 .. 207) - their MFMAs and the piece that carries their fragments are skipped (2 of 52: 4 % of the kernel)
+  const bool short_k = M <= 16 * (MB - 1) + 8;
+  const int npiece_live = NPIECE - (short_k ? 1 : 0);
 
   // where this workgroup starts: (problem b, column tile t, row tile rt)
   int rt = (int)(u0 % MB);
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
     const char* sp__ = abase + (long long)(B_) * PB + (RT_) * 512;                                           \
     const unsigned l__ = lds0 + (unsigned)(SLOT_) * (SLOT * 8) + (unsigned)wstart * 1024;                     \
     _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                        \
-      if (w + 4 * i < NPIECE) { /* wave-uniform */                                                           \
+      if (w + 4 * i < npiece_live) { /* wave-uniform */                                                      \
         if ((i & 3) == 0) proj_set_m0(l__ + i * 1024);                                                       \
         const char* g__ = sp__ + (long long)i * (8LL * MB * 512);                                            \
         if ((i & 3) == 0) proj_glds16<0>(g__);                                                               \
@@ -177,6 +181,7 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int f = 4 * g + e;
+        if (g == NG - 1 && e >= 2 && short_k) continue;  // (uniform)
         if (e & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[e], slab[f >> 2][f & 3], acc1, 0, 0, 0);
         else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[e], slab[f >> 2][f & 3], acc0, 0, 0, 0);
       }
@@ -282,10 +287,13 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
   static const int dbg = [] { const char* e = getenv("GPSA_PROJ64_SKIP"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   // at least MB units per workgroup: a column tile (MB consecutive units) then meets at most two workgroups
-  static const int occ = [] {
+  // workgroups per CU: three for the fp32 right-hand side (168 registers), two for the fp64 one (its three-per-CU
+  // instantiation spills five registers; measured equal: LAB_NOTES); GPSA_PROJ64_OCC = 1 / 2 / 3 forces one
+  static const int occ_env = [] {
     const char* e = getenv("GPSA_PROJ64_OCC");
-    return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 3;
+    return e && (e[0] == '1' || e[0] == '2' || e[0] == '3') ? e[0] - '0' : 0;
   }();
+  const int occ = occ_env ? occ_env : (sizeof(TI) == 8 ? 2 : 3);
   long long grid = (long long)occ * num_cus();
   if (grid > (long long)batch * a.T) grid = (long long)batch * a.T;
   if (q != nullptr && !q_zeroed) {
