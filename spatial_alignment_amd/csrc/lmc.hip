@@ -25,8 +25,10 @@ typedef float lm_f32x4 __attribute__((ext_vector_type(4)));
 
 // NLT: 16-row tiles of the latent outputs (L <= 16 NLT); NPT: 16-column tiles of the outputs per wave and chunk (a chunk
 // = 64 NPT outputs: W's columns are walked in chunks so that its fragments and the dW accumulators stay in registers)
+// (two workgroups per CU: 193 - 223 registers; left to itself the compiler took 272 and the kernel - two barriers and an LDS
+//  staging per 96 MFMAs of a wave - ran one wave per SIMD at half the MFMA rate)
 template <int NLT, int NPT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 lmc_mfma_kernel(const float* __restrict__ F, const float* __restrict__ W, const float* __restrict__ Y,
                 const float* __restrict__ noise_u, int S, long long N, int L, int P, double* __restrict__ zpart,
                 int nparts, float* __restrict__ dF, float* __restrict__ dWpart) {
