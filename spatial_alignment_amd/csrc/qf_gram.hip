@@ -171,10 +171,13 @@ __device__ __forceinline__ void gram_wave_chunk(const float* __restrict__ img,
           a[q][u] = arow[q];
         }
       }
+      // (surplus slots of the wave's last group issue nothing: 5 of the 96 slots of a K block at MB = 13 - they used to
+      //  repeat the last tile into scratch accumulators, 5 % of the kernel's MFMAs)
 #define GPSA_GR_MMA(F)                                                                          \
   _Pragma("unroll") for (int q = 0; q < NL; ++q)                                                \
     _Pragma("unroll") for (int u = 0; u < GR_G; ++u)                                            \
-      acc[q][sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][u].F, fb[cur][u].F, acc[q][sl[u]], 0, 0, 0);
+      if (GR_G * gp + u < N)                                                                    \
+        acc[q][sl[u]] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][u].F, fb[cur][u].F, acc[q][sl[u]], 0, 0, 0);
       GPSA_GR_MMA(x)
       GPSA_GR_MMA(y)
       GPSA_GR_MMA(z)
