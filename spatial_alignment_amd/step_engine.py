@@ -141,18 +141,30 @@ def view_rows(model, view_idx, Ns):
     import numpy as np
 
     V = model.n_views
-    # a training loop passes the same index objects every step: the answer for them is remembered (keyed by the objects'
-    # identities and lengths; held alive by the memo so that an id cannot come back on another object)
+    # a training loop passes the same index objects every step.  The answer is remembered only for what cannot change
+    # under the memo's feet: a tensor is keyed by identity, storage and autograd version counter (every in-place write
+    # bumps ``_version``); an ndarray has no such counter, so its CONTENT is compared with the block it stood for on
+    # every hit (one vectorised compare: ~5 us for 10^4 rows); anything else (lists) is walked again each call.
+    # The engine path ignores view_idx altogether, so a stale "consecutive blocks" answer would silently assign rows to
+    # the wrong views.
+    items = [view_idx[m][v] for m in model.modality_names for v in range(V)]
+    if not all(torch.is_tensor(x) or isinstance(x, np.ndarray) for x in items):
+        return _view_rows(model, view_idx, Ns, np)
     memo = model.__dict__.setdefault("_view_rows_memo", {})
-    key = tuple((id(view_idx[m][v]), len(view_idx[m][v])) for m in model.modality_names for v in range(V)) + \
+    key = tuple((id(x), len(x), x._version, x.data_ptr()) if torch.is_tensor(x) else (id(x), len(x)) for x in items) + \
         tuple(int(Ns[m]) for m in model.modality_names)
     hit = memo.get(key)
     if hit is not None:
-        return hit[0]
+        res, _, blocks = hit
+        if all(b is None or (x.shape == b.shape and np.array_equal(x, b)) for x, b in zip(items, blocks)):
+            return res
+        del memo[key]
     res = _view_rows(model, view_idx, Ns, np)
     if len(memo) >= 8:
         memo.clear()
-    memo[key] = (res, [view_idx[m][v] for m in model.modality_names for v in range(V)])
+    # (the objects are held alive by the memo so that an id cannot come back on another object; an ndarray is stored
+    # next to a private copy of what it held when it was validated)
+    memo[key] = (res, items, [None if torch.is_tensor(x) else np.array(x, copy=True) for x in items])
     return res
 
 

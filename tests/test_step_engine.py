@@ -360,3 +360,25 @@ def test_step_graph_cache_training_trajectory_is_bitwise():
         # most calls were replays - or, in a process whose allocator never hands out the same blocks twice, the cache
         # captured its quota of never-replayed graphs and stood down
         assert tot[0] > 100 or tot[2] >= 9, tot
+
+
+def test_index_mutated_in_place_between_forwards_leaves_the_engine_path():
+    """the engine path ignores view_idx (it knows the views as consecutive row blocks), so the check that
+    lets a forward take it must see an index array that was re-ordered IN PLACE between two forwards."""
+    g = Golden("c2_three_free_views")
+    model, dd = build_model(g, device=DEV)
+    view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
+    Xs = {m: dd[m]["spatial_coords"] for m in g.mods}
+    outs = []
+    for swap in (False, True):
+        if swap:  # rows of views 0 and 1 trade places, the objects and their lengths stay
+            m0 = g.mods[0]
+            a, b = view_idx[m0][0].copy(), view_idx[m0][1].copy()
+            n = min(len(a), len(b))
+            view_idx[m0][0][:n], view_idx[m0][1][:n] = b[:n], a[:n]
+        model.inject_noise(g.eps_G, g.eps_F, g.eps_F_test)
+        with torch.no_grad():
+            out = model.forward(Xs, view_idx=view_idx, Ns=Ns, S=g.S)
+        outs.append((model._cache.kl is not None, out[0][g.mods[0]].detach().cpu().numpy().copy()))
+    assert outs[0][0] and not outs[1][0]        # engine first, the per-layer (index-honouring) path after the write
+    assert not np.allclose(outs[0][1], outs[1][1])  # and the rows did go to the other views' warps

@@ -91,3 +91,42 @@ def test_row_total_must_match():
     out = (C.c_longlong * 7)()
     assert lib.gpsa_step_describe(C.byref(d), out) == _lib.GPSA_EINVAL
     assert lib.gpsa_step_describe(C.byref(d), None) == _lib.GPSA_EINVAL
+
+
+def test_view_rows_memo_sees_in_place_mutation():
+    """the memo of 'views are consecutive row blocks' must not outlive the index objects' CONTENT (the engine
+    path ignores view_idx, so a stale answer would assign rows to the wrong views)."""
+    import types
+
+    import numpy as np
+    import torch
+
+    from spatial_alignment_amd import step_engine as SE
+
+    model = types.SimpleNamespace(n_views=2, modality_names=["m"])
+    Ns = {"m": 10}
+    # ndarrays (what create_view_idx_dict returns)
+    vi = {"m": [np.arange(0, 4), np.arange(4, 10)]}
+    assert SE.view_rows(model, vi, Ns) == (4, 6)
+    assert SE.view_rows(model, vi, Ns) == (4, 6)            # the memo's hit
+    vi["m"][0][1], vi["m"][0][2] = 2, 1                     # same object, same length, another order
+    assert SE.view_rows(model, vi, Ns) is None
+    vi["m"][0][1], vi["m"][0][2] = 1, 2
+    assert SE.view_rows(model, vi, Ns) == (4, 6)
+    # tensors: the version counter is part of the key
+    vt = {"m": [torch.arange(0, 4), torch.arange(4, 10)]}
+    assert SE.view_rows(model, vt, Ns) == (4, 6)
+    assert SE.view_rows(model, vt, Ns) == (4, 6)
+    vt["m"][1][[0, 1]] = vt["m"][1][[1, 0]]
+    assert SE.view_rows(model, vt, Ns) is None
+    # a write through another view of the same storage is seen too
+    base = torch.arange(0, 10)
+    vb = {"m": [base[:4], base[4:]]}
+    assert SE.view_rows(model, vb, Ns) == (4, 6)
+    base[5] = 7
+    assert SE.view_rows(model, vb, Ns) is None
+    # lists are never memoised
+    vl = {"m": [list(range(0, 4)), list(range(4, 10))]}
+    assert SE.view_rows(model, vl, Ns) == (4, 6)
+    vl["m"][0][0] = 3
+    assert SE.view_rows(model, vl, Ns) is None
