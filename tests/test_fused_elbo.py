@@ -80,7 +80,7 @@ def test_fused_matches_reference_fp64(name):
     # the draws the handles show after the step (written by the fused pass itself) are the reference's too
     for m in g.mods:
         res[f"F_obs/{m}"] = F[m].detach().cpu().numpy()
-    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4 if not big else 3e-3)
+    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert any(k.startswith("F_obs/") for k in errs)
     assert not bad, bad

@@ -44,7 +44,7 @@ def test_engine_matches_reference_fp64(name):
     res = run_step(model, dd, g, device=DEV)
     assert model._cache.kl is not None
     big = bool(g.cfg.get("summary_only"))
-    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4 if not big else 3e-3)
+    bad, errs = compare(res, g, tol_out=1e-4, tol_grad=1e-4)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert not bad, bad
 
