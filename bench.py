@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--shard", choices=["rows", "outputs"], default="rows",
                     help="N > 1: rows of every view (default, strong scaling of the contract metric) or the output "
                          "axis (parallel.shard_outputs: per-output parameters and gradients never leave their rank)")
+    ap.add_argument("--kl-share", choices=["owner", "scaled"], default="owner",
+                    help="row-sharded ranks: 'owner' = each rank evaluates its own range of the KL terms at weight 1 "
+                         "(factorises only its variational covariances; the all-reduce sums the shares), 'scaled' = "
+                         "every rank evaluates all of them at weight 1/world (rounds 1-5)")
     ap.add_argument("--emulate-shard", type=int, default=1,
                     help="diagnostic: time rank 0's share of a K-way row sharding on ONE GPU (no all-reduce); "
                          "the line is then NOT the contract metric")
@@ -418,6 +422,10 @@ def main():
     out_reducer = None
     if by_outputs:
         out_reducer = setup_output_sharding(model, rank, world * emu)  # (broadcasts the shared parameters)
+    elif args.kl_share == "owner" and world * emu > 1:
+        from spatial_alignment_amd.parallel import own_kl_terms
+
+        own_kl_terms(model, rank, world * emu)  # a contiguous range of the KL terms at weight 1 (owner computes)
     else:
         model.kl_scale = 1.0 / (world * emu)
     if args.no_check:

@@ -101,6 +101,13 @@ int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream);
  *   Same reference lines as the pair it fuses. */
 int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
                       void* stream);
+/* gpsa_chol_inv_sel_f64: the same for a SELECTION of a batch in one launch (M <= 256): the matrices
+ *   b < n_always and keep_lo <= b < keep_hi of A [batch,M,M]; results land at their own index b in Linv,
+ *   logdet and info, the other entries are not touched.  A data-parallel rank that owns only a range of the
+ *   KL terms of vgpsa.py:498-530 factorises the priors and ITS variational covariances (owner computes; the
+ *   gradient all-reduce sums the shares) - still one launch, i.e. one matrix's latency. */
+int gpsa_chol_inv_sel_f64(const void* A, void* Linv, int M, int batch, int n_always, int keep_lo, int keep_hi,
+                          void* logdet, int* info, void* stream);
 /* gpsa_chol_inv_blocked_f64: the same result for any M: right-looking over diagonal blocks of <= 256
  *   columns (register-resident kernel per block, fp64-MFMA products for the panel, the trailing update and
  *   the rows of the inverse).  workspace >= gpsa_chol_inv_blocked_workspace(M, batch) bytes. */
@@ -476,6 +483,13 @@ typedef struct gpsa_step_desc {
                                                C-long fp64 product.  The K_uu and K_uf shares of that gradient cancel to
                                                1e-4 .. 1e-5 of their size, so fp32 roundings of alpha / gamma are 1e-3 of
                                                the result at M >= 200.  +8 M C bytes, one M x M x C fp64 product */
+  int kl_own_lo, kl_own_hi;                 /* data-parallel ranks, OWNER COMPUTES: this plan evaluates only the KL terms
+                                               kl_own_lo <= t < kl_own_hi of the V*D + sum L_m terms (order: Omega_G rows
+                                               r = j*V+v, then every modality's outputs; vgpsa.py:498-530) - the other
+                                               terms come out as 0 with zero gradients and their variational covariances
+                                               are neither factorised nor inverted.  kl_own_hi <= 0: every term (one
+                                               process, or the 1/world weighting).  Summed over ranks whose ranges
+                                               partition the terms, loss and gradients are the full ELBO's. */
 } gpsa_step_desc;
 
 typedef struct gpsa_step_params {           /* device pointers, fp32, the reference's parameter layout */
@@ -582,6 +596,9 @@ int gpsa_step_fused(const void* plan, int m);         /* 1: modality m's trainin
 long long gpsa_step_scratch_bytes(const void* plan);
 long long gpsa_step_bwd_acc_bytes(const void* plan);  /* gpsa_step_io.bwd_acc */
 int gpsa_step_n_kl(const void* plan);                 /* V*D + sum_m L_m */
+int gpsa_step_n_factorised(const void* plan);         /* matrices a forward with want_kl factorises: the priors + the
+                                                         variational covariances of the plan's own KL terms
+                                                         (gpsa_step_desc.kl_own_lo / _hi; all of them by default) */
 long long gpsa_step_eps_g_numel(const void* plan);    /* floats in gpsa_step_io.eps_G */
 /* EXPERIMENTAL, off by default: gpsa_step_forward / _backward can replay a cached hipGraph of their launch sequence
  * when they meet an argument set (pointer structs, arenas, stages, stream) for the second time, instead of enqueueing

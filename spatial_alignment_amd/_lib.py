@@ -30,6 +30,7 @@ SIGNATURES = {
     "gpsa_chol_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "gpsa_chol_inv_sel_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gpsa_chol_inv_blocked_workspace": (_ll, [_i, _i]),
     "gpsa_chol_inv_blocked_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_quadform_workspace": (_ll, [_i, _i, _ll, _i]),
@@ -78,7 +79,7 @@ class StepDesc(C.Structure):
         ("n_latent", _i * MAX_MODS), ("n_out", _i * MAX_MODS), ("has_lmc", _i * MAX_MODS),
         ("n_rows", _ll * MAX_MODS), ("s_test", _i), ("n_test", _ll * MAX_MODS), ("want_kl", _i),
         ("view_fixed", C.POINTER(_i)), ("view_rows", C.POINTER(_ll)), ("keep_budget_bytes", _ll),
-        ("exact_inducing_grad", _i),
+        ("exact_inducing_grad", _i), ("kl_own_lo", _i), ("kl_own_hi", _i),
     ]
 
 
@@ -167,6 +168,7 @@ SIGNATURES.update({
     "gpsa_step_scratch_bytes": (_ll, [_vp]),
     "gpsa_step_bwd_acc_bytes": (_ll, [_vp]),
     "gpsa_step_n_kl": (_i, [_vp]),
+    "gpsa_step_n_factorised": (_i, [_vp]),
     "gpsa_step_eps_g_numel": (_ll, [_vp]),
     "gpsa_step_batch_layout": (_i, [_vp, C.POINTER(_ll)]),
     "gpsa_step_graph": (_i, [_vp, _i, C.POINTER(_ll)]),

@@ -196,18 +196,20 @@ template <int NT, int TS>
 __global__ void __launch_bounds__(TS * TS)
 chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Linv,
                     double* __restrict__ logdet, int* __restrict__ info, int lda, long long sA, int ldo,
-                    long long sO, int col0, int accumulate) {
+                    long long sO, int col0, int accumulate, int n0, int gap) {
   // lda / sA, ldo / sO: row and batch strides of the input and output (a diagonal block of a larger
   // matrix in the blocked factorisation); col0: column offset reported in info; accumulate: add to
-  // logdet and keep an earlier block's info
+  // logdet and keep an earlier block's info; n0 / gap: workgroup x handles matrix x (x < n0) or x + gap (a selection
+  // of the batch in one launch: gpsa_chol_inv_sel_f64)
   constexpr int NTH = TS * TS;
+  const int bx = (int)blockIdx.x < n0 ? (int)blockIdx.x : (int)blockIdx.x + gap;
   __shared__ double col[2][NT * TS];
   __shared__ double xrow[2][NT * TS];
   __shared__ double sdiag[NT * TS];
   __shared__ double red[16];
   const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
-  const double* G = A + (long long)blockIdx.x * sA;
-  double* O = Linv + (long long)blockIdx.x * sO;
+  const double* G = A + (long long)bx * sA;
+  double* O = Linv + (long long)bx * sO;
   double t[NT][NT];
 #pragma unroll
   for (int qa = 0; qa < NT; ++qa)
@@ -293,11 +295,11 @@ chol_inv_reg_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   if (tid == 0) {
     const double ld = bad ? __builtin_nan("") : 2.0 * lg;
     if (accumulate) {
-      logdet[blockIdx.x] += ld;
-      if (info[blockIdx.x] == 0 && bad) info[blockIdx.x] = col0 + bad;
+      logdet[bx] += ld;
+      if (info[bx] == 0 && bad) info[bx] = col0 + bad;
     } else {
-      logdet[blockIdx.x] = ld;
-      info[blockIdx.x] = bad ? col0 + bad : 0;
+      logdet[bx] = ld;
+      info[bx] = bad ? col0 + bad : 0;
     }
   }
 #pragma unroll
@@ -452,8 +454,9 @@ static inline long long chol_blk_lds_bytes(int NT) {
 template <int NT>
 __global__ void __launch_bounds__(256)
 chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Linv,
-                    double* __restrict__ logdet, int* __restrict__ info, int skip) {
+                    double* __restrict__ logdet, int* __restrict__ info, int skip, int n0, int gap) {
   constexpr int MP = NT * 16;
+  const int bx = (int)blockIdx.x < n0 ? (int)blockIdx.x : (int)blockIdx.x + gap;  // (chol_inv_reg_kernel: n0 / gap)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* Lp0 = sm;                       // [MP][CB_LS]  panel (rows >= i0 of the 16 columns), buffer 0
   double* Lp1 = Lp0 + MP * CB_LS;         //              buffer 1
@@ -466,8 +469,8 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
   __shared__ double red[16];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double* G = A + (long long)blockIdx.x * M * M;
-  double* O = Linv + (long long)blockIdx.x * M * M;
+  const double* G = A + (long long)bx * M * M;
+  double* O = Linv + (long long)bx * M * M;
   double t[NT][NT];
 #pragma unroll
   for (int qa = 0; qa < NT; ++qa)
@@ -529,8 +532,8 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
     for (int j = tid; j < M; j += 256) lg -= log(sdiag[j]);  // sdiag = 1 / L(j,j)
   lg = block_sum(lg, red);
   if (tid == 0) {
-    logdet[blockIdx.x] = bad ? __builtin_nan("") : 2.0 * lg;
-    info[blockIdx.x] = bad;
+    logdet[bx] = bad ? __builtin_nan("") : 2.0 * lg;
+    info[bx] = bad;
   }
 #pragma unroll
   for (int qa = 0; qa < NT; ++qa)
@@ -543,7 +546,7 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
 
 template <int NT>
 static int chol_inv_blk_launch_nt(const double* A, int M, double* Linv, double* logdet, int* info, int batch,
-                                  hipStream_t st) {
+                                  hipStream_t st, int n0, int gap) {
   static bool attr_set = false;
   const long long lds = chol_blk_lds_bytes(NT);
   if (!attr_set) {
@@ -554,20 +557,20 @@ static int chol_inv_blk_launch_nt(const double* A, int M, double* Linv, double* 
   }
   // timing-only experiments (results are then wrong): bit 0 skips the block factorisation, 1 the solves, 2 the update
   static const int skip = [] { const char* e = getenv("GPSA_CHOL_SKIP"); return e ? atoi(e) : 0; }();
-  chol_inv_blk_kernel<NT><<<batch, 256, (size_t)lds, st>>>(A, M, Linv, logdet, info, skip);
+  chol_inv_blk_kernel<NT><<<batch, 256, (size_t)lds, st>>>(A, M, Linv, logdet, info, skip, n0, gap);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
 
 // contiguous batch, M <= 208: the blocked kernel (GPSA_CHOL_BLOCKED=0 falls back to one barrier per column)
 static int chol_inv_blk_launch(const double* A, int M, double* Linv, double* logdet, int* info, int batch,
-                               hipStream_t st) {
+                               hipStream_t st, int n0 = 0x7fffffff, int gap = 0) {
   const int nt = (M + 15) / 16;
-  if (nt <= 2) return chol_inv_blk_launch_nt<2>(A, M, Linv, logdet, info, batch, st);
-  if (nt <= 4) return chol_inv_blk_launch_nt<4>(A, M, Linv, logdet, info, batch, st);
-  if (nt <= 7) return chol_inv_blk_launch_nt<7>(A, M, Linv, logdet, info, batch, st);
-  if (nt <= 10) return chol_inv_blk_launch_nt<10>(A, M, Linv, logdet, info, batch, st);
-  if (nt <= 13) return chol_inv_blk_launch_nt<13>(A, M, Linv, logdet, info, batch, st);
+  if (nt <= 2) return chol_inv_blk_launch_nt<2>(A, M, Linv, logdet, info, batch, st, n0, gap);
+  if (nt <= 4) return chol_inv_blk_launch_nt<4>(A, M, Linv, logdet, info, batch, st, n0, gap);
+  if (nt <= 7) return chol_inv_blk_launch_nt<7>(A, M, Linv, logdet, info, batch, st, n0, gap);
+  if (nt <= 10) return chol_inv_blk_launch_nt<10>(A, M, Linv, logdet, info, batch, st, n0, gap);
+  if (nt <= 13) return chol_inv_blk_launch_nt<13>(A, M, Linv, logdet, info, batch, st, n0, gap);
   return GPSA_EUNSUPPORTED;
 }
 
@@ -605,10 +608,10 @@ __global__ void add_diag_kernel(T* __restrict__ A, int M, int batch, T s) {
 // one launch of the register-resident kernel on (a diagonal block of) a batch of matrices
 static int chol_inv_reg_launch(const double* A, int M, double* Linv, double* logdet, int* info, int lda,
                                long long sA, int ldo, long long sO, int col0, int accumulate, int batch,
-                               hipStream_t st) {
+                               hipStream_t st, int n0 = 0x7fffffff, int gap = 0) {
 #define GPSA_CI_CASE(V, TSV)                                                                        \
   chol_inv_reg_kernel<V, TSV><<<batch, TSV * TSV, 0, st>>>(A, M, Linv, logdet, info, lda, sA, ldo, sO, \
-                                                            col0, accumulate)
+                                                            col0, accumulate, n0, gap)
   // 16 x 16 threads (one wave per SIMD) while a thread's share fits comfortably in registers: 166 vs
   // 185 us at M = 200; 32 x 32 above (252 vs 287 us at M = 256)
   static const int forced = [] { const char* e = getenv("GPSA_CHOL_TS"); return e ? atoi(e) : 0; }();
@@ -751,6 +754,26 @@ int gpsa_chol_inv_f64(const void* A, void* Linv, int M, int batch, void* logdet,
   }
   return chol_inv_reg_launch((const double*)A, M, (double*)Linv, (double*)logdet, info, M,
                              (long long)M * M, M, (long long)M * M, 0, 0, batch, as_stream(stream));
+}
+
+int gpsa_chol_inv_sel_f64(const void* A, void* Linv, int M, int batch, int n_always, int keep_lo, int keep_hi,
+                          void* logdet, int* info, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || batch < 1 || n_always < 0 || n_always > batch) return GPSA_EINVAL;
+  if (M > 256) return GPSA_EUNSUPPORTED;
+  if (keep_lo < n_always) keep_lo = n_always;
+  if (keep_hi > batch) keep_hi = batch;
+  if (keep_hi < keep_lo) keep_hi = keep_lo;
+  const int n = n_always + (keep_hi - keep_lo), gap = keep_lo - n_always;
+  if (n == 0) return 0;
+  static const bool blocked = [] { const char* e = getenv("GPSA_CHOL_BLOCKED"); return !(e && e[0] == '0'); }();
+  if (blocked && M <= 208) {
+    int rc = chol_inv_blk_launch((const double*)A, M, (double*)Linv, (double*)logdet, info, n, as_stream(stream),
+                                 n_always, gap);
+    if (rc != GPSA_EUNSUPPORTED) return rc;
+  }
+  return chol_inv_reg_launch((const double*)A, M, (double*)Linv, (double*)logdet, info, M, (long long)M * M, M,
+                             (long long)M * M, 0, 0, n, as_stream(stream), n_always, gap);
 }
 
 long long gpsa_chol_inv_blocked_workspace(int M, int batch) {

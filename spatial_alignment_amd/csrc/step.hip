@@ -99,10 +99,16 @@ struct PrepArgs {
   double* resid;   // [V, Mx, D]
   double* Dw;      // [V*D, Mx]
   double* Dd;      // [sum L, Mg]
+  int* zinfo[2];   // owner computes: the Cholesky infos of a group (the matrices left out keep 0); else null
+  int nzinfo[2];
 };
 
 __global__ void __launch_bounds__(256) step_prep_kernel(PrepArgs a) {
   const int D = a.D;
+  if (blockIdx.x == 0)
+    for (int g = 0; g < 2; ++g)
+      if (a.zinfo[g] != nullptr)
+        for (int i = threadIdx.x; i < a.nzinfo[g]; i += 256) a.zinfo[g][i] = 0;
   if ((int)blockIdx.x < a.V) {
     const int v = blockIdx.x;
     const double scale = a.bidx[v] < 0 ? 100.0 : 1.0;
@@ -511,6 +517,10 @@ struct Group {  // matrices of one size, factorised together: the priors first, 
   long long o_mats = 0, o_inv = 0, o_logdet = 0, o_info = 0, o_D = 0, o_KD = 0;
   // device index tables of the grouped KL kernels
   int *om_idx = nullptr, *pr_idx = nullptr, *pr_list = nullptr, *grp_off = nullptr, *order = nullptr;
+  // owner computes (gpsa_step_desc.kl_own_lo / _hi): the terms own_lo <= t < own_hi of this group are this plan's; the
+  // others are listed as absent in the tables above and their covariances are never factorised
+  int own_lo = 0, own_hi = 0;
+  bool own_all() const { return own_lo == 0 && own_hi == n_omega; }
   int nb() const { return n_prior + n_omega; }
 };
 
@@ -704,6 +714,16 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
     p->grp[0].M = p->Mx; p->grp[0].n_prior = p->nf; p->grp[0].n_omega = V * D; p->grp[0].kl_off = 0;
     p->grp[1].M = p->Mg; p->grp[1].n_prior = 1; p->grp[1].n_omega = p->Ltot; p->grp[1].kl_off = V * D;
   }
+  for (int g = 0; g < p->ng; ++g) {
+    Group& G = p->grp[g];
+    G.own_lo = 0;
+    G.own_hi = G.n_omega;
+    if (dsc->kl_own_hi > 0) {  // this plan's range of the global term list, cut to the group's terms
+      const int lo = dsc->kl_own_lo - G.kl_off, hi = dsc->kl_own_hi - G.kl_off;
+      G.own_lo = lo < 0 ? 0 : (lo > G.n_omega ? G.n_omega : lo);
+      G.own_hi = hi < G.own_lo ? G.own_lo : (hi > G.n_omega ? G.n_omega : hi);
+    }
+  }
   // data-GP passes
   for (int m = 0; m < nm; ++m)
     if (dsc->n_rows[m] > 0 && S > 0) {
@@ -822,6 +842,7 @@ static Plan* make_plan(const gpsa_step_desc* dsc, bool host_only = false) {
     for (int t = 0; t < G.n_omega; ++t) {
       if (g == 0 && t < V * D) prior[t] = p->bidx[t % V];  // quirk 2: row r pairs with view r % V
       else prior[t] = p->merged ? p->nf : 0;
+      if (t < G.own_lo || t >= G.own_hi) prior[t] = -1;  // another rank's term (owner computes)
     }
     G.om_idx = di + io;
     for (int t = 0; t < G.n_omega; ++t) hi[io++] = G.n_prior + t;
@@ -977,6 +998,11 @@ static int mm_stage_fwd(Ctx& c) {
     a.resid = c.sv<double>(P.o_resid);
     a.Dw = kl ? c.sv<double>(GW.o_D) : nullptr;
     a.Dd = kl ? c.sv<double>(GD.o_D) + (P.merged ? (long long)V * D * Mx : 0) : nullptr;
+    for (int g = 0; g < P.ng; ++g)
+      if (kl && !P.grp[g].own_all() && !c.io.reuse_mm) {
+        a.zinfo[g] = c.sv<int>(P.grp[g].o_info);
+        a.nzinfo[g] = P.grp[g].nb();
+      }
     const long long nd = kl ? cdiv((long long)P.Ltot * Mg, 256) : 0;
     if (!dry) {
       step_prep_kernel<<<(unsigned)(V + nd), 256, 0, c.st>>>(a);
@@ -1037,36 +1063,65 @@ static int mm_stage_fwd(Ctx& c) {
     double* logdet = c.sv<double>(G.o_logdet);
     int* info = c.sv<int>(G.o_info);
     const bool split = kl && P.side != nullptr;  // priors on the caller's stream, the rest on the side stream
-    const int nb_main = split ? G.n_prior : (kl ? G.nb() : G.n_prior);
+    const int np = G.n_prior, n_own = G.own_hi - G.own_lo;
+    // owner computes: only the priors and this plan's own variational covariances (batch positions np + own_lo ..
+    // np + own_hi) are factorised and inverted - in ONE launch all the same (a second one would cost a second matrix's
+    // latency); the entries of the others in Linv / inv / logdet stay unwritten and nobody reads them (their terms are
+    // listed as absent), their infos were zeroed by step_prep_kernel
+    const bool sel = kl && !split && !G.own_all();
+    const int nb_main = split ? np : (kl ? G.nb() : np);
+    // K^-1 = L^-T L^-1 for ``cnt`` matrices in one product
+    // (the triangle mode contracts k >= max(i, j) only and mirrors; it needs split-K 1: a large batch)
+    auto inverse_product = [&](const double* Lin, double* out, int cnt) -> int {
+      if (cnt <= 0) return 0;
+      if (splitk_small(G.M, G.M, G.M, cnt) == 1)
+        GPSA_RUN(gemm_launch_tri<double>(1, 0, G.M, G.M, G.M, 1.0, Lin, G.M, mm, Lin, G.M, mm, 0.0, out, G.M, mm, cnt, 1,
+                                         nullptr, 0, c.st, GEMM_TRI_LTL));
+      else
+        GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Lin, G.M, mm, Lin, G.M, mm, 0.0, out, G.M, mm, cnt,
+                       splitk_small(G.M, G.M, G.M, cnt)));
+      return 0;
+    };
     if (nb_main > 0) {
       const long long mk = c.sc.mark();
       double* Linv = c.sc.get<double>(nb_main * mm);
       if (G.M > 256) {
         const long long wsb = gpsa_chol_inv_blocked_workspace(G.M, nb_main);
         void* ws = c.sc.get<char>(wsb);
-        GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, 0), Linv, G.M, nb_main, logdet, info, ws, wsb, c.stv()));
-      } else {
+        if (!sel) {
+          GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, 0), Linv, G.M, nb_main, logdet, info, ws, wsb, c.stv()));
+        } else {  // (beyond the single-launch kernels the factorisation is a launch sequence anyway: two of them)
+          if (np > 0)
+            GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, 0), Linv, G.M, np, logdet, info, ws, wsb, c.stv()));
+          if (n_own > 0)
+            GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, np + G.own_lo), Linv + (long long)(np + G.own_lo) * mm, G.M,
+                                               n_own, logdet + np + G.own_lo, info + np + G.own_lo, ws, wsb, c.stv()));
+        }
+      } else if (!sel) {
         GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, 0), Linv, G.M, nb_main, logdet, info, c.stv()));
+      } else {
+        GPSA_RUN(gpsa_chol_inv_sel_f64(c.mats(G, 0), Linv, G.M, nb_main, np, np + G.own_lo, np + G.own_hi, logdet, info,
+                                       c.stv()));
       }
-      // K^-1 = L^-T L^-1 for the whole batch in one product
-      // (the triangle mode contracts k >= max(i, j) only and mirrors; it needs split-K 1: a large batch)
-      if (splitk_small(G.M, G.M, G.M, nb_main) == 1)
-        GPSA_RUN(gemm_launch_tri<double>(1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M,
-                                         mm, nb_main, 1, nullptr, 0, c.st, GEMM_TRI_LTL));
-      else
-        GPSA_CK(gemm64(c, 1, 0, G.M, G.M, G.M, 1.0, Linv, G.M, mm, Linv, G.M, mm, 0.0, c.inv(G, 0), G.M, mm, nb_main,
-                       splitk_small(G.M, G.M, G.M, nb_main)));
+      if (!sel) {
+        GPSA_CK(inverse_product(Linv, c.inv(G, 0), nb_main));
+      } else if (G.own_lo == 0) {  // the priors and the owned covariances are neighbours in the batch
+        GPSA_CK(inverse_product(Linv, c.inv(G, 0), np + n_own));
+      } else {
+        GPSA_CK(inverse_product(Linv, c.inv(G, 0), np));
+        GPSA_CK(inverse_product(Linv + (long long)(np + G.own_lo) * mm, c.inv(G, np + G.own_lo), n_own));
+      }
       c.sc.release(mk);
     }
-    if (split && G.n_omega > 0) {
-      const int np = G.n_prior;
+    if (split && n_own > 0) {
+      const int o0 = np + G.own_lo;
       if (G.M > 256)
-        GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, np), LinvO[g], G.M, G.n_omega, logdet + np, info + np, wsO[g],
+        GPSA_RUN(gpsa_chol_inv_blocked_f64(c.mats(G, o0), LinvO[g], G.M, n_own, logdet + o0, info + o0, wsO[g],
                                            wsOb[g], (void*)sst));
       else
-        GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, np), LinvO[g], G.M, G.n_omega, logdet + np, info + np, (void*)sst));
+        GPSA_RUN(gpsa_chol_inv_f64(c.mats(G, o0), LinvO[g], G.M, n_own, logdet + o0, info + o0, (void*)sst));
       GPSA_RUN((gemm_launch_tri<double>(1, 0, G.M, G.M, G.M, 1.0, LinvO[g], G.M, mm, LinvO[g], G.M, mm, 0.0,
-                                        c.inv(G, np), G.M, mm, G.n_omega, 1, nullptr, 0, sst, GEMM_TRI_LTL)));
+                                        c.inv(G, o0), G.M, mm, n_own, 1, nullptr, 0, sst, GEMM_TRI_LTL)));
     }
   }
   if (fork) {  // the KL kernels read the priors' inverses too
@@ -2242,6 +2297,13 @@ int gpsa_step_n_kl(const void* plan) {
   if (!plan) return -1;
   const gpsa::Plan* p = reinterpret_cast<const gpsa::Plan*>(plan);
   return p->V * p->D + p->Ltot;
+}
+int gpsa_step_n_factorised(const void* plan) {
+  if (!plan) return -1;
+  const gpsa::Plan* p = reinterpret_cast<const gpsa::Plan*>(plan);
+  int n = 0;
+  for (int g = 0; g < p->ng; ++g) n += p->grp[g].n_prior + (p->grp[g].own_hi - p->grp[g].own_lo);
+  return n;
 }
 long long gpsa_step_eps_g_numel(const void* plan) { return plan ? reinterpret_cast<const gpsa::Plan*>(plan)->eps_total : -1; }
 long long gpsa_step_early_backwards(const void* plan) {

@@ -104,6 +104,11 @@ class VariationalGPSA(GPSA):
         # keeps queueing the ELBO while the warp GPs run.  "strict": always wait inside forward.  False: never.
         self.check_numerics = True
         self.kl_scale = 1.0  # data-parallel ranks add 1/world of the KL each (parallel.py)
+        # ... or, OWNER COMPUTES (round 6): ``(rank, world)`` - this rank evaluates a contiguous share of the
+        # V*D + sum L KL terms with weight 1 (kl_scale stays 1), the others come out as 0 with zero gradients, and the
+        # gradient all-reduce sums the shares: a rank factorises and inverts only ITS variational covariances
+        # (3 + ceil(54 / world) matrices instead of 57 at BASELINE config 2).  parallel.own_kl_terms sets it.
+        self.kl_owner = None
         # output-sharded ranks (parallel.shard_outputs) own their outputs' KL terms in full and share the
         # warp GPs': weight of the warp-GP KL terms inside the KL sum, and separate generators for the
         # draws every rank must agree on (warp) and the ones it must not share (its own outputs)
@@ -884,6 +889,11 @@ class VariationalGPSA(GPSA):
         priors = [cache.warp[v][0] for v in free] + [cache.data[0]]
         kl = E.MvnKLGroupedFn.apply(plan, cache.batch, Dall, *priors, cache.Omega_G,
                                     *[cache.Omega_F[m] for m in mods])
+        own = SE.kl_own_range(self)
+        if own is not None:  # owner computes (this path evaluates every term and drops the others': same numbers, no
+            keep = torch.zeros_like(kl)  # saving - the saving is the step engine's)
+            keep[own[0]:own[1]] = 1.0
+            kl = kl * keep
         if self.kl_weight_G != 1.0:  # output-sharded rank: its share of the warp GPs' terms
             return kl[: V * D].sum() * self.kl_weight_G + kl[V * D:].sum()
         return kl.sum()
@@ -960,6 +970,14 @@ class VariationalGPSA(GPSA):
         grouped = cache.batch is not None
         if grouped:  # every KL term of the step (all views, all outputs) in one launch each way
             kl = self._kl_grouped(cache)
+        own = None if grouped else SE.kl_own_range(self)
+
+        def owned(terms, first, stride):  # term i of ``terms`` is global term first + i * stride (owner computes)
+            if own is None:
+                return terms
+            idx = first + stride * torch.arange(terms.shape[0], device=terms.device)
+            return terms * ((idx >= own[0]) & (idx < own[1])).to(terms.dtype)
+
         for v in range(V):
             if grouped or self._is_fixed(v) or v not in cache.warp:
                 continue
@@ -967,16 +985,18 @@ class VariationalGPSA(GPSA):
             Dm = cache.resid[v]
             Om = cache.Om_kl[v]  # quirk 2: the KL uses rows j*V+v, j = 0..D-1
             ofac = (cache.Omega_G_fac[0][v::V], cache.Omega_G_fac[1][v::V])
-            term = E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac).sum()
+            term = owned(E.MvnKLFn.apply(Kuu, Dm, Om, fac, ofac), v, V).sum()
             if self.kl_weight_G != 1.0:
                 term = term * self.kl_weight_G
             kl = term if kl is None else kl + term
         KuuF, facF = cache.data
         lls = []
+        l_first = V * D
         for i, m in enumerate(self.modality_names):
             if not grouped:
-                term = E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF,
-                                       cache.Omega_F_fac[m]).sum()
+                term = owned(E.MvnKLFn.apply(KuuF, self.delta_F_dict[m], cache.Omega_F[m], facF,
+                                             cache.Omega_F_fac[m]), l_first, 1).sum()
+                l_first += int(self.n_latent_outputs[m])
                 kl = term if kl is None else kl + term
             noise_u = self.noise_variance[-self.n_modalities + i]  # quirk 5 (used as a std)
             Y = data_dict[m]["outputs"]

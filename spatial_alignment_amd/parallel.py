@@ -2,7 +2,8 @@
 
 Everything N-scaled is independent per spot given the (replicated) M x M factors, so each rank owns
 a contiguous slice of EVERY view's rows: it runs the warp + data layers and the likelihood for its
-rows, adds 1/world of the KL terms, and one all-reduce (RCCL over xGMI; backend "nccl" on ROCm) of
+rows, adds its share of the KL terms (``own_kl_terms``: a contiguous range of them at weight 1 - owner
+computes, round 6 - or all of them at 1/world: ``model.kl_scale``), and one all-reduce (RCCL over xGMI; backend "nccl" on ROCm) of
 the flattened gradient makes every rank's gradient the full-ELBO gradient.  No other collective.
 
 For many outputs (L = P in the thousands: BASELINE.json configs 4/5) the L axis shards instead
@@ -53,6 +54,24 @@ def shard_outputs(data_dict, rank, world):
             "n_samples_list": list(d["n_samples_list"]),
         }
     return out
+
+
+def own_kl_terms(model, rank, world):
+    """Row-sharded rank ``rank`` of ``world``: OWNER COMPUTES for everything only the KL needs (round 6).
+
+    Instead of every rank evaluating all V*D + sum L KL terms at weight 1/world (``model.kl_scale = 1 / world``), each
+    rank evaluates a contiguous share of them at weight 1: it factorises and inverts only the priors and ITS OWN
+    variational covariances (3 + ceil(54 / world) matrices instead of 57 at BASELINE config 2), runs the KL forward and
+    backward for those, and the all-reduce of the gradient - which the step needs anyway - sums the shares.  The sum of
+    the ranks' losses is the full negative ELBO, the sum of their gradients its gradient (vgpsa.py:498-530 are sums of
+    independent terms).  Returns the [lo, hi) this rank owns."""
+    from . import step_engine as SE
+
+    model.kl_scale = 1.0
+    model.kl_owner = (int(rank), int(world)) if int(world) > 1 else None
+    own = SE.kl_own_range(model)
+    n = model.n_views * model.n_spatial_dims + sum(int(model.n_latent_outputs[m]) for m in model.modality_names)
+    return own if own is not None else (0, n)
 
 
 OUTPUT_LOCAL_PREFIXES = ("Omega_sqt_F_dict.", "delta_F_dict.")

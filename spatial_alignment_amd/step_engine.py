@@ -219,6 +219,26 @@ def keep_budget_bytes(model, desc, keep_gb=None):
     return budget if budget > 0 else -1
 
 
+def kl_own_range(model):
+    """[lo, hi) of the KL terms this process evaluates (``model.kl_owner = (rank, world)``: a data-parallel rank owns a
+    contiguous share of the V*D + sum L_m terms, weight 1; the gradient all-reduce sums the shares - parallel.py), or
+    None: every term (one process, or the 1/world weighting of ``kl_scale``).  Term order: Omega_G rows r = j*V + v,
+    then every modality's outputs (vgpsa.py:498-530)."""
+    owner = getattr(model, "kl_owner", None)
+    if owner is None:
+        return None
+    rank, world = int(owner[0]), int(owner[1])
+    if world <= 1:
+        return None
+    n = model.n_views * model.n_spatial_dims + sum(int(model.n_latent_outputs[m]) for m in model.modality_names)
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    # (hi > 0 says "a range" to gpsa_step_desc; a rank left without a term - more ranks than terms - gets the empty
+    #  range [n, n))
+    return (lo, hi) if hi > lo else (n, n)
+
+
 def get_plan(model, rows, S, test_shapes, want_kl):
     """plan for this model / data shape (cached on the model)"""
     mods = model.modality_names
@@ -238,8 +258,9 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     if exact is None:  # the default: every gradient within 1e-4 of the reference's fp64 run
         exact = True
     exact = int(bool(exact))
+    own = kl_own_range(model)
     key = (V, D, len(mods), int(S), int(model.Xtilde.shape[1]), int(model.Gtilde.shape[0]), kw, kd, L, P, lmc, N,
-           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index, keep_gb, exact)
+           s_test, n_test, int(bool(want_kl)), fixed, rows, model.Xtilde.device.index, keep_gb, exact, own)
     cache = model.__dict__.setdefault("_step_plans", {})
     plan = cache.get(key)
     if plan is not None:
@@ -254,6 +275,7 @@ def get_plan(model, rows, S, test_shapes, want_kl):
     vr = (C.c_longlong * len(rows))(*rows)
     d.view_fixed, d.view_rows = vf, vr
     d.exact_inducing_grad = exact
+    d.kl_own_lo, d.kl_own_hi = own if own is not None else (0, 0)
     d.keep_budget_bytes = keep_budget_bytes(model, d, keep_gb)
     with torch.cuda.device(model.Xtilde.device):
         plan = StepPlan(_lib.load(), key, d, (vf, vr))

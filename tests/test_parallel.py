@@ -31,9 +31,14 @@ def _problem():
     return dd, model
 
 
-def _grads(model, dd, eps_G, eps_F, kl_scale=1.0):
+def _grads(model, dd, eps_G, eps_F, kl_scale=1.0, owner=None):
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     model.kl_scale = kl_scale
+    if owner is not None:  # owner computes: this rank's contiguous range of the KL terms at weight 1
+        from spatial_alignment_amd.parallel import own_kl_terms
+
+        lo, hi = own_kl_terms(model, *owner)
+        assert model.kl_scale == 1.0 and 0 <= lo < hi <= 2 * 2 + 3
     model.inject_noise(eps_G, eps_F)
     model.zero_grad()
     out = model.forward({"expression": dd["expression"]["spatial_coords"]}, view_idx, Ns, S=2)
@@ -42,7 +47,7 @@ def _grads(model, dd, eps_G, eps_F, kl_scale=1.0):
     return loss.detach()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, owner=False):
     sys.path.insert(0, HERE)
     from fake_ops import FakeOps
     from spatial_alignment_amd import ops as ops_mod
@@ -58,7 +63,8 @@ def _worker(rank, world, port, q):
     sdd = shard_data_dict(dd, rank, world)
     lo, hi = shard_rows(64, rank, world)
     rows = torch.cat([torch.arange(lo, hi), 64 + torch.arange(lo, hi)])
-    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], {"expression": eF[:, rows]}, 1.0 / world)
+    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], {"expression": eF[:, rows]}, 1.0 / world,
+                  owner=(rank, world) if owner else None)
     GradAllReducer(model.parameters())()
     dist.all_reduce(loss)
     if rank == 0:
@@ -67,14 +73,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_step_equals_full_step():
+@pytest.mark.parametrize("owner", [False, True])
+def test_sharded_step_equals_full_step(owner):
+    """``owner``: each rank evaluates its own range of the KL terms at weight 1 (parallel.own_kl_terms) instead of all
+    of them at 1 / world - the all-reduce sums the shares to the same loss and gradients"""
     from fake_ops import FakeOps
     from spatial_alignment_amd import ops as ops_mod
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if owner else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, owner)) for r in range(2)]
     for p in procs:
         p.start()
     loss2, g2 = q.get(timeout=300)

@@ -30,9 +30,14 @@ def _noise(side=None):
     return [torch.randn(3, n, 2, generator=gen) for _ in range(2)], torch.randn(3, 2 * n, 6, generator=gen)
 
 
-def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False):
+def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False, owner=None):
     view_idx, Ns, _, _ = model.create_view_idx_dict(dd)
     model.kl_scale = kl_scale
+    if owner is not None:  # owner computes: this rank's range of the 2*2 + 6 KL terms at weight 1
+        from spatial_alignment_amd.parallel import own_kl_terms
+
+        lo, hi = own_kl_terms(model, *owner)
+        assert model.kl_scale == 1.0 and 0 <= lo <= hi <= 10
     model.inject_noise(eG, {"expression": eF})
     model.zero_grad()
     model.fuse_elbo = fuse  # True: what the reference's loop gets (the likelihood folded into the data GP's pass)
@@ -41,10 +46,14 @@ def _grads(model, dd, eG, eF, kl_scale, S=3, fuse=False):
     loss = model.loss_fn(dd, out[3])
     assert not fuse or model._cache.fuse["state"] == ["fused"]
     loss.backward()
+    if owner is not None:  # the plan factorised the 3 priors and this rank's own covariances only
+        plan = next(iter(model._step_plans.values()))
+        lo, hi = own_kl_terms(model, *owner)
+        assert plan.lib.gpsa_step_n_factorised(plan.handle) == 3 + (hi - lo), (lo, hi)
     return loss.detach()
 
 
-def _worker(rank, world, port, q, fuse=False, overlap=False):
+def _worker(rank, world, port, q, fuse=False, overlap=False, owner=False):
     import __graft_entry__ as ge
     from spatial_alignment_amd.parallel import GradAllReducer, shard_data_dict, shard_rows
 
@@ -62,7 +71,8 @@ def _worker(rank, world, port, q, fuse=False, overlap=False):
     # overlap: the data GP's span of the flat buffer is reduced on a side stream while the rest of the backward runs
     # (the engine finishes it first: gpsa_step_io.f_event); the reducer must exist BEFORE the backward
     reducer = GradAllReducer(model.parameters(), overlap=overlap, model=model)
-    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0 / world, fuse=fuse)
+    loss = _grads(model, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0 / world, fuse=fuse,
+                  owner=(rank, world) if owner else None)
     if overlap:
         assert reducer._early is not None, "the early all-reduce was not started by the backward"
         plan = next(iter(model._step_plans.values()))
@@ -121,17 +131,21 @@ def test_overlapped_reducer_on_rccl_one_rank():
         assert np.linalg.norm(a[k] - b[k]) <= 1e-5 * max(np.linalg.norm(b[k]), 1e-6), k
 
 
-@pytest.mark.parametrize("fuse,overlap", [(False, False), (True, False), (True, True), (False, True)])
-def test_row_sharded_hip_step_equals_full_hip_step(fuse, overlap):
+@pytest.mark.parametrize("fuse,overlap,owner", [(False, False, False), (True, False, False), (True, True, False),
+                                                (False, True, False), (False, False, True), (True, False, True),
+                                                (True, True, True)])
+def test_row_sharded_hip_step_equals_full_hip_step(fuse, overlap, owner):
     """two ranks' row shards + one all-reduce against the single-process step (the full step always through the
-    separate kernels: ``fuse`` also pins the fused ELBO step to them across processes)"""
+    separate kernels: ``fuse`` also pins the fused ELBO step to them across processes).  ``owner``: each rank
+    evaluates - factorises, inverts, differentiates - only its own range of the KL terms, at weight 1, instead of all
+    of them at 1 / world (parallel.own_kl_terms): the all-reduce sums the shares to the same loss and gradients"""
     import __graft_entry__ as ge
 
     ge.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + (7 if fuse else 0) + (13 if overlap else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fuse, overlap)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + (7 if fuse else 0) + (13 if overlap else 0) + (29 if owner else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fuse, overlap, owner)) for r in range(2)]
     for p in procs:
         p.start()
     loss2, g2 = q.get(timeout=600)
@@ -145,6 +159,35 @@ def test_row_sharded_hip_step_equals_full_hip_step(fuse, overlap):
     for k, p in model.named_parameters():
         a, b = p.grad.detach().cpu().numpy(), g2[k]
         assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_owner_computes_world8_summed_equals_full_step(fuse):
+    """an emulated world of 8 on one device: rank r's row shard with ITS range of the KL terms (owner computes), the
+    eight losses and gradients summed by hand - what the all-reduce does - equal the full step's to rounding"""
+    import __graft_entry__ as ge
+    from spatial_alignment_amd.parallel import shard_data_dict, shard_rows
+
+    ge.build()
+    dev = torch.device("cuda:0")
+    world, n = 8, SIDE * SIDE
+    eG, eF = _noise()
+    dd, model = _problem(dev)
+    loss1 = _grads(model, dd, eG, eF, 1.0)
+    want = {k: p.grad.detach().double().clone() for k, p in model.named_parameters()}
+    tot, acc = 0.0, {k: torch.zeros_like(v) for k, v in want.items()}
+    for r in range(world):
+        dd_r, model_r = _problem(dev)  # (same seed: the same parameters on every "rank")
+        sdd = shard_data_dict(dd_r, r, world)
+        lo, hi = shard_rows(n, r, world)
+        rows = torch.cat([torch.arange(lo, hi), n + torch.arange(lo, hi)])
+        tot += float(_grads(model_r, sdd, [e[:, lo:hi] for e in eG], eF[:, rows], 1.0, fuse=fuse, owner=(r, world)))
+        for k, p in model_r.named_parameters():
+            acc[k] += p.grad.detach().double()
+    assert abs(tot - float(loss1)) <= 1e-5 * abs(float(loss1)), (tot, float(loss1))
+    for k in want:
+        e = float((acc[k] - want[k]).norm()) / max(float(want[k].norm()), 1e-6)
+        assert e <= 1e-4, (k, e)
 
 
 def test_microbatched_hip_step_equals_full_hip_step():

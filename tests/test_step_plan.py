@@ -9,9 +9,11 @@ from spatial_alignment_amd import _lib
 
 
 def describe(V=2, D=2, S=5, mx=200, mg=200, mods=((50, 50, 0, (10000, 10000)),), fixed=None, s_test=0, n_test=None,
-             want_kl=1, kw=0, kd=0):
+             want_kl=1, kw=0, kd=0, kl_own=None):
     lib = _lib.load()
     d = _lib.StepDesc()
+    if kl_own is not None:
+        d.kl_own_lo, d.kl_own_hi = kl_own
     d.n_views, d.n_dims, d.n_mods, d.n_samples = V, D, len(mods), S
     d.m_x, d.m_g, d.kind_warp, d.kind_data = mx, mg, kw, kd
     rows = []
@@ -130,3 +132,12 @@ def test_view_rows_memo_sees_in_place_mutation():
     assert SE.view_rows(model, vl, Ns) == (4, 6)
     vl["m"][0][0] = 3
     assert SE.view_rows(model, vl, Ns) is None
+
+
+def test_owner_computes_range_leaves_the_arena_layout_alone():
+    """gpsa_step_desc.kl_own_lo / _hi (a data-parallel rank evaluates its own range of the KL terms): the batch keeps
+    every matrix's slot - the data GP's pass reads all the Omega_l -, only the factorisation and the KL kernels skip"""
+    base = describe()
+    for own in ((0, 7), (7, 14), (48, 54), (54, 54)):
+        got = describe(kl_own=own)
+        assert got[0] == 0 and got[1] == base[1] and got[2] == base[2], own
