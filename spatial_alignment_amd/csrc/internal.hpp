@@ -31,9 +31,10 @@ int omega_bwd_dma_launch(const double* G0, const float* A0, float* D0, int n0, c
                          float* D1, int n1, int M, hipStream_t st);
 
 // kl.hip: gpsa_mvn_kl_grouped_fwd that also writes the terms to kl_copy (may be NULL)
+int mvn_kl_grouped_fwd_slices(int M);  // row slices per term (sizes the partial sums: [T][slices] doubles)
 int mvn_kl_grouped_fwd_copy(const double* mats, const double* inv, const double* logdet, const int* om_idx,
                             const int* pr_idx, const double* D, int M, int T, double* kl, double* KD,
-                            double* kl_copy, hipStream_t st);
+                            double* kl_copy, double* part, int* cnt, hipStream_t st);
 
 // lmc.hip: the LMC likelihood, its gradient and the two LMC gradient products on the matrix cores, G workgroups
 // (zpart [nparts >= G], dWpart [G][L][P]); GPSA_EUNSUPPORTED beyond 64 latent outputs

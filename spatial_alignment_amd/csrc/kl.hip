@@ -57,15 +57,23 @@ mvn_kl_bwd_kernel(const double* __restrict__ Kuu, const double* __restrict__ Kin
 // The step's M x M matrices live in one batch (priors first, then every Omega): term t pairs the
 // covariance mats[om_idx[t]] with the prior mats[pr_idx[t]] (pr_idx < 0: the term is absent, kl = 0);
 // inverses and log-determinants come from the same batch.  D [T,M]: d_t = delta_t - mu_t.
+// Round 6: a term's rows are dealt to gridDim.y workgroups (one workgroup per term took 21 us at M = 200 whatever the
+// number of terms: a single CU pulling two 320 KB matrices).  Slice q takes the row groups q, q + gridDim.y, ... of 64;
+// its partial sum goes to part[t][q], and the slice that arrives LAST (a counter per term, zeroed by the caller -
+// the step's step_prep_kernel - before the launch and left at zero again) adds the partials in the fixed order
+// q = 0, 1, ...: bitwise repeatable whichever slice that is.  gridDim.y == 1: no counter, no partials (part / cnt unused).
 __global__ void __launch_bounds__(1024)
 mvn_kl_grouped_fwd_kernel(const double* __restrict__ mats, const double* __restrict__ inv,
                           const double* __restrict__ logdet, const int* __restrict__ om_idx,
                           const int* __restrict__ pr_idx, const double* __restrict__ D, int M,
-                          double* __restrict__ kl, double* __restrict__ KD, double* __restrict__ kl_copy) {
+                          double* __restrict__ kl, double* __restrict__ KD, double* __restrict__ kl_copy,
+                          double* part, int* cnt) {
   __shared__ double red[16];
   const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = blockIdx.y, NS = gridDim.y;
   const int p = pr_idx[t], o = om_idx[t];
   if (p < 0) {  // uniform
+    if (q != 0) return;
     if (threadIdx.x == 0) {
       kl[t] = 0.0;
       if (kl_copy != nullptr) kl_copy[t] = 0.0;
@@ -81,7 +89,7 @@ mvn_kl_grouped_fwd_kernel(const double* __restrict__ mats, const double* __restr
   // matrices are requested before anything is added (round 4: a row at a time was one memory latency per row,
   // thirteen in a chain per wave at M = 200 - 25 us for 54 terms); out-of-range pieces read a clamped address
   // and count as zero.
-  for (int i0 = w; i0 < M; i0 += 64) {
+  for (int i0 = w + 64 * q; i0 < M; i0 += 64 * NS) {
     double tr[4] = {0.0, 0.0, 0.0, 0.0}, kd[4] = {0.0, 0.0, 0.0, 0.0};
     for (int j0 = 0; j0 < M; j0 += 256) {
       double kv[4][4], ov[4][4], dv[4];
@@ -120,8 +128,17 @@ mvn_kl_grouped_fwd_kernel(const double* __restrict__ mats, const double* __restr
       }
     }
   }
-  const double tot = block_sum(acc, red);
+  double tot = block_sum(acc, red);
   if (threadIdx.x == 0) {
+    if (NS > 1) {
+      part[(long long)t * NS + q] = tot;
+      __threadfence();
+      if (atomicAdd(&cnt[t], 1) != NS - 1) return;
+      __threadfence();
+      tot = 0.0;
+      for (int i = 0; i < NS; ++i) tot += __hip_atomic_load(&part[(long long)t * NS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cnt[t] = 0;
+    }
     const double v = 0.5 * (logdet[p] - logdet[o] + tot - (double)M);
     kl[t] = v;
     if (kl_copy != nullptr) kl_copy[t] = v;  // (the step's cache for passes that reuse the M x M stage)
@@ -195,11 +212,15 @@ mvn_kl_grouped_bwd_kernel(const double* __restrict__ mats, const double* __restr
 }
 
 // gpsa_mvn_kl_grouped_fwd with a second copy of the terms (the step engine's cache) written by the same launch
+// part [T][slices] doubles and cnt [T] ints ZEROED by the caller (both may be null: one workgroup per term)
+int mvn_kl_grouped_fwd_slices(int M) { return M > 64 ? (M + 63) / 64 < 8 ? (M + 63) / 64 : 8 : 1; }
 int mvn_kl_grouped_fwd_copy(const double* mats, const double* inv, const double* logdet, const int* om_idx,
                             const int* pr_idx, const double* D, int M, int T, double* kl, double* KD,
-                            double* kl_copy, hipStream_t st) {
+                            double* kl_copy, double* part, int* cnt, hipStream_t st) {
   if (M < 1 || T < 1) return GPSA_EINVAL;
-  mvn_kl_grouped_fwd_kernel<<<T, 1024, 0, st>>>(mats, inv, logdet, om_idx, pr_idx, D, M, kl, KD, kl_copy);
+  const int ns = (part != nullptr && cnt != nullptr) ? mvn_kl_grouped_fwd_slices(M) : 1;
+  mvn_kl_grouped_fwd_kernel<<<dim3((unsigned)T, (unsigned)ns), 1024, 0, st>>>(mats, inv, logdet, om_idx, pr_idx, D, M, kl,
+                                                                             KD, kl_copy, part, cnt);
   GPSA_LAUNCH_CHECK();
   return 0;
 }
@@ -213,7 +234,7 @@ int gpsa_mvn_kl_grouped_fwd(const double* mats, const double* inv, const double*
                             double* kl, double* KD, void* stream) {
   if (M < 1 || T < 1) return GPSA_EINVAL;
   gpsa::mvn_kl_grouped_fwd_kernel<<<T, 1024, 0, as_stream(stream)>>>(mats, inv, logdet, om_idx, pr_idx, D,
-                                                                     M, kl, KD, nullptr);
+                                                                     M, kl, KD, nullptr, nullptr, nullptr);
   GPSA_LAUNCH_CHECK();
   return 0;
 }

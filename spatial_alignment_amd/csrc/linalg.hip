@@ -340,110 +340,152 @@ __device__ __forceinline__ double lane_bcast(double v) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-// P[c] -= mi * (column R entry of row c).  The two columns next to the pivot take that entry by register
-// broadcast (they feed the next pivots: no LDS latency in the chain), the others read it back from the column
-// the lanes published to LDS at the start of the step (their loads are issued early and land under the chain).
+// 16 x 16 factorisation of the diagonal block by ONE wave (lane l holds row l & 15 in registers): D row-major, stride
+// CB_LS.  The pivot and the entries of the two columns next to it cross the lanes as v_readlane broadcasts from the
+// owning lane's register, the other columns' entries come back from a per-step LDS buffer the lanes publish to (their
+// loads land under the chain): the 16-step dependency chain holds no LDS round trip.
+// Round 6: a SHORTER chain per pivot.  Round 2's was  readlane -> 5 selects (padding / positivity) -> rsq -> 4
+// refinement ops -> two scalings -> the update of the next pivot: ~14 dependent fp64 operations, 16 pivots per block,
+// 13 blocks per matrix at M = 200 (43 us of the kernel's 155; 36 now).  The chain now carries only what the NEXT
+// pivot needs:
+//     d -> 1/d (rcp + one third-order correction: 4 operations) -> mi = column * (1/d) -> the update's FMA,
+// i.e. the square-root-free (L D L^T) recurrence: P(i,c) -= P(i,r) P(c,r) / d_r.  The lanes keep the UNSCALED
+// columns; 1/sqrt(d) of all 16 pivots is formed once, in parallel across the lanes, after the last step, and the
+// factor's columns are scaled then.  Padding needs no select (the identity padding the kernel loads keeps d = 1
+// through every update: the padded rows' off-diagonal entries are exact zeros), and a non-positive pivot is only
+// RECORDED (nothing on the chain reads the flag; the caller drops the matrix).
 template <int R, int C>
-struct Chol16Col {
+struct Ldl16Col {
   static __device__ __forceinline__ void run(double (&P)[16], double mi, double colr, const lds_f64* cb) {
     if (C <= R + 2) P[C] = fma(-mi, lane_bcast<C>(colr), P[C]);
     else P[C] = fma(-mi, cb[C], P[C]);
-    Chol16Col<R, C + 1>::run(P, mi, colr, cb);
+    Ldl16Col<R, C + 1>::run(P, mi, colr, cb);
   }
 };
 template <int R>
-struct Chol16Col<R, 16> {
+struct Ldl16Col<R, 16> {
   static __device__ __forceinline__ void run(double (&)[16], double, double, const lds_f64*) {}
 };
 
 template <int R>
-struct Chol16Step {
-  static __device__ __forceinline__ void run(double (&P)[16], lds_f64* dinv, lds_f64* colbuf, int j0, int M, int lane,
-                                             int& bad) {
-    const double colr = P[R];          // this row's entry of column R (lanes 0..15 hold rows 0..15, repeated)
-    lds_f64* cb = colbuf + R * 16;     // a buffer per step: no reuse hazards
+struct Ldl16Step {
+  static __device__ __forceinline__ void run(double (&P)[16], lds_f64* colbuf, int j0, int lane, int& bad) {
+    const double colr = P[R];          // this row's entry of column R (unscaled)
+    lds_f64* cb = colbuf + R * 16;
     if (R + 3 < 16) {
       if (lane < 16) cb[lane] = colr;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    double d = lane_bcast<R>(colr);    // the pivot, straight from lane R's register
-    if (j0 + R >= M) d = 1.0;          // identity padding beyond the matrix
-    if (!(d > 0.0)) {
-      if (!bad) bad = j0 + R + 1;
-      d = 1.0;
+    const double d = lane_bcast<R>(colr);
+    if (!(d > 0.0) && !bad) bad = j0 + R + 1;  // (off the chain)
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r0, 1.0);
+    const double rinv = fma(r0 * e, 1.0 + e, r0);  // 1/d to e^3 (e ~ 2^-23 from the hardware estimate)
+    if (R + 1 < 16) {
+      const double mi = colr * rinv;
+      Ldl16Col<R, R + 1>::run(P, mi, colr, cb);
     }
-    const double y0 = __builtin_amdgcn_rsq(d);
-    const double e = fma(-(d * y0), y0, 1.0);
-    const double inv = fma(y0 * e, fma(0.375, e, 0.5), y0);
-    if (lane == 0) dinv[R] = inv;
-    const double mine = colr * inv;
-    P[R] = mine;
-    const double mi = mine * inv;  // L(i,r) L(c,r) = (P(i,r) inv) (P(c,r) inv)
-    Chol16Col<R, R + 1>::run(P, mi, colr, cb);
-    Chol16Step<R + 1>::run(P, dinv, colbuf, j0, M, lane, bad);
+    Ldl16Step<R + 1>::run(P, colbuf, j0, lane, bad);
   }
 };
 template <>
-struct Chol16Step<16> {
-  static __device__ __forceinline__ void run(double (&)[16], lds_f64*, lds_f64*, int, int, int, int&) {}
+struct Ldl16Step<16> {
+  static __device__ __forceinline__ void run(double (&)[16], lds_f64*, int, int, int&) {}
 };
 
-// 16 x 16 Cholesky of the diagonal block by ONE wave (lane l holds row l & 15): D row-major, stride CB_LS.
-// The pivot and the entries of the two columns next to it cross the lanes as v_readlane broadcasts from the
-// owning lane's register, so the 16-step dependency chain holds no LDS round trip (publishing every column
-// through LDS cost a store -> load latency per step on top of the reciprocal square root: 3.7 us per block;
-// broadcasting ALL entries by readlane is 2 instructions per multiply-add: 3.2 us, issue-bound).
-// colbuf: [16][16] doubles of this wave.  Writes this wave's copy of the factor (Ld, row-major [16][16]) and
-// the pivots' inverses; returns 0 or 1 + the global column of the first non-positive pivot.
-__device__ __noinline__ int chol16_wave(const lds_f64* D, lds_f64* Ld, lds_f64* dinv, lds_f64* colbuf, int j0,
-                                        int M) {
+template <int C>
+struct Ldl16Scale {
+  static __device__ __forceinline__ void run(double (&P)[16], double rs) {
+    P[C] *= lane_bcast<C>(rs);
+    Ldl16Scale<C + 1>::run(P, rs);
+  }
+};
+template <>
+struct Ldl16Scale<16> {
+  static __device__ __forceinline__ void run(double (&)[16], double) {}
+};
+
+__device__ __noinline__ int chol16_wave_ldl(const lds_f64* D, lds_f64* Ld, lds_f64* dinv, lds_f64* colbuf, int j0) {
   const int lane = threadIdx.x & 63, row = lane & 15;
   double P[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) P[c] = D[row * CB_LS + c];
   int bad = 0;
-  Chol16Step<0>::run(P, dinv, colbuf, j0, M, lane, bad);
-  if (lane < 16) {
+  Ldl16Step<0>::run(P, colbuf, j0, lane, bad);
+  // lane i's pivot d_i sits in P[i] (its own column was never scaled): 1/sqrt for all 16 at once
+  double dm = P[0];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Ld[lane * 16 + c] = P[c];
+  for (int c = 1; c < 16; ++c) dm = (row == c) ? P[c] : dm;
+  if (!(dm > 0.0)) dm = 1.0;  // (a flagged block: keep the arithmetic finite)
+  const double y0 = __builtin_amdgcn_rsq(dm);
+  const double e = fma(-(dm * y0), y0, 1.0);
+  const double rs = fma(y0 * e, fma(0.375, e, 0.5), y0);
+  Ldl16Scale<0>::run(P, rs);  // column c of the factor = unscaled column * 1/sqrt(d_c)
+  if (lane < 16) {  // COLUMN-major (LdT[m * 16 + c] = L(c, m)): panel_solves_col reads a column per step
+    dinv[lane] = rs;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Ld[c * 16 + lane] = P[c];
   }
   return bad;
 }
 
-// step (3): threads [0, R-16): row 16 + t of the panel; threads [R-16, R+i0): column k = t - (R-16) of X(J, :)
-__device__ __noinline__ void panel_solves(lds_f64* Lp, int R, const lds_f64* Ld, const lds_f64* dinv,
-                                          const lds_f64* Tb, int MP, lds_f64* XpT, int i0) {
+// step (3), round 6.  Both kinds of thread solve the SAME recurrence against the block's factor,
+//     x[c] = (x[c] - sum_{m < c} x[m] L(c, m)) / L(c, c):
+// thread t < R - 16 for row 16 + t of the panel (L(i,J) L_JJ^T = A(i,J)), thread R - 16 + k for column k of
+// X(J, :) (L_JJ X(J,k) = T(J,k), T = e_k inside the block) - only where x comes from and goes to differs, so one
+// instruction stream serves a wave that holds both kinds (the round-2 form ran its two branches one after the other
+// there).  Column-oriented: once x[m] is final the 15 - m updates it feeds are independent FMAs (the round-2 form
+// walked each x[c]'s sum serially: 136 dependent FMAs per thread with an LDS read in front of each - 2.6 us per panel,
+// 34 us per matrix), and column m + 1 of the factor is requested from LDS while column m is applied.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) dbl2* lds_d2;
+__device__ __noinline__ void panel_solves_col(lds_f64* Lp, int R, const lds_f64* LdT, const lds_f64* dinv,
+                                              const lds_f64* Tb, int MP, lds_f64* XpT, int i0) {
   const int t = threadIdx.x, na = R - 16;
-  if (t < na) {
-    lds_f64* a = Lp + (16 + t) * CB_LS;
-    double x[16];
+  if (t >= na + i0 + 16) return;
+  const bool isrow = t < na;
+  const int k = t - na;
+  const bool unit = !isrow && k >= i0;  // identity column k - i0 of the block itself
+  // x[e] <- src[e * sstride]; rows: the panel row, columns: Tb[e][k] (identity columns read a valid dummy)
+  const lds_f64* src = isrow ? (const lds_f64*)(Lp + (16 + t) * CB_LS) : (Tb + (unit ? 0 : k));
+  const int sstride = isrow ? 1 : MP;
+  lds_f64* dst = isrow ? Lp + (16 + t) * CB_LS : XpT + k * CB_LS;
+  double x[16], di[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) x[c] = a[c];
+  for (int e = 0; e < 16; ++e) x[e] = src[e * sstride];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {  // (four partial sums per c were measured SLOWER: 33 -> 45 us per 13 panels)
-      double s = x[c];
-#pragma unroll
-      for (int m = 0; m < c; ++m) s = fma(-x[m], Ld[c * 16 + m], s);
-      x[c] = s * dinv[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = x[c];
-  } else if (t < na + i0 + 16) {
-    const int k = t - na;
-    double x[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = (k < i0) ? Tb[j * MP + k] : ((k - i0 == j) ? 1.0 : 0.0);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      double s = x[j];
-#pragma unroll
-      for (int m = 0; m < j; ++m) s = fma(-Ld[j * 16 + m], x[m], s);
-      x[j] = s * dinv[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) XpT[k * CB_LS + j] = x[j];
+  for (int e = 0; e < 16; e += 2) {
+    const dbl2 d2 = *reinterpret_cast<lds_d2>(&dinv[e]);
+    di[e] = d2.x;
+    di[e + 1] = d2.y;
   }
+  if (unit) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = (k - i0 == e) ? 1.0 : 0.0;
+  }
+  dbl2 col[2][8];  // col[m & 1][p] = L(2p .. 2p+1, m)
+#pragma unroll
+  for (int p_ = 0; p_ < 8; ++p_) col[0][p_] = *reinterpret_cast<lds_d2>(&LdT[0 * 16 + 2 * p_]);
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m + 1 < 16) {
+#pragma unroll
+      for (int p_ = (m + 2) / 2; p_ < 8; ++p_)
+        col[(m + 1) & 1][p_] = *reinterpret_cast<lds_d2>(&LdT[(m + 1) * 16 + 2 * p_]);
+    }
+    // (left alone, the scheduler sinks every load to one instruction in front of its first use - an LDS round trip
+    //  per pair of FMAs; the fence keeps column m + 1's requests in front of column m's arithmetic)
+    __builtin_amdgcn_sched_barrier(0);
+    x[m] *= di[m];
+#pragma unroll
+    for (int c = m + 1; c < 16; ++c) {
+      const double lcm = (c & 1) ? col[m & 1][c >> 1].y : col[m & 1][c >> 1].x;
+      x[c] = fma(-x[m], lcm, x[c]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dst[e] = x[e];
 }
 
 static inline long long chol_blk_lds_bytes(int NT) {
@@ -493,13 +535,15 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
     for (int qb = 0; qb < q0; ++qb) Tb[ty * MP + 16 * qb + tx] = t[q0][qb];
     __syncthreads();
     // (2) diagonal block, every wave for itself
-    if (!(skip & 1)) bad = chol16_wave((const lds_f64*)Lp, (lds_f64*)(Ldw + w * 256), (lds_f64*)(dinvw + w * 16),
-                      (lds_f64*)(colw + w * 256), i0, M);
+    if (!(skip & 1))
+      bad = chol16_wave_ldl((const lds_f64*)Lp, (lds_f64*)(Ldw + w * 256), (lds_f64*)(dinvw + w * 16),
+                            (lds_f64*)(colw + w * 256), i0);
     if (tid < 16) sdiag[i0 + tid] = dinvw[tid];  // wave 0's copy (written by its lane 0 above; same wave)
     if (bad) break;  // uniform: every wave factorised the same block
     // (3) panel rows and X columns, one thread each
-    if (!(skip & 2)) panel_solves((lds_f64*)Lp, R, (const lds_f64*)(Ldw + w * 256), (const lds_f64*)(dinvw + w * 16),
-                 (const lds_f64*)Tb, MP, (lds_f64*)XpT, i0);
+    if (!(skip & 2))
+      panel_solves_col((lds_f64*)Lp, R, (const lds_f64*)(Ldw + w * 256), (const lds_f64*)(dinvw + w * 16),
+                       (const lds_f64*)Tb, MP, (lds_f64*)XpT, i0);
     __syncthreads();
     // (4) the row block of t is final; rank-16 update of the rows below
 #pragma unroll

@@ -99,14 +99,14 @@ struct PrepArgs {
   double* resid;   // [V, Mx, D]
   double* Dw;      // [V*D, Mx]
   double* Dd;      // [sum L, Mg]
-  int* zinfo[2];   // owner computes: the Cholesky infos of a group (the matrices left out keep 0); else null
-  int nzinfo[2];
+  int* zinfo[4];   // int words this launch zeroes: [0..1] owner computes: the Cholesky infos of a group (the matrices
+  int nzinfo[4];   // left out keep 0); [2..3] the arrival counters of the KL forward's row slices (kl.hip); else null
 };
 
 __global__ void __launch_bounds__(256) step_prep_kernel(PrepArgs a) {
   const int D = a.D;
   if (blockIdx.x == 0)
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < 4; ++g)
       if (a.zinfo[g] != nullptr)
         for (int i = threadIdx.x; i < a.nzinfo[g]; i += 256) a.zinfo[g][i] = 0;
   if ((int)blockIdx.x < a.V) {
@@ -986,6 +986,16 @@ static int mm_stage_fwd(Ctx& c) {
   Group& GW = P.gw();
   Group& GD = P.gd();
   const bool kl = P.d.want_kl != 0;
+  // the KL forward deals a term's rows to several workgroups: their partial sums and arrival counters (zeroed by the
+  // launch below) live in the scratch arena for the length of this call
+  double* klpart[2] = {nullptr, nullptr};
+  int* klcnt[2] = {nullptr, nullptr};
+  if (kl && !c.io.reuse_mm)
+    for (int g = 0; g < P.ng; ++g)
+      if (P.grp[g].n_omega > 0) {
+        klpart[g] = c.sc.get<double>((long long)P.grp[g].n_omega * mvn_kl_grouped_fwd_slices(P.grp[g].M));
+        klcnt[g] = c.sc.get<int>(P.grp[g].n_omega);
+      }
   // mean function at the inducing points, residuals, the KL terms' mean differences
   {
     PrepArgs a;
@@ -1002,6 +1012,11 @@ static int mm_stage_fwd(Ctx& c) {
       if (kl && !P.grp[g].own_all() && !c.io.reuse_mm) {
         a.zinfo[g] = c.sv<int>(P.grp[g].o_info);
         a.nzinfo[g] = P.grp[g].nb();
+      }
+    for (int g = 0; g < P.ng; ++g)
+      if (klcnt[g] != nullptr) {
+        a.zinfo[2 + g] = klcnt[g];
+        a.nzinfo[2 + g] = P.grp[g].n_omega;
       }
     const long long nd = kl ? cdiv((long long)P.Ltot * Mg, 256) : 0;
     if (!dry) {
@@ -1135,7 +1150,8 @@ static int mm_stage_fwd(Ctx& c) {
       if (G.n_omega > 0)
         GPSA_RUN(mvn_kl_grouped_fwd_copy(c.mats(G, 0), c.inv(G, 0), c.sv<double>(G.o_logdet), G.om_idx, G.pr_idx,
                                          c.sv<double>(G.o_D), G.M, G.n_omega, c.io.kl + G.kl_off,
-                                         c.sv<double>(G.o_KD), c.sv<double>(P.o_klcache) + G.kl_off, sst));
+                                         c.sv<double>(G.o_KD), c.sv<double>(P.o_klcache) + G.kl_off, klpart[g], klcnt[g],
+                                         sst));
     }
   if (fork) GPSA_CK((int)hipEventRecord(P.sev[2], P.side));
   return 0;
