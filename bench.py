@@ -68,6 +68,9 @@ def parse():
                     help="row-sharded ranks: 'owner' = each rank evaluates its own range of the KL terms at weight 1 "
                          "(factorises only its variational covariances; the all-reduce sums the shares), 'scaled' = "
                          "every rank evaluates all of them at weight 1/world (rounds 1-5)")
+    ap.add_argument("--sustained", type=int, default=1000,
+                    help="extra (default line only): that many consecutive headline steps after the timed blocks, with "
+                         "the clock and power rocm-smi saw meanwhile (0: skip)")
     ap.add_argument("--emulate-shard", type=int, default=1,
                     help="diagnostic: time rank 0's share of a K-way row sharding on ONE GPU (no all-reduce); "
                          "the line is then NOT the contract metric")
@@ -180,7 +183,9 @@ def cpu_baseline(args, state, dd_cpu):
         value=1.0 / (med * scale), unit="steps/s (forward+ELBO+backward+Adam)",
         cores=torch.get_num_threads(), nproc=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
         sample=f"oracle steps at the full config with S={S_run}: 1 warm-up, then median of {n_timed} timed "
-               f"({', '.join(f'{t:.3g}' for t in times[:5])}{' ...' if len(times) > 5 else ''} s)"
+               + ("[3 of the 20 steps BASELINE.md section 3 planned: a step is ~11 s here, 20 would not fit the default "
+                  "run's few minutes] " if n_timed == 3 else "")
+               + f"({', '.join(f'{t:.3g}' for t in times[:5])}{' ...' if len(times) > 5 else ''} s)"
                + (f", time scaled x{scale:.0f} to S={args.S}" if scale != 1 else "")
                + f"; anomaly mode off, host RAM avail {avail:.0f} GB",
     )
@@ -345,6 +350,73 @@ def launch_ranks(args):
     return proc.wait()
 
 
+_SMI_SAMPLER = r'''
+import subprocess, sys, time, os
+out, stop, life = sys.argv[1], sys.argv[2], float(sys.argv[3])
+t_end = time.time() + life
+with open(out, "w") as f:
+    while time.time() < t_end and not os.path.exists(stop):
+        t = time.time()
+        try:
+            r = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        except Exception as e:
+            r = "rocm-smi failed: %r" % (e,)
+        keep = [ln.strip() for ln in r.splitlines() if ("Power" in ln or "sclk" in ln or "failed" in ln)]
+        f.write("%.3f\t%s\n" % (t, " | ".join(keep)))
+        f.flush()
+        time.sleep(max(0.0, 0.25 - (time.time() - t)))
+'''
+
+
+def start_smi_sampler(life_s=900.0):
+    """a child process that asks rocm-smi for the package power and the shader clock four times a second until told to
+    stop; started BEFORE this process touches the GPU (it never does so itself: rocm-smi reads sysfs)"""
+    import subprocess
+    import tempfile
+
+    d = tempfile.mkdtemp(prefix="gpsa_smi_")
+    out, stop = os.path.join(d, "samples.tsv"), os.path.join(d, "stop")
+    try:
+        proc = subprocess.Popen([sys.executable, "-c", _SMI_SAMPLER, out, stop, str(life_s)],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:  # noqa: BLE001
+        return None
+    return dict(proc=proc, out=out, stop=stop)
+
+
+def stop_smi_sampler(smp, t0, t1):
+    """-> what rocm-smi reported between t0 and t1 (time.time() stamps): samples, shader clock (MHz) and power (W)"""
+    import re
+
+    if smp is None:
+        return dict(error="sampler not started")
+    try:
+        open(smp["stop"], "w").close()
+        smp["proc"].wait(timeout=30)
+    except Exception:  # noqa: BLE001
+        pass
+    clk, pw, n, raw = [], [], 0, None
+    try:
+        for ln in open(smp["out"]):
+            ts, _, txt = ln.partition("\t")
+            if not (t0 <= float(ts) <= t1):
+                continue
+            n += 1
+            raw = txt.strip()[:200]
+            c = re.search(r"sclk[^|]*\((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if c:
+                clk.append(int(c.group(1)))
+            if w:
+                pw.append(float(w.group(1)))
+    except OSError as e:
+        return dict(error=str(e))
+    st = lambda v: dict(min=min(v), mean=round(sum(v) / len(v), 1), max=max(v)) if v else None  # noqa: E731
+    return dict(samples=n, sclk_mhz=st(clk), power_w=st(pw), last_sample=raw,
+                source="rocm-smi --showpower --showclocks from a child process started before the first GPU call, "
+                       "4 samples/s, those inside the sustained run's wall-clock window")
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -352,6 +424,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    want_sustained = (args.sustained > 0 and args.workload == "2" and not args.no_extras and not args.graph_only
+                      and args.emulate_shard <= 1)
+    smi = start_smi_sampler() if (want_sustained and rank == 0) else None
     # diagnostics for a 1-GPU box: GPSA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and the collectives
     # on gloo (RCCL refuses two ranks per device), which exercises this file's N > 1 path end to end
     one_dev = os.environ.get("GPSA_BENCH_ONE_DEVICE", "0") == "1"
@@ -573,6 +648,38 @@ def main():
     if args.S != 1 and not args.no_s1:
         s1 = dict(S=1, **summary(time_blocks(reference_step, 1, min(nblk, 3))[0]))
 
+    # sustained: --sustained consecutive headline steps (1000 = ~7 s on one GPU), one synchronise per 100, next to what
+    # rocm-smi saw of the clock and the power meanwhile - the timed blocks above are 5 x 20 steps
+    sustained = None
+    if want_sustained:
+        nb_s = max(1, args.sustained // 100)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        w0 = time.time()
+        tb = []
+        for b in range(nb_s):
+            t0 = time.perf_counter()
+            for _ in range(100):
+                reference_step(args.S)
+            torch.cuda.synchronize()
+            tb.append(time.perf_counter() - t0)
+        if world > 1:
+            dist.barrier()
+        w1 = time.time()
+        tot = torch.tensor([sum(tb)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+        sustained = dict(steps=100 * nb_s, seconds=round(float(tot.item()), 3), value=100 * nb_s / float(tot.item()),
+                         unit="steps/s", ms_per_step=1e3 * float(tot.item()) / (100 * nb_s),
+                         ms_per_step_min_block=round(1e3 * min(tb) / 100, 4),
+                         ms_per_step_max_block=round(1e3 * max(tb) / 100, 4), steps_per_block=100,
+                         note="the headline step (the reference's two calls + FusedAdam), back to back; rank 0's blocks")
+        if rank == 0:
+            sustained["device"] = stop_smi_sampler(smi, w0, w1)
+    elif smi is not None:
+        stop_smi_sampler(smi, 0, 0)
+
     graph_info = None
     if world == 1 and not args.no_graph and not args.graph_only:
         # extra: the SAME step captured into a hipGraph and replayed (train.GraphedTrainStep); run in a
@@ -772,6 +879,7 @@ def main():
             },
             "roofline": roof,
             "secondary_S1": s1,
+            "sustained": sustained,
             "graph_replay": graph_info,
         }
         if not args.no_cpu_baseline:

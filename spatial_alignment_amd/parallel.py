@@ -223,9 +223,21 @@ class GradAllReducer:
                                          list(tail.split([p.numel() for p in outside])))
                 main.wait_stream(self._side)
                 return
-            main.wait_stream(self._side)  # (not the layout this shortcut knows: the span is reduced, undo nothing -
-            # the general path below would reduce it a second time, so bring it back to the local share first)
-            raise RuntimeError("GradAllReducer(overlap=True): the gradients are not the step engine's single bucket")
+            # Not the layout the shortcut knows (StepFn.backward declines the early reduce when it can tell beforehand;
+            # this is the net under it): the span eflat[lo:hi] IS reduced, so finish WITHOUT touching it again - every
+            # parameter whose .grad is not a view inside that span goes through a packed buffer - instead of raising
+            # with the ranks' gradients half summed.
+            main.wait_stream(self._side)
+            es = eflat.element_size()
+            a, b = eflat.data_ptr() + lo * es, eflat.data_ptr() + hi * es
+            rest = [p for p in self.params
+                    if not (p.grad.is_contiguous() and p.grad.dtype == eflat.dtype and a <= p.grad.data_ptr() < b)]
+            if rest:
+                tmp = torch.cat([p.grad.reshape(-1).to(eflat.dtype) for p in rest])
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+                for p, t in zip(rest, tmp.split([p.numel() for p in rest])):
+                    p.grad.copy_(t.view_as(p.grad))
+            return
         if bucket is not None and bucket[3] is not None:
             flat, used, outside, spans = bucket
             for a, b in spans:

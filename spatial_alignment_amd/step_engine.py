@@ -594,6 +594,24 @@ class StepFn(torch.autograd.Function):
         # starts that span's all-reduce on its own stream while the rest of this backward runs
         early = model.__dict__.get("_early_reducer") if model is not None else None
         if early is not None and closes:
+            # ... but only when, for every parameter in that span, what autograd will store as ``.grad`` IS this node's
+            # view of the flat buffer: a parameter that already holds a gradient (accumulation over several
+            # backwards: AccumulateGrad adds the view in place on the main stream, under the all-reduce in flight) or
+            # that collects a second share elsewhere (an LMC modality's W on the fused-loss path: ElboLossFn's dW is
+            # summed with the engine's view into a fresh tensor) would leave the ranks with different gradients.
+            # Then: the ordinary order, no early reduce - the reducer's __call__ takes its general path.
+            if early._early is not None:
+                raise RuntimeError(
+                    "GradAllReducer(overlap=True): a second backward() before the reducer was called - the first one's "
+                    "data-GP span is already being all-reduced on the side stream and autograd would add this one's "
+                    "gradients into it.  Call the reducer after every backward, or use overlap=False when "
+                    "accumulating gradients over several backwards.")
+            span = list(tensors[8:])
+            # (any LMC modality declines: whether loss_fn took the fused likelihood is not this node's to know)
+            if any(plan.lmc) or any(t.grad is not None for t in span if t.requires_grad):
+                early = None
+                STATS["early_reduce_declined"] = STATS.get("early_reduce_declined", 0) + 1
+        if early is not None and closes:
             ctx.io.f_event = early.event_handle()
         else:
             ctx.io.f_event = None
