@@ -8,9 +8,16 @@ namespace gpsa {
 // KiB of piece P_ (0 .. 15) inside a ring slot of the 128 x 128 kernels: wave-major, see gram_big_kernel's stage
 #define GPSA_BIG_POS(P_) ((((P_) & 3) << 2) + ((P_) >> 2))
 
-__global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[3][16 * 256];
-  __shared__ __attribute__((aligned(16))) float sg[3][16];
+// PAIR (round 6, the lever the round-5 counters pointed at): ONE wait + barrier per TWO 16-column chunks.  Four
+// one-chunk slots (64 KB a workgroup: two workgroups still share a CU); iteration k multiplies the chunks 2k, 2k + 1 out
+// of the slots (2k, 2k + 1) mod 4 while the stages of the chunks 2k + 2, 2k + 3 - requested at the top of the iteration
+// into the slots the barrier that ended iteration k - 1 released - are in flight; the iteration ends on vmcnt(0) + barrier.
+// GPSA_BIG_PAIR=1 selects it (A/B: profiles/r06_big_pair_ab.txt).
+template <bool PAIR>
+__global__ void __launch_bounds__(256, 2) gram_big_kernel_t(GramBigArgs a) {
+  constexpr int NSLOT = PAIR ? 4 : 3;
+  __shared__ __attribute__((aligned(16))) float lds[NSLOT][16 * 256];
+  __shared__ __attribute__((aligned(16))) float sg[NSLOT][16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4, wr = w >> 1, wc = w & 1;
@@ -85,38 +92,62 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
       glds16_m0<0>(gl + (long long)(CH) * 16 + lane * 4);                                     \
     }                                                                                         \
   }
-  if (ch0 < ch1) {
-    GPSA_GB_STAGE(ch0, 0)
-    GPSA_GB_STAGE(ch0 + 1 < ch1 ? ch0 + 1 : ch0, 1)
-  }
-  GPSA_DMA_WAIT(5);
-  __syncthreads();
-  int buf = 0;
-  for (long long ch = ch0; ch < ch1; ++ch) {
-    // slot (buf + 2) % 3 held chunk ch - 1: everyone left it before the barrier that ended that iteration
-    GPSA_GB_STAGE(ch + 2 < ch1 ? ch + 2 : ch1 - 1, buf == 0 ? 2 : buf - 1)
-    const float* base = &lds[buf][lane * 4];
-    const float4 gk = *reinterpret_cast<const float4*>(&sg[buf][kq * 4]);
-    float4 av[4], bv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 x = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(wr * 4 + i) * 256);
-      av[i] = make_float4(x.x * gk.x, x.y * gk.y, x.z * gk.z, x.w * gk.w);
-      bv[i] = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(8 + wc * 4 + i) * 256);
-    }
 #define GPSA_GB_MMA(F)                                                                        \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                             \
       acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].F, bv[k].F, acc[i][k], 0, 0, 0);
-    GPSA_GB_MMA(x)
-    GPSA_GB_MMA(y)
-    GPSA_GB_MMA(z)
-    GPSA_GB_MMA(w)
-#undef GPSA_GB_MMA
+#define GPSA_GB_CHUNK(BUF)                                                                    \
+  {                                                                                           \
+    const float* base = &lds[BUF][lane * 4];                                                  \
+    const float4 gk = *reinterpret_cast<const float4*>(&sg[BUF][kq * 4]);                     \
+    float4 av[4], bv[4];                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+      const float4 x = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(wr * 4 + i) * 256); \
+      av[i] = make_float4(x.x * gk.x, x.y * gk.y, x.z * gk.z, x.w * gk.w);                    \
+      bv[i] = *reinterpret_cast<const float4*>(base + GPSA_BIG_POS(8 + wc * 4 + i) * 256);    \
+    }                                                                                         \
+    GPSA_GB_MMA(x)                                                                            \
+    GPSA_GB_MMA(y)                                                                            \
+    GPSA_GB_MMA(z)                                                                            \
+    GPSA_GB_MMA(w)                                                                            \
+  }
+  if (PAIR) {
+    if (ch0 < ch1) {
+      GPSA_GB_STAGE(ch0, 0)
+      GPSA_GB_STAGE(ch0 + 1 < ch1 ? ch0 + 1 : ch0, 1)
+    }
+    GPSA_DMA_WAIT(0);
+    __syncthreads();
+    int buf = 0;  // 0 or 2: the pair's first slot
+    for (long long ch = ch0; ch < ch1; ch += 2) {
+      const int nb = buf ^ 2;
+      GPSA_GB_STAGE(ch + 2 < ch1 ? ch + 2 : ch1 - 1, nb)
+      GPSA_GB_STAGE(ch + 3 < ch1 ? ch + 3 : ch1 - 1, nb + 1)
+      GPSA_GB_CHUNK(buf)
+      if (ch + 1 < ch1) GPSA_GB_CHUNK(buf + 1)
+      GPSA_DMA_WAIT(0);
+      __syncthreads();
+      buf = nb;
+    }
+  } else {
+    if (ch0 < ch1) {
+      GPSA_GB_STAGE(ch0, 0)
+      GPSA_GB_STAGE(ch0 + 1 < ch1 ? ch0 + 1 : ch0, 1)
+    }
     GPSA_DMA_WAIT(5);
     __syncthreads();
-    buf = (buf == 2) ? 0 : buf + 1;
+    int buf = 0;
+    for (long long ch = ch0; ch < ch1; ++ch) {
+      // slot (buf + 2) % 3 held chunk ch - 1: everyone left it before the barrier that ended that iteration
+      GPSA_GB_STAGE(ch + 2 < ch1 ? ch + 2 : ch1 - 1, buf == 0 ? 2 : buf - 1)
+      GPSA_GB_CHUNK(buf)
+      GPSA_DMA_WAIT(5);
+      __syncthreads();
+      buf = (buf == 2) ? 0 : buf + 1;
+    }
   }
+#undef GPSA_GB_CHUNK
+#undef GPSA_GB_MMA
   GPSA_DMA_DRAIN();
 #undef GPSA_GB_STAGE
   float* P = a.part + ((long long)l * a.nsplit + sp) * M * M;
@@ -129,6 +160,13 @@ __global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a) {
         const int row = bi * 128 + wr * 64 + i * 16 + kq * 4 + r, col = bj * 128 + wc * 64 + k * 16 + j;
         if (row < M && col < M) P[(long long)row * M + col] = acc[i][k][r];
       }
+}
+template __global__ void gram_big_kernel_t<false>(GramBigArgs);
+template __global__ void gram_big_kernel_t<true>(GramBigArgs);
+void gram_big_launch(dim3 grid, hipStream_t st, const GramBigArgs& a) {
+  static const bool pair = [] { const char* e = getenv("GPSA_BIG_PAIR"); return e && e[0] == '1'; }();
+  if (pair) gram_big_kernel_t<true><<<grid, 256, 0, st>>>(a);
+  else gram_big_kernel_t<false><<<grid, 256, 0, st>>>(a);
 }
 
 // The large-M full product W[l] = P[l] X  ([M,M] x [M,C], fp32 matrix cores) with both operands staged by LDS-DMA

@@ -206,7 +206,7 @@ struct GramBigArgs {
 };
 __global__ void pad_rows_kernel(const float* __restrict__ g, int L, long long C, long long Cpad,
                                 float* __restrict__ gpad);
-__global__ void __launch_bounds__(256, 2) gram_big_kernel(GramBigArgs a);
+void gram_big_launch(dim3 grid, hipStream_t st, const GramBigArgs& a);  // qf_big.hip (GPSA_BIG_PAIR: the A/B)
 // W[l] = P[l] X for large M (see prod_big_kernel)
 struct ProdBigArgs {
   const float* P;  // [L][M][Mp], zero for k >= M (Mp = a multiple of 16)

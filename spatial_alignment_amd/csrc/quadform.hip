@@ -368,9 +368,9 @@ int generic_quadform_bwd_omega(const T* alpha, const T* g, int M, long long C, i
       const long long combos = (long long)pairs * ns * cdiv(L, lb > 0 ? lb : 1);
       if (lb > 0 && 8 * lb * cdiv(combos, 8) < 0x7fffffffLL) {
         a.lb = lb;
-        gram_big_kernel<<<(unsigned)(8 * lb * cdiv(combos, 8)), 256, 0, st>>>(a);
+        gram_big_launch(dim3((unsigned)(8 * lb * cdiv(combos, 8))), st, a);
       } else {
-        gram_big_kernel<<<dim3((unsigned)pairs, (unsigned)ns, (unsigned)L), 256, 0, st>>>(a);
+        gram_big_launch(dim3((unsigned)pairs, (unsigned)ns, (unsigned)L), st, a);
       }
       GPSA_LAUNCH_CHECK();
       gram_big_reduce_kernel<float><<<dim3((unsigned)cdiv((long long)M * M, 256), (unsigned)L), 256, 0, st>>>(
