@@ -14,6 +14,17 @@
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// "set once" flags (hipFuncSetAttribute: dynamic LDS beyond 64 KiB) are per DEVICE: a process that drives two GPUs must
+// set the attribute on each (a per-process flag left the second device launching without it)
+struct per_device_flag {
+  bool done[64] = {};
+  bool& here() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return done[d & 63];
+  }
+};
+
 namespace gpsa {
 
 constexpr int WAVE = 64;

@@ -591,7 +591,8 @@ chol_inv_blk_kernel(const double* __restrict__ A, int M, double* __restrict__ Li
 template <int NT>
 static int chol_inv_blk_launch_nt(const double* A, int M, double* Linv, double* logdet, int* info, int batch,
                                   hipStream_t st, int n0, int gap) {
-  static bool attr_set = false;
+  static per_device_flag attr_flag;
+  bool& attr_set = attr_flag.here();
   const long long lds = chol_blk_lds_bytes(NT);
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_blk_kernel<NT>),
@@ -749,7 +750,8 @@ int gpsa_chol_f64(void* A, int M, int batch, void* logdet, int* info, void* stre
   hipStream_t st = as_stream(stream);
   if (M <= LA_PACKED_MAX) {
     const size_t lds = ((size_t)M * (M + 1) / 2 + M) * sizeof(double);
-    static bool attr_set = false;
+    static per_device_flag attr_flag;
+    bool& attr_set = attr_flag.here();
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)chol_packed_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -771,7 +773,8 @@ int gpsa_tri_inv_f64(const void* L, void* Linv, int M, int batch, void* stream) 
   hipStream_t st = as_stream(stream);
   if (M <= LA_PACKED_MAX) {
     const size_t lds = ((size_t)M * (M + 1) / 2 + M) * sizeof(double);
-    static bool attr_set = false;
+    static per_device_flag attr_flag;
+    bool& attr_set = attr_flag.here();
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)tri_inv_packed_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

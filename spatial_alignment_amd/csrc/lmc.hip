@@ -182,7 +182,8 @@ template <int NLT, int NPT>
 static int lmc_mfma_launch_t(const float* F, const float* W, const float* Y, const float* noise_u, int S, long long N,
                              int L, int P, double* zpart, int nparts, float* dF, float* dWpart, int G, hipStream_t st) {
   const int sm = (int)lmc_mfma_smem(NLT, NPT);
-  static bool attr_set = false;
+  static per_device_flag attr_flag;
+  bool& attr_set = attr_flag.here();
   if (!attr_set && sm > 65536) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lmc_mfma_kernel<NLT, NPT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, sm) != hipSuccess)

@@ -325,7 +325,8 @@ template <int MB, bool HASG, int DT>
 static int longk64_launch_mb(const LongKArgs& a, hipStream_t st) {
   constexpr int NPIECE = MB * (HASG ? 2 : 1) * 2, NPW = (NPIECE + LK_WAVES - 1) / LK_WAVES;
   constexpr int lds = 2 * (NPW * LK_WAVES * 1024 + (DT ? LK_WAVES * (DT == 2 ? 1024 : 256) : 0));
-  static bool attr_set = false;
+  static per_device_flag attr_flag;
+  bool& attr_set = attr_flag.here();
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&longk64_kernel<MB, HASG, DT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)

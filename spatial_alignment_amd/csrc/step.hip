@@ -33,13 +33,17 @@ constexpr int KM_MAXB_STEP = 16;  // views per batched launch (kmat.hip: KM_MAXB
 struct Arena {
   char* base = nullptr;
   long long off = 0, high = 0;
+  long long limit = -1;  // bytes behind ``base`` (the plan's scratch_bytes; -1: a dry run, nothing behind it)
   bool dry = false;
+  bool overflow = false;  // a request went past ``limit``: GPSA_RUN refuses every launch from then on (the
+                          // arena is sized by a dry run; a branch that run did not walk must not write past it silently)
   template <typename T>
   T* get(long long n) {
     off = (off + 255) & ~255LL;
     T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
     off += n * (long long)sizeof(T);
     if (off > high) high = off;
+    if (!dry && limit >= 0 && off > limit) overflow = true;
     return p;
   }
   long long mark() const { return off; }
@@ -52,9 +56,12 @@ struct Arena {
     if (rc__ != 0) return rc__;  \
   } while (0)
 // launches are skipped in a dry run (which only measures the arenas)
-#define GPSA_RUN(x)      \
-  do {                   \
-    if (!dry) GPSA_CK(x); \
+#define GPSA_RUN(x)                                   \
+  do {                                                \
+    if (!dry) {                                       \
+      if (c.sc.overflow) return GPSA_EWORKSPACE;      \
+      GPSA_CK(x);                                     \
+    }                                                 \
   } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -605,6 +612,8 @@ struct Plan {
     GraphKey key;
     hipGraphExec_t exec;
     unsigned long long used;
+    hipStream_t last;  // the stream of its most recent launch (the key holds the stream, so this is the key's - kept
+                       // explicitly: the eviction below retires a graph behind ITS stream, not the current call's)
   };
   std::vector<GraphEntry> graphs;
   // executable graphs dropped from the cache while a launch of theirs may still be queued on the caller's stream: each
@@ -1518,7 +1527,8 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       const double al[1] = {-1.0}, be[1] = {1.0};
       double* os[1] = {dKuu};
       int rc = longk(c, 1, Gs, Bs, ds, GPSA_F32, Mg, C, C, 0, al, be, os);
-      if (rc == GPSA_EUNSUPPORTED) {  // (M > 256, an odd or short C, an unaligned panel: the generic product)
+      // (the dry run walks the fallback as well: a launch-time refusal - operand alignment - must find its workspace)
+      if (rc == GPSA_EUNSUPPORTED || (dry && rc == 0)) {  // (M > 256, an odd or short C, an unaligned panel: the generic product)
         const long long wsb2 = gpsa_exact_dkuu_workspace(Mg, C);
         const long long mk2 = c.sc.mark();
         void* ws2 = c.sc.get<char>(wsb2);
@@ -1576,6 +1586,13 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(2, 0, false, c.st);
     int rc = 0;
+    if (dry) {  // what a launch-time refusal of either call below would need: the C-long product's split-K partials
+      const long long mk3 = c.sc.mark();  // and the fp32 staging copy of the generic Gram path
+      if (ddelta_in_gram)
+        GPSA_CK(gemm32(c, 0, 1, Mg, L, C, 1.0, alpha, C, 0, dmeanT, C, 0, 0.0, B.ddc_F[m], L, 0, 1, splitk_for(C, Mg, L)));
+      c.sc.get<float>((long long)L * mm);
+      c.sc.release(mk3);
+    }
     if (!dry && ddelta_in_gram) {
       rc = gpsa_quadform_bwd_omega_delta_f32(GPSA_F64, alpha, g_ext, dmeanT, Mg, C, L, dst, B.ddc_F[m],
                                              first_for_mod ? 0.0 : 1.0, ws, wsb, c.stv());
@@ -1753,8 +1770,8 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B, boo
         return rc;
       }
     }
-    if (!done) {
-      if (acc) return GPSA_EINVAL;  // (the early order is only taken when every run is covered: warp_runs_longk)
+    if (!done || dry) {  // (the dry run sizes the arena for this path too)
+      if (acc && !dry) return GPSA_EINVAL;  // (the early order is only taken when every run is covered: warp_runs_longk)
       {
         const long long mk2 = c.sc.mark();
         const long long wsb = gpsa_gram_batched_workspace(Mx, Cs, D, r.cnt);
@@ -2137,6 +2154,7 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
     if (memcmp(ge.key.b, key.b, Plan::GraphKey::BYTES) == 0) {
       if (ge.used == 0) P.g_idle_captures = 0;
       ge.used = P.gtick;
+      ge.last = st;
       ++P.g_hits;
       return (int)hipGraphLaunch(ge.exec, st);
     }
@@ -2212,16 +2230,18 @@ static int graph_call(Plan& P, const Plan::GraphKey& key, hipStream_t st, F&& en
     // and therefore evicts).  It retires behind an event on the stream it was launched into instead.
     static const bool unsafe = [] { const char* e = getenv("GPSA_STEP_GRAPH_UNSAFE_DESTROY"); return e && e[0] == '1'; }();
     hipEvent_t ev = nullptr;
-    if (!unsafe && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, st) == hipSuccess) {
+    // (the victim may have been launched into ANOTHER stream than this call's - the key includes the stream)
+    hipStream_t vst = P.graphs[lru].last;
+    if (!unsafe && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, vst) == hipSuccess) {
       P.retired.push_back(Plan::Retired{P.graphs[lru].exec, ev});
     } else {
       if (ev != nullptr) (void)hipEventDestroy(ev);
-      if (!unsafe) (void)hipStreamSynchronize(st);
+      if (!unsafe) (void)hipStreamSynchronize(vst);
       (void)hipGraphExecDestroy(P.graphs[lru].exec);
     }
     P.graphs.erase(P.graphs.begin() + (long)lru);
   }
-  P.graphs.push_back(Plan::GraphEntry{key, exec, 0});  // used == 0: captured, not replayed yet
+  P.graphs.push_back(Plan::GraphEntry{key, exec, 0, st});  // used == 0: captured, not replayed yet
   ++P.g_captures;
   ++P.g_idle_captures;
   return (int)hipGraphLaunch(exec, st);
@@ -2389,6 +2409,7 @@ int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_ste
   auto enqueue = [&](hipStream_t s) {
     Arena a;
     a.base = reinterpret_cast<char*>(scratch);
+    a.limit = reinterpret_cast<gpsa::Plan*>(plan)->scratch_bytes;
     return step_forward(P, *params, *io, reinterpret_cast<char*>(saved), a, s, stages);
   };
   if (!graph_usable(P, st)) return enqueue(st);
@@ -2407,9 +2428,12 @@ int gpsa_step_backward(void* plan, const gpsa_step_params* params, const gpsa_st
   auto enqueue = [&](hipStream_t s) {
     Arena a;
     a.base = reinterpret_cast<char*>(scratch);
+    a.limit = reinterpret_cast<gpsa::Plan*>(plan)->scratch_bytes;
     return step_backward(P, *params, *io, *og, reinterpret_cast<char*>(saved), a, *grads, s);
   };
-  if (!graph_usable(P, st)) return enqueue(st);
+  // (a backward that records the caller's event - the overlapped reducer's f_event - stays eager: an event record
+  //  captured into a cached graph and waited for from outside it is a combination nobody has tested)
+  if (io->f_event != nullptr || !graph_usable(P, st)) return enqueue(st);
   Plan::GraphKey key;
   key.set(params, io, og, grads, saved, scratch, stream, 0, 1);
   return graph_call(P, key, st, enqueue);

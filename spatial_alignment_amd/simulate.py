@@ -52,14 +52,19 @@ def _exact_draw_hip(x64, z, variance, lengthscale, jitter):
     L z = K (L^-T z) as two ``gpsa_gemm`` products.  A smooth kernel without jitter is numerically semi-definite
     (the GP warp asks for jitter 0): the factorisation then flags a non-positive pivot and the draw is retried with
     a floor of 1e-8 * variance on the diagonal (1e-4 of the prior standard deviation: far below the lattice
-    spacing).  Returns None when even that is flagged (the caller's eigen-decomposition path takes over)."""
+    spacing).  Returns None when even 1e-4 of the variance is flagged (the caller raises)."""
     from . import ops as _ops
 
     o = _ops.get_ops()
     dev = x64.device
     ls_u = torch.full((1,), math.log(float(lengthscale)), dtype=torch.float64, device=dev)
     var_u = torch.full((1,), math.log(float(variance)), dtype=torch.float64, device=dev)
-    for jit in (float(jitter), max(float(jitter), 1e-8 * float(variance))):
+    # the jitter is raised in decades up to 1e-4 of the variance before giving up (round 6: a smooth kernel on a dense
+    # lattice is numerically semi-definite, and the fallback for that used to be torch.linalg.cholesky_ex / eigh -
+    # rocSOLVER - on the device; a draw from N(0, K + 1e-4 s^2 I) instead of N(0, K) is white noise 40 dB under the
+    # signal, which the simulator adds by the percent anyway: generate_twod_data.py:77)
+    floor = float(variance)
+    for jit in (float(jitter),) + tuple(max(float(jitter), f * floor) for f in (1e-8, 1e-7, 1e-6, 1e-5, 1e-4)):
         K = o.kmat("rbf", x64, x64, ls_u, var_u, jitter=jit, dtype=torch.float64)
         Linv, _, info = o.chol_inv(K.unsqueeze(0))
         if int(info.item()) == 0:
@@ -84,7 +89,11 @@ def gp_draws(x, n_draws, variance=1.0, lengthscale=1.0, mean=None, jitter=1e-3, 
         x64 = x.to(f64)
         z = torch.randn(n, n_draws, dtype=f64, device=dev, generator=generator)
         f = _exact_draw_hip(x64, z, variance, lengthscale, jitter) if x.is_cuda else None
-        if f is None:  # CPU tensors, or a covariance this package's factorisation flags even with the floor jitter
+        if f is None and x.is_cuda:  # never a vendor solver on the device: the caller picks method="rff" or more jitter
+            raise torch.linalg.LinAlgError(
+                "gp_draws(method='exact'): the covariance is not positive definite even with a jitter of 1e-4 of the "
+                "variance (this package's fp64 factorisation); use method='rff' or a larger jitter")
+        if f is None:  # CPU tensors: plain torch
             K = rbf_covariance(x64, x64, variance, lengthscale)
             K.diagonal().add_(jitter)
             L, info = torch.linalg.cholesky_ex(K)

@@ -67,7 +67,7 @@ def test_kernel_resources():
     by = dict(zip(names, ks))
     assert len(by) > 150
     families = ("panel_mfma_kernel<", "panel_elbo_kernel<", "quad_sym_mfma_kernel<", "gram_mfma_kernel<", "big_quad_kernel<",
-                "big_accum_kernel<", "gram_big_kernel(", "prod_big_kernel(", "whiten_mfma_kernel<", "omega_fwd_dma_kernel(",
+                "big_accum_kernel<", "gram_big_kernel_t<", "prod_big_kernel(", "whiten_mfma_kernel<", "omega_fwd_dma_kernel(",
                 "omega_bwd_dma_kernel(")
     seen = {f: 0 for f in families}
     for nm, k in by.items():
