@@ -222,7 +222,7 @@ def parity_at_bench_size(args, model, dd_cpu, dd, view_idx, Ns):
     loss = model.loss_fn(dd, out[3])
     loss.backward()
     fuse = getattr(model._cache, "fuse", None)
-    exact = bool(model._cache.plan.key[-1])  # (the plan this very forward ran)
+    exact = bool(model._cache.plan.exact)  # (the plan this very forward ran)
     cfg = dict(modality_names=[m], n_views=args.views, n_spatial_dims=2, kernel_warp="rbf", kernel_data="rbf",
                n_latent_gps={m: None}, fixed_view_idx=None)
     ref = orc.evaluate(state, cfg, {m: dd_cpu[m]["spatial_coords"]}, {m: dd_cpu[m]["outputs"]},
@@ -354,6 +354,9 @@ _SMI_SAMPLER = r'''
 import subprocess, sys, time, os
 out, stop, life = sys.argv[1], sys.argv[2], float(sys.argv[3])
 t_end = time.time() + life
+go = stop + ".go"
+while time.time() < t_end and not os.path.exists(go) and not os.path.exists(stop):
+    time.sleep(0.05)  # idle until the sustained run begins: no rocm-smi call lands inside the timed blocks
 with open(out, "w") as f:
     while time.time() < t_end and not os.path.exists(stop):
         t = time.time()
@@ -369,8 +372,9 @@ with open(out, "w") as f:
 
 
 def start_smi_sampler(life_s=900.0):
-    """a child process that asks rocm-smi for the package power and the shader clock four times a second until told to
-    stop; started BEFORE this process touches the GPU (it never does so itself: rocm-smi reads sysfs)"""
+    """a child process that asks rocm-smi for the package power and the shader clock four times a second, from the
+    moment the sustained run begins (a ``.go`` file) until told to stop; started BEFORE this process touches the GPU (it
+    never does so itself: rocm-smi reads sysfs) and idle until then"""
     import subprocess
     import tempfile
 
@@ -630,7 +634,7 @@ def main():
     # the same loop with the inducing-point gradient in the other mode (model.exact_inducing_grad)
     exact_info = None
     if args.workload == "2" and not args.headline_only:
-        timed_exact = bool(model._cache.plan.key[-1])  # (the plan the last timed step ran)
+        timed_exact = bool(model._cache.plan.exact)  # (the plan the last timed step ran)
         saved_mode = model.exact_inducing_grad
         model.exact_inducing_grad = not timed_exact
         try:
@@ -656,6 +660,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if smi is not None:
+            open(smi["stop"] + ".go", "w").close()
         w0 = time.time()
         tb = []
         for b in range(nb_s):

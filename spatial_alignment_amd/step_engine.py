@@ -281,6 +281,7 @@ def get_plan(model, rows, S, test_shapes, want_kl):
         plan = StepPlan(_lib.load(), key, d, (vf, vr))
     plan.mods, plan.V, plan.D, plan.S, plan.L, plan.P, plan.lmc, plan.N = mods, V, D, int(S), L, P, lmc, N
     plan.s_test, plan.n_test, plan.fixed, plan.rows = s_test, n_test, fixed, rows
+    plan.exact, plan.kl_own = bool(exact), own  # (what the plan was built with: bench.py reports the timed mode)
     cache[key] = plan
     return plan
 
@@ -679,11 +680,18 @@ class StepFn(torch.autograd.Function):
             stages = 1 | ((2 | mask) if mask else 0)
             extra = ([y for y in fuse["Y"] if y is not None] + [fuse["noise"]]
                      + [f for f in fuse["F_real"] if f is not None] + [t for t in fuse["FT"] if t is not None])
+        # the numerics word of this forward was read on the first pass: the re-run writes a throwaway device word instead
+        # of the forward's pinned host slot (the two slots alternate, and a LATER forward that owns this one
+        # by now could have its pending non-zero flag overwritten by this re-run's stale 0 before its check reads it)
+        junk = torch.empty(1, dtype=torch.int32, device=dev)
+        flag0 = ctx.io.flag
+        ctx.io.flag = junk.data_ptr() if flag0 else flag0
         call = TO.stash(dict(lib=plan.lib, handle=plan.handle, prm=ctx.prm, io=ctx.io))
         try:
-            torch.ops.gpsa.step_forward(list(tensors), re["ins"] + extra, re["outs"], saved, scratch, call, stages)
+            torch.ops.gpsa.step_forward(list(tensors), re["ins"] + extra + [junk], re["outs"], saved, scratch, call, stages)
         finally:
             TO.CALLS.pop(call, None)
+            ctx.io.flag = flag0
         ctx.arena = saved
         ctx.shared_arena = False
         if fuse is not None:
