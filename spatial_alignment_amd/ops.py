@@ -226,6 +226,19 @@ class HipOps:
         _lib.check(rc, "gpsa_chol_inv_f64")
         return Linv, logdet, info
 
+    def chol_inv_sel(self, A, n_always, keep_lo, keep_hi, Linv=None, logdet=None, info=None):
+        """``chol_inv`` for a SELECTION of the batch in one launch (gpsa_chol_inv_sel_f64; M <= 256): the matrices
+        b < n_always and keep_lo <= b < keep_hi; the other entries of Linv / logdet / info are left as they are"""
+        A = self._c(A)
+        Bn, M = A.shape[0], A.shape[-1]
+        Linv = torch.empty_like(A) if Linv is None else Linv
+        logdet = torch.empty(Bn, dtype=torch.float64, device=A.device) if logdet is None else logdet
+        info = torch.empty(Bn, dtype=torch.int32, device=A.device) if info is None else info
+        rc = self.lib.gpsa_chol_inv_sel_f64(_p(A), _p(Linv), M, Bn, int(n_always), int(keep_lo), int(keep_hi),
+                                            _p(logdet), _p(info), self._stream(A))
+        _lib.check(rc, "gpsa_chol_inv_sel_f64")
+        return Linv, logdet, info
+
     # ------------------------------------------------------------------ quadratic forms
     def _qf_ws(self, alpha, L):
         M, Cn = alpha.shape

@@ -400,6 +400,26 @@ def test_chol_inv_fused(hip, M, B):
     assert float(resid.abs().max()) < 1e-9
 
 
+@pytest.mark.parametrize("M,B,n_always,lo,hi", [(200, 57, 3, 10, 17), (200, 57, 3, 3, 10), (200, 57, 3, 50, 57),
+                                                (64, 9, 1, 4, 4), (240, 6, 2, 3, 5), (200, 12, 0, 5, 9)])
+def test_chol_inv_selection(hip, M, B, n_always, lo, hi):
+    """gpsa_chol_inv_sel_f64: the priors and ONE rank's own range of the batch in one launch (owner computes): the
+    selected entries equal the full call's bit for bit, the others are not touched"""
+    A = rnd(B, M, M, dtype=torch.float64, seed=M + B)
+    K = (A @ A.transpose(1, 2) / M + 0.05 * torch.eye(M, dtype=torch.float64)).to(DEV)
+    full = hip.chol_inv(K)
+    Linv = torch.full_like(K, -7.0)
+    logdet = torch.full((B,), -7.0, dtype=torch.float64, device=DEV)
+    info = torch.full((B,), -7, dtype=torch.int32, device=DEV)
+    hip.chol_inv_sel(K, n_always, lo, hi, Linv, logdet, info)
+    sel = [b for b in range(B) if b < n_always or lo <= b < hi]
+    rest = [b for b in range(B) if b not in sel]
+    for got, want in zip((Linv, logdet, info), full):
+        assert torch.equal(got[sel], want[sel])
+        if rest:
+            assert bool((got[rest] == -7).all())
+
+
 def test_chol_inv_on_covariance_conditioning(hip):
     """K_uu of the warp GP at init (RBF on a grid + 1e-5 jitter, cond ~ 1e7): fp64 residual stays small."""
     g = torch.linspace(0, 10, 15, dtype=torch.float64)
