@@ -289,6 +289,21 @@ def measure_traffic(args):
         return dict(error=f"{type(e).__name__}: {e}"[:300])
 
 
+def split_bf16_experiment():
+    """EXPLORATORY extra (never the headline; the timed dtype stays f32): the three-way bf16 split of the fp32 contraction
+    - kernel-level parity of real v_mfma_f32_16x16x32_bf16 products against fp64 and the loop-level rate against the
+    fp32 loop (tools/split_bf16_parity.py, a child process)"""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "split_bf16_parity.py"), "--json"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(last[-1]) if last else dict(error=f"rc={r.returncode}", stderr=r.stderr[-300:])
+    except Exception as e:  # noqa: BLE001
+        return dict(error=f"{type(e).__name__}: {e}"[:300])
+
+
 def extra_workload(which, args):
     """the JSON line of ``bench.py --workload which`` (a child process: nothing it does can take the contract line down),
     cut to what the default line carries for it"""
@@ -903,6 +918,7 @@ def main():
             # BASELINE configs 1 and 3 on this GPU, each as a child process running this file with --workload
             line["config1"] = extra_workload("1", args)
             line["config3"] = extra_workload("3", args)
+            line["split_bf16_experiment"] = split_bf16_experiment()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

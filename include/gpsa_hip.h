@@ -115,6 +115,19 @@ long long gpsa_chol_inv_blocked_workspace(int M, int batch);
 int gpsa_chol_inv_blocked_f64(const void* A, void* Linv, int M, int batch, void* logdet, int* info,
                               void* workspace, long long workspace_bytes, void* stream);
 
+/* ---- EXPERIMENT (not on the product path, never the timed step; csrc/split_bf16.hip) ------------------------------
+ * The contraction W_l = Omega_l alpha of vgpsa.py:192-196 with every fp32 operand written as a sum of bf16 pieces and
+ * the product as bf16 matrix instructions accumulated in fp32 (fp32 MFMA is 1/16 of the bf16 rate on gfx950):
+ *   nprod 6: three pieces, the six products a_i b_j with i + j <= 4;  4: two pieces, four products;  3: two pieces
+ *   without a2 b2;  1: plain bf16 operands;  0: the fp32 instruction on the same tiling (comparison).
+ * Omega [L,M,M], alpha [M,C], W [L,M,C] fp32.  A plain kernel (operands from global memory): numerics, not speed.
+ * gpsa_experiment_split_bf16_rate: the MFMA + LDS-fragment-read loop of the fused ELBO kernel's tile (13 x 2
+ * accumulators, ``outputs`` outputs per workgroup, 256 workgroups) in fp32 (nprod 0) or split form (6 / 4 / 3); the
+ * caller times it; out >= 65536 floats. */
+int gpsa_experiment_split_bf16_product(const float* Omega, const float* alpha, int M, long long C, int L, int nprod,
+                                       float* W, void* stream);
+int gpsa_experiment_split_bf16_rate(int nprod, int outputs, float* out, void* stream);
+
 /* ---- the dominant contraction: variational variance term --------------------------------------
  * v[l,c] = alpha[:,c]^T Omega[l] alpha[:,c]            (vgpsa.py:192-196 a_t_Omega_tril, square, sum;
  *                                                        Omega_tril Omega_tril^T == Omega exactly)

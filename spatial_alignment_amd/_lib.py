@@ -30,6 +30,8 @@ SIGNATURES = {
     "gpsa_chol_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "gpsa_tri_inv_f64": (_i, [_vp, _vp, _i, _i, _vp]),
     "gpsa_chol_inv_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "gpsa_experiment_split_bf16_product": (_i, [_vp, _vp, _i, _ll, _i, _i, _vp, _vp]),
+    "gpsa_experiment_split_bf16_rate": (_i, [_i, _i, _vp, _vp]),
     "gpsa_chol_inv_sel_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gpsa_chol_inv_blocked_workspace": (_ll, [_i, _i]),
     "gpsa_chol_inv_blocked_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _ll, _vp]),
