@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 SIDE = 20  # (the overlap variants run a larger grid: the early order needs the long-K kernel, i.e. >= 1536 spots a shard)
 
 
-def _problem(dev, side=None):
+def _problem(dev, side=None, m=25):
     from spatial_alignment_amd.synthetic import make_grid_problem, make_model
 
     dd = make_grid_problem(side=side or SIDE, n_views=2, n_outputs=6)
-    model = make_model(dd, m=25, device=dev)
+    model = make_model(dd, m=m, device=dev)
     dd = {m: {"spatial_coords": d["spatial_coords"].to(dev), "outputs": d["outputs"].to(dev),
               "n_samples_list": d["n_samples_list"]} for m, d in dd.items()}
     return dd, model
@@ -335,23 +335,24 @@ def test_overlapped_reducer_declines_what_it_cannot_vouch_for(case):
         assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(a), 1e-6), (k, np.linalg.norm(a - b), np.linalg.norm(a))
 
 
-@pytest.mark.parametrize("fuse", [False, True])
-def test_owner_computes_world8_summed_equals_full_step(fuse):
+@pytest.mark.parametrize("fuse,world,m", [(False, 8, 25), (True, 8, 25), (False, 3, 300)])
+def test_owner_computes_world8_summed_equals_full_step(fuse, world, m):
     """an emulated world of 8 on one device: rank r's row shard with ITS range of the KL terms (owner computes), the
-    eight losses and gradients summed by hand - what the all-reduce does - equal the full step's to rounding"""
+    eight losses and gradients summed by hand - what the all-reduce does - equal the full step's to rounding.
+    (m = 300: the blocked factorisation beyond the single-launch kernels - two launch sequences, priors and own range)"""
     import __graft_entry__ as ge
     from spatial_alignment_amd.parallel import shard_data_dict, shard_rows
 
     ge.build()
     dev = torch.device("cuda:0")
-    world, n = 8, SIDE * SIDE
+    n = SIDE * SIDE
     eG, eF = _noise()
-    dd, model = _problem(dev)
+    dd, model = _problem(dev, m=m)
     loss1 = _grads(model, dd, eG, eF, 1.0)
     want = {k: p.grad.detach().double().clone() for k, p in model.named_parameters()}
     tot, acc = 0.0, {k: torch.zeros_like(v) for k, v in want.items()}
     for r in range(world):
-        dd_r, model_r = _problem(dev)  # (same seed: the same parameters on every "rank")
+        dd_r, model_r = _problem(dev, m=m)  # (same seed: the same parameters on every "rank")
         sdd = shard_data_dict(dd_r, r, world)
         lo, hi = shard_rows(n, r, world)
         rows = torch.cat([torch.arange(lo, hi), n + torch.arange(lo, hi)])
