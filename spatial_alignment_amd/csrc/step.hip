@@ -906,6 +906,17 @@ static inline int splitk_small(long long k, int m, int n, int batch) {  // ops.H
   return 1;
 }
 
+// the same rule for the handful of priors' products of the KL backward (0.5 K^-1 S K^-1: two dependent M x M x M
+// products, batch = the number of priors): 48 workgroups with a 13-step K loop each were 21.5 us apiece at M = 200
+static inline int splitk_few(long long k, int m, int n, int batch) {
+  static const bool on = [] { const char* e = getenv("GPSA_SPLITK_FEW"); return !(e && e[0] == '0'); }();
+  if (on && batch <= 4 && k >= 128 && k <= 1024 && cdiv(m, 64) * cdiv(n, 64) * batch <= 64) {
+    int s = (int)(k / 48);
+    return s > 4 ? 4 : (s < 1 ? 1 : s);
+  }
+  return splitk_small(k, m, n, batch);
+}
+
 struct Ctx {
   Plan& P;
   const gpsa_step_params& prm;
@@ -1989,9 +2000,9 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
                                            c.sv<double>(G.o_D), c.sv<double>(G.o_KD), og.dkl + G.kl_off, G.M, G.n_omega,
                                            G.n_prior, B.dstack[g] + (long long)G.n_prior * mm, B.dD[g], S, 1, c.stv()));
       GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 1.0, c.inv(G, 0), G.M, mm, S, G.M, mm, 0.0, T1, G.M, mm, G.n_prior,
-                     splitk_small(G.M, G.M, G.M, G.n_prior)));
+                     splitk_few(G.M, G.M, G.M, G.n_prior)));
       GPSA_CK(gemm64(c, 0, 0, G.M, G.M, G.M, 0.5, T1, G.M, mm, c.inv(G, 0), G.M, mm, 1.0, B.dstack[g], G.M, mm, G.n_prior,
-                     splitk_small(G.M, G.M, G.M, G.n_prior)));
+                     splitk_few(G.M, G.M, G.M, G.n_prior)));
       sc.release(mk);
     }
     return 0;
