@@ -1040,7 +1040,12 @@ long long gpsa_quadform_keep_f32_workspace(int M, int L) {
   if (M < 1 || L < 1) return 0;
   if (keep_mfma_path(M)) {
     const int MB = gpsa::mfma_mb_for(M);
-    return (long long)L * MB * 16 * MB * 16 * 4;
+    // + four chunks of slack behind the packed operand (round 6): the staging ring of the panel kernels keeps
+    // requesting chunks behind a workgroup's last one until its loop ends (values it never multiplies); for the
+    // workgroup that owns the LAST chunk those requests used to leave the workspace - a device fault when the
+    // workspace happened to end at a mapping boundary (found by tools/fuzz_kernels.py through the raw C ABI; inside the
+    // step engine the bytes behind it were the arena's own).  The sibling workspaces have their slabs there.
+    return (long long)L * MB * 16 * MB * 16 * 4 + 4LL * MB * 16 * 16 * 4;
   }
   return (long long)L * M * ((M + 15) / 16 * 16) * 4 + 256;  // fp32 copy of Omega, contraction index padded to 16
 }

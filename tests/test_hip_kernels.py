@@ -726,3 +726,18 @@ def test_mvn_kl_fwd_bwd(hip, M, L, strided):
     want = FK.mvn_kl_bwd(K, Kinv, Om_all[sel], Oinv_all[sel], Dm, rKD, g)
     for a, b in zip(got, want):
         close(a, b, 1e-10)
+
+
+def test_kept_products_stay_inside_their_workspace():
+    """round 6 (found by tools/fuzz_kernels.py): the panel kernels' staging ring kept requesting chunks behind the
+    packed operand's last one; with the workspace at the very end of its device allocation that was a memory fault.
+    tools/keep_probe.py puts it there (a child process per shape: a fault would take the process down)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "keep_probe.py"), "--quick"], capture_output=True,
+                       text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("M=")]
+    assert len(lines) == 3 and all(ln.endswith("rc=0 ok") for ln in lines), (r.stdout[-600:], r.stderr[-300:])
