@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, (MB * NCT >= 14) ? 1 : 2) panel_elbo_kern
       sp = Ppk + (long long)sa_ * MB * CHUNK + lane * 4;                                       \
       srem = (sb_ - sa_ + 1) * MB;                                                             \
     } else {                                                                                   \
-      srem = 0x7fffffff; /* nothing left: the surplus stages re-read the last chunk */         \
+      srem = 0x7fffffff; /* nothing left: the surplus stages walk on BEHIND the last chunk (up to AHEAD chunks, never multiplied: every workspace holds slabs or slack there) */         \
     }                                                                                          \
   }
 #define GPSA_STAGE_NEXT(BUF)                                                                   \

@@ -89,7 +89,7 @@ panel_mfma_kernel(const float* __restrict__ Ppk,  // [L][MB][MP][16]
       sp = Ppk + (long long)sa_ * MB * CHUNK + lane * 4;                                       \
       srem = (sb_ - sa_ + 1) * MB;                                                             \
     } else {                                                                                   \
-      srem = 0x7fffffff; /* nothing left: the surplus stages re-read the last chunk */         \
+      srem = 0x7fffffff; /* nothing left: the surplus stages walk on BEHIND the last chunk (up to AHEAD chunks, never multiplied: every workspace holds slabs or slack there) */         \
     }                                                                                          \
   }
 #define GPSA_STAGE_NEXT(BUF)                                                                   \
