@@ -304,6 +304,29 @@ def split_bf16_experiment():
         return dict(error=f"{type(e).__name__}: {e}"[:300])
 
 
+def emulated_shards(args):
+    """EXTRA, one GPU: rank 0's share of a K-way row sharding (``--emulate-shard K``: the rank's rows, its own range of
+    the KL terms, no all-reduce) for K = 2, 4, 8 - a child process each.  Not a scaling measurement (no second device,
+    no collective): it is the per-rank step time a K-GPU run would have BEFORE its all-reduce, i.e. an upper bound on
+    what the sharding can give."""
+    import subprocess
+
+    out = {}
+    for k in (2, 4, 8):
+        cmd = [sys.executable, os.path.abspath(__file__), "--headline-only", "--blocks", "3", "--emulate-shard", str(k),
+               "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(last[-1]) if last else None
+            out[str(k)] = dict(ms_per_step=d["ms_per_step"]) if d else dict(error=f"rc={r.returncode}")
+        except Exception as e:  # noqa: BLE001
+            out[str(k)] = dict(error=f"{type(e).__name__}: {e}"[:200])
+    out["note"] = ("rank 0's share of a K-way row sharding on ONE GPU, no all-reduce: per-rank step time before the "
+                   "collective, not a scaling measurement")
+    return out
+
+
 def extra_workload(which, args):
     """the JSON line of ``bench.py --workload which`` (a child process: nothing it does can take the contract line down),
     cut to what the default line carries for it"""
@@ -919,6 +942,11 @@ def main():
             line["config1"] = extra_workload("1", args)
             line["config3"] = extra_workload("3", args)
             line["split_bf16_experiment"] = split_bf16_experiment()
+            es = emulated_shards(args)
+            for k in ("2", "4", "8"):
+                if "ms_per_step" in es.get(k, {}):
+                    es[k]["step_time_ratio_vs_1"] = line["ms_per_step"] / es[k]["ms_per_step"]
+            line["emulated_shards"] = es
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
