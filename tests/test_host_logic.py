@@ -244,3 +244,56 @@ def test_reference_import_lines_resolve():
     assert ns["rbf_kernel"] is pkg.rbf_kernel  # the plug-in identity the fused path recognises
     with pytest.raises(NotImplementedError, match="out of scope"):
         ns["callback_twod"](None, None, None)
+
+
+def test_kl_owner_ranges_partition_the_terms():
+    """parallel.own_kl_terms / step_engine.kl_own_range: over the ranks of any world the ranges are contiguous, disjoint
+    and cover the V*D + sum L terms; a world of one (or no owner) means every term"""
+    import types
+
+    from spatial_alignment_amd import step_engine as SE
+
+    for V, D, Ls in ((2, 2, [50]), (3, 1, [5, 7]), (8, 2, [2000]), (2, 2, [1])):
+        n = V * D + sum(Ls)
+        m = types.SimpleNamespace(n_views=V, n_spatial_dims=D, modality_names=[f"m{i}" for i in range(len(Ls))],
+                                  n_latent_outputs={f"m{i}": L for i, L in enumerate(Ls)}, kl_owner=None)
+        assert SE.kl_own_range(m) is None
+        m.kl_owner = (0, 1)
+        assert SE.kl_own_range(m) is None
+        for world in (2, 3, 8, n, n + 3):
+            edge, sizes = 0, []
+            for r in range(world):
+                m.kl_owner = (r, world)
+                lo, hi = SE.kl_own_range(m)
+                if hi > lo and (lo, hi) != (n, n):
+                    assert lo == edge
+                    edge = hi
+                    sizes.append(hi - lo)
+                else:  # more ranks than terms: the ranks left over own the empty range [n, n)
+                    assert (lo, hi) == (n, n) and hi > 0
+            assert edge == n and max(sizes) - min(sizes) <= 1
+
+
+def test_bench_smi_sample_parsing(tmp_path):
+    """bench.py's ``sustained`` leg: the rocm-smi sampler's lines inside the run's window -> clock and power statistics"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = tmp_path / "samples.tsv"
+    line = ("GPU[0]\t\t: sclk clock level: 1: (%dMhz) | ===== Power Consumption ===== | "
+            "GPU[0]\t\t: Current Socket Graphics Package Power (W): %.1f")
+    out.write_text("".join("%.3f\t%s\n" % (t, line % (c, p)) for t, c, p in
+                           ((5.0, 2100, 300.0), (10.2, 2390, 990.0), (10.7, 2394, 1010.0), (20.0, 2000, 200.0))))
+
+    class P:
+        def wait(self, timeout=None):
+            return 0
+
+    res = bench.stop_smi_sampler(dict(proc=P(), out=str(out), stop=str(tmp_path / "stop")), 10.0, 11.0)
+    assert res["samples"] == 2
+    assert res["sclk_mhz"] == dict(min=2390, mean=2392.0, max=2394)
+    assert res["power_w"] == dict(min=990.0, mean=1000.0, max=1010.0)
