@@ -926,9 +926,9 @@ def main():
             "sustained": sustained,
             "graph_replay": graph_info,
         }
-        if not args.no_cpu_baseline:
-            if world > 1:  # (the launcher hands each rank 1/N of the host threads: take what a 1-GPU run uses)
-                torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+        # (the CPU leg runs at N = 1 only: at N > 1 the other ranks would sit in the process group's teardown for the
+        #  ~45 s rank 0 spends on the host, and the figure would not differ)
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, state, dd_full)
             if emu == 1 and world == 1 and args.workload == "2":
                 try:
