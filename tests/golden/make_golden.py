@@ -310,6 +310,28 @@ def main():
         n_latent_gps={"expression": None}, kernel_warp="rbf", kernel_data="rbf",
         fixed_view_idx=0,
     )
+    # round 6: unequal view sizes with TWO fixed views given as a list (vgpsa.py:230-234, 262-273), Matern-1/2 data
+    # kernel, S = 1 (forward's default)
+    X, Y, ns = recipes.grid_views(side=8, n_views=4, n_out=5, seed=20)
+    keep = [64, 50, 57, 40]
+    rows = np.concatenate([np.arange(v * 64, v * 64 + k) for v, k in enumerate(keep)])
+    cases["c10_unequal_two_fixed"] = dict(
+        mods=["expression"], X={"expression": X[rows]}, Y={"expression": Y[rows]},
+        n_samples={"expression": keep}, m_X=12, m_G=13, S=1, seed=10,
+        n_latent_gps={"expression": None}, kernel_warp="rbf", kernel_data="matern12",
+        fixed_view_idx=[0, 2],
+    )
+    # round 6: LMC + G_test with two test samples (the 6-tuple of vgpsa.py:437-489) on unequal views, Matern-3/2 warp
+    X, Y, ns = recipes.grid_views(side=9, n_views=2, n_out=9, seed=21)
+    keep = [81, 60]
+    rows = np.concatenate([np.arange(v * 81, v * 81 + k) for v, k in enumerate(keep)])
+    gt = np.random.default_rng(210).uniform(0, 10, size=(2, 11, 2)).astype(np.float32)
+    cases["c11_lmc_gtest_unequal"] = dict(
+        mods=["expression"], X={"expression": X[rows]}, Y={"expression": Y[rows]},
+        n_samples={"expression": keep}, m_X=14, m_G=12, S=3, seed=11,
+        n_latent_gps={"expression": 3}, kernel_warp="matern32", kernel_data="rbf",
+        fixed_view_idx=None, G_test={"expression": gt},
+    )
     # conditioning study: M=200 (warp-GP K_uu cond ~ 2e7), parameters from a seeded recipe
     rc = dict(side=50, n_views=2, n_out=4, seed=18, m=200, state_seed=180)
     X, Y, ns = recipes.grid_views(side=rc["side"], n_views=2, n_out=rc["n_out"], seed=rc["seed"])
