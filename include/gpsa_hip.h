@@ -421,6 +421,14 @@ int gpsa_kmat_bwd_x64_axpy(int kind, const float* Z, int M, const double* X, lon
  * GP keeps both (gpsa_step_desc.exact_inducing_grad; autograd of vgpsa.py:177-180, 409) */
 int gpsa_whiten_f64_dual(const double* Kinv, const double* Kuf, int M, long long C, double* alpha64, float* alpha32,
                          double* q, void* workspace, long long workspace_bytes, void* stream);
+
+/* gpsa_whiten_f64_dual with K_uf[m, c] = k(Z_m, x_c) formed inside the projection kernel (Z [M,D] fp32, X64 [C,D]
+ * fp64, log-parameters fp32: what gpsa_kmat(GPSA_F64, GPSA_F32_X64, ...) evaluates) - vgpsa.py:171-189 in one pass,
+ * no K_uf in memory.  GPSA_EUNSUPPORTED for shapes the persistent kernel does not take (the caller then runs
+ * gpsa_kmat + gpsa_whiten_f64_dual; GPSA_PROJ64_GEN=0 forces that). */
+int gpsa_whiten_gen_f64_dual(const double* Kinv, int kind, const float* Z, const double* X64, int D, const float* ls_u,
+                             const float* var_u, int M, long long C, double* alpha64, float* alpha32, double* q,
+                             void* workspace, long long workspace_bytes, void* stream);
 /* gpsa_whiten_f64 on an fp32 panel with gpsa_col_axpy fused into its store:
  *   out[m,c] = (Kinv X)[m,c] + s * d[c] * X2[m,c]      (X, X2, out [M,C] fp32; d [C] fp32; fp64 arithmetic)
  * the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) in one pass. */

@@ -48,5 +48,9 @@ bool proj64_ok(int MB, long long C, int batch);
 template <typename TI>
 int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, double* alpha, float* out32, double* q,
                   int batch, long long sX, hipStream_t st, bool q_zeroed);
+// the same with the right-hand side K_uf[m, c] = k(Z_m, x_c) formed inside the kernel (round 6)
+int proj64_gen_launch(int MB, const double* Apk, int kind, const float* Z, const double* X64, int D, const float* ls_u,
+                      const float* var_u, int M, long long C, double* alpha, float* out32, double* q, hipStream_t st,
+                      bool q_zeroed);
 
 }  // namespace gpsa

@@ -18,6 +18,7 @@
 // One barrier per stage; the only vmcnt wait is a vmcnt(0) between a stage's last MFMA and its stores, when everything
 // older (the next stage's pieces, the previous stage's stores) has been in flight for a whole stage.
 #include "internal.hpp"
+#include "kmat_cov.hpp"
 
 #include <stdlib.h>
 
@@ -37,6 +38,12 @@ struct ProjArgs {
   int M, T;           // T = column tiles of 64 per problem
   int dbg;            // timing experiments (GPSA_PROJ64_SKIP; results are then wrong): 1 no stores, 2 one slab load per
                       // workgroup, 4 no LDS-DMA after the first stage, 8 no barrier / vmcnt wait
+  // GEN (round 6): the right-hand side is not read but FORMED - K_uf[m, c] = k(Z_m, x_c) as the wave loads its 16
+  // columns: the covariance launch in front (kmat_fwd: C M doubles written, then read back here) disappears
+  const float* gZ;    // [M][gD] inducing points (fp32 parameters)
+  const double* gX;   // [C][gD] points (the warp GPs' unrounded draws)
+  const float *g_ls, *g_var;  // log lengthscale, log variance
+  int gD;
 };
 
 template <int IMM>
@@ -61,7 +68,7 @@ __host__ __device__ constexpr int proj_pos(int p) {
   return proj_wave_start<NPIECE>(p & 3) + (p >> 2);
 }
 
-template <int MB, typename TI, int OCC>
+template <int MB, typename TI, int OCC, int GEN = 0>  // GEN: 0 = read X; 1 + GPSA_K_* = form K_uf from (gZ, gX)
 __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
   constexpr int NF = 4 * MB;             // 512-byte fragments of a stage: f = 4 kc + ks
   constexpr int NPIECE = NF / 2;         // 1-KiB pieces
@@ -69,6 +76,7 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
   constexpr int SLOT = NF * 64;          // doubles per ring slot
   constexpr long long PB = (long long)MB * 4 * MB * 64 * 8;  // bytes of one packed inverse
   __shared__ __attribute__((aligned(16))) double lds[2][SLOT];
+  __shared__ double Zs[GEN ? MB * 16 : 1][MAXD];  // GEN: the inducing points (rows >= M repeat row M - 1: any finite value)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,6 +122,17 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
   }
   GPSA_PJ_STAGE(rt, b, 0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  double g_ell = 1.0, g_inv_ell = 1.0, g_var = 1.0;
+  if (GEN) {
+    for (int i = tid; i < MB * 16 * MAXD; i += 256) {
+      const int r = i / MAXD, d = i % MAXD;
+      Zs[r][d] = d < a.gD ? (double)a.gZ[(long long)(r < M ? r : M - 1) * a.gD + d] : 0.0;
+    }
+    g_ell = exp((double)a.g_ls[0]);
+    g_inv_ell = 1.0 / g_ell;
+    g_var = exp((double)a.g_var[0]);
+    // (the loop's first barrier publishes Zs before any wave forms a slab)
+  }
 
   double slab[MB][4];  // the wave's 16 columns of the right-hand side: slab[kc][ks] = X[16 kc + 4 ks + kq][c]
   double s = 0.0;      // this segment's share of q[c]
@@ -144,6 +163,19 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
       // columns (any finite value does), a column >= C computes on column 0 and is never stored.  (A select on the
       // loaded value lets the compiler sink every load into its own branch with a vmcnt(0) behind it; offsets that are
       // loop-invariant get hoisted into 104 registers and spilled - hence the opaque copies of M and C.)
+      if (GEN) {
+        double x[MAXD];
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d) x[d] = d < a.gD ? a.gX[(okc ? c : 0) * a.gD + d] : 0.0;
+#pragma unroll
+        for (int kc = 0; kc < MB; ++kc)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            double k, cd, pl;
+            cov_eval<double, (GEN ? GEN - 1 : 0)>(Zs[16 * kc + 4 * ks + kq], x, a.gD, g_ell, g_inv_ell, g_var, k, cd, pl);
+            slab[kc][ks] = k;
+          }
+      } else {
       const TI* xp = Xb + (okc ? c : 0);
       int Mv = M;
       long long Cv = C;
@@ -155,6 +187,7 @@ __global__ void __launch_bounds__(256, OCC) proj64_kernel(ProjArgs a) {
           const int row = 16 * kc + 4 * ks + kq;
           slab[kc][ks] = (double)xp[(long long)(row < Mv ? row : Mv - 1) * Cv];
         }
+      }
       s = 0.0;
       seg_rt0 = rt;
     }
@@ -286,6 +319,7 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
   a.U = (long long)batch * a.T * MB;
   static const int dbg = [] { const char* e = getenv("GPSA_PROJ64_SKIP"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
+  a.gZ = nullptr; a.gX = nullptr; a.g_ls = a.g_var = nullptr; a.gD = 0;
   // at least MB units per workgroup: a column tile (MB consecutive units) then meets at most two workgroups
   // workgroups per CU: three for the fp32 right-hand side (168 registers), two for the fp64 one (its three-per-CU
   // instantiation spills five registers; measured equal: LAB_NOTES); GPSA_PROJ64_OCC = 1 / 2 / 3 forces one
@@ -312,6 +346,56 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
       break;
     default: return GPSA_EUNSUPPORTED;
   }
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+// alpha = Kinv K_uf with K_uf[m, c] = k(Z_m, x_c) formed inside the kernel (one problem; the data GP's forward)
+int proj64_gen_launch(int MB, const double* Apk, int kind, const float* Z, const double* X64, int D, const float* ls_u,
+                      const float* var_u, int M, long long C, double* alpha, float* out32, double* q, hipStream_t st,
+                      bool q_zeroed) {
+  if (D < 1 || D > MAXD) return GPSA_EUNSUPPORTED;
+  ProjArgs a;
+  a.Apk = Apk;
+  a.X = nullptr;
+  a.alpha = alpha;
+  a.out32 = out32;
+  a.q = q;
+  a.C = C;
+  a.sX = 0;
+  a.M = M;
+  a.T = (int)cdiv(C, 64);
+  a.U = (long long)a.T * MB;
+  a.dbg = 0;
+  a.gZ = Z;
+  a.gX = X64;
+  a.g_ls = ls_u;
+  a.g_var = var_u;
+  a.gD = D;
+  long long grid = 2LL * num_cus();  // (three workgroups per CU do not fit: 60 KB of LDS each with the inducing points)
+  if (grid > a.T) grid = a.T;
+  if (q != nullptr && !q_zeroed) {
+    hipError_t e = hipMemsetAsync(q, 0, (size_t)(C * 8), st);
+    if (e != hipSuccess) return (int)e;
+  }
+#define GPSA_PJG(MB_, K_)                                                             \
+  case K_:                                                                            \
+    proj64_kernel<MB_, double, 2, 1 + K_><<<(unsigned)grid, 256, 0, st>>>(a);         \
+    break;
+  if (MB == 13) {
+    switch (kind) {
+      GPSA_PJG(13, GPSA_K_RBF) GPSA_PJG(13, GPSA_K_MATERN12) GPSA_PJG(13, GPSA_K_MATERN32)
+      default: return GPSA_EUNSUPPORTED;
+    }
+  } else if (MB == 7) {
+    switch (kind) {
+      GPSA_PJG(7, GPSA_K_RBF) GPSA_PJG(7, GPSA_K_MATERN12) GPSA_PJG(7, GPSA_K_MATERN32)
+      default: return GPSA_EUNSUPPORTED;
+    }
+  } else {
+    return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_PJG
   GPSA_LAUNCH_CHECK();
   return 0;
 }

@@ -1313,6 +1313,20 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
   {
     const long long mk2 = c.sc.mark();
     double* Kuf = c.sc.get<double>((long long)Mg * C);
+    const long long wsb = gpsa_whiten_workspace(Mg);
+    const bool exact = ps.o_alpha64 >= 0;  // the unrounded projection stays for the backward
+    // long panels of the training pass: K_uf formed inside the projection kernel, never in memory (the scratch above
+    // stays reserved: the plan's dry run cannot know whether the shape is taken)
+    bool fused = false;
+    if (!ps.test && exact && wsb > 0 && !dry) {
+      if (c.sc.overflow) return GPSA_EWORKSPACE;
+      const int rc = gpsa_whiten_gen_f64_dual(c.apk_d ? nullptr : Kinv, P.d.kind_data, c.prm.Gtilde,
+                                              c.sv<double>(P.o_G64[m]), D, c.prm.data_ls, c.prm.data_var, Mg, C,
+                                              c.sv<double>(ps.o_alpha64), alpha, q, c.sv<char>(P.o_apk_d), wsb, c.stv());
+      if (rc == 0) fused = true, c.apk_d = true;
+      else if (rc != GPSA_EUNSUPPORTED) return rc;
+    }
+    if (!fused) {
     // covariance on the warp GP's UNROUNDED draws (fp64), fp32 parameters as stored; G_test is the caller's fp32
     if (ps.test)
       GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D, c.prm.data_ls,
@@ -1320,8 +1334,6 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
     else
       GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32_X64, P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D,
                          c.prm.data_ls, c.prm.data_var, 0.0, Kuf, c.stv()));
-    const long long wsb = gpsa_whiten_workspace(Mg);
-    const bool exact = ps.o_alpha64 >= 0;  // the unrounded projection stays for the backward
     if (wsb > 0 && !exact) {  // the packed inverse stays in the saved arena: later passes and the backward reuse it
       void* ws = c.sv<char>(P.o_apk_d);
       GPSA_RUN(gpsa_whiten_f64(c.apk_d ? nullptr : Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb, c.stv()));
@@ -1341,6 +1353,7 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
             a64, (long long)Mg * C, alpha);
         GPSA_LAUNCH_CHECK();
       }
+    }
     }
     c.sc.release(mk2);
   }

@@ -397,6 +397,34 @@ int gpsa_whiten_f64_dual(const double* Kinv, const double* Kuf, int M, long long
   return whiten_launch<double, double>(MB, Apk, Kuf, M, C, alpha64, q, st, 1, 0, ax, qz != nullptr);
 }
 
+/* gpsa_whiten_f64_dual with the right-hand side FORMED inside the projection kernel instead of read:
+ *   K_uf[m, c] = k(Z_m, x_c)   (kind: GPSA_K_*; Z [M,D] fp32, X64 [C,D] fp64, log-parameters fp32 - exactly what
+ *   gpsa_kmat(GPSA_F64, GPSA_F32_X64, ...) evaluates, the same device function in the same precision)
+ * so the covariance launch in front and its C*M doubles written and read back disappear (vgpsa.py:171-189: Kuf and
+ * the product with Kuu^-1 in one pass).  GPSA_EUNSUPPORTED when the persistent kernel does not take the shape (short
+ * panels, M beyond 208, D > 4) or GPSA_PROJ64_GEN=0: the caller then runs gpsa_kmat + gpsa_whiten_f64_dual. */
+int gpsa_whiten_gen_f64_dual(const double* Kinv, int kind, const float* Z, const double* X64, int D, const float* ls_u,
+                             const float* var_u, int M, long long C, double* alpha64, float* alpha32, double* q,
+                             void* workspace, long long workspace_bytes, void* stream) {
+  using namespace gpsa;
+  if (M < 1 || C < 1 || !Z || !X64 || !ls_u || !var_u || alpha64 == nullptr || alpha32 == nullptr) return GPSA_EINVAL;
+  static const bool off = [] { const char* e = getenv("GPSA_PROJ64_GEN"); return e && e[0] == '0'; }();
+  const int MB = whiten_mb_for(M);
+  if (off || MB == 0 || D < 1 || D > MAXD || !proj64_ok(MB, C, 1)) return GPSA_EUNSUPPORTED;
+  if (kind != GPSA_K_RBF && kind != GPSA_K_MATERN12 && kind != GPSA_K_MATERN32) return GPSA_EINVAL;
+  if (workspace_bytes < gpsa_whiten_workspace(M)) return GPSA_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* Apk = (double*)workspace;
+  const long long tot = (long long)MB * 4 * MB * 64;
+  double* qz = nullptr;
+  if (Kinv != nullptr) {
+    qz = pack_zeroes_q(MB, C, 1, q, true, false);
+    pack_whiten_kernel<<<(unsigned)cdiv(tot, 256), 256, 0, st>>>(Kinv, M, MB, Apk, 0, qz, C);
+    GPSA_LAUNCH_CHECK();
+  }
+  return proj64_gen_launch(MB, Apk, kind, Z, X64, D, ls_u, var_u, M, C, alpha64, alpha32, q, st, qz != nullptr);
+}
+
 /* gamma = Kinv X (fp32 panel, fp64 arithmetic) with the column-scaled update fused into the store:
  *   out[m,c] = (Kinv X)[m,c] + s * d[c] * X2[m,c]      (X, X2, out [M,C] fp32; d [C] fp32)
  * the data GP's dK_uf = K^-1 abar + 2 qbar o alpha (autograd of vgpsa.py:177-196) in one pass.

@@ -614,6 +614,50 @@ def test_whiten_f64_mfma(hip, out_dtype, M, C):
     close(q3, rq3, 1e-13)
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32"])
+@pytest.mark.parametrize("M,C,D", [(200, 100000, 2), (197, 98403, 1), (100, 98500, 3), (120, 100001, 2)])
+def test_whiten_gen_forms_the_same_projection(hip, kind, M, C, D):
+    """K_uf formed INSIDE the projection kernel (gpsa_whiten_gen_f64_dual, the headline step's data-GP forward) against
+    the two launches it replaces (gpsa_kmat fp64 on fp64 points + gpsa_whiten_f64_dual): the same device function in
+    the same precision feeds the same matrix instructions - bit-equal alpha (both copies) and q."""
+    from spatial_alignment_amd import _lib
+    f64, lib = torch.float64, hip.lib
+    Z, X = (rnd(M, D) * 3.0).to(DEV), (rnd(C, D, dtype=f64, seed=1) * 3.0).to(DEV)
+    ls, var = torch.tensor([0.3], device=DEV), torch.tensor([-0.2], device=DEV)
+    Kinv = rnd(M, M, dtype=f64, seed=2)
+    Kinv = (Kinv + Kinv.t()).to(DEV)
+    st = hip._stream(X)
+    wsb = lib.gpsa_whiten_workspace(M)
+    kid = {"rbf": 0, "matern12": 1, "matern32": 2}[kind]
+    Kuf = torch.empty(M, C, dtype=f64, device=DEV)
+    assert lib.gpsa_kmat(1, 2, kid,  # (GPSA_F64, GPSA_F32_X64)
+                         Z.data_ptr(), M, X.data_ptr(), C, D, ls.data_ptr(),
+                         var.data_ptr(), 0.0, Kuf.data_ptr(), st) == 0
+    out = []
+    for gen in (False, True):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        a64, a32 = torch.full((M, C), float("nan"), dtype=f64, device=DEV), torch.full((M, C), float("nan"), device=DEV)
+        q = torch.full((C,), float("nan"), dtype=f64, device=DEV)
+        if gen:
+            rc = lib.gpsa_whiten_gen_f64_dual(Kinv.data_ptr(), kid, Z.data_ptr(), X.data_ptr(), D, ls.data_ptr(),
+                                              var.data_ptr(), M, C, a64.data_ptr(), a32.data_ptr(), q.data_ptr(),
+                                              ws.data_ptr(), wsb, st)
+        else:
+            rc = lib.gpsa_whiten_f64_dual(Kinv.data_ptr(), Kuf.data_ptr(), M, C, a64.data_ptr(), a32.data_ptr(),
+                                          q.data_ptr(), ws.data_ptr(), wsb, st)
+        assert rc == 0
+        out.append((a64, a32, q))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    ra, rq = FK.whiten(Kinv.cpu(), FK.kmat(kind, Z.cpu().double(), X.cpu(), ls.cpu().double(), var.cpu().double()), f64)
+    close(out[1][0], ra, 1e-9)
+    close(out[1][2], rq, 1e-9)
+    # short panels are declined (the caller keeps the two launches)
+    assert lib.gpsa_whiten_gen_f64_dual(Kinv.data_ptr(), kid, Z.data_ptr(), X.data_ptr(), D, ls.data_ptr(),
+                                        var.data_ptr(), M, 20000, out[1][0].data_ptr(), out[1][1].data_ptr(),
+                                        out[1][2].data_ptr(), ws.data_ptr(), wsb, st) == _lib.GPSA_EUNSUPPORTED
+
+
 def test_whiten_unsupported_size_is_reported(hip):
     f64 = torch.float64
     assert hip.whiten(torch.eye(400, dtype=f64, device=DEV), torch.ones(400, 8, dtype=f64, device=DEV), f64) is None
