@@ -1576,6 +1576,23 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       c.sc.release(mk2);
     }
   }
+  // exact training pass: the covariance backward HERE, straight behind the C-long product that has just read the same
+  // two fp64 panels (gamma, alpha: 320 MB at the headline size - what of them the memory-side cache still holds is
+  // not fetched again; behind the Gram kernel, where it stood until round 6, nothing of them was left).
+  // GPSA_COV_BWD_EARLY=0: the old place
+  static const bool cov_early_on = [] { const char* e = getenv("GPSA_COV_BWD_EARLY"); return !(e && e[0] == '0'); }();
+  const bool cov_early = exact && !ps.test && cov_early_on;
+  if (cov_early) {
+    const long long mk2 = c.sc.mark();
+    const long long wsb = gpsa_kmat_bwd_workspace(GPSA_F64, Mg, C, D);
+    void* ws = c.sc.get<char>(wsb);
+    GPSA_RUN(gpsa_kmat_bwd_x64_f64_axpy(P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D, c.prm.data_ls,
+                                        c.prm.data_var, gamma64, c.sv<double>(ps.o_alpha64), qbar, 2.0,
+                                        B.dZ_df + (long long)pass_idx * Mg * D, B.dG64[m],
+                                        B.dpar_df + (long long)pass_idx * 2, ws, wsb, c.stv()));
+    B.have_dG[m] = true;
+    c.sc.release(mk2);
+  }
   // gamma = K^-1 abar (fp64 product on the fp32 panel).  With many columns dK_uu comes from the identity below
   // and only dK_uf = gamma + 2 qbar a is needed: the column-scaled update rides in the solve's store
   float* gamma = exact ? nullptr : c.sc.get<float>((long long)Mg * C);
@@ -1687,7 +1704,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   }
   // covariance backward: fp32 panel, fp64 arithmetic and results; the coordinates' gradient goes back to
   // the warp GPs in fp64
-  {
+  if (!cov_early) {
     const long long wsb = gpsa_kmat_bwd_workspace(GPSA_F64, Mg, C, D);
     void* ws = c.sc.get<char>(wsb);
     double* dZ = B.dZ_df + (long long)pass_idx * Mg * D;
@@ -2392,9 +2409,13 @@ int gpsa_step_timing(void* plan, int slots) {
   P.tev.clear();
   P.tslots = 0;
   P.tfwd = P.tbwd = 0;
+  // timing-only events: no system-scope fence at the record (each cost the stream 5.6 us of cache write-back and
+  // invalidation - seven of them per step; the reader synchronises the stream itself).  GPSA_TIMING_FENCE=1: plain events
+  static const bool fence = [] { const char* e = getenv("GPSA_TIMING_FENCE"); return e && e[0] == '1'; }();
   for (int i = 0; i < slots * 6; ++i) {
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return GPSA_EINVAL;
+    if ((fence ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableSystemFence)) != hipSuccess)
+      return GPSA_EINVAL;
     P.tev.push_back(e);
   }
   P.tslots = slots;
