@@ -73,6 +73,12 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
               long long strideB, double beta, void* C, long long ldc, long long strideC, int batch,
               int splitk, void* workspace, long long workspace_bytes, void* stream);
 
+/* out[M,C] += A[M,L] B[L,C] (fp32, row-major, contiguous): a thin inner dimension under a long panel, in ONE pass
+ * over the panel - the mean term's share of the data GP's projection gradient, autograd of vgpsa.py:192
+ * (abar += delta_F dmean^T: M = 200, L = 50, C = 100k at the headline size).  GPSA_EUNSUPPORTED outside M <= 256,
+ * L <= 64, C >= 4096: use gpsa_gemm with beta = 1. */
+int gpsa_thin_update_f32(const float* A, int M, int L, const float* B, long long C, float* out, void* stream);
+
 /* ---- variational covariances (vgpsa.py:206-210): Omega[b] = A[b] A[b]^T + jitter I ---------------
  * A [batch,M,M] is the fp32 parameter (Omega_sqt_*), read as stored; Omega [batch,M,M] fp64 (matrix
  * cores).  gpsa_omega_bwd is its adjoint: dA[b] = (G[b] + G[b]^T) A[b] with G = dLoss/dOmega (fp64);

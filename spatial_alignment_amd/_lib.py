@@ -139,6 +139,7 @@ SIGNATURES.update({
     "gpsa_longk_f64": (_i, [_i, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_kmat_bwd_x64_axpy": (_i, [_i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _ll,
                                     _vp]),
+    "gpsa_thin_update_f32": (_i, [_vp, _i, _i, _vp, _ll, _vp, _vp]),
     "gpsa_whiten_f64_dual": (_i, [_vp, _vp, _i, _ll, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_whiten_gen_f64_dual": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _ll, _vp, _vp, _vp, _vp, _ll, _vp]),
     "gpsa_whiten_axpy_f32": (_i, [_vp, _vp, _i, _ll, _vp, _vp, _d, _vp, _vp, _ll, _vp]),

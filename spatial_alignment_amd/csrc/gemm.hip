@@ -598,6 +598,70 @@ template int gemm_launch<double>(int, int, int, int, long long, double, const do
                                  long long, const double*, long long, long long, double, double*,
                                  long long, long long, int, int, void*, long long, hipStream_t);
 
+// ---- thin update: out[M,C] += A[M,L] B[L,C], L small, C long (round 6) ------------------------------------------
+// The data GP's "abar += delta_F dmean^T" (M = 200, L = 50, C = 100k): 180 MB that have to move once.  The tiled
+// product above takes it as 4 x 1563 tiles of 64 x 64 and reads B once per row tile (240 MB, 58.8 us).  Here a
+// workgroup owns 64 columns over ALL rows: A sits in LDS (row stride = 4 mod 8 words: the A-fragment reads are
+// conflict-free), a wave keeps its 16 columns of B as MFMA fragments and walks the row tiles - load 16 x 16 of out,
+// KS chained 16x16x4 products, store.
+template <int KS>
+__global__ void __launch_bounds__(256) thin_update_kernel(const float* __restrict__ A, int M, int L,
+                                                          const float* __restrict__ B, long long C,
+                                                          float* __restrict__ out, long long ntiles) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int ST = (KS % 2) ? 4 * KS : 4 * KS + 4;
+  extern __shared__ float As[];  // [MB * 16][ST]
+  const int MB = (M + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < MB * 16 * ST; i += 256) As[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < M * L; i += 256) As[(i / L) * ST + (i % L)] = A[i];
+  __syncthreads();
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long c = t * 64 + w * 16 + j;
+    const bool okc = c < C;
+    const long long cc = okc ? c : 0;
+    float b[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kq;
+      const float v = B[(long long)(k < L ? k : L - 1) * C + cc];  // (clamped, unconditional: the loads stay in one block)
+      b[ks] = (k < L && okc) ? v : 0.f;
+    }
+    for (int rt = 0; rt < MB; rt += 2) {  // two row tiles at a time: two independent MFMA chains, eight loads in flight
+      f32x4 acc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 16 * (rt + u) + 4 * kq + i;
+          acc[u][i] = out[(long long)(r < M ? r : M - 1) * C + cc];
+        }
+      const float* ap = As + (16 * rt + j) * ST + kq;
+      const float* ap2 = ap + (rt + 1 < MB ? 16 * ST : 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], b[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap2[4 * ks], b[ks], acc[1], 0, 0, 0);
+      }
+      if (okc) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 16 * (rt + u) + 4 * kq + i;
+            if (r < M) out[(long long)r * C + c] = acc[u][i];
+          }
+      }
+    }
+  }
+}
+
+static inline bool thin_update_ok(int M, int L, long long C) {
+  static const bool off = [] { const char* e = getenv("GPSA_THIN_UPDATE"); return e && e[0] == '0'; }();
+  return !off && M >= 1 && M <= 256 && L >= 1 && L <= 64 && C >= 4096;
+}
+
 }  // namespace gpsa
 
 extern "C" {
@@ -694,6 +758,45 @@ int gpsa_omega_bwd2(const double* G0, const float* A0, float* dA0, int n0, const
   else
     gpsa::gemm_mfma_kernel<double, false, false, double, float, float, true><<<grid, 256, 0, as_stream(stream)>>>(
         M, M, M, 1.0, G0, M, mm, A0, M, mm, 0.0, dA0, M, mm, 1, nullptr, 0.0, 0, nullptr, 0, nullptr, 0, seg);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+
+
+/* out[M,C] += A[M,L] B[L,C] (fp32, row-major, contiguous; matrix cores): the thin-inner-dimension update of a long
+ * panel in ONE pass over it.  GPSA_EUNSUPPORTED outside M <= 256, L <= 64, C >= 4096 (use gpsa_gemm with beta = 1). */
+int gpsa_thin_update_f32(const float* A, int M, int L, const float* B, long long C, float* out, void* stream) {
+  using namespace gpsa;
+  if (!A || !B || !out || M < 1 || L < 1 || C < 1) return GPSA_EINVAL;
+  if (!thin_update_ok(M, L, C)) return GPSA_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  const long long ntiles = cdiv(C, 64);
+  const int KS = (L + 3) / 4, MB = (M + 15) / 16;
+  const int ST = (KS % 2) ? 4 * KS : 4 * KS + 4;
+  const size_t lds = (size_t)MB * 16 * ST * 4;
+  // persistent: the A fill (M L scattered words) is paid once per workgroup; as many workgroups as stay resident
+  long long per_cu = (long long)(160 * 1024) / (long long)(lds + 1024);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  long long grid = per_cu * num_cus();
+  if (grid > ntiles) grid = ntiles;
+#define GPSA_TU(KS_)                                                                                   \
+  case KS_: {                                                                                          \
+    static per_device_flag flag;                                                                       \
+    bool& set = flag.here();                                                                           \
+    if (!set && lds > 65536) {                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_update_kernel<KS_>),                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)    \
+        return GPSA_EUNSUPPORTED;                                                                      \
+      set = true;                                                                                      \
+    }                                                                                                  \
+    thin_update_kernel<KS_><<<(unsigned)grid, 256, lds, st>>>(A, M, L, B, C, out, ntiles);             \
+  } break;
+  switch (KS) {
+    GPSA_TU(1) GPSA_TU(2) GPSA_TU(3) GPSA_TU(4) GPSA_TU(5) GPSA_TU(6) GPSA_TU(7) GPSA_TU(8)
+    GPSA_TU(9) GPSA_TU(10) GPSA_TU(11) GPSA_TU(12) GPSA_TU(13) GPSA_TU(14) GPSA_TU(15) GPSA_TU(16)
+    default: return GPSA_EUNSUPPORTED;
+  }
+#undef GPSA_TU
   GPSA_LAUNCH_CHECK();
   return 0;
 }

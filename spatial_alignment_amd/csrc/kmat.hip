@@ -445,9 +445,13 @@ int kmat_bwd_launch(int kind, const TI* Z, int M, const TX* X, long long C, int 
     const int mr = kmat_bwd_d2_rows();
     const long long nby2 = cdiv(M, mr);
     static const int per_env = [] { const char* e = getenv("GPSA_KMAT_BWD_PER"); return e ? atoi(e) : 0; }();
-    // column blocks per workgroup: ~400 workgroups (measured: 1 at C = 2.5k, 2 - 3 at 12.5k - 20k, 4 - 12 alike at 100k)
-    long long per = (ncb * nby2 * batch + 200) / 400;
-    per = per < 1 ? 1 : (per > 8 ? 8 : per);
+    // column blocks per workgroup: the fewest with which the whole grid is resident at once - two workgroups per CU
+    // (launch bounds; ~200 registers).  Round 6, the exact data-GP backward at C = 100k (391 column blocks x 13 row
+    // chunks): 8 blocks each = 637 workgroups ran as one full round and a quarter-full second one, 88 - 90 us; 10 (520
+    // workgroups, 8 too many) 95 us; 11 (468) 74 us; 12 / 13 / 16 / 20: 76 / 78 / 88 / 98 us (profiles/r06_kmat_bwd_per.txt)
+    const long long slots = 2LL * num_cus();
+    long long per = 1;
+    while (per < ncb && cdiv(ncb, per) * nby2 * batch > slots) ++per;
     if (per_env > 0) per = per_env;
     nbx = cdiv(ncb, per);
     const int rows = (int)cdiv(M, nby2);  // M spread evenly over the row chunks

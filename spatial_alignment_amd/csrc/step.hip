@@ -966,6 +966,15 @@ static int gemm32(Ctx& c, int ta, int tb, int m, int n, long long k, double alph
   c.sc.release(mk);
   return 0;
 }
+// out[M,C] += A[M,L] B[L,C]: the one-pass kernel where it takes the shape, the tiled product otherwise
+static int thin_update(Ctx& c, const float* A, int M, int L, const float* B, long long C, float* out) {
+  if (!c.dry) {
+    if (c.sc.overflow) return GPSA_EWORKSPACE;
+    const int rc = gpsa_thin_update_f32(A, M, L, B, C, out, c.stv());
+    if (rc != GPSA_EUNSUPPORTED) return rc;
+  }
+  return gemm32(c, 0, 0, M, (int)C, L, 1.0, A, L, 0, B, C, 0, 1.0, out, C, 0, 1, 1);
+}
 template <typename TIA, typename TIB, typename TO>
 static int gemmx(Ctx& c, int ta, int tb, int m, int n, long long k, double alpha, const TIA* A, long long lda,
                  long long sA, const TIB* B, long long ldb, long long sB, double beta, TO* C, long long ldc,
@@ -1493,7 +1502,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     if (timed) P.tick(1, 0, false, c.st);  // (slot 1: what is left of the alpha-gradient - the mean term's share)
     GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, GPSA_F64, B.dvar_ds + pass_idx,
                                   ws, wsb, c.stv()));
-    GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
+    GPSA_CK(thin_update(c, c.prm.delta_F[m], Mg, L, dmeanT, C, abar));
     if (timed) P.tick(1, 1, false, c.st);
   } else {
     const long long wsb = gpsa_quadform_workspace(GPSA_F32, Mg, C, L);
@@ -1509,8 +1518,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
       GPSA_RUN(gpsa_quadform_bwd_alpha(GPSA_F32, GPSA_F64, alpha, Om, g_ext, Mg, C, L, abar, ws, wsb, c.stv()));
     if (timed) P.tick(1, 1, false, c.st);
     c.sc.release(mk2);
-    if (!kept)
-      GPSA_CK(gemm32(c, 0, 0, Mg, (int)C, L, 1.0, c.prm.delta_F[m], L, 0, dmeanT, C, 0, 1.0, abar, C, 0, 1, 1));
+    if (!kept) GPSA_CK(thin_update(c, c.prm.delta_F[m], Mg, L, dmeanT, C, abar));
   }
   // d delta_F = alpha dmean^T - as a C-long product here, unless the Gram kernel below can carry it in the first padding
   // row of its last tile row (gpsa_quadform_bwd_omega_delta_f32)

@@ -658,6 +658,21 @@ def test_whiten_gen_forms_the_same_projection(hip, kind, M, C, D):
                                         out[1][2].data_ptr(), ws.data_ptr(), wsb, st) == _lib.GPSA_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("M,L,C", [(200, 50, 100000), (197, 7, 4100), (256, 64, 5000), (16, 1, 4096), (200, 50, 12500),
+                                   (33, 10, 20001), (208, 49, 4097)])
+def test_thin_update(hip, M, L, C):
+    """out += A B with a thin inner dimension in one pass over the long panel (gpsa_thin_update_f32: the mean term's
+    share of the data GP's projection gradient) against the fp64 product."""
+    A, B, out = rnd(M, L), rnd(L, C, seed=1), rnd(M, C, seed=2)
+    want = out.double() + A.double() @ B.double()
+    Ad, Bd, od = A.to(DEV), B.to(DEV), out.to(DEV)
+    assert hip.lib.gpsa_thin_update_f32(Ad.data_ptr(), M, L, Bd.data_ptr(), C, od.data_ptr(), hip._stream(od)) == 0
+    close(od, want, 2e-6)
+    # shapes it declines: the caller runs gpsa_gemm with beta = 1
+    for m, l, c in ((300, 50, C), (M, 65, C), (M, L, 1000)):
+        assert hip.lib.gpsa_thin_update_f32(Ad.data_ptr(), m, l, Bd.data_ptr(), c, od.data_ptr(), hip._stream(od)) == -3
+
+
 def test_whiten_unsupported_size_is_reported(hip):
     f64 = torch.float64
     assert hip.whiten(torch.eye(400, dtype=f64, device=DEV), torch.ones(400, 8, dtype=f64, device=DEV), f64) is None
