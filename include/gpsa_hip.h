@@ -76,7 +76,7 @@ int gpsa_gemm(int dtype, int transA, int transB, int m, int n, long long k, doub
 /* out[M,C] += A[M,L] B[L,C] (fp32, row-major, contiguous): a thin inner dimension under a long panel, in ONE pass
  * over the panel - the mean term's share of the data GP's projection gradient, autograd of vgpsa.py:192
  * (abar += delta_F dmean^T: M = 200, L = 50, C = 100k at the headline size).  GPSA_EUNSUPPORTED outside M <= 256,
- * L <= 64, C >= 4096: use gpsa_gemm with beta = 1. */
+ * L <= 64, C >= 4096 a multiple of 4, out 16-byte aligned: use gpsa_gemm with beta = 1. */
 int gpsa_thin_update_f32(const float* A, int M, int L, const float* B, long long C, float* out, void* stream);
 
 /* ---- variational covariances (vgpsa.py:206-210): Omega[b] = A[b] A[b]^T + jitter I ---------------

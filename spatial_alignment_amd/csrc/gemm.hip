@@ -600,66 +600,87 @@ template int gemm_launch<double>(int, int, int, int, long long, double, const do
 
 // ---- thin update: out[M,C] += A[M,L] B[L,C], L small, C long (round 6) ------------------------------------------
 // The data GP's "abar += delta_F dmean^T" (M = 200, L = 50, C = 100k): 180 MB that have to move once.  The tiled
-// product above takes it as 4 x 1563 tiles of 64 x 64 and reads B once per row tile (240 MB, 58.8 us).  Here a
-// workgroup owns 64 columns over ALL rows: A sits in LDS (row stride = 4 mod 8 words: the A-fragment reads are
-// conflict-free), a wave keeps its 16 columns of B as MFMA fragments and walks the row tiles - load 16 x 16 of out,
-// KS chained 16x16x4 products, store.
+// product above takes it as 4 x 1563 tiles of 64 x 64 and reads B once per row tile (240 MB, 59 us).  Here a
+// workgroup owns 64 columns over ALL rows: A sits in LDS (row stride = 4 mod 8 words: the fragment reads are
+// conflict-free), a wave keeps its 16 columns of B as MFMA fragments and walks the row tiles.  The product is formed
+// TRANSPOSED (out^T tile = B^T A^T: the operands of the instruction swapped), so a lane's four accumulator values are
+// four CONSECUTIVE COLUMNS of one row: one 16-byte load and store per lane and tile, and the next four tiles' loads
+// are in flight while the current four are multiplied (a first version with 4-byte accesses and two tiles at a time
+// ran at the tiled product's speed: 56 us, 3.2 TB/s - bytes in flight, not arithmetic).
 template <int KS>
-__global__ void __launch_bounds__(256) thin_update_kernel(const float* __restrict__ A, int M, int L,
+__global__ void __launch_bounds__(256, 3) thin_update_kernel(const float* __restrict__ A, int M, int L,
                                                           const float* __restrict__ B, long long C,
                                                           float* __restrict__ out, long long ntiles) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int ST = (KS % 2) ? 4 * KS : 4 * KS + 4;
+  constexpr int G = 4;  // row tiles per group
   extern __shared__ float As[];  // [MB * 16][ST]
   const int MB = (M + 15) / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   for (int i = tid; i < MB * 16 * ST; i += 256) As[i] = 0.f;
   __syncthreads();
-  for (int i = tid; i < M * L; i += 256) As[(i / L) * ST + (i % L)] = A[i];
+  // (the fill is a chain of cache latencies per thread if its loads are requested one at a time: 40 of them made the
+  //  kernel no faster than the tiled product - 16-byte loads, several in flight)
+  if ((M * L) % 4 == 0 && ((uintptr_t)A & 15) == 0) {
+    const int n4 = M * L / 4;
+#pragma unroll 4
+    for (int i = tid; i < n4; i += 256) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(A)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[((4 * i + e) / L) * ST + ((4 * i + e) % L)] = v[e];
+    }
+  } else {
+#pragma unroll 8
+    for (int i = tid; i < M * L; i += 256) As[(i / L) * ST + (i % L)] = A[i];
+  }
   __syncthreads();
   for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long long c = t * 64 + w * 16 + j;
-    const bool okc = c < C;
-    const long long cc = okc ? c : 0;
+    const long long cb = t * 64 + w * 16;        // the wave's 16 columns
+    const long long c4 = cb + 4 * kq;            // this lane's four columns of out (C % 4 == 0: all or none exist)
+    const bool ok4 = c4 < C;
+    const long long cj = cb + j;                 // this lane's column of B
+    const bool okj = cj < C;
     float b[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = 4 * ks + kq;
-      const float v = B[(long long)(k < L ? k : L - 1) * C + cc];  // (clamped, unconditional: the loads stay in one block)
-      b[ks] = (k < L && okc) ? v : 0.f;
+      const float v = B[(long long)(k < L ? k : L - 1) * C + (okj ? cj : 0)];  // (clamped, unconditional)
+      b[ks] = (k < L && okj) ? v : 0.f;
     }
-    for (int rt = 0; rt < MB; rt += 2) {  // two row tiles at a time: two independent MFMA chains, eight loads in flight
-      f32x4 acc[2];
+    // (no branches in the group: a tile past the last one repeats the last one - its loads hit the cache, its products
+    //  are dropped; a branch around each tile cut the MFMA chains into blocks of one: 135 us)
+    f32x4 cur[G], nxt[G];
+#define GPSA_TU_LOAD(DST, RT0)                                                                                 \
+  _Pragma("unroll") for (int u = 0; u < G; ++u) {                                                              \
+    const int r = 16 * min((RT0) + u, MB - 1) + j;                                                             \
+    DST[u] = *reinterpret_cast<const f32x4*>(out + (long long)(r < M ? r : M - 1) * C + (ok4 ? c4 : 0));       \
+  }
+    GPSA_TU_LOAD(cur, 0)
+    for (int rt0 = 0; rt0 < MB; rt0 += G) {
+      GPSA_TU_LOAD(nxt, rt0 + G)  // (past the end: the last tile again)
+      const float* ap[G];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < G; ++u) ap[u] = As + (16 * min(rt0 + u, MB - 1) + j) * ST + kq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 16 * (rt + u) + 4 * kq + i;
-          acc[u][i] = out[(long long)(r < M ? r : M - 1) * C + cc];
-        }
-      const float* ap = As + (16 * rt + j) * ST + kq;
-      const float* ap2 = ap + (rt + 1 < MB ? 16 * ST : 0);
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks], b[ks], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap2[4 * ks], b[ks], acc[1], 0, 0, 0);
+        for (int u = 0; u < G; ++u)  // out^T tile: rows = the wave's columns (B^T fragment), columns = the tile's rows (A^T)
+          cur[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ks], ap[u][4 * ks], cur[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int r = 16 * (rt0 + u) + j;
+        if (rt0 + u < MB && r < M && ok4) *reinterpret_cast<f32x4*>(out + (long long)r * C + c4) = cur[u];
       }
-      if (okc) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 16 * (rt + u) + 4 * kq + i;
-            if (r < M) out[(long long)r * C + c] = acc[u][i];
-          }
-      }
+      for (int u = 0; u < G; ++u) cur[u] = nxt[u];
     }
+#undef GPSA_TU_LOAD
   }
 }
 
 static inline bool thin_update_ok(int M, int L, long long C) {
   static const bool off = [] { const char* e = getenv("GPSA_THIN_UPDATE"); return e && e[0] == '0'; }();
-  return !off && M >= 1 && M <= 256 && L >= 1 && L <= 64 && C >= 4096;
+  return !off && M >= 1 && M <= 256 && L >= 1 && L <= 64 && C >= 4096 && C % 4 == 0;
 }
 
 }  // namespace gpsa
@@ -768,7 +789,7 @@ int gpsa_omega_bwd2(const double* G0, const float* A0, float* dA0, int n0, const
 int gpsa_thin_update_f32(const float* A, int M, int L, const float* B, long long C, float* out, void* stream) {
   using namespace gpsa;
   if (!A || !B || !out || M < 1 || L < 1 || C < 1) return GPSA_EINVAL;
-  if (!thin_update_ok(M, L, C)) return GPSA_EUNSUPPORTED;
+  if (!thin_update_ok(M, L, C) || ((uintptr_t)out & 15)) return GPSA_EUNSUPPORTED;  // (16-byte accesses of out)
   hipStream_t st = as_stream(stream);
   const long long ntiles = cdiv(C, 64);
   const int KS = (L + 3) / 4, MB = (M + 15) / 16;
@@ -776,7 +797,7 @@ int gpsa_thin_update_f32(const float* A, int M, int L, const float* B, long long
   const size_t lds = (size_t)MB * 16 * ST * 4;
   // persistent: the A fill (M L scattered words) is paid once per workgroup; as many workgroups as stay resident
   long long per_cu = (long long)(160 * 1024) / (long long)(lds + 1024);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);  // (launch bounds: three)
   long long grid = per_cu * num_cus();
   if (grid > ntiles) grid = ntiles;
 #define GPSA_TU(KS_)                                                                                   \

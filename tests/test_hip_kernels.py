@@ -659,7 +659,7 @@ def test_whiten_gen_forms_the_same_projection(hip, kind, M, C, D):
 
 
 @pytest.mark.parametrize("M,L,C", [(200, 50, 100000), (197, 7, 4100), (256, 64, 5000), (16, 1, 4096), (200, 50, 12500),
-                                   (33, 10, 20001), (208, 49, 4097)])
+                                   (33, 10, 20004), (208, 49, 4108), (65, 50, 8000)])
 def test_thin_update(hip, M, L, C):
     """out += A B with a thin inner dimension in one pass over the long panel (gpsa_thin_update_f32: the mean term's
     share of the data GP's projection gradient) against the fp64 product."""
@@ -669,7 +669,7 @@ def test_thin_update(hip, M, L, C):
     assert hip.lib.gpsa_thin_update_f32(Ad.data_ptr(), M, L, Bd.data_ptr(), C, od.data_ptr(), hip._stream(od)) == 0
     close(od, want, 2e-6)
     # shapes it declines: the caller runs gpsa_gemm with beta = 1
-    for m, l, c in ((300, 50, C), (M, 65, C), (M, L, 1000)):
+    for m, l, c in ((300, 50, C), (M, 65, C), (M, L, 1000), (M, L, C - 1)):
         assert hip.lib.gpsa_thin_update_f32(Ad.data_ptr(), m, l, Bd.data_ptr(), c, od.data_ptr(), hip._stream(od)) == -3
 
 
