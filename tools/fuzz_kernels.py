@@ -87,6 +87,38 @@ for it in range(cases):
         note("fwd_keep.v", rel(v, FK.quadform_fwd(al.double(), Om.double())), t, ctx)
         note("fwd_keep.mean", rel(mean, dcT.double().t() @ al.double()), t, ctx)
         note("bwd_alpha_kept", rel(hip.quadform_bwd_alpha_kept(W, gd), FK.quadform_bwd_alpha(al.double(), Om.double(), g.double())), t, ctx)
+    if M <= 256 and dt == torch.float32:  # the thin-inner-dimension update (abar += delta dmean^T)
+        Lt, Ct = rng.choice([1, 3, 4, 7, 31, 50, 64]), rng.choice([4096, 4100, 5000, 12500, 20004])
+        At, Bt, ot = rnd(M, Lt), rnd(Lt, Ct), rnd(M, Ct)
+        Atd, Btd, otd = At.to(DEV), Bt.to(DEV), ot.to(DEV)
+        assert hip.lib.gpsa_thin_update_f32(Atd.data_ptr(), M, Lt, Btd.data_ptr(), Ct, otd.data_ptr(), hip._stream(otd)) == 0
+        note("thin_update", rel(otd, ot.double() + At.double() @ Bt.double()), 2e-6, dict(ctx, Lt=Lt, Ct=Ct))
+    if it % 8 == 0 and M <= 208 and M > 96:  # K_uf formed inside the projection kernel (long panels only) vs kmat + whiten
+        Cg, Dg = rng.choice([98304, 98403, 100000, 131075]), rng.choice([1, 2, 3])
+        kg = rng.choice(["rbf", "matern12", "matern32"])
+        Zg, Xg = (rnd(M, Dg, scale=3.0)).to(DEV), rnd(Cg, Dg, dtype=torch.float64, scale=3.0).to(DEV)
+        lsg, varg = torch.tensor([0.3], device=DEV), torch.tensor([-0.2], device=DEV)
+        Kg = rnd(M, M, dtype=torch.float64)
+        Kg = (Kg + Kg.t()).to(DEV)
+        wsb = hip.lib.gpsa_whiten_workspace(M)
+        wsg = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        a64 = torch.full((M, Cg), float("nan"), dtype=torch.float64, device=DEV)
+        a32 = torch.full((M, Cg), float("nan"), device=DEV)
+        qg = torch.full((Cg,), float("nan"), dtype=torch.float64, device=DEV)
+        rc = hip.lib.gpsa_whiten_gen_f64_dual(Kg.data_ptr(), {"rbf": 0, "matern12": 1, "matern32": 2}[kg], Zg.data_ptr(),
+                                              Xg.data_ptr(), Dg, lsg.data_ptr(), varg.data_ptr(), M, Cg, a64.data_ptr(),
+                                              a32.data_ptr(), qg.data_ptr(), wsg.data_ptr(), wsb, hip._stream(Xg))
+        if rc == 0:  # (-3: the persistent kernel does not take the shape - M outside its two row-tile counts)
+            Kuf = hip.kmat(kg, Zg, Xg, lsg, varg, 0.0, dtype=torch.float64)
+            ra, rq = hip.whiten(Kg, Kuf, torch.float64)
+            gctx = dict(ctx, Cg=Cg, Dg=Dg, kind=kg)
+            note("whiten_gen.alpha64", rel(a64, ra), 1e-13, gctx)
+            note("whiten_gen.alpha32", rel(a32, ra), 1e-6, gctx)
+            note("whiten_gen.q", rel(qg, rq), 1e-13, gctx)
+            del Kuf, ra, rq
+        else:
+            assert rc == -3, rc
+        del a64, a32, qg, Xg
     P = rnd(M, M, dtype=torch.float64).tril()
     Y, cs = hip.panel_mm(P.to(DEV), ald, want_colsq=True, transP=rng.random() < 0.5 and False)
     rY, rcs = FK.panel_mm(P, al.double(), want_colsq=True)
