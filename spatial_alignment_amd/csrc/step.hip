@@ -1336,33 +1336,34 @@ static int data_pass_fwd(Ctx& c, const Pass& ps) {
       else if (rc != GPSA_EUNSUPPORTED) return rc;
     }
     if (!fused) {
-    // covariance on the warp GP's UNROUNDED draws (fp64), fp32 parameters as stored; G_test is the caller's fp32
-    if (ps.test)
-      GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D, c.prm.data_ls,
-                         c.prm.data_var, 0.0, Kuf, c.stv()));
-    else
-      GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32_X64, P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D,
-                         c.prm.data_ls, c.prm.data_var, 0.0, Kuf, c.stv()));
-    if (wsb > 0 && !exact) {  // the packed inverse stays in the saved arena: later passes and the backward reuse it
-      void* ws = c.sv<char>(P.o_apk_d);
-      GPSA_RUN(gpsa_whiten_f64(c.apk_d ? nullptr : Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb, c.stv()));
-      c.apk_d = true;
-    } else if (wsb > 0) {
-      void* ws = c.sv<char>(P.o_apk_d);
-      double* a64 = c.sv<double>(ps.o_alpha64);
-      GPSA_RUN(gpsa_whiten_f64_dual(c.apk_d ? nullptr : Kinv, Kuf, Mg, C, a64, alpha, q, ws, wsb, c.stv()));
-      c.apk_d = true;
-    } else {  // beyond the projection kernel: alpha (fp64) = K^-1 K_uf, q from it, then rounded
-      double* a64 = exact ? c.sv<double>(ps.o_alpha64) : c.sc.get<double>((long long)Mg * C);
-      GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, Kuf, C, 0, 0.0, a64, C, 0, 1, 1));
-      if (!dry) {
-        coldot2_kernel<<<dim3((unsigned)cdiv(C, 256), 1), 256, 0, c.st>>>(Kuf, a64, Mg, C, q);
-        GPSA_LAUNCH_CHECK();
-        convert_kernel_step<double, float><<<(unsigned)cdiv((long long)Mg * C, 256), 256, 0, c.st>>>(
-            a64, (long long)Mg * C, alpha);
-        GPSA_LAUNCH_CHECK();
+      // covariance on the warp GP's UNROUNDED draws (fp64), fp32 parameters as stored; G_test is the caller's fp32
+      if (ps.test)
+        GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32, P.d.kind_data, c.prm.Gtilde, Mg, c.io.G_test[m], C, D, c.prm.data_ls,
+                           c.prm.data_var, 0.0, Kuf, c.stv()));
+      else
+        GPSA_RUN(gpsa_kmat(GPSA_F64, GPSA_F32_X64, P.d.kind_data, c.prm.Gtilde, Mg, c.sv<double>(P.o_G64[m]), C, D,
+                           c.prm.data_ls, c.prm.data_var, 0.0, Kuf, c.stv()));
+      if (wsb > 0 && !exact) {  // the packed inverse stays in the saved arena: later passes and the backward reuse it
+        void* ws = c.sv<char>(P.o_apk_d);
+        GPSA_RUN(gpsa_whiten_f64(c.apk_d ? nullptr : Kinv, GPSA_F64, Kuf, Mg, C, GPSA_F32, alpha, q, ws, wsb,
+                                 c.stv()));
+        c.apk_d = true;
+      } else if (wsb > 0) {
+        void* ws = c.sv<char>(P.o_apk_d);
+        double* a64 = c.sv<double>(ps.o_alpha64);
+        GPSA_RUN(gpsa_whiten_f64_dual(c.apk_d ? nullptr : Kinv, Kuf, Mg, C, a64, alpha, q, ws, wsb, c.stv()));
+        c.apk_d = true;
+      } else {  // beyond the projection kernel: alpha (fp64) = K^-1 K_uf, q from it, then rounded
+        double* a64 = exact ? c.sv<double>(ps.o_alpha64) : c.sc.get<double>((long long)Mg * C);
+        GPSA_CK(gemm64(c, 0, 0, Mg, (int)C, Mg, 1.0, Kinv, Mg, 0, Kuf, C, 0, 0.0, a64, C, 0, 1, 1));
+        if (!dry) {
+          coldot2_kernel<<<dim3((unsigned)cdiv(C, 256), 1), 256, 0, c.st>>>(Kuf, a64, Mg, C, q);
+          GPSA_LAUNCH_CHECK();
+          convert_kernel_step<double, float><<<(unsigned)cdiv((long long)Mg * C, 256), 256, 0, c.st>>>(
+              a64, (long long)Mg * C, alpha);
+          GPSA_LAUNCH_CHECK();
+        }
       }
-    }
     }
     c.sc.release(mk2);
   }
@@ -2417,8 +2418,8 @@ int gpsa_step_timing(void* plan, int slots) {
   P.tev.clear();
   P.tslots = 0;
   P.tfwd = P.tbwd = 0;
-  // timing-only events: no system-scope fence at the record (each cost the stream 5.6 us of cache write-back and
-  // invalidation - seven of them per step; the reader synchronises the stream itself).  GPSA_TIMING_FENCE=1: plain events
+  // timing-only events: no system-scope fence (cache write-back and invalidation) at the record - the reader
+  // synchronises the stream itself.  (Measured: no difference in the bench loop either way; GPSA_TIMING_FENCE=1: plain events)
   static const bool fence = [] { const char* e = getenv("GPSA_TIMING_FENCE"); return e && e[0] == '1'; }();
   for (int i = 0; i < slots * 6; ++i) {
     hipEvent_t e;
