@@ -19,6 +19,10 @@ CONFIGS = {
     "LMC (M=64, 2x400 spots, 12 outputs through 3 latent GPs)": dict(side=20, views=2, outputs=12, M=64, S=3, latent=3),
     "large M (M=300, 2x400 spots, 5 outputs, S=1)": dict(side=20, views=2, outputs=5, M=300, S=1),
     "large M, odd columns (M=300, 2x169 spots, 5 outputs, S=1)": dict(side=13, views=2, outputs=5, M=300, S=1),
+    # the headline's column count (C = 100k: the projection that forms K_uf itself, the thin update, the covariance
+    # backward's resident grid - none of which the small shapes reach) at a few outputs
+    "headline columns (M=200, 2x10000 spots, 6 outputs, S=5)": dict(side=100, views=2, outputs=6, M=200, S=5),
+    "headline columns, odd count (M=197, 2x9801 spots, 3 outputs, S=5)": dict(side=99, views=2, outputs=3, M=197, S=5),
 }
 
 
