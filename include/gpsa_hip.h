@@ -658,6 +658,9 @@ int gpsa_step_forward(void* plan, const gpsa_step_params* params, const gpsa_ste
  * form, its alpha-gradient, its Omega-gradient) of the first data-GP pass, on the stream they are launched on,
  * for a ring of ``slots`` steps; gpsa_step_timing_read returns the recorded steps' durations [n][3] in ms
  * (after the caller synchronised).  slots = 0 switches the events off. */
+/* id of the stream capture ``stream`` belongs to (0: not capturing).  For hosts that cache scratch per stream: a block
+ * allocated inside a capture lives in that graph's private pool and must not be reused by another capture. */
+unsigned long long gpsa_stream_capture_id(void* stream);
 int gpsa_step_timing(void* plan, int slots);
 int gpsa_step_timing_read(void* plan, float* ms, int max_steps);
 /* backward of the forward that filled ``saved`` (same params / io pointers and contents) */

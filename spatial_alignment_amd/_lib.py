@@ -177,6 +177,7 @@ SIGNATURES.update({
     "gpsa_step_batch_layout": (_i, [_vp, C.POINTER(_ll)]),
     "gpsa_step_graph": (_i, [_vp, _i, C.POINTER(_ll)]),
     "gpsa_step_early_backwards": (_ll, [_vp]),
+    "gpsa_stream_capture_id": (C.c_ulonglong, [_vp]),
     "gpsa_step_timing": (_i, [_vp, _i]),
     "gpsa_step_timing_read": (_i, [_vp, _vp, _i]),
     "gpsa_step_forward": (_i, [_vp, C.POINTER(StepParams), C.POINTER(StepIO), _vp, _vp, _i, _vp]),

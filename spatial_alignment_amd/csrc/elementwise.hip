@@ -421,10 +421,15 @@ __global__ void __launch_bounds__(256) elbo_loss_finish_kernel(ElboFinishArgs a)
 // ---- fused ELBO (gpsa_quadform_elbo_f32) -> the backward's conventions ------------------------------------------
 // per column: qbar[c] = -gl sum_l g[l,c]; part[block] = gl sum g (for d var);  with an upstream gradient gl != 1
 // g and dmeanT are scaled in place (they were formed at gl = 1)
+// tick != nullptr (a zeroed word; the step engine): the LAST block to arrive closes dvar = exp(var_u) sum(part) itself, in
+// the order sum_scale_kernel adds them - the finishing launch is not needed (round 6)
+template <typename TO>
 __global__ void __launch_bounds__(256)
 elbo_post_kernel(float* __restrict__ g, float* __restrict__ dmeanT, long long C, int L, const float* __restrict__ gloss,
-                 float* __restrict__ qbar, double* __restrict__ part, float* __restrict__ abar, int M) {
+                 float* __restrict__ qbar, double* __restrict__ part, float* __restrict__ abar, int M,
+                 int* __restrict__ tick, const float* __restrict__ var_u, TO* __restrict__ dvar) {
   __shared__ double red[4];
+  __shared__ int last_s;
   const float gl = gloss[0];
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   float s = 0.f;
@@ -452,7 +457,26 @@ elbo_post_kernel(float* __restrict__ g, float* __restrict__ dmeanT, long long C,
     qbar[c] = -s;
   }
   const double t = block_sum((double)s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = t;
+    last_s = 0;
+    if (tick != nullptr) {
+      __threadfence();
+      last_s = atomicAdd(tick, 1) == (int)gridDim.x - 1;
+    }
+  }
+  __syncthreads();
+  if (last_s) {  // (block-uniform)
+    __threadfence();
+    double a = 0.0;
+    for (long long i = threadIdx.x; i < (long long)gridDim.x; i += 256)
+      a += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) {
+      dvar[0] = (TO)(a * exp((double)var_u[0]));
+      *tick = 0;
+    }
+  }
 }
 __global__ void __launch_bounds__(256) scale_unless_one_kernel(float* __restrict__ x, long long n,
                                                                const float* __restrict__ gloss) {
@@ -807,7 +831,8 @@ int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long l
   if (workspace_bytes < nb * 8) return GPSA_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   double* part = (double*)workspace;
-  gpsa::elbo_post_kernel<<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part, abar, M);
+  gpsa::elbo_post_kernel<double><<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part,
+                                                               abar, M, nullptr, nullptr, nullptr);
   if (dvar_dtype == GPSA_F64)
     gpsa::sum_scale_kernel<float, double><<<1, 256, 0, st>>>(part, nb, var_u, nullptr, 1.0, (double*)dvar_u);
   else
@@ -815,6 +840,43 @@ int gpsa_elbo_fused_post(float* g_ext, float* dmeanT, float* abar, int M, long l
   GPSA_LAUNCH_CHECK();
   return 0;
 }
+
+}  // extern "C"
+
+namespace gpsa {
+// Zero fill as a KERNEL of this library (round 6).  hipMemsetAsync inside a stream capture becomes a memset node, and
+// in a replayed graph with parallel branches that node was seen to land AFTER the kernel node behind it on the same
+// stream (the step's backward: the word the next kernel read still held the forward's scratch; found when that kernel
+// became the region's first reader - tests/test_hip_parity.py::test_eager_forward_between_graph_replays...).  A kernel
+// node is ordered like every other launch.  GPSA_ZERO_KERNEL=0: the runtime's memset.
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4* __restrict__ p, long long n16, int tail) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) reinterpret_cast<unsigned char*>(p + n16)[threadIdx.x] = 0;
+}
+int zero_fill_async(void* ptr, size_t bytes, hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("GPSA_ZERO_KERNEL"); return e && e[0] == '0'; }();
+  if (bytes == 0) return 0;
+  if (off || (reinterpret_cast<uintptr_t>(ptr) & 15)) return (int)hipMemsetAsync(ptr, 0, bytes, st);
+  const long long n16 = (long long)(bytes / 16);
+  const long long blocks = n16 > 0 ? cdiv(n16, 256) : 1;
+  zero_fill_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<uint4*>(ptr), n16, (int)(bytes % 16));
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+// gpsa_elbo_fused_post in ONE launch (dvar_u fp64): the post kernel's last block closes dvar through ``tick``, a device
+// word that is zero at entry and zero again afterwards (the step engine's backward keeps a few in its zero-filled region)
+int elbo_fused_post_ticket(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
+                           const float* var_u, double* dvar_u, double* part, int* tick, hipStream_t st) {
+  const long long nb = cdiv(C, 256);
+  elbo_post_kernel<double><<<(unsigned)nb, 256, 0, st>>>(g_ext, dmeanT, C, L, gloss, g_ext + (long long)L * C, part, abar,
+                                                         M, tick, var_u, dvar_u);
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace gpsa
+
+extern "C" {
 
 /* gpsa_elbo_loss_fwd / _bwd with some likelihood terms FUSED into the step (gpsa_step_io.fuse_elbo): zpart[i] non-null
  * = term i's partial sums of z^2 (nparts doubles, gpsa_step_io.ll_part); F[i] / dF[i] are then ignored. */

@@ -48,6 +48,12 @@ bool proj64_ok(int MB, long long C, int batch);
 template <typename TI>
 int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, double* alpha, float* out32, double* q,
                   int batch, long long sX, hipStream_t st, bool q_zeroed);
+// zero fill as a kernel of this library, not a runtime memset (elementwise.hip: a memset NODE of a replayed graph was
+// seen to land behind the kernel that follows it); returns 0 or a hipError_t
+int zero_fill_async(void* ptr, size_t bytes, hipStream_t st);
+// gpsa_elbo_fused_post as one launch (elementwise.hip): tick = a device word that is zero at entry
+int elbo_fused_post_ticket(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
+                           const float* var_u, double* dvar_u, double* part, int* tick, hipStream_t st);
 // the same with the right-hand side K_uf[m, c] = k(Z_m, x_c) formed inside the kernel (round 6)
 int proj64_gen_launch(int MB, const double* Apk, int kind, const float* Z, const double* X64, int D, const float* ls_u,
                       const float* var_u, int M, long long C, double* alpha, float* out32, double* q, hipStream_t st,

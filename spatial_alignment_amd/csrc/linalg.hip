@@ -4,6 +4,7 @@
 // Replaces torch.cholesky (gpsa/models/vgpsa.py:257, 320, 394, 412) and the triangular solves of
 // torch.cholesky_solve (vgpsa.py:177).  Also: batched dot product and diagonal shift for the KL terms.
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace gpsa {
 
@@ -710,8 +711,10 @@ static int chol_inv_blocked(const double* A, double* Linv, int M, int batch, dou
   const long long sT = (long long)bs * M;
   hipError_t e = hipMemcpyAsync(W, A, (size_t)batch * mm * 8, hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(Linv, 0, (size_t)batch * mm * 8, st);
-  if (e != hipSuccess) return (int)e;
+  {
+    const int ez = zero_fill_async(Linv, (size_t)batch * mm * 8, st);
+    if (ez != 0) return ez;
+  }
   for (int k = 0; k < nb; ++k) {
     const long long o = (long long)k * bs;
     const int b = (int)((M - o < bs) ? M - o : bs);

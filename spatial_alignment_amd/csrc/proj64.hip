@@ -331,8 +331,8 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
   long long grid = (long long)occ * num_cus();
   if (grid > (long long)batch * a.T) grid = (long long)batch * a.T;
   if (q != nullptr && !q_zeroed) {
-    hipError_t e = hipMemsetAsync(q, 0, (size_t)((long long)batch * C * 8), st);
-    if (e != hipSuccess) return (int)e;
+    const int e = zero_fill_async(q, (size_t)((long long)batch * C * 8), st);
+    if (e != 0) return e;
   }
   switch (MB) {
     case 13:
@@ -375,8 +375,8 @@ int proj64_gen_launch(int MB, const double* Apk, int kind, const float* Z, const
   long long grid = 2LL * num_cus();  // (three workgroups per CU do not fit: 60 KB of LDS each with the inducing points)
   if (grid > a.T) grid = a.T;
   if (q != nullptr && !q_zeroed) {
-    hipError_t e = hipMemsetAsync(q, 0, (size_t)(C * 8), st);
-    if (e != hipSuccess) return (int)e;
+    const int e = zero_fill_async(q, (size_t)(C * 8), st);
+    if (e != 0) return e;
   }
 #define GPSA_PJG(MB_, K_)                                                             \
   case K_:                                                                            \

@@ -252,8 +252,10 @@ warp_sample_views_fwd_kernel(ViewTab t, int m, const float* __restrict__ X, cons
 __global__ void __launch_bounds__(256)
 warp_sample_views_bwd_kernel(ViewTab t, const int* __restrict__ free_views, ModPtrs p,
                              const float* __restrict__ eps, double* __restrict__ dmeanT,
-                             double* __restrict__ g, double* __restrict__ qbar, double* __restrict__ part) {
+                             double* __restrict__ g, double* __restrict__ qbar, double* __restrict__ part,
+                             int* __restrict__ tick, const float* __restrict__ var_u, double* __restrict__ dvar_s) {
   __shared__ double red[4];
+  __shared__ int last_s;
   const int b = blockIdx.y, v = free_views[b], D = t.D, S = t.S;
   const long long c = blockIdx.x * 256LL + threadIdx.x;
   double gtot = 0.0;
@@ -284,7 +286,25 @@ warp_sample_views_bwd_kernel(ViewTab t, const int* __restrict__ free_views, ModP
     qbar[(long long)b * t.Cs + c] = -gtot;
   }
   const double tot = block_sum(gtot, red);
-  if (threadIdx.x == 0) part[(long long)b * gridDim.x + blockIdx.x] = tot;
+  // dvar_s[b] = exp(var_u[v]) * sum_blocks part[b][.] (the variance enters var = sigma^2 - q + v directly), closed by the
+  // view's LAST block to arrive, in the fixed order the finishing launch of rounds 1 - 5 used (round 6: one launch less)
+  if (threadIdx.x == 0) {
+    part[(long long)b * gridDim.x + blockIdx.x] = tot;
+    __threadfence();
+    last_s = tick != nullptr && atomicAdd(&tick[b], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last_s && threadIdx.x < 64) {  // (block-uniform; the first wave)
+    __threadfence();
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < (long long)gridDim.x; i += 64)
+      s += __hip_atomic_load(&part[(long long)b * gridDim.x + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+      dvar_s[b] = s * exp((double)var_u[v]);
+      tick[b] = 0;
+    }
+  }
 }
 
 // dvar_s[b] = exp(var_u[v]) * sum_blocks part[b][.]   (the variance enters var = sigma^2 - q + v directly)
@@ -1448,7 +1468,9 @@ struct BwdBufs {          // fp64 pieces of the parameter gradients (scratch, al
   double* dD[2];
   bool have_dG[MAXMODS];
   bool have_ddc[MAXMODS];
+  int* tick;              // [BWD_TICKS] arrival counters of the kernels that close their own block partials (zero at entry)
 };
+constexpr int BWD_TICKS = 64;  // [0 .. 31] the sampler backward's free views; [32 ..] the data GP passes' fused post
 
 static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_in, const float* dFo_in,
                          BwdBufs& B, const gpsa_step_param_grads& out, bool first_for_mod, const float* gloss) {
@@ -1501,8 +1523,13 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
     void* ws = c.sc.get<char>(wsb);
     const bool timed = !dry && !c.quiet && &ps == &P.passes[0];
     if (timed) P.tick(1, 0, false, c.st);  // (slot 1: what is left of the alpha-gradient - the mean term's share)
-    GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, GPSA_F64, B.dvar_ds + pass_idx,
-                                  ws, wsb, c.stv()));
+    static const int fold = [] { const char* e = getenv("GPSA_FOLD_FINISH"); return e ? atoi(e) : 3; }();
+    if (pass_idx < BWD_TICKS - 32 && (fold & 2))  // (a ticket per pass: the post kernel's last block closes dvar itself)
+      GPSA_RUN(elbo_fused_post_ticket(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, B.dvar_ds + pass_idx,
+                                      (double*)ws, B.tick + 32 + pass_idx, c.st));
+    else
+      GPSA_RUN(gpsa_elbo_fused_post(g_ext, dmeanT, abar, Mg, C, L, gloss, c.prm.data_var, GPSA_F64,
+                                    B.dvar_ds + pass_idx, ws, wsb, c.stv()));
     GPSA_CK(thin_update(c, c.prm.delta_F[m], Mg, L, dmeanT, C, abar));
     if (timed) P.tick(1, 1, false, c.st);
   } else {
@@ -1761,11 +1788,16 @@ static int warp_stage_bwd(Ctx& c, const gpsa_step_out_grads& og, BwdBufs& B, boo
     const double* dG64[MAXMODS];
     for (int m = 0; m < MAXMODS; ++m) dG64[m] = (m < P.nm && B.have_dG[m]) ? B.dG64[m] : nullptr;
     dim3 grid((unsigned)nblk, (unsigned)nf);
+    static const int fold = [] { const char* e = getenv("GPSA_FOLD_FINISH"); return e ? atoi(e) : 3; }();
+    const bool closes = nf <= 32 && (fold & 1);  // (a ticket per free view)
     warp_sample_views_bwd_kernel<<<grid, 256, 0, c.st>>>(P.tab, P.d_free, mod_ptrs(c, &og, dG64), c.io.eps_G, dmeanT,
-                                                         g, qbar, part);
+                                                         g, qbar, part, closes ? B.tick : nullptr, c.prm.warp_var,
+                                                         B.dvar_ws);
     GPSA_LAUNCH_CHECK();
-    warp_sample_views_bwd_finish_kernel<<<nf, 64, 0, c.st>>>(part, nblk, P.d_free, c.prm.warp_var, B.dvar_ws);
-    GPSA_LAUNCH_CHECK();
+    if (!closes) {
+      warp_sample_views_bwd_finish_kernel<<<nf, 64, 0, c.st>>>(part, nblk, P.d_free, c.prm.warp_var, B.dvar_ws);
+      GPSA_LAUNCH_CHECK();
+    }
   }
   double* abar = c.sc.get<double>((long long)nf * Mx * Cs);   // abar, then gamma's right-hand side
   double* gamma = c.sc.get<double>((long long)nf * Mx * Cs);
@@ -1906,10 +1938,11 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
   B.dZ_df = sc.get<double>((long long)(npass > 0 ? npass : 1) * Mg * D);
   B.dpar_df = sc.get<double>(2LL * (npass > 0 ? npass : 1));
   B.dvar_ds = sc.get<double>(npass > 0 ? npass : 1);
+  B.tick = sc.get<int>(BWD_TICKS);
   const long long zf = sc.off;  // the region is all doubles (the samplers' scalars were fp32 until round 5)
   sc.get<char>(256);  // (round the region up to the arena's 256-byte granule: the runtime fills an unaligned tail
   const long long z1 = (sc.off + 255) & ~255LL;  //  with a second launch)
-  if (!dry) GPSA_CK((int)hipMemsetAsync(sc.base + z0, 0, (size_t)(z1 - z0), st));
+  if (!dry) GPSA_CK(zero_fill_async(sc.base + z0, (size_t)(z1 - z0), st));
   if (dry) {
     long long ab = z1 - z0;
     for (int m = 0; m < P.nm; ++m) ab += ((long long)Mg * P.d.n_latent[m] * 4 + 255) & ~255LL;
@@ -1987,7 +2020,7 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
       float* a = reinterpret_cast<float*>(accb + aoff);
       aoff += (n * 4 + 255) & ~255LL;
       if (!B.have_ddc[m]) {  // no gradient reached this modality's draws in this slice
-        if (io.bwd_acc_mode == 1) GPSA_CK((int)hipMemsetAsync(a, 0, (size_t)(n * 4), st));
+        if (io.bwd_acc_mode == 1) GPSA_CK(zero_fill_async(a, (size_t)(n * 4), st));
         continue;
       }
       if (io.bwd_acc_mode == 1) {
@@ -2410,6 +2443,16 @@ int gpsa_step_batch_layout(const void* plan, long long* out) {
 
 /* timing of the contraction kernels (diagnostic; bench.py): events around gpsa_quadform_fwd / _bwd_alpha /
  * _bwd_omega of the first data-GP pass for the next ``slots`` steps (a ring); 0 switches it off */
+/* id of the stream capture ``stream`` is part of, 0 when it is not capturing (hipStreamGetCaptureInfo): a host that
+ * caches device scratch per stream must not hand a block it allocated INSIDE one capture - it lives in that graph's
+ * private pool - to a later capture */
+unsigned long long gpsa_stream_capture_id(void* stream) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(as_stream(stream), &cs, &id) != hipSuccess) return 0;
+  return cs == hipStreamCaptureStatusActive ? (id ? id : ~0ULL) : 0;
+}
+
 int gpsa_step_timing(void* plan, int slots) {
   using namespace gpsa;
   if (!plan || slots < 0) return GPSA_EINVAL;

@@ -4,6 +4,8 @@ PyTorch is used here only as plumbing: it owns device memory (torch.empty), the 
 (torch.cuda.current_stream) and autograd bookkeeping.  Every numerical kernel below is a
 hand-written HIP kernel in csrc/, reached through ctypes with raw device pointers.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -61,13 +63,24 @@ class HipOps:
         (device, stream), grown on demand: launches on a stream are ordered, scratch never outlives its
         call, so consecutive calls can share it."""
         dev = like.get_device()
-        key = (dev, _raw_stream(dev))
+        stream = _raw_stream(dev)
+        # Inside a stream capture the buffer is the CAPTURE's own (round 6): a block allocated while capturing lives in
+        # that graph's private pool; cached per stream alone, the next capture on the same stream baked it into a second
+        # graph, and once the first graph was destroyed the allocator handed the block out again under the second
+        # one's replays.  Nor may a capture bake the eager buffer: a later, larger request frees that one.  Entries of
+        # finished captures are dropped here - that only returns their blocks to their own graphs' pools.
+        cid = int(self.lib.gpsa_stream_capture_id(stream))
+        key = (dev, stream, cid)
+        if cid and key not in self._scratch:
+            for k in [k for k in self._scratch if k[2] not in (0, cid)]:
+                del self._scratch[k]
+            self.__dict__["_retired"] = []
         buf = self._scratch.get(key)
         if buf is None or buf.numel() < nbytes:
             # doubling only while that is cheap: the large-M plans ask for tens of GB
             grow = max(int(nbytes), 1 << 20, 0 if buf is None else min(2 * buf.numel(), int(nbytes) + (256 << 20)))
             if buf is not None:
-                if torch.cuda.is_current_stream_capturing():
+                if cid:
                     # a block must not go back to the allocator inside a capture (its stream bookkeeping records
                     # events): the old buffer outlives the capture in this list
                     self.__dict__.setdefault("_retired", []).append(buf)

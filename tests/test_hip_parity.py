@@ -234,7 +234,10 @@ def test_graphed_step_equals_eager_step():
 def test_eager_forward_between_graph_replays_leaves_the_graph_intact(monkeypatch):
     """with arenas parked on the plan, a captured step must not bake a parked (eagerly allocated)
     block into the graph - an eager forward between two replays takes that block from the plan, frees it, and later
-    replays would write into memory other tensors own.  Every arena is parked here (threshold 1 byte)."""
+    replays would write into memory other tensors own.  Every arena is parked here (threshold 1 byte).
+    Round 6: the same test caught a hipGraph memset NODE landing behind the kernel that follows it (the backward's zero
+    fill, once a kernel read the region straight away): the library fills with a kernel of its own since
+    (csrc/elementwise.hip: zero_fill_async), and HipOps._ws no longer hands a capture's scratch to the next capture."""
     from spatial_alignment_amd import step_engine as SE
     from spatial_alignment_amd.optim import FusedAdam
     from spatial_alignment_amd.train import GraphedTrainStep
