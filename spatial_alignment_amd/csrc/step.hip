@@ -2203,7 +2203,9 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
  *     tools/graph_stress.py and tests/test_step_engine.py train models twice from one seed, cache off / on, and
  *     compare the loss trajectories bit for bit).  One real hazard of that day's code is closed: an evicted graph
  *     was destroyed at once, possibly under a launch of its own still queued behind the host - it now retires behind
- *     an event.
+ *     an event.  A second one was found at the end of round 6 (LAB_NOTES): a hipMemsetAsync captured into a graph - the
+ *     backward's zero fill was one - can land BEHIND the kernel node that follows it; the library zero-fills with a
+ *     kernel of its own since.  Whether that was the error of round 5 is not known: it never reproduced.
  * Hence OFF unless asked for (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)): safe for callers of the C ABI that
  * own fixed buffers (tests/test_step_engine.py replays a repeated call bit for bit); the model's route to one launch
  * per step stays the whole-step graph, train.GraphedTrainStep / fit(graphed=True). */
