@@ -93,6 +93,23 @@ def parse():
     return args
 
 
+def step_graph_stats(model):
+    """[replays, eager calls, captures, graphs held] of the engine's hipGraph cache over the model's plans (on by default
+    for launch-bound plans only: GPSA_STEP_GRAPH=0 / 1 overrides)"""
+    import ctypes
+
+    tot = [0, 0, 0, 0]
+    try:
+        for plan in model.__dict__.get("_step_plans", {}).values():
+            st = (ctypes.c_longlong * 4)()
+            if plan.lib.gpsa_step_graph(plan.handle, -1, st) == 0:
+                tot = [a + int(b) for a, b in zip(tot, st)]
+    except Exception as e:  # (diagnostic only)
+        return dict(error=f"{type(e).__name__}: {e}"[:200])
+    return dict(replays=tot[0], eager_calls=tot[1], captures=tot[2], graphs_held=tot[3],
+                env=os.environ.get("GPSA_STEP_GRAPH", "unset (off)"))
+
+
 _GC_DONE = []  # (time_blocks: one full collection + freeze before the first timed block of the process)
 
 
@@ -335,6 +352,15 @@ def extra_workload(which, args):
     cut to what the default line carries for it"""
     import subprocess
 
+    def with_cache(cmd):  # config 1 once more with the engine's hipGraph cache on (off by default: csrc/step.hip)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, GPSA_STEP_GRAPH="1"))
+            d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            return dict(steps_per_s=d["value"], verbatim_loop_steps_per_s=(d.get("verbatim_loop") or {}).get("value"),
+                        **(d.get("step_graph_cache") or {}))
+        except Exception as e:
+            return dict(error=f"{type(e).__name__}: {e}"[:200])
+
     # (config 1's step is ~0.6 ms of ~60 tiny launches: the first ~1000 steps of a process run 30-70 % slow on these
     #  boxes (clocks), so its child warms up for 1000 steps and times blocks of at least 200)
     steps, warm = (max(args.steps, 200), max(args.warmup, 1000)) if which == "1" else (args.steps, args.warmup)
@@ -352,6 +378,8 @@ def extra_workload(which, args):
                ms_per_step_min_max=[d["timing"]["ms_per_step_min"], d["timing"]["ms_per_step_max"]])
     if d.get("graph_replay"):
         out["graph_replay_steps_per_s"] = d["graph_replay"].get("value")
+    if which == "1":
+        out["with_step_graph_cache"] = with_cache(cmd)
     if d.get("verbatim_loop"):
         out["verbatim_loop"] = {k: d["verbatim_loop"][k] for k in ("value", "ms_per_step", "over_headline_loop", "loop")}
     if d.get("cpu_baseline"):
@@ -659,7 +687,10 @@ def main():
                     ms_per_step_blocks=[round(1e3 * t / args.steps, 4) for t in ts])
 
     nblk = max(1, args.blocks)
-    times, loss = time_blocks(reference_step, args.S, nblk, before=timer.start)
+    # (with the engine's hipGraph cache asked for - GPSA_STEP_GRAPH=1, config 1's extra leg - no kernel-timing events: the
+    #  engine does not replay with them on)
+    cache_on = os.environ.get("GPSA_STEP_GRAPH") == "1"
+    times, loss = time_blocks(reference_step, args.S, nblk, before=None if cache_on else timer.start)
     head = summary(times)
     dt = args.steps / head["value"]  # the median block
     final_loss = float(loss.item())
@@ -937,6 +968,7 @@ def main():
             "secondary_S1": s1,
             "sustained": sustained,
             "graph_replay": graph_info,
+            "step_graph_cache": step_graph_stats(model),
         }
         # (the CPU leg runs at N = 1 only: at N > 1 the other ranks would sit in the process group's teardown for the
         #  ~45 s rank 0 spends on the host, and the figure would not differ)

@@ -864,6 +864,27 @@ int zero_fill_async(void* ptr, size_t bytes, hipStream_t st) {
   GPSA_LAUNCH_CHECK();
   return 0;
 }
+// ... and device-to-device copies likewise (a memcpy NODE is the same kind of node; none was seen to misbehave, but the
+// consumers of the step's copies - the KL terms in front of the loss kernel, a slice's accumulator - follow them at once)
+__global__ void __launch_bounds__(256) copy_kernel(uint4* __restrict__ d, const uint4* __restrict__ s, long long n16,
+                                                   int tail) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i < n16) d[i] = s[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail)
+    reinterpret_cast<unsigned char*>(d + n16)[threadIdx.x] = reinterpret_cast<const unsigned char*>(s + n16)[threadIdx.x];
+}
+int copy_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("GPSA_ZERO_KERNEL"); return e && e[0] == '0'; }();
+  if (bytes == 0) return 0;
+  if (off || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15))
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+  const long long n16 = (long long)(bytes / 16);
+  const long long blocks = n16 > 0 ? cdiv(n16, 256) : 1;
+  copy_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), n16,
+                                                (int)(bytes % 16));
+  GPSA_LAUNCH_CHECK();
+  return 0;
+}
 // gpsa_elbo_fused_post in ONE launch (dvar_u fp64): the post kernel's last block closes dvar through ``tick``, a device
 // word that is zero at entry and zero again afterwards (the step engine's backward keeps a few in its zero-filled region)
 int elbo_fused_post_ticket(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,

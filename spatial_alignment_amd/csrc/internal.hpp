@@ -51,6 +51,7 @@ int proj64_launch(int MB, const double* Apk, const TI* X, int M, long long C, do
 // zero fill as a kernel of this library, not a runtime memset (elementwise.hip: a memset NODE of a replayed graph was
 // seen to land behind the kernel that follows it); returns 0 or a hipError_t
 int zero_fill_async(void* ptr, size_t bytes, hipStream_t st);
+int copy_async(void* dst, const void* src, size_t bytes, hipStream_t st);  // device to device, as a kernel
 // gpsa_elbo_fused_post as one launch (elementwise.hip): tick = a device word that is zero at entry
 int elbo_fused_post_ticket(float* g_ext, float* dmeanT, float* abar, int M, long long C, int L, const float* gloss,
                            const float* var_u, double* dvar_u, double* part, int* tick, hipStream_t st);

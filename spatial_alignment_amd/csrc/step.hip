@@ -1075,8 +1075,7 @@ static int mm_stage_fwd(Ctx& c) {
   }
   if (c.io.reuse_mm) {  // same parameters, same arena: everything below is still there
     if (kl && !dry)
-      GPSA_CK((int)hipMemcpyAsync(c.io.kl, c.sv<double>(P.o_klcache), (size_t)((long long)V * D + P.Ltot) * 8,
-                                  hipMemcpyDeviceToDevice, c.st));
+      GPSA_CK(copy_async(c.io.kl, c.sv<double>(P.o_klcache), (size_t)((long long)V * D + P.Ltot) * 8, c.st));
     return 0;
   }
   // prior covariances K_uu + 1e-5 I of the free views (batched over runs) and of the data GP
@@ -1492,7 +1491,7 @@ static int data_pass_bwd(Ctx& c, const Pass& ps, int pass_idx, const float* dFl_
   const float* dFl = dFl_in;
   if (P.d.has_lmc[m] && dFo_in != nullptr) {
     float* buf = c.sc.get<float>(C * L);
-    if (dFl_in != nullptr) GPSA_RUN((int)hipMemcpyAsync(buf, dFl_in, (size_t)(C * L * 4), hipMemcpyDeviceToDevice, c.st));
+    if (dFl_in != nullptr) GPSA_RUN(copy_async(buf, dFl_in, (size_t)(C * L * 4), c.st));
     GPSA_CK(gemm32(c, 0, 1, (int)C, L, Pm, 1.0, dFo_in, Pm, 0, c.prm.W[m], Pm, 0, dFl_in != nullptr ? 1.0 : 0.0, buf, L,
                    0, 1, 1));
     if (out.W[m] != nullptr)  // dW = F^T dF_obs
@@ -2008,7 +2007,7 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
     double* aD = reinterpret_cast<double*>(accb);  // (the accumulator mirrors the region byte for byte)
     long long aoff = z1 - z0;
     if (io.bwd_acc_mode == 1) {
-      GPSA_CK((int)hipMemcpyAsync(aD, rD, (size_t)(nD * 8), hipMemcpyDeviceToDevice, st));
+      GPSA_CK(copy_async(aD, rD, (size_t)(nD * 8), st));
     } else {
       double* dst = io.bwd_acc_mode == 2 ? aD : rD;
       const double* src = io.bwd_acc_mode == 2 ? rD : aD;
@@ -2024,7 +2023,7 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
         continue;
       }
       if (io.bwd_acc_mode == 1) {
-        GPSA_CK((int)hipMemcpyAsync(a, B.ddc_F[m], (size_t)(n * 4), hipMemcpyDeviceToDevice, st));
+        GPSA_CK(copy_async(a, B.ddc_F[m], (size_t)(n * 4), st));
       } else {
         add_inplace_f32_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? a : B.ddc_F[m],
                                                                         io.bwd_acc_mode == 2 ? B.ddc_F[m] : a, n);
@@ -2040,7 +2039,7 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
       aoff += (n * 4 + 255) & ~255LL;
       if (out.W[m] == nullptr) continue;
       if (io.bwd_acc_mode == 1) {
-        GPSA_CK((int)hipMemcpyAsync(a, out.W[m], (size_t)(n * 4), hipMemcpyDeviceToDevice, st));
+        GPSA_CK(copy_async(a, out.W[m], (size_t)(n * 4), st));
       } else {
         add_inplace_f32_kernel<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(io.bwd_acc_mode == 2 ? a : out.W[m],
                                                                         io.bwd_acc_mode == 2 ? out.W[m] : a, n);
@@ -2206,9 +2205,13 @@ static int step_backward(Plan& P, const gpsa_step_params& prm, const gpsa_step_i
  *     an event.  A second one was found at the end of round 6 (LAB_NOTES): a hipMemsetAsync captured into a graph - the
  *     backward's zero fill was one - can land BEHIND the kernel node that follows it; the library zero-fills with a
  *     kernel of its own since.  Whether that was the error of round 5 is not known: it never reproduced.
- * Hence OFF unless asked for (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)): safe for callers of the C ABI that
- * own fixed buffers (tests/test_step_engine.py replays a repeated call bit for bit); the model's route to one launch
- * per step stays the whole-step graph, train.GraphedTrainStep / fit(graphed=True). */
+ * Hence OFF unless asked for (GPSA_STEP_GRAPH=1, gpsa_step_graph(plan, 1, ...)).  End of round 6, with the memset
+ * hazard closed: 18 more model runs clean (profiles/r06_graph_cache_stress_final.txt), the whole GPU suite green with the
+ * cache forced on (500 tests), and again with it on for launch-bound plans only (a default that was built and taken
+ * back: BASELINE config 1 gained 0 - 90 % with FusedAdam and 0 - 35 % in the verbatim loop depending on the box and
+ * the run - 1017 / 1380 against 1016 steps/s on a slow host, 1590 - 1740 on a fast one - which does not buy back one
+ * open question in the last round).  bench.py reports config 1 with the cache on as an extra key.  The model's route
+ * to one launch per step stays the whole-step graph, train.GraphedTrainStep / fit(graphed=True). */
 namespace gpsa {
 
 static bool graph_usable(Plan& P, hipStream_t st) {
